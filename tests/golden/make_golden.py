@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+Test infrastructure. Run once here (where /root/reference exists); the GPU box only ever sees the
+committed outputs (`*.npz`, `files/*`).  Nothing from the reference is copied: fixtures hold
+seeded inputs and the reference's outputs only.
+
+How the reference is run (SURVEY.md §8c recipe):
+  * oracle/build_ref.sh compiles the reference's own CPython extension `c_recode` from
+    /root/reference/pyrecode/pyrecode.cpp (+ c_extensions/reader.h) into oracle/_ref/.
+  * `numba` is not installed, so an identity-`jit` stand-in (oracle/_ref/shim/numba) lets
+    `pyrecode.recode_writer` import; its @jit kernels (_pack_binary_frame, _bit_pack) then run as
+    the plain Python they are written in.  Reader-side modules need no stand-in.
+  * ReCoDeServer is not used (zmq absent; np.bool/np.int at recode_server.py:410-411): one
+    ReCoDeWriter per node_id is driven in-process, then merge_parts.
+
+Fixture groups:
+  G1  thr / binary map / L1 residuals          (recode_writer.py:126-137, 437, 440)
+  G2  _pack_binary_frame / _bit_pack outputs   (recode_writer.py:622-634, 637-652)
+  G3  whole part files + merged file           (recode_writer.py:184-607, recode_reader.py:495-595)
+  G4  512-byte header bytes                    (recode_header.py:58-94, 257-275)
+  G5  get_frame_sparse triplets                (pyrecode.cpp:95-119, reader.h:10-68)
+"""
+import contextlib
+import io
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("RECODE_REFERENCE", "/root/reference")
+REFBUILD = os.path.join(REPO, "oracle", "_ref")
+
+subprocess.check_call([os.path.join(REPO, "oracle", "build_ref.sh")])
+sys.path[:0] = [os.path.join(REFBUILD, "shim"), REFBUILD, REF]
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import pyrecode.recode_writer as ref_writer
+    import pyrecode.recode_reader as ref_reader
+    from pyrecode.params import InputParams
+    from pyrecode.recode_header import ReCoDeHeader
+    import c_recode as ref_c
+
+FILES = os.path.join(HERE, "files")
+os.makedirs(FILES, exist_ok=True)
+
+PARAM_DEFAULTS = dict(
+    l4_centroiding=0, source_file_type=0, num_frames=8, source_header_length=0,
+    calibration_frame_offset=0, compression_scheme=0, calibration_file_type=0, compression_level=1,
+    l2_statistics=0, calibration_threshold_epsilon=0, frame_offset=0, num_threads=3,
+    rc_operation_mode=1, num_calibration_frames=1, reduction_level=1, keep_calibration_data=1,
+    source_bit_depth=12, target_bit_depth=12, keep_part_files=0, num_rows=40, num_cols=56,
+    source_data_type=0, target_data_type=0)
+
+
+def make_params(tmp, **over):
+    cfg = dict(PARAM_DEFAULTS)
+    cfg.update(over)
+    path = os.path.join(tmp, "params.txt")
+    with open(path, "w") as f:
+        for k, v in cfg.items():
+            f.write("%s = %d\n" % (k, v))
+    ip = InputParams()
+    ip.load(path)
+    return ip, cfg
+
+
+def synth_stack(seed, nz, ny, nx, sparsity, depth, dark_lo=3, dark_hi=20):
+    """Seeded frames: Bernoulli(sparsity) events above a random dark level, background <= thr."""
+    rng = np.random.default_rng(seed)
+    dark = rng.integers(dark_lo, dark_hi + 1, (ny, nx)).astype(np.uint16)
+    top = (1 << depth) - 1
+    frames = np.empty((nz, ny, nx), np.uint16)
+    for z in range(nz):
+        mask = rng.random((ny, nx)) < sparsity
+        amp = rng.integers(1, top - dark_hi - 8, (ny, nx)).astype(np.uint16)
+        below = np.floor(rng.random((ny, nx)) * (dark + 1)).astype(np.uint16)
+        frames[z] = np.where(mask, dark + amp, below)
+    return dark, frames
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+# --------------------------------------------------------------------------------------------
+# G1 + G2: per-frame reduce pieces straight from the reference's expressions / kernels
+# --------------------------------------------------------------------------------------------
+def g1_g2():
+    out = {}
+    cases = [("a", 37, 53, 0.10, 12, 0), ("b", 40, 56, 0.05, 12, 7), ("c", 64, 64, 0.01, 10, 0),
+             ("d", 16, 24, 0.50, 14, 3), ("e", 9, 7, 0.30, 9, 0), ("f", 32, 128, 0.02, 16, 0)]
+    for tag, ny, nx, s, depth, eps in cases:
+        dark, frames = synth_stack(1000 + len(out), 2, ny, nx, s, depth)
+        if tag == "f":  # exercise 65535 and exact-threshold pixels at depth 16
+            frames[0, 0, 0] = 65535
+            frames[0, 0, 1] = dark[0, 1] + eps          # == thr  -> NOT foreground (strict >)
+            frames[0, 0, 2] = dark[0, 2] + eps + 1      # thr + 1 -> residual 1
+        # recode_writer.py:127 (NumPy 2: uint16 + python int stays uint16)
+        thr = dark + eps
+        out[f"g1_{tag}_dark"] = dark
+        out[f"g1_{tag}_eps"] = np.int64(eps)
+        out[f"g1_{tag}_depth"] = np.int64(depth)
+        out[f"g1_{tag}_frames"] = frames
+        out[f"g1_{tag}_thr"] = thr
+        for z in range(frames.shape[0]):
+            frame = frames[z]
+            binary = frame > thr                              # recode_writer.py:437
+            pix = frame[binary] - thr[binary]                 # recode_writer.py:440
+            nb = int(np.ceil(ny * nx / 8))
+            packed_map = ref_writer._pack_binary_frame(binary, nb)   # recode_writer.py:622-634
+            out[f"g1_{tag}_binary{z}"] = binary
+            out[f"g1_{tag}_pix{z}"] = pix
+            out[f"g2_{tag}_bitmap{z}"] = np.asarray(packed_map, np.uint8)
+            if depth % 8 != 0:
+                out[f"g2_{tag}_packed{z}"] = np.asarray(ref_writer._bit_pack(pix, depth), np.uint8)
+            else:
+                out[f"g2_{tag}_packed{z}"] = np.frombuffer(pix.tobytes(), np.uint8)  # :463-464
+    # _bit_pack on its own for every depth, including values with bits above the depth (dropped)
+    rng = np.random.default_rng(77)
+    vals = rng.integers(0, 65536, 41).astype(np.uint16)
+    out["g2_vals"] = vals
+    for d in (1, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16):
+        out[f"g2_bitpack_d{d}"] = np.asarray(ref_writer._bit_pack(vals, d), np.uint8)
+    # the reference C packer called directly (first call into a zeroed buffer == intended semantics)
+    np.savez_compressed(os.path.join(HERE, "g1_g2_reduce.npz"), **out)
+    print("g1_g2:", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------------------------
+# G3 + G4: whole files
+# --------------------------------------------------------------------------------------------
+def write_parts(tmp, base, dark, frames, n_nodes, **over):
+    nz, ny, nx = frames.shape
+    ip, cfg = make_params(tmp, num_frames=nz, num_rows=ny, num_cols=nx, num_threads=n_nodes, **over)
+    for node in range(n_nodes):
+        ip, cfg = make_params(tmp, num_frames=nz, num_rows=ny, num_cols=nx, num_threads=n_nodes, **over)
+        w = quiet(ref_writer.ReCoDeWriter, base, dark_data=dark, output_directory=tmp, input_params=ip,
+                  mode="batch", validation_frame_gap=-1, node_id=node)
+        quiet(w.start)
+        quiet(w.run, frames)
+        quiet(w.close)
+    return cfg
+
+
+def g3_g4():
+    meta = {}
+    cases = [
+        # tag,     nz ny  nx  s     depth nodes overrides
+        ("l1z12", 8, 40, 56, 0.10, 12, 3, dict()),
+        ("l1z16", 5, 37, 53, 0.05, 16, 2, dict(source_bit_depth=16, target_bit_depth=16,
+                                               calibration_threshold_epsilon=7)),
+        ("l1ro16", 4, 16, 24, 0.20, 16, 2, dict(source_bit_depth=16, target_bit_depth=16,
+                                                rc_operation_mode=0)),
+        ("l3z", 4, 24, 40, 0.10, 12, 2, dict(reduction_level=3)),
+    ]
+    for tag, nz, ny, nx, s, depth, nodes, over in cases:
+        tmp = tempfile.mkdtemp()
+        dark, frames = synth_stack(2000 + len(meta), nz, ny, nx, s, depth)
+        base = "g3_" + tag
+        cfg = write_parts(tmp, base, dark, frames, nodes, **over)
+        level = cfg["reduction_level"]
+        names = []
+        for node in range(nodes):
+            fn = "%s.rc%d_part%03d" % (base, level, node)
+            shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+            names.append(fn)
+        quiet(ref_reader.merge_parts, tmp, "%s.rc%d" % (base, level), nodes)
+        fn = "%s.rc%d" % (base, level)
+        shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+        # decoded frames through the reference reader (L1 only: the reference cannot read L3)
+        dec = None
+        if level == 1:
+            rd = ref_reader.ReCoDeReader(os.path.join(tmp, fn), is_intermediate=False)
+            quiet(rd.open, print_header=False)
+            dec = np.zeros_like(frames)
+            for z in range(nz):
+                fr = quiet(rd.get_frame, z)
+                dec[z] = np.asarray(fr[z]["data"].todense()).astype(np.uint16)
+            rd.close()
+        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames,
+                            cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array(list(cfg.values())),
+                            n_nodes=nodes, decoded=dec if dec is not None else np.zeros(0))
+        meta[tag] = names
+        shutil.rmtree(tmp)
+    print("g3_g4:", meta)
+
+
+# --------------------------------------------------------------------------------------------
+# G5: sparse expand through the reference's compiled extension
+# --------------------------------------------------------------------------------------------
+def g5():
+    out = {}
+    rng = np.random.default_rng(55)
+    for tag, ny, nx, s, depth, level in [("a", 37, 53, 0.10, 12, 1), ("b", 40, 56, 0.05, 16, 1),
+                                         ("c", 24, 40, 0.20, 9, 1), ("d", 24, 40, 0.10, 12, 3)]:
+        binary = rng.random((ny, nx)) < s
+        n = int(binary.sum())
+        vals = rng.integers(1, 1 << depth, n).astype(np.uint16)
+        bitmap = np.packbits(binary.ravel(), bitorder="little")
+        packed = np.asarray(ref_writer._bit_pack(vals, depth), np.uint8)
+        rd = ref_c.Reader()
+        rd.create_buffers(ny, nx, depth)
+        buf = bytearray(ny * nx * 3 * 8)
+        got = rd.get_frame_sparse(level, bitmap.tobytes(), packed.tobytes(), buf)
+        trip = np.frombuffer(bytes(buf), np.uint64, count=got * 3).reshape(got, 3).copy()
+        out[f"g5_{tag}_shape"] = np.array([ny, nx, depth, level])
+        out[f"g5_{tag}_bitmap"] = bitmap
+        out[f"g5_{tag}_packed"] = packed
+        out[f"g5_{tag}_vals"] = vals
+        out[f"g5_{tag}_triplets"] = trip
+    np.savez_compressed(os.path.join(HERE, "g5_expand.npz"), **out)
+    print("g5:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    g1_g2()
+    g3_g4()
+    g5()

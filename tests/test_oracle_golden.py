@@ -1,0 +1,146 @@
+"""The oracle (oracle/recode_oracle.c via oracle/oracle.py) against fixtures captured from the reference
+itself (tests/golden/make_golden.py).  CPU only.  This is what pins the oracle (task §3)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_npz
+from oracle import oracle as orc
+
+G12 = load_npz("g1_g2_reduce.npz")
+TAGS = sorted({k.split("_")[1] for k in G12.files if k.startswith("g1_")})
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_g1_threshold_binary_residuals(tag):
+    dark, eps, frames = G12[f"g1_{tag}_dark"], int(G12[f"g1_{tag}_eps"]), G12[f"g1_{tag}_frames"]
+    thr = orc.threshold(dark, eps)
+    assert np.array_equal(thr, G12[f"g1_{tag}_thr"])
+    for z in range(frames.shape[0]):
+        binary, pix = orc.binarize_l1(frames[z], thr)
+        assert np.array_equal(binary, G12[f"g1_{tag}_binary{z}"])
+        assert np.array_equal(pix, G12[f"g1_{tag}_pix{z}"])
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_g2_bitmap_and_packed(tag):
+    d = int(G12[f"g1_{tag}_depth"])
+    frames, thr = G12[f"g1_{tag}_frames"], G12[f"g1_{tag}_thr"]
+    for z in range(frames.shape[0]):
+        bm = orc.pack_binary_frame(G12[f"g1_{tag}_binary{z}"])
+        assert np.array_equal(bm, G12[f"g2_{tag}_bitmap{z}"])
+        pk = orc.bit_pack(G12[f"g1_{tag}_pix{z}"], d)
+        assert np.array_equal(pk, G12[f"g2_{tag}_packed{z}"])
+        # the fused CPU-baseline form must agree with the staged form
+        fbm, fpk, nnz = orc.reduce_frame_l1(frames[z], thr, d)
+        assert nnz == len(G12[f"g1_{tag}_pix{z}"])
+        assert np.array_equal(fbm, bm) and np.array_equal(fpk, pk)
+
+
+@pytest.mark.parametrize("d", [1, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+def test_g2_bit_pack_all_depths(d):
+    vals = G12["g2_vals"]
+    out = np.empty((vals.size * d + 7) // 8, np.uint8)
+    import ctypes as C
+    n = orc.lib().orc_bit_pack(vals.ctypes.data_as(C.POINTER(C.c_uint16)), vals.size, d,
+                               out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert n == out.size
+    assert np.array_equal(out, G12[f"g2_bitpack_d{d}"])
+    # numpy identity quoted in SURVEY §0.2
+    bits = ((vals[:, None] >> np.arange(d)) & 1).astype(np.uint8).ravel()
+    assert np.array_equal(out, np.packbits(bits, bitorder="little"))
+    back = orc.bit_unpack(out, vals.size, d)
+    assert np.array_equal(back, vals.astype(np.uint64) & ((1 << d) - 1))
+
+
+def test_g5_sparse_expand():
+    g5 = load_npz("g5_expand.npz")
+    for tag in "abcd":
+        ny, nx, d, level = (int(x) for x in g5[f"g5_{tag}_shape"])
+        trip = orc.unpack_frame_sparse(nx, ny, d, g5[f"g5_{tag}_bitmap"], g5[f"g5_{tag}_packed"], level)
+        assert np.array_equal(trip, g5[f"g5_{tag}_triplets"])
+
+
+def _parse_part(path, level, mode):
+    """SURVEY appendix A part-file layout -> list of raw record bytes."""
+    blob = open(path, "rb").read()
+    nx, ny = struct.unpack_from("<II", blob, 15)
+    nb = (nx * ny + 7) // 8
+    pos, recs = 512, []
+    while pos < len(blob):
+        if level == 1 and mode == 1:
+            _, cb, cp, _ = struct.unpack_from("<IIII", blob, pos)
+            ln = 16 + cb + cp
+        elif level == 1 and mode == 0:
+            _, npk = struct.unpack_from("<II", blob, pos)
+            ln = 8 + nb + npk
+        elif mode == 1:
+            _, cb = struct.unpack_from("<II", blob, pos)
+            ln = 8 + cb
+        else:
+            ln = 4 + nb
+        recs.append(blob[pos:pos + ln])
+        pos += ln
+    assert pos == len(blob)
+    return recs
+
+
+@pytest.mark.parametrize("tag,level", [("l1z12", 1), ("l1z16", 1), ("l1ro16", 1), ("l3z", 3)])
+def test_g3_records_byte_exact(tag, level):
+    g = load_npz(f"g3_{tag}.npz")
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    dark, frames, nodes = g["dark"], g["frames"], int(g["n_nodes"])
+    thr = orc.threshold(dark, cfg["calibration_threshold_epsilon"])
+    mode, d = cfg["rc_operation_mode"], cfg["source_bit_depth"]
+    merged_md, merged_data = [], b""
+    for node in range(nodes):
+        recs = _parse_part(os.path.join(GOLDEN, "files", "g3_%s.rc%d_part%03d" % (tag, level, node)), level, mode)
+        lo, cnt = orc.node_frames(frames.shape[0], nodes, node)
+        assert len(recs) == cnt
+        for i, ref_rec in enumerate(recs):
+            if level == 1:
+                rec, md = orc.l1_record(frames[lo + i], thr, d, lo + i, mode)
+            else:
+                rec, md = orc.l3_record(frames[lo + i], thr, lo + i, mode)
+            assert rec == ref_rec
+            hdr = 4 + 4 * len(md)
+            merged_md.append(struct.pack("<%dI" % len(md), *md))
+            merged_data += rec[hdr:]
+    # merged-file layout (recode_reader.py:518-592): header | nz x metadata | data blobs
+    merged = open(os.path.join(GOLDEN, "files", "g3_%s.rc%d" % (tag, level)), "rb").read()
+    assert merged[512:] == b"".join(merged_md) + merged_data
+    part0 = open(os.path.join(GOLDEN, "files", "g3_%s.rc%d_part000" % (tag, level)), "rb").read()
+    assert merged[:23] == part0[:23] and merged[27:512] == part0[27:512]
+    assert struct.unpack_from("<I", merged, 23)[0] == frames.shape[0]
+    if level == 1 and g["decoded"].size:
+        assert np.array_equal(g["decoded"], np.where(frames > thr, frames - thr, 0).astype(np.uint16))
+
+
+def test_against_reference_c_loops_when_built():
+    """oracle/_ref/libreader_ref.so = the reference's own reader.h compiled in place (build_ref.sh)."""
+    import ctypes as C
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libreader_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    ref = C.CDLL(path)
+    ref._unpack_frame_sparse.restype = C.c_int64
+    ref._unpack_frame_sparse.argtypes = [C.c_uint16, C.c_uint16, C.c_uint8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint8]
+    ref._bit_pack_pixel_intensities.restype = C.c_float
+    ref._bit_pack_pixel_intensities.argtypes = [C.c_uint64, C.c_uint32, C.c_uint8, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9)
+    for ny, nx, d, s in [(33, 47, 12, 0.2), (64, 64, 16, 0.01), (10, 130, 9, 0.5), (8, 8, 13, 1.0), (8, 8, 12, 0.0)]:
+        binary = rng.random((ny, nx)) < s
+        vals = rng.integers(0, 65536, int(binary.sum())).astype(np.uint16)
+        mine = orc.bit_pack(vals, d) if d != 16 else orc.bit_pack(vals, 16)
+        theirs = np.full(max((vals.size * d + 7) // 8, 1), 0xAA, np.uint8)  # dirty buffer: zeroing is part of the spec
+        ref._bit_pack_pixel_intensities((vals.size * d + 7) // 8, vals.size, d, vals.ctypes.data, theirs.ctypes.data)
+        assert np.array_equal(mine, theirs[: mine.size])
+        bitmap = np.packbits(binary.ravel(), bitorder="little")
+        buf = np.zeros((max(vals.size, 1), 3), np.uint64)
+        pk = np.concatenate([mine, np.zeros(8, np.uint8)])
+        n = ref._unpack_frame_sparse(nx, ny, d, bitmap.ctypes.data, pk.ctypes.data, buf.ctypes.data, 1)
+        got = orc.unpack_frame_sparse(nx, ny, d, bitmap, pk, 1)
+        assert n == vals.size == got.shape[0]
+        assert np.array_equal(got, buf[:n])

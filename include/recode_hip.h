@@ -1,0 +1,159 @@
+/* recode_hip.h - C ABI of librecode_hip.so: the MI355X (gfx950) implementation of pyReCoDe's per-frame
+ * reduce -> bit-pack -> compress hot path and of the reader's sparse expand.
+ *
+ * This is the drop-in boundary.  Plain C: pointers and sizes only, no torch / HIP types.
+ * Every entry point names the reference interface it replaces (paths relative to the reference repo).
+ * All kernels behind it are hand-written HIP for gfx950; there is NO CPU fallback in this library: on a
+ * machine without a usable GPU every compute entry point returns RC_ERR_DEVICE.
+ *
+ * Conventions
+ *   - Return value: RC_OK (0) or a negative rc_status.  Nothing throws across the ABI.
+ *   - Buffers are caller-owned (as in the reference: recode_writer.py:229-230, recode_reader.py:115).
+ *     A data pointer may be host memory or device memory of the ctx's GPU; the library detects which
+ *     (hipPointerGetAttributes) and stages host buffers itself.  It never allocates or frees caller memory.
+ *   - A ctx is bound to one GPU and one HIP stream and is not thread-safe; distinct ctxs are independent
+ *     (reference: one ReCoDeWriter per process, recode_server.py:358-363).
+ *   - All multi-byte fields the library writes are little-endian (reference uses sys.byteorder on x86).
+ */
+#ifndef RECODE_HIP_H
+#define RECODE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_ABI_VERSION 1
+
+typedef enum rc_status {
+    RC_OK = 0,
+    RC_ERR_BAD_ARG = -1,          /* python shim: ValueError */
+    RC_ERR_OUT_TOO_SMALL = -2,    /* caller's output capacity insufficient; nothing useful written */
+    RC_ERR_DEVICE = -3,           /* no GPU / HIP error; rc_last_error() has the HIP message; python: RuntimeError */
+    RC_ERR_UNSUPPORTED = -4,      /* scheme / level not implemented on device; python: NotImplementedError
+                                     (recode_compressors.py:78-79,119-120) */
+    RC_ERR_RECORD_TOO_LARGE = -5, /* a record exceeds the raw frame size; python: ValueError('Buffer size smaller
+                                     than compressed data size') (recode_writer.py:565-566) */
+    RC_ERR_CORRUPT = -6           /* malformed compressed stream / bitmap-vs-pixvals mismatch on the read side */
+} rc_status;
+
+/* compression_scheme codes of the reference (recode_compressors.py:3-4, config/README.md). Device codecs:
+ * 2 (LZ4 frame), 1 (zstd frame), 8 (blosc1 + lz4 + bitshuffle).  Every other code: the ctx emits the
+ * reduce-only pieces and the host layer runs the reference's own library call (zlib, bz2, lzma, ...). */
+enum { RC_SCHEME_ZLIB = 0, RC_SCHEME_ZSTD = 1, RC_SCHEME_LZ4 = 2, RC_SCHEME_BLOSC_LZ4 = 8 };
+
+typedef struct rc_ctx rc_ctx;
+
+/* ---- library ------------------------------------------------------------------------------------- */
+int rc_abi_version(void);
+const char *rc_strerror(int status);
+const char *rc_last_error(void);                 /* thread-local detail of the last failure */
+int rc_device_count(int *count);                 /* RC_OK with *count == 0 when no GPU is visible */
+int rc_scheme_on_device(uint32_t scheme);        /* 1 if rc_reduce_compress_batch emits this scheme itself */
+
+/* ---- seam 1: the per-frame operator, batched ---------------------------------------------------------
+ * Replaces ReCoDeWriter._reduce_compress (pyrecode/recode_writer.py:430-557) and the buffers ReCoDeWriter.start()
+ * allocates for it (:212-230).  One ctx == one writer (one node_id).
+ *
+ *   nx, ny            frame shape (header fields nx, ny; recode_header.py:66-67)
+ *   src_bit_depth     source_bit_depth: pixvals are bit-packed when it is not a multiple of 8 (recode_writer.py:463-475)
+ *   reduction_level   1 (binary map + residuals) or 3 (binary map only); 2/4 -> RC_ERR_UNSUPPORTED this round
+ *   op_mode           rc_operation_mode: 0 reduce only, 1 reduce + compress (recode_writer.py:482,497)
+ *   scheme, clevel    compression_scheme / compression_level (recode_writer.py:503-511)
+ *   device_id         HIP device ordinal
+ *   max_batch         largest n later passed to rc_reduce_compress_batch; sizes the device scratch
+ */
+rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth, uint32_t reduction_level,
+                      uint32_t op_mode, uint32_t scheme, uint32_t clevel, int device_id, uint32_t max_batch,
+                      int *status);
+int rc_ctx_destroy(rc_ctx *ctx);
+
+/* Use a caller-provided hipStream_t (passed as void*) instead of the ctx's own stream, e.g. torch's current
+ * stream so that caller-side events bracket the kernels.  NULL restores the ctx's own stream. */
+int rc_ctx_set_stream(rc_ctx *ctx, void *hip_stream);
+
+/* thr = calibration frame + epsilon in uint16 arithmetic (wraps mod 2^16 like NumPy 2):
+ * ReCoDeWriter.__init__, recode_writer.py:126-137.  dark: uint16[ny*nx], C order. */
+int rc_set_dark(rc_ctx *ctx, const uint16_t *dark, int64_t epsilon);
+/* Or hand over the finished threshold frame (self._calibration_frame_p_threshold). */
+int rc_set_threshold(rc_ctx *ctx, const uint16_t *thr);
+
+/* Worst-case bytes one batch of n frames can occupy in `out` (n * raw frame size, the reference's own bound,
+ * recode_writer.py:217-218,565-566), and the number of u32 metadata fields per frame for this ctx's
+ * (level, mode) (structures.py:18-46): L1/mode1 3, L1/mode0 1, L3/mode1 1, L3/mode0 0. */
+uint64_t rc_out_capacity(const rc_ctx *ctx, uint32_t n);
+uint32_t rc_md_fields(const rc_ctx *ctx);
+
+/* n frames in, n part-file records out.
+ *   frames         uint16[n][ny][nx] C order (host or device)
+ *   first_frame_id absolute_frame_index of frames[0] (recode_writer.py:385); frame i gets first_frame_id + i
+ *   out            records back to back, byte-identical in layout to what _write_to_frame_buffer assembles
+ *                  (recode_writer.py:485-494,518-525,546-550):
+ *                    L1 mode 1: u32 frame_id | u32 n_comp_bitmap | u32 n_comp_pix | u32 n_packed_pix | comp_bitmap | comp_pix
+ *                    L1 mode 0: u32 frame_id | u32 n_packed_pix | bitmap[ceil(nx*ny/8)] | packed_pix
+ *                    L3 mode 1: u32 frame_id | u32 n_comp_bitmap | comp_bitmap
+ *                    L3 mode 0: u32 frame_id | bitmap
+ *                  With op_mode 1 and a scheme that is not a device codec the ctx emits the mode-0 record and the
+ *                  host layer compresses (see rc_scheme_on_device).
+ *   out_cap        capacity of out in bytes
+ *   rec_offsets    uint64[n+1]: record i is out[rec_offsets[i] .. rec_offsets[i+1])
+ *   md             uint32[n][3]: the record's metadata fields after frame_id, zero padded to 3
+ * Synchronous: returns after the records (and offsets, md) are readable by the caller.
+ * RC_ERR_RECORD_TOO_LARGE / RC_ERR_OUT_TOO_SMALL leave out undefined. */
+int rc_reduce_compress_batch(rc_ctx *ctx, const uint16_t *frames, uint32_t n, uint32_t first_frame_id,
+                             uint8_t *out, uint64_t out_cap, uint64_t *rec_offsets, uint32_t *md);
+
+/* Asynchronous form for device-resident pipelines: every pointer must be device memory; work is enqueued on the
+ * ctx's stream and nothing is read back.  rc_ctx_sync waits for the stream and returns the status the device
+ * recorded for the most recent batch (RC_OK, RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL). */
+int rc_reduce_compress_batch_async(rc_ctx *ctx, const uint16_t *frames_dev, uint32_t n, uint32_t first_frame_id,
+                                   uint8_t *out_dev, uint64_t out_cap, uint64_t *rec_offsets_dev, uint32_t *md_dev);
+int rc_ctx_sync(rc_ctx *ctx);
+
+/* Packed binary map (ceil(nx*ny/8) bytes, LSB-first) of frame i of the most recent batch: what the third element
+ * of _reduce_compress's return value carries for validation frames (recode_writer.py:386,402-415,557). */
+int rc_get_binary_map(rc_ctx *ctx, uint32_t i, uint8_t *bitmap_out);
+
+/* Per-stage device time of the most recent batch in milliseconds (HIP events), keyed like the reference's
+ * run metrics (recode_writer.py:451,457,479,506,512,555):
+ *   [0] frame_thresholding_and_counting_time + frame_binary_image_packing_time (fused reduce kernel)
+ *   [1] scans / record layout   [2] frame_binary_image_compression_time   [3] frame_pixel_intensity_packing_time
+ *       + frame_pixel_intensity_compression_time (assemble kernel)   [4] whole batch (frame_time * n)
+ * Only filled by the synchronous entry point. */
+int rc_get_stage_ms(rc_ctx *ctx, float ms[5]);
+
+/* ---- seam 2: compressor backend -----------------------------------------------------------------------
+ * compress()/de_compress() of pyrecode/recode_compressors.py:82-120 / :40-79 for the device codecs.
+ * Host or device pointers.  *out_n receives the produced byte count.  Uses GPU `RC_DEVICE` (env, default 0). */
+int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap,
+                uint64_t *out_n);
+int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n);
+uint64_t rc_compress_bound(uint32_t scheme, uint64_t n);
+
+/* ---- seam 3: the native c_recode.Reader methods (pyrecode/pyrecode.cpp:143-150) ---------------------------
+ * get_frame_sparse -> _unpack_frame_sparse (pyrecode.cpp:95-119, c_extensions/reader.h:10-68): for every set bit of
+ * the bitmap in row-major order write (row, col, val) as three uint64; level 1: val = next d-bit LSB-first field
+ * of pixvals; other levels: val = 1.  out must hold 3 * popcount(bitmap) uint64 (the reference sizes it
+ * nx*ny*3, recode_reader.py:111-115); out_cap_triplets bounds it.  Returns nnz >= 0 or a negative rc_status. */
+int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_depth, const uint8_t *bitmap,
+                               const uint8_t *pixvals, uint64_t pixvals_bytes, uint64_t *out,
+                               uint64_t out_cap_triplets, uint32_t reduction_level);
+/* bit_pack_pixel_intensities -> _bit_pack_pixel_intensities (reader.h:105-140) with the intended semantics of
+ * the numba _bit_pack (recode_writer.py:637-652): zero, then LSB-first d-bit fields.  out_n = ceil(n*d/8). */
+int rc_bit_pack(const uint16_t *pixvals, uint64_t n, uint32_t bit_depth, uint8_t *out, uint64_t out_n);
+/* bit_unpack_pixel_intensities -> intended semantics of reader.h:74-99: n d-bit fields -> uint64[n]. */
+int rc_bit_unpack(const uint8_t *packed, uint64_t packed_bytes, uint64_t n, uint32_t bit_depth, uint64_t *out);
+
+/* ---- synthetic stacks for tests / bench --------------------------------------------------
+ * Counter-based integer generator, identical on host (pyrecode_amd/synth.py) and device:
+ * dark in [80,120]; Bernoulli(sparsity_ppm / 1e6) events of amplitude [1,2047] above dark; background <= dark. */
+int rc_synth_dark(int device_id, uint32_t seed, uint64_t n_pixels, uint16_t *dark_dev);
+int rc_synth_frames(int device_id, uint32_t seed, uint32_t first_frame, uint32_t n_frames, uint64_t n_pixels,
+                    uint32_t sparsity_ppm, const uint16_t *dark_dev, uint16_t *frames_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECODE_HIP_H */

@@ -1,0 +1,185 @@
+"""ctypes binding of librecode_hip.so (C ABI: include/recode_hip.h).
+
+The library is hand-written HIP for gfx950 and has no CPU path; this module fails loudly when the shared object
+is missing or when a compute call finds no GPU.  Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librecode_hip.so")
+
+RC_OK = 0
+RC_ERR_BAD_ARG = -1
+RC_ERR_OUT_TOO_SMALL = -2
+RC_ERR_DEVICE = -3
+RC_ERR_UNSUPPORTED = -4
+RC_ERR_RECORD_TOO_LARGE = -5
+RC_ERR_CORRUPT = -6
+
+# every symbol include/recode_hip.h declares: (restype, argtypes)
+_u8p, _u16p, _u32p, _u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses: host or device
+SIGNATURES = {
+    "rc_abi_version": (C.c_int, []),
+    "rc_strerror": (C.c_char_p, [C.c_int]),
+    "rc_last_error": (C.c_char_p, []),
+    "rc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rc_scheme_on_device": (C.c_int, [C.c_uint32]),
+    "rc_ctx_create": (C.c_void_p, [C.c_uint32] * 7 + [C.c_int, C.c_uint32, C.POINTER(C.c_int)]),
+    "rc_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "rc_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rc_set_dark": (C.c_int, [C.c_void_p, _u16p, C.c_int64]),
+    "rc_set_threshold": (C.c_int, [C.c_void_p, _u16p]),
+    "rc_out_capacity": (C.c_uint64, [C.c_void_p, C.c_uint32]),
+    "rc_md_fields": (C.c_uint32, [C.c_void_p]),
+    "rc_reduce_compress_batch": (C.c_int, [C.c_void_p, _u16p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u64p, _u32p]),
+    "rc_reduce_compress_batch_async": (C.c_int, [C.c_void_p, _u16p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u64p, _u32p]),
+    "rc_ctx_sync": (C.c_int, [C.c_void_p]),
+    "rc_get_binary_map": (C.c_int, [C.c_void_p, C.c_uint32, _u8p]),
+    "rc_get_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rc_compress": (C.c_int, [C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "rc_decompress": (C.c_int, [C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "rc_compress_bound": (C.c_uint64, [C.c_uint32, C.c_uint64]),
+    "rc_unpack_frame_sparse": (C.c_int64, [C.c_uint32, C.c_uint32, C.c_uint32, _u8p, _u8p, C.c_uint64, _u64p, C.c_uint64, C.c_uint32]),
+    "rc_bit_pack": (C.c_int, [_u16p, C.c_uint64, C.c_uint32, _u8p, C.c_uint64]),
+    "rc_bit_unpack": (C.c_int, [_u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
+    "rc_synth_dark": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, _u16p]),
+    "rc_synth_frames": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _u16p, _u16p]),
+}
+
+_lib = None
+
+
+class RecodeHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librecode_hip.so (once).  If torch is going to be used in this process it must be imported first: both link
+    the HIP runtime by SONAME and exactly one copy may be live ("one HIP runtime per process")."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RecodeHipError(
+                "librecode_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C pyrecode_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        if "torch" not in sys.modules:
+            try:  # keep a single HIP runtime in the process: let torch (if installed) load its own first
+                import torch  # noqa: F401
+            except Exception:
+                pass
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here == header / library mismatch
+            fn.restype, fn.argtypes = res, args
+        if L.rc_abi_version() != 1:
+            raise RecodeHipError("librecode_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return (lib().rc_last_error() or b"").decode()
+
+
+def check(status, what=""):
+    """Map an rc_status to the exception type the reference raises at the same point."""
+    if status >= 0:
+        return status
+    msg = "%s%s: %s" % (what + ": " if what else "", lib().rc_strerror(status).decode(), last_error())
+    if status == RC_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if status in (RC_ERR_BAD_ARG, RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL, RC_ERR_CORRUPT):
+        raise ValueError(msg)
+    raise RecodeHipError(msg)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().rc_device_count(C.byref(n)))
+    return n.value
+
+
+def ptr(a):
+    """Address of a numpy array's data, or an int address (e.g. torch.Tensor.data_ptr()) passed through."""
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return a.ctypes.data
+    if a is None:
+        return None
+    return int(a)
+
+
+class ReduceContext:
+    """One writer's device state: rc_ctx_create .. rc_ctx_destroy.  Mirrors what ReCoDeWriter.start() sets up
+    (reference recode_writer.py:212-230) plus the threshold frame of __init__ (:126-137)."""
+
+    def __init__(self, nx, ny, src_bit_depth, reduction_level=1, op_mode=1, scheme=2, clevel=1, device_id=0, max_batch=16):
+        st = C.c_int(0)
+        self._h = lib().rc_ctx_create(nx, ny, src_bit_depth, reduction_level, op_mode, scheme, clevel, device_id, max_batch,
+                                      C.byref(st))
+        if not self._h:
+            check(st.value, "rc_ctx_create")
+        self.nx, self.ny, self.depth, self.level = nx, ny, src_bit_depth, reduction_level
+        self.op_mode, self.scheme, self.max_batch, self.device_id = op_mode, scheme, max_batch, device_id
+        self.n_pixels = nx * ny
+        self.bitmap_bytes = (self.n_pixels + 7) // 8
+        self.on_device_codec = bool(op_mode == 1 and lib().rc_scheme_on_device(scheme))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rc_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stream(self, hip_stream):
+        check(lib().rc_ctx_set_stream(self._h, hip_stream), "rc_ctx_set_stream")
+
+    def set_dark(self, dark, epsilon=0):
+        dark = np.ascontiguousarray(dark, dtype=np.uint16) if isinstance(dark, np.ndarray) else dark
+        check(lib().rc_set_dark(self._h, ptr(dark), int(epsilon)), "rc_set_dark")
+
+    def set_threshold(self, thr):
+        thr = np.ascontiguousarray(thr, dtype=np.uint16) if isinstance(thr, np.ndarray) else thr
+        check(lib().rc_set_threshold(self._h, ptr(thr)), "rc_set_threshold")
+
+    def out_capacity(self, n):
+        return lib().rc_out_capacity(self._h, n)
+
+    def reduce_compress_batch(self, frames, first_frame_id=0, out=None):
+        """frames: uint16[n, ny, nx] (numpy).  Returns (out u8 array, rec_offsets u64[n+1], md u32[n,3])."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint16)
+        n = frames.shape[0]
+        if out is None:
+            out = np.empty(self.out_capacity(n), np.uint8)
+        rec = np.zeros(n + 1, np.uint64)
+        md = np.zeros((n, 3), np.uint32)
+        check(lib().rc_reduce_compress_batch(self._h, ptr(frames), n, first_frame_id, ptr(out), out.size, ptr(rec), ptr(md)),
+              "rc_reduce_compress_batch")
+        return out, rec, md
+
+    def enqueue(self, frames_dev, n, first_frame_id, out_dev, out_cap, rec_dev, md_dev):
+        check(lib().rc_reduce_compress_batch_async(self._h, ptr(frames_dev), n, first_frame_id, ptr(out_dev), out_cap,
+                                                   ptr(rec_dev), ptr(md_dev)), "rc_reduce_compress_batch_async")
+
+    def sync(self):
+        check(lib().rc_ctx_sync(self._h), "rc_ctx_sync")
+
+    def binary_map(self, i):
+        out = np.empty(self.bitmap_bytes, np.uint8)
+        check(lib().rc_get_binary_map(self._h, i, ptr(out)), "rc_get_binary_map")
+        return out
+
+    def stage_ms(self):
+        ms = (C.c_float * 5)()
+        check(lib().rc_get_stage_ms(self._h, ms))
+        return list(ms)

@@ -1,0 +1,582 @@
+// rc_api.hip - the C ABI of librecode_hip.so (include/recode_hip.h): contexts, staging, entry points.
+// No CPU implementation lives here: every compute entry point runs HIP kernels or returns RC_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "../../include/recode_hip.h"
+#include "rc_expand.h"
+#include "rc_launch.h"
+
+#define RC_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *what)
+{
+    g_last_error = what ? what : "";
+    return code;
+}
+int hip_fail(hipError_t e, const char *where)
+{
+    g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+    return RC_ERR_DEVICE;
+}
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);     \
+    } while (0)
+
+// true when p is memory the GPU kernels can dereference (device or managed); false for ordinary host memory
+bool is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host pointer: clear the sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+template <class T>
+int ensure(T *&buf, uint64_t &cap, uint64_t need)
+{
+    if (need <= cap && buf) return RC_OK;
+    if (buf) HIP_TRY(hipFree(buf));
+    buf = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), need ? need : 16));
+    cap = need;
+    return RC_OK;
+}
+
+int copy_out(void *dst, const void *src_dev, uint64_t bytes, hipStream_t s)
+{
+    if (!bytes) return RC_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src_dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    return RC_OK;
+}
+
+}  // namespace
+
+struct rc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    uint32_t nx = 0, ny = 0, depth = 0, level = 0, op_mode = 0, scheme = 0, clevel = 0, max_batch = 0;
+    uint32_t emit = 0;  // 0: mode-0 record pieces, 2: LZ4 frames
+    rc::Scratch sc;
+    bool thr_set = false;
+    uint32_t last_n = 0;
+    // staging for host callers
+    uint16_t *d_frames = nullptr; uint64_t d_frames_cap = 0;
+    uint8_t *d_out = nullptr;     uint64_t d_out_cap = 0;
+    uint16_t *d_dark = nullptr;   uint64_t d_dark_cap = 0;
+    uint64_t *d_rec_off = nullptr;
+    uint32_t *d_md = nullptr;
+    rc::BatchStatus *h_status = nullptr;  // pinned
+    hipEvent_t ev[5] = {};
+    float stage_ms[5] = {};
+};
+
+// ---- library ---------------------------------------------------------------------------------------------
+RC_EXPORT int rc_abi_version(void) { return RC_ABI_VERSION; }
+
+RC_EXPORT const char *rc_strerror(int status)
+{
+    switch (status) {
+    case RC_OK: return "ok";
+    case RC_ERR_BAD_ARG: return "bad argument";
+    case RC_ERR_OUT_TOO_SMALL: return "output buffer too small";
+    case RC_ERR_DEVICE: return "GPU / HIP error";
+    case RC_ERR_UNSUPPORTED: return "not implemented on device";
+    case RC_ERR_RECORD_TOO_LARGE: return "Buffer size smaller than compressed data size";
+    case RC_ERR_CORRUPT: return "corrupt input stream";
+    default: return "unknown status";
+    }
+}
+RC_EXPORT const char *rc_last_error(void) { return g_last_error.c_str(); }
+
+RC_EXPORT int rc_device_count(int *count)
+{
+    if (!count) return fail(RC_ERR_BAD_ARG, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return RC_OK;
+}
+RC_EXPORT int rc_scheme_on_device(uint32_t scheme) { return scheme == RC_SCHEME_LZ4 ? 1 : 0; }
+
+// ---- seam 1 --------------------------------------------------------------------------------------------------
+static int ctx_alloc(rc_ctx *c)
+{
+    using namespace rc;
+    Scratch &sc = c->sc;
+    const uint64_t B = c->max_batch, T = sc.ntiles;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipMalloc((void **)&sc.thr, sc.N * 2));
+    HIP_TRY(hipMalloc((void **)&sc.bitmap, B * sc.nb_stride));
+    HIP_TRY(hipMalloc((void **)&sc.tile_cnt, B * T * 4));
+    HIP_TRY(hipMalloc((void **)&sc.tile_off, B * T * 4));
+    HIP_TRY(hipMalloc((void **)&sc.tile_next, B * T * 4));
+    HIP_TRY(hipMalloc((void **)&sc.frame_nnz, B * 4));
+    HIP_TRY(hipMalloc((void **)&sc.frame_cbytes, B * 4));
+    HIP_TRY(hipMalloc((void **)&sc.status, sizeof(BatchStatus)));
+    if (c->level == 1) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2));
+    if (c->emit != 0) {
+        HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * BLK_SLOT));
+        HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
+        HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
+    }
+    HIP_TRY(hipMalloc((void **)&c->d_rec_off, (B + 1) * 8));
+    HIP_TRY(hipMalloc((void **)&c->d_md, B * 3 * 4));
+    HIP_TRY(hipHostMalloc((void **)&c->h_status, sizeof(BatchStatus), hipHostMallocDefault));
+    HIP_TRY(hipMemset(sc.frame_nnz, 0, B * 4));
+    HIP_TRY(hipMemset(sc.frame_cbytes, 0, B * 4));
+    for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    return RC_OK;
+}
+
+RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth, uint32_t reduction_level,
+                                uint32_t op_mode, uint32_t scheme, uint32_t clevel, int device_id, uint32_t max_batch,
+                                int *status)
+{
+    int dummy;
+    if (!status) status = &dummy;
+    *status = RC_OK;
+    if (nx == 0 || ny == 0 || max_batch == 0 || op_mode > 1) {
+        *status = fail(RC_ERR_BAD_ARG, "nx, ny, max_batch must be > 0 and op_mode 0 or 1");
+        return nullptr;
+    }
+    if ((uint64_t)nx * ny >= (1ull << 32)) {
+        *status = fail(RC_ERR_BAD_ARG, "nx*ny must be < 2^32");
+        return nullptr;
+    }
+    if (reduction_level != 1 && reduction_level != 3) {
+        *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 2 and 4 are not implemented on device");
+        return nullptr;
+    }
+    if (src_bit_depth < 9 || src_bit_depth > 16) {
+        *status = fail(RC_ERR_UNSUPPORTED, "source_bit_depth must be 9..16 (uint16 source frames)");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
+        (void)hipGetLastError();
+        *status = fail(RC_ERR_DEVICE, "no such HIP device (this library has no CPU path)");
+        return nullptr;
+    }
+    rc_ctx *c = new (std::nothrow) rc_ctx();
+    if (!c) {
+        *status = fail(RC_ERR_DEVICE, "out of host memory");
+        return nullptr;
+    }
+    c->device = device_id;
+    c->nx = nx; c->ny = ny; c->depth = src_bit_depth; c->level = reduction_level; c->op_mode = op_mode;
+    c->scheme = scheme; c->clevel = clevel; c->max_batch = max_batch;
+    c->emit = (op_mode == 1 && rc_scheme_on_device(scheme)) ? scheme : 0;
+    rc::Scratch &sc = c->sc;
+    sc.N = (uint64_t)nx * ny;
+    sc.ntiles = (uint32_t)((sc.N + rc::TILE_PX - 1) / rc::TILE_PX);
+    sc.nb = (sc.N + 7) / 8;
+    sc.nb_stride = (uint64_t)sc.ntiles * rc::TILE_BM;
+    sc.max_batch = max_batch;
+    int rcode = ctx_alloc(c);
+    if (rcode != RC_OK) {
+        *status = rcode;
+        std::string keep = g_last_error;
+        rc_ctx_destroy(c);
+        g_last_error = keep;
+        return nullptr;
+    }
+    return c;
+}
+
+RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
+{
+    if (!c) return RC_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    rc::Scratch &sc = c->sc;
+    void *bufs[] = {sc.thr, sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
+                    sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.status, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
+                    c->d_md};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_ctx_set_stream(rc_ctx *c, void *hip_stream)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_set_threshold(rc_ctx *c, const uint16_t *thr)
+{
+    if (!c || !thr) return fail(RC_ERR_BAD_ARG, "ctx / thr is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->sc.thr, thr, c->sc.N * 2, is_device_ptr(thr) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->thr_set = true;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_set_dark(rc_ctx *c, const uint16_t *dark, int64_t epsilon)
+{
+    if (!c || !dark) return fail(RC_ERR_BAD_ARG, "ctx / dark is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint16_t *src = dark;
+    if (!is_device_ptr(dark)) {
+        int r = ensure(c->d_dark, c->d_dark_cap, c->sc.N * 2);
+        if (r != RC_OK) return r;
+        HIP_TRY(hipMemcpyAsync(c->d_dark, dark, c->sc.N * 2, hipMemcpyHostToDevice, c->stream));
+        src = c->d_dark;
+    }
+    rc::launch_threshold(src, epsilon, c->sc.N, c->sc.thr, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->thr_set = true;
+    return RC_OK;
+}
+
+RC_EXPORT uint64_t rc_out_capacity(const rc_ctx *c, uint32_t n) { return c ? (uint64_t)n * c->sc.N * 2 : 0; }
+
+RC_EXPORT uint32_t rc_md_fields(const rc_ctx *c)
+{
+    if (!c) return 0;
+    const bool comp = c->emit != 0;
+    if (c->level == 1) return comp ? 3 : 1;
+    return comp ? 1 : 0;
+}
+
+static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint32_t first_frame_id, uint8_t *out_dev,
+                         uint64_t out_cap, uint64_t *rec_off_dev, uint32_t *md_dev, bool timed)
+{
+    using namespace rc;
+    hipStream_t s = c->stream;
+    RecordParams rp;
+    rp.level = c->level; rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
+    rp.frame_bytes = c->sc.N * 2;
+    HIP_TRY(hipMemsetAsync(c->sc.status, 0, sizeof(BatchStatus), s));
+    if (timed) HIP_TRY(hipEventRecord(c->ev[0], s));
+    launch_reduce(c->sc, frames_dev, n, c->level == 1, s);
+    if (timed) HIP_TRY(hipEventRecord(c->ev[1], s));
+    if (c->level == 1) launch_scan_counts(c->sc, n, s);
+    if (timed) HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (c->emit == RC_SCHEME_LZ4) {
+        launch_lz4_encode_bitmap(c->sc, n, s);
+        launch_scan_blocks(c->sc, n, s);
+    }
+    if (timed) HIP_TRY(hipEventRecord(c->ev[3], s));
+    launch_layout(c->sc, rp, n, out_cap, rec_off_dev, md_dev, s);
+    launch_assemble(c->sc, rp, n, out_dev, rec_off_dev, s);
+    if (timed) HIP_TRY(hipEventRecord(c->ev[4], s));
+    HIP_TRY(hipGetLastError());
+    c->last_n = n;
+    return RC_OK;
+}
+
+static int check_batch_args(rc_ctx *c, const void *frames, uint32_t n, const void *out, const void *rec, const void *md)
+{
+    if (!c || !frames || !out || !rec || !md) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    if (n == 0 || n > c->max_batch) return fail(RC_ERR_BAD_ARG, "n must be in 1..max_batch");
+    if (!c->thr_set) return fail(RC_ERR_BAD_ARG, "threshold not set (rc_set_threshold / rc_set_dark)");
+    return RC_OK;
+}
+
+RC_EXPORT int rc_reduce_compress_batch_async(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint32_t first_frame_id,
+                                             uint8_t *out_dev, uint64_t out_cap, uint64_t *rec_offsets_dev, uint32_t *md_dev)
+{
+    int r = check_batch_args(c, frames_dev, n, out_dev, rec_offsets_dev, md_dev);
+    if (r != RC_OK) return r;
+    HIP_TRY(hipSetDevice(c->device));
+    return enqueue_batch(c, frames_dev, n, first_frame_id, out_dev, out_cap, rec_offsets_dev, md_dev, false);
+}
+
+RC_EXPORT int rc_ctx_sync(rc_ctx *c)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_status->code != 0) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "%s (frame %u of the batch)", rc_strerror(c->h_status->code), c->h_status->frame);
+        return fail(c->h_status->code, msg);
+    }
+    return RC_OK;
+}
+
+RC_EXPORT int rc_reduce_compress_batch(rc_ctx *c, const uint16_t *frames, uint32_t n, uint32_t first_frame_id, uint8_t *out,
+                                       uint64_t out_cap, uint64_t *rec_offsets, uint32_t *md)
+{
+    int r = check_batch_args(c, frames, n, out, rec_offsets, md);
+    if (r != RC_OK) return r;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t frame_bytes = c->sc.N * 2;
+    const uint16_t *fdev = frames;
+    if (!is_device_ptr(frames)) {
+        r = ensure(c->d_frames, c->d_frames_cap, (uint64_t)n * frame_bytes);
+        if (r != RC_OK) return r;
+        HIP_TRY(hipMemcpyAsync(c->d_frames, frames, (uint64_t)n * frame_bytes, hipMemcpyHostToDevice, c->stream));
+        fdev = c->d_frames;
+    }
+    uint8_t *odev = out;
+    uint64_t cap = out_cap;
+    const bool out_host = !is_device_ptr(out);
+    if (out_host) {
+        const uint64_t worst = (uint64_t)n * frame_bytes;
+        cap = out_cap < worst ? out_cap : worst;
+        r = ensure(c->d_out, c->d_out_cap, cap);
+        if (r != RC_OK) return r;
+        odev = c->d_out;
+    }
+    r = enqueue_batch(c, fdev, n, first_frame_id, odev, cap, c->d_rec_off, c->d_md, true);
+    if (r != RC_OK) return r;
+    r = rc_ctx_sync(c);
+    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
+    (void)hipEventElapsedTime(&c->stage_ms[4], c->ev[0], c->ev[4]);
+    if (r != RC_OK) return r;
+    int r2 = copy_out(rec_offsets, c->d_rec_off, (uint64_t)(n + 1) * 8, c->stream);
+    if (r2 == RC_OK) r2 = copy_out(md, c->d_md, (uint64_t)n * 12, c->stream);
+    if (r2 == RC_OK && out_host) r2 = copy_out(out, c->d_out, c->h_status->total, c->stream);
+    if (r2 != RC_OK) return r2;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RC_OK;
+}
+
+RC_EXPORT int rc_get_binary_map(rc_ctx *c, uint32_t i, uint8_t *bitmap_out)
+{
+    if (!c || !bitmap_out) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    if (i >= c->last_n) return fail(RC_ERR_BAD_ARG, "frame index outside the most recent batch");
+    HIP_TRY(hipSetDevice(c->device));
+    int r = copy_out(bitmap_out, c->sc.bitmap + (uint64_t)i * c->sc.nb_stride, c->sc.nb, c->stream);
+    if (r != RC_OK) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RC_OK;
+}
+
+RC_EXPORT int rc_get_stage_ms(rc_ctx *c, float ms[5])
+{
+    if (!c || !ms) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    memcpy(ms, c->stage_ms, sizeof c->stage_ms);
+    return RC_OK;
+}
+
+// ---- utility context for the stateless seams (2 and 3) ----------------------------------------------------------
+namespace {
+struct Util {
+    std::mutex mu;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint8_t *a = nullptr; uint64_t a_cap = 0;   // input 1
+    uint8_t *b = nullptr; uint64_t b_cap = 0;   // input 2
+    uint8_t *o = nullptr; uint64_t o_cap = 0;   // output
+    uint8_t *w = nullptr; uint64_t w_cap = 0;   // work
+    uint64_t *h_scalar = nullptr;               // pinned
+};
+Util g_util;
+
+int util_init()
+{
+    if (g_util.device >= 0) {
+        HIP_TRY(hipSetDevice(g_util.device));
+        return RC_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return fail(RC_ERR_DEVICE, "no HIP device visible (this library has no CPU path)");
+    }
+    const char *env = getenv("RC_DEVICE");
+    int dev = env ? atoi(env) : 0;
+    if (dev < 0 || dev >= ndev) return fail(RC_ERR_BAD_ARG, "RC_DEVICE out of range");
+    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(hipStreamCreateWithFlags(&g_util.stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void **)&g_util.h_scalar, 64, hipHostMallocDefault));
+    g_util.device = dev;
+    return RC_OK;
+}
+
+// device-visible view of caller memory: the pointer itself, or a staged copy in `buf`
+template <class T>
+int stage_in(const T *src, uint64_t bytes, uint8_t *&buf, uint64_t &cap, const T *&dev, uint64_t pad = 0)
+{
+    if (is_device_ptr(src) && pad == 0) {
+        dev = src;
+        return RC_OK;
+    }
+    int r = ensure(buf, cap, bytes + pad);
+    if (r != RC_OK) return r;
+    if (pad) HIP_TRY(hipMemsetAsync(buf + bytes, 0, pad, g_util.stream));
+    if (bytes)
+        HIP_TRY(hipMemcpyAsync(buf, src, bytes, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                               g_util.stream));
+    dev = reinterpret_cast<const T *>(buf);
+    return RC_OK;
+}
+}  // namespace
+
+// ---- seam 3 ------------------------------------------------------------------------------------------------------
+RC_EXPORT int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_depth, const uint8_t *bitmap,
+                                         const uint8_t *pixvals, uint64_t pixvals_bytes, uint64_t *out,
+                                         uint64_t out_cap_triplets, uint32_t reduction_level)
+{
+    if (!bitmap || !out || nx == 0 || ny == 0) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
+    if (reduction_level == 1 && (bit_depth == 0 || bit_depth > 64)) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..64");
+    if (reduction_level == 1 && !pixvals && pixvals_bytes) return fail(RC_ERR_BAD_ARG, "pixvals is NULL");
+    std::lock_guard<std::mutex> lock(g_util.mu);
+    int r = util_init();
+    if (r != RC_OK) return r;
+    Util &u = g_util;
+    const uint64_t N = (uint64_t)nx * ny, nb = (N + 7) / 8, nb8 = (nb + 7) / 8;
+    const uint32_t nblk = (uint32_t)((nb8 + rc::WG - 1) / rc::WG);
+    const uint8_t *d_bm = nullptr, *d_px = nullptr;
+    r = stage_in(bitmap, nb, u.a, u.a_cap, d_bm, nb8 * 8 - nb + 8);
+    if (r != RC_OK) return r;
+    if (reduction_level == 1 && pixvals_bytes) {
+        r = stage_in(pixvals, pixvals_bytes, u.b, u.b_cap, d_px);
+        if (r != RC_OK) return r;
+    }
+    r = ensure(u.w, u.w_cap, (uint64_t)nblk * 8 + 16);
+    if (r != RC_OK) return r;
+    uint32_t *blk_cnt = reinterpret_cast<uint32_t *>(u.w), *blk_off = blk_cnt + nblk;
+    uint64_t *nnz_dev = reinterpret_cast<uint64_t *>(blk_cnt + 2 * (uint64_t)nblk);
+    // pass 1: count, so the output can be bounds-checked (and sized) before anything is written
+    rc::launch_expand_count(d_bm, nb8, blk_cnt, blk_off, nnz_dev, u.stream);
+    HIP_TRY(hipMemcpyAsync(u.h_scalar, nnz_dev, 8, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    const uint64_t nnz = *u.h_scalar;
+    if (nnz > out_cap_triplets) return fail(RC_ERR_OUT_TOO_SMALL, "out holds fewer triplets than the bitmap has set bits");
+    if (reduction_level == 1 && (nnz * bit_depth + 7) / 8 > pixvals_bytes)
+        return fail(RC_ERR_CORRUPT, "pixvals shorter than popcount(bitmap) * bit_depth bits");
+    if (nnz == 0) return 0;
+    uint64_t *d_out = out;
+    const bool out_host = !is_device_ptr(out);
+    if (out_host) {
+        r = ensure(u.o, u.o_cap, nnz * 24);
+        if (r != RC_OK) return r;
+        d_out = reinterpret_cast<uint64_t *>(u.o);
+    }
+    rc::launch_expand_emit(d_bm, nb8, N, nx, blk_off, d_px, pixvals_bytes, bit_depth, reduction_level, nnz, d_out, u.stream);
+    HIP_TRY(hipGetLastError());
+    if (out_host) HIP_TRY(hipMemcpyAsync(out, d_out, nnz * 24, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    return (int64_t)nnz;
+}
+
+RC_EXPORT int rc_bit_pack(const uint16_t *pixvals, uint64_t n, uint32_t bit_depth, uint8_t *out, uint64_t out_n)
+{
+    if (!out || (!pixvals && n)) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    if (bit_depth == 0 || bit_depth > 32) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..32");
+    if (out_n != (n * bit_depth + 7) / 8) return fail(RC_ERR_BAD_ARG, "out_n must be ceil(n*bit_depth/8)");
+    if (out_n == 0) return RC_OK;
+    std::lock_guard<std::mutex> lock(g_util.mu);
+    int r = util_init();
+    if (r != RC_OK) return r;
+    Util &u = g_util;
+    const uint16_t *d_in = nullptr;
+    r = stage_in(pixvals, n * 2, u.a, u.a_cap, d_in);
+    if (r != RC_OK) return r;
+    uint8_t *d_out = out;
+    const bool out_host = !is_device_ptr(out);
+    if (out_host) {
+        r = ensure(u.o, u.o_cap, out_n);
+        if (r != RC_OK) return r;
+        d_out = u.o;
+    }
+    rc::launch_bit_pack(d_in, n, bit_depth, d_out, out_n, u.stream);
+    HIP_TRY(hipGetLastError());
+    if (out_host) HIP_TRY(hipMemcpyAsync(out, d_out, out_n, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    return RC_OK;
+}
+
+RC_EXPORT int rc_bit_unpack(const uint8_t *packed, uint64_t packed_bytes, uint64_t n, uint32_t bit_depth, uint64_t *out)
+{
+    if (!out || (!packed && packed_bytes)) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    if (bit_depth == 0 || bit_depth > 64) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..64");
+    if ((n * bit_depth + 7) / 8 > packed_bytes) return fail(RC_ERR_CORRUPT, "packed shorter than n * bit_depth bits");
+    if (n == 0) return RC_OK;
+    std::lock_guard<std::mutex> lock(g_util.mu);
+    int r = util_init();
+    if (r != RC_OK) return r;
+    Util &u = g_util;
+    const uint8_t *d_in = nullptr;
+    r = stage_in(packed, packed_bytes, u.a, u.a_cap, d_in);
+    if (r != RC_OK) return r;
+    uint64_t *d_out = out;
+    const bool out_host = !is_device_ptr(out);
+    if (out_host) {
+        r = ensure(u.o, u.o_cap, n * 8);
+        if (r != RC_OK) return r;
+        d_out = reinterpret_cast<uint64_t *>(u.o);
+    }
+    rc::launch_bit_unpack(d_in, packed_bytes, n, bit_depth, d_out, u.stream);
+    HIP_TRY(hipGetLastError());
+    if (out_host) HIP_TRY(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    return RC_OK;
+}
+
+// ---- seam 2 ----------------------------------------------------------------------------------------------------
+RC_EXPORT int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap,
+                          uint64_t *out_n)
+{
+    (void)level; (void)src; (void)n; (void)dst; (void)dst_cap; (void)out_n; (void)scheme;
+    return fail(RC_ERR_UNSUPPORTED, "rc_compress: scheme not implemented on device");
+}
+RC_EXPORT int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
+{
+    (void)src; (void)n; (void)dst; (void)dst_cap; (void)out_n; (void)scheme;
+    return fail(RC_ERR_UNSUPPORTED, "rc_decompress: scheme not implemented on device");
+}
+RC_EXPORT uint64_t rc_compress_bound(uint32_t scheme, uint64_t n)
+{
+    if (scheme != RC_SCHEME_LZ4) return 0;
+    const uint64_t blocks = (n + rc::TILE_BM - 1) / rc::TILE_BM;
+    return 7 + n + 4 * blocks + 4;
+}
+
+// ---- synthetic stacks -------------------------------------------------------------------------------------------
+RC_EXPORT int rc_synth_dark(int device_id, uint32_t seed, uint64_t n_pixels, uint16_t *dark_dev)
+{
+    if (!dark_dev) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(device_id));
+    rc::launch_synth_dark(seed, n_pixels, dark_dev, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return RC_OK;
+}
+RC_EXPORT int rc_synth_frames(int device_id, uint32_t seed, uint32_t first_frame, uint32_t n_frames, uint64_t n_pixels,
+                              uint32_t sparsity_ppm, const uint16_t *dark_dev, uint16_t *frames_dev)
+{
+    if (!dark_dev || !frames_dev || n_frames == 0) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
+    HIP_TRY(hipSetDevice(device_id));
+    rc::launch_synth_frames(seed, first_frame, n_frames, n_pixels, sparsity_ppm, dark_dev, frames_dev, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return RC_OK;
+}

@@ -1,0 +1,82 @@
+// rc_device.h - shared device-side helpers and geometry for librecode_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rc {
+
+// ---- geometry -----------------------------------------------------------------------------------
+// A frame of N = nx*ny uint16 pixels is cut, in row-major (linear) order, into tiles of TILE_PX pixels.
+// One 256-thread workgroup owns one tile position for several consecutive frames.  Inside a tile a
+// "group" is 512 consecutive pixels = one 16-byte load per lane of one wavefront (64 lanes x 8 px);
+// wave w of the workgroup owns groups [w*R, (w+1)*R).  8 pixels per lane == exactly one bitmap byte.
+constexpr int WG = 256;                    // threads per workgroup (4 wavefronts of 64)
+constexpr int WAVES = WG / 64;
+constexpr int R = 8;                       // 16-byte loads per lane per frame-tile
+constexpr int GROUP_PX = 64 * 8;           // 512
+constexpr int TILE_PX = WG * R * 8;        // 16384 pixels = 32 KiB of uint16
+constexpr int TILE_BM = TILE_PX / 8;       // 2048 bitmap bytes per tile == one LZ4 / zstd block
+constexpr int BLK_SLOT = TILE_BM + 16;     // per-tile scratch slot for an encoded block (4-byte size word + payload)
+
+// ---- wavefront primitives (64 lanes) ------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_zero(uint32_t x)
+{
+    // lanes whose DPP source is invalid, or whose row is masked off, receive 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true);
+}
+
+// inclusive add-scan across the 64 lanes: 4 row_shr steps inside each row of 16, then two row broadcasts
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
+{
+    x += dpp_zero<0x111>(x);        // row_shr:1
+    x += dpp_zero<0x112>(x);        // row_shr:2
+    x += dpp_zero<0x114>(x);        // row_shr:4
+    x += dpp_zero<0x118>(x);        // row_shr:8
+    x += dpp_zero<0x142, 0xA>(x);   // row_bcast:15 -> rows 1 and 3
+    x += dpp_zero<0x143, 0xC>(x);   // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
+__device__ __forceinline__ uint32_t wave_last(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
+
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t x)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t y = __shfl_up(x, d);
+        if (lane_id() >= d) x += y;
+    }
+    return x;
+}
+
+// block-wide exclusive scan of one uint32 per thread (WG threads); returns exclusive prefix, *total = sum.
+// sm must hold WAVES+1 uint32.  Contains two barriers.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t *total)
+{
+    const int w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane_id() == 63) sm[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) {
+        uint32_t t = sm[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ---- status word written by the layout kernel, read by every later kernel of the batch -----------------
+struct BatchStatus {
+    int32_t code;       // rc_status
+    uint32_t frame;     // first offending frame
+    uint64_t total;     // total record bytes of the batch
+};
+
+}  // namespace rc

@@ -1,0 +1,16 @@
+// rc_expand.h - launchers of rc_expand.hip
+#pragma once
+#include "rc_device.h"
+
+namespace rc {
+void launch_expand_count(const uint8_t *bitmap_pad8, uint64_t nb8, uint32_t *blk_cnt, uint32_t *blk_off, uint64_t *nnz_dev,
+                         hipStream_t s);
+void launch_expand_emit(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, uint32_t nx, const uint32_t *blk_off,
+                        const uint8_t *pix, uint64_t pix_bytes, uint32_t d, uint32_t level, uint64_t cap, uint64_t *out,
+                        hipStream_t s);
+void launch_bit_pack(const uint16_t *vals, uint64_t n, uint32_t d, uint8_t *out, uint64_t out_n, hipStream_t s);
+void launch_bit_unpack(const uint8_t *packed, uint64_t nbytes, uint64_t n, uint32_t d, uint64_t *out, hipStream_t s);
+void launch_synth_dark(uint32_t seed, uint64_t N, uint16_t *dark, hipStream_t s);
+void launch_synth_frames(uint32_t seed, uint32_t first_frame, uint32_t nframes, uint64_t N, uint32_t sparsity_ppm,
+                         const uint16_t *dark, uint16_t *frames, hipStream_t s);
+}  // namespace rc

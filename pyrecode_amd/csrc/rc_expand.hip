@@ -1,0 +1,179 @@
+// rc_expand.hip - reader-side kernels: sparse expand (bitmap + packed pixvals -> (row, col, val) triplets), stand-alone
+// d-bit pack / unpack, and the synthetic stack generator (gfx950).
+//
+//   A10  _unpack_frame_sparse            pyrecode/c_extensions/reader.h:10-68  (via pyrecode.cpp:95-119)
+//   A5   _bit_pack_pixel_intensities     pyrecode/c_extensions/reader.h:105-140 (intended semantics = recode_writer.py:637-652)
+//        _bit_unpack_pixel_intensities   pyrecode/c_extensions/reader.h:74-99   (intended semantics)
+#include "rc_expand.h"
+
+namespace rc {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// bitmap is padded with zero bytes to a multiple of 8 by the host wrapper, so 8-byte loads are always in bounds.
+__global__ __launch_bounds__(WG) void k_expand_count(const uint8_t *__restrict__ bitmap, uint64_t nb8, uint32_t *__restrict__ blk_cnt)
+{
+    __shared__ uint32_t sm[WAVES + 1];
+    const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;  // 8-byte word index
+    uint32_t c = 0;
+    if (i < nb8) {
+        const u32x2 v = reinterpret_cast<const u32x2 *>(bitmap)[i];
+        c = (uint32_t)(__builtin_popcount(v[0]) + __builtin_popcount(v[1]));
+    }
+    uint32_t tot;
+    (void)block_excl_scan(c, sm, &tot);
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of blk_cnt[0..nblk) in place into blk_off, total -> *nnz
+__global__ __launch_bounds__(WG) void k_expand_scan(const uint32_t *__restrict__ blk_cnt, uint32_t *__restrict__ blk_off,
+                                                      uint32_t nblk, uint64_t *__restrict__ nnz)
+{
+    __shared__ uint32_t sm[WAVES + 1];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += WG) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < nblk ? blk_cnt[b] : 0;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, sm, &tot);
+        if (b < nblk) blk_off[b] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *nnz = carry;
+}
+
+// d-bit LSB-first field number `idx` of a packed stream of `nbytes` bytes (bytes past the end read as zero)
+__device__ __forceinline__ uint64_t read_field(const uint8_t *__restrict__ p, uint64_t nbytes, uint64_t idx, uint32_t d)
+{
+    const uint64_t bit = idx * d;
+    uint64_t byte = bit >> 3;
+    const uint32_t sh = (uint32_t)(bit & 7);
+    const uint32_t need = (sh + d + 7) >> 3;  // <= 9 bytes for d <= 64
+    uint64_t lo = 0, hi = 0;
+    for (uint32_t k = 0; k < need && k < 8; ++k)
+        if (byte + k < nbytes) lo |= (uint64_t)p[byte + k] << (8 * k);
+    if (need > 8 && byte + 8 < nbytes) hi = p[byte + 8];
+    uint64_t v = lo >> sh;
+    if (sh && need > 8) v |= hi << (64 - sh);
+    return d >= 64 ? v : (v & ((1ull << d) - 1));
+}
+
+__global__ __launch_bounds__(WG) void k_expand_emit(const uint8_t *__restrict__ bitmap, uint64_t nb8, uint64_t N, uint32_t nx,
+                                                      const uint32_t *__restrict__ blk_off,
+                                                      const uint8_t *__restrict__ pix, uint64_t pix_bytes, uint32_t d,
+                                                      uint32_t level, uint64_t cap, uint64_t *__restrict__ out)
+{
+    __shared__ uint32_t sm[WAVES + 1];
+    const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t bits = 0;
+    if (i < nb8) {
+        const u32x2 v = reinterpret_cast<const u32x2 *>(bitmap)[i];
+        bits = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    }
+    // pixels at or past N never count (a well-formed bitmap has them zero; be safe on foreign files)
+    const uint64_t k0 = i * 64;
+    if (k0 + 64 > N) bits = k0 >= N ? 0 : bits & ((1ull << (N - k0)) - 1);
+    uint32_t tot;
+    uint64_t rank = blk_off[blockIdx.x] + block_excl_scan((uint32_t)__builtin_popcountll(bits), sm, &tot);
+    for (; bits; bits &= bits - 1, ++rank) {
+        if (rank >= cap) break;
+        const uint64_t k = k0 + (uint64_t)__builtin_ctzll(bits);
+        const uint32_t row = (uint32_t)(k / nx), col = (uint32_t)(k - (uint64_t)row * nx);
+        out[3 * rank] = row;
+        out[3 * rank + 1] = col;
+        out[3 * rank + 2] = level == 1 ? read_field(pix, pix_bytes, rank, d) : 1ull;
+    }
+}
+
+void launch_expand_count(const uint8_t *bitmap_pad8, uint64_t nb8, uint32_t *blk_cnt, uint32_t *blk_off, uint64_t *nnz_dev,
+                         hipStream_t s)
+{
+    const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
+    hipLaunchKernelGGL(k_expand_count, dim3(nblk), dim3(WG), 0, s, bitmap_pad8, nb8, blk_cnt);
+    hipLaunchKernelGGL(k_expand_scan, dim3(1), dim3(WG), 0, s, blk_cnt, blk_off, nblk, nnz_dev);
+}
+void launch_expand_emit(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, uint32_t nx, const uint32_t *blk_off,
+                        const uint8_t *pix, uint64_t pix_bytes, uint32_t d, uint32_t level, uint64_t cap, uint64_t *out,
+                        hipStream_t s)
+{
+    const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
+    hipLaunchKernelGGL(k_expand_emit, dim3(nblk), dim3(WG), 0, s, bitmap_pad8, nb8, N, nx, blk_off, pix, pix_bytes, d, level,
+                       cap, out);
+}
+
+// ---- stand-alone pack / unpack ------------------------------------------------------------------------------
+__global__ void k_bit_pack(const uint16_t *__restrict__ vals, uint64_t n, uint32_t d, uint8_t *__restrict__ out, uint64_t out_n)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= out_n) return;
+    const uint32_t dmask = d >= 16 ? 0xFFFFu : ((1u << d) - 1);
+    const uint64_t bit0 = b * 8;
+    uint64_t v = bit0 / d;
+    const uint32_t o = (uint32_t)(bit0 - v * d);
+    uint32_t acc = v < n ? ((vals[v] & dmask) >> o) : 0;
+    uint32_t filled = d - o;
+    while (filled < 8) {
+        ++v;
+        if (v < n) acc |= (uint32_t)(vals[v] & dmask) << filled;
+        filled += d;
+    }
+    out[b] = (uint8_t)acc;
+}
+__global__ void k_bit_unpack(const uint8_t *__restrict__ packed, uint64_t nbytes, uint64_t n, uint32_t d, uint64_t *__restrict__ out)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) out[v] = read_field(packed, nbytes, v, d);
+}
+void launch_bit_pack(const uint16_t *vals, uint64_t n, uint32_t d, uint8_t *out, uint64_t out_n, hipStream_t s)
+{
+    if (out_n == 0) return;
+    hipLaunchKernelGGL(k_bit_pack, dim3((uint32_t)((out_n + 255) / 256)), dim3(256), 0, s, vals, n, d, out, out_n);
+}
+void launch_bit_unpack(const uint8_t *packed, uint64_t nbytes, uint64_t n, uint32_t d, uint64_t *out, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_bit_unpack, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, packed, nbytes, n, d, out);
+}
+
+// ---- synthetic stacks, integer counter-based generator mirrored in pyrecode_amd/synth.py -------------
+__host__ __device__ inline uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__global__ void k_synth_dark(uint32_t seed, uint64_t N, uint16_t *__restrict__ dark)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < N; i += stride) dark[i] = (uint16_t)(80u + mix32((uint32_t)i ^ mix32(seed ^ 0xD1B54A32u)) % 41u);
+}
+__global__ void k_synth_frames(uint32_t seed, uint32_t first_frame, uint32_t nframes, uint64_t N, uint32_t thresh24,
+                               const uint16_t *__restrict__ dark, uint16_t *__restrict__ frames)
+{
+    const uint32_t z = blockIdx.y;
+    const uint32_t fkey = mix32(seed + 0x9E3779B9u * (first_frame + z + 1u));
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint16_t *fr = frames + (uint64_t)z * N;
+    for (; i < N; i += stride) {
+        const uint32_t h = mix32((uint32_t)i ^ fkey);
+        const uint32_t h2 = mix32(h ^ 0x68E31DA4u);
+        const uint32_t dk = dark[i];
+        const uint32_t v = (h & 0xFFFFFFu) < thresh24 ? dk + 1u + (h2 % 2047u) : (h2 % (dk + 1u));
+        fr[i] = (uint16_t)v;
+    }
+    (void)nframes;
+}
+void launch_synth_dark(uint32_t seed, uint64_t N, uint16_t *dark, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_synth_dark, dim3(2048), dim3(256), 0, s, seed, N, dark);
+}
+void launch_synth_frames(uint32_t seed, uint32_t first_frame, uint32_t nframes, uint64_t N, uint32_t sparsity_ppm,
+                         const uint16_t *dark, uint16_t *frames, hipStream_t s)
+{
+    const uint32_t thresh24 = (uint32_t)(((uint64_t)sparsity_ppm << 24) / 1000000ull);
+    hipLaunchKernelGGL(k_synth_frames, dim3(1024, nframes), dim3(256), 0, s, seed, first_frame, nframes, N, thresh24, dark,
+                       frames);
+}
+
+}  // namespace rc

@@ -1,0 +1,51 @@
+// rc_launch.h - host-side launcher declarations shared by the .hip translation units of librecode_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rc_device.h"
+
+namespace rc {
+
+// Device scratch of one ctx, laid out for a batch of up to max_batch frames (DESIGN.md "data layout in HBM").
+struct Scratch {
+    uint64_t N = 0;            // pixels per frame
+    uint32_t ntiles = 0;       // ceil(N / TILE_PX)
+    uint64_t nb = 0;           // ceil(N / 8) bitmap bytes per frame
+    uint64_t nb_stride = 0;    // ntiles * TILE_BM (bitmap rows padded to whole tiles)
+    uint32_t max_batch = 0;
+    uint16_t *thr = nullptr;           // [N]
+    uint8_t *bitmap = nullptr;         // [B][nb_stride]            packed binary maps
+    uint16_t *pix_slots = nullptr;     // [B][ntiles][TILE_PX]      per-tile residuals, row-major inside the tile
+    uint32_t *tile_cnt = nullptr;      // [B][ntiles]               set pixels per tile
+    uint32_t *tile_off = nullptr;      // [B][ntiles]               exclusive prefix of tile_cnt inside the frame
+    uint32_t *tile_next = nullptr;     // [B][ntiles]               next tile index > t with tile_cnt > 0 (ntiles if none)
+    uint8_t *blk_slots = nullptr;      // [B][ntiles][BLK_SLOT]     encoded bitmap blocks (codec dependent)
+    uint32_t *blk_size = nullptr;      // [B][ntiles]               bytes used in each slot
+    uint32_t *blk_off = nullptr;       // [B][ntiles]               exclusive prefix of blk_size inside the frame
+    uint32_t *frame_nnz = nullptr;     // [B]
+    uint32_t *frame_cbytes = nullptr;  // [B]                       sum of blk_size
+    BatchStatus *status = nullptr;     // [1]
+};
+
+struct RecordParams {
+    uint32_t level;        // 1 or 3
+    uint32_t emit;         // 0 = raw pieces (mode-0 record), 2 = LZ4 frames, 1 = zstd frames, 8 = blosc-lz4
+    uint32_t depth;        // source_bit_depth
+    uint32_t first_frame_id;
+    uint64_t frame_bytes;  // raw frame size = N * 2 (record upper bound, recode_writer.py:565-566)
+};
+
+// rc_reduce.hip
+void launch_threshold(const uint16_t *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s);
+void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, hipStream_t s);
+void launch_scan_counts(const Scratch &sc, uint32_t B, hipStream_t s);
+void launch_scan_blocks(const Scratch &sc, uint32_t B, hipStream_t s);
+void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
+                   uint32_t *md, hipStream_t s);
+void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off,
+                     hipStream_t s);
+// rc_lz4.hip
+void launch_lz4_encode_bitmap(const Scratch &sc, uint32_t B, hipStream_t s);
+
+}  // namespace rc

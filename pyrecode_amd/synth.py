@@ -1,0 +1,38 @@
+"""Host (numpy) mirror of the device synthetic-stack generator in csrc/rc_expand.hip: same integers."""
+import numpy as np
+
+_M1, _M2 = np.uint32(0x7FEB352D), np.uint32(0x846CA68B)
+
+
+def _mix32(x):
+    x = x.astype(np.uint32, copy=True)
+    x ^= x >> np.uint32(16)
+    x *= _M1
+    x ^= x >> np.uint32(15)
+    x *= _M2
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def _mix32s(v):
+    return int(_mix32(np.array([v & 0xFFFFFFFF], np.uint32))[0])
+
+
+def dark_frame(seed, n_pixels):
+    i = np.arange(n_pixels, dtype=np.uint32)
+    key = np.uint32(_mix32s(seed ^ 0xD1B54A32))
+    return (np.uint32(80) + _mix32(i ^ key) % np.uint32(41)).astype(np.uint16)
+
+
+def frames(seed, first_frame, n_frames, n_pixels, sparsity_ppm, dark):
+    thresh24 = np.uint32((sparsity_ppm << 24) // 1000000)
+    i = np.arange(n_pixels, dtype=np.uint32)
+    dk = dark.astype(np.uint32).ravel()
+    out = np.empty((n_frames, n_pixels), np.uint16)
+    for z in range(n_frames):
+        fkey = np.uint32(_mix32s((seed + 0x9E3779B9 * (first_frame + z + 1)) & 0xFFFFFFFF))
+        h = _mix32(i ^ fkey)
+        h2 = _mix32(h ^ np.uint32(0x68E31DA4))
+        ev = (h & np.uint32(0xFFFFFF)) < thresh24
+        out[z] = np.where(ev, dk + np.uint32(1) + h2 % np.uint32(2047), h2 % (dk + np.uint32(1))).astype(np.uint16)
+    return out

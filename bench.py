@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the per-frame reduce -> bit-pack -> compress hot path on N MI355X GPUs.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+
+  step      one pass of the hot path over one batch of B synthetic frames per GPU, inputs resident in HBM:
+            rc_reduce_compress_batch_async = reduce kernel -> scans -> bitmap codec -> record layout -> assembly,
+            records + offsets + metadata left in HBM; for N > 1 followed by the path's one exchange step, the
+            RCCL all-gather of the per-frame metadata (12 B / frame).
+  workload  BASELINE.json configs[1]: 4096x4096 uint16, 1 % sparsity, L1 + LZ4 (d = 16 primary; --depth 12 secondary).
+  value     frames/s, whole job (all ranks' frames / max-over-ranks time); gb_per_s_in = value * 2*nx*ny.
+  roofline  dominant kernel = the reduce kernel (k_reduce_tiles): algorithmic bytes per launch = B * 2*nx*ny
+            (one read of the uint16 frames) / its mean duration, measured with HIP events on the ctx's
+            stream inside the timed region; peak = 8000 GB/s (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle's C restatement (+ stock liblz4 for the LZ4 stage) on the box's host cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--stack", type=int, default=256, help="distinct frames resident per GPU")
+    ap.add_argument("--ny", type=int, default=4096)
+    ap.add_argument("--nx", type=int, default=4096)
+    ap.add_argument("--sparsity-ppm", type=int, default=10000)
+    ap.add_argument("--depth", type=int, default=16)
+    ap.add_argument("--scheme", type=int, default=2, help="2 = LZ4 (headline), 0 = reduce-only pieces")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_h, thr_h, depth, scheme):
+    """Oracle (CPU restatement, oracle/recode_oracle.c) + stock liblz4 on the host cores; bounded to ~15 core-seconds."""
+    import ctypes as C
+    import ctypes.util
+    import threading
+    from oracle import oracle as orc
+    orc.lib()
+    lz4 = None
+    if scheme == 2:
+        name = ctypes.util.find_library("lz4")
+        if name:
+            lz4 = C.CDLL(name)
+            lz4.LZ4F_compressFrameBound.restype = C.c_size_t
+            lz4.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+            lz4.LZ4F_compressFrame.restype = C.c_size_t
+            lz4.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    n_pix = frames_h.shape[1]
+    thr_flat = np.ascontiguousarray(thr_h.ravel())
+
+    def one(frame, scratch):
+        bitmap, packed, nnz = orc.reduce_frame_l1(frame, thr_flat, depth)
+        if lz4 is not None:
+            for src in (bitmap, packed):
+                n = lz4.LZ4F_compressFrame(scratch.ctypes.data, scratch.size, src.ctypes.data, src.size, None)
+                assert n > 0
+        return nnz
+
+    bound = int(lz4.LZ4F_compressFrameBound(n_pix // 8 + 64, None)) + n_pix * 2 if lz4 is not None else 16
+    t0 = time.perf_counter()
+    one(frames_h[0], np.empty(bound, np.uint8))
+    t_one = time.perf_counter() - t0
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    repeats = max(1, int(round(15.0 / max(t_one, 1e-4) / (frames_h.shape[0]))))
+    per = -(-frames_h.shape[0] // threads)  # contiguous block per worker: the reference's own DP rule (recode_writer.py:320-322)
+
+    def work(i):
+        scratch = np.empty(bound, np.uint8)
+        for _ in range(repeats):
+            for f in frames_h[i * per:(i + 1) * per]:
+                one(f, scratch)
+
+    # single core first (short), then all workers
+    t0 = time.perf_counter()
+    scratch = np.empty(bound, np.uint8)
+    n1 = min(8, frames_h.shape[0])
+    for f in frames_h[:n1]:
+        one(f, scratch)
+    single = n1 / (time.perf_counter() - t0)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = frames_h.shape[0] * repeats
+    return {
+        "value": round(total / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+        "single_core_value": round(single, 2),
+        "sample": "%d distinct synthetic frames of the GPU stack x %d passes (%.1f s wall), oracle C reduce+pack%s" % (
+            frames_h.shape[0], repeats, dt, " + liblz4 LZ4F_compressFrame on bitmap and pixvals" if lz4 is not None else
+            (" (no compress stage: liblz4 not found)" if scheme == 2 else " (reduce-only)")),
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from pyrecode_amd import _lib as hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    L = hip.lib()
+    N = a.ny * a.nx
+    B, S = a.batch, max(a.stack, a.batch)
+    S -= S % B
+    # synthetic stack generated on the device; rank-distinct seed
+    seed = 20261003 + rank
+    dark = torch.empty(N, dtype=torch.int16, device=dev)
+    stack = torch.empty((S, N), dtype=torch.int16, device=dev)
+    hip.check(L.rc_synth_dark(local, seed, N, dark.data_ptr()))
+    for lo in range(0, S, 64):
+        n = min(64, S - lo)
+        hip.check(L.rc_synth_frames(local, seed, lo, n, N, a.sparsity_ppm, dark.data_ptr(), stack[lo].data_ptr()))
+
+    op_mode = 1
+    ctx = hip.ReduceContext(a.nx, a.ny, a.depth, 1, op_mode, a.scheme, 1, local, max_batch=B)
+    ctx.set_dark(dark.data_ptr(), 0)  # eps = 0 -> thr = dark
+    out_cap = B * (N // 2)  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
+    out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
+    rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    md = torch.empty((B, 3), dtype=torch.int32, device=dev)
+    md_all = torch.empty((world * B, 3), dtype=torch.int32, device=dev) if world > 1 else None
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    nb = S // B
+
+    def step(i):
+        lo = (i % nb) * B
+        ctx.enqueue(stack[lo].data_ptr(), B, lo, out.data_ptr(), out_cap, rec.data_ptr(), md.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(md_all, md)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for i in range(a.warmup):
+            step(i)
+        ctx.sync()
+        ctx.set_profiling(True)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        ctx.sync()  # also raises if the device flagged the last batch
+    sums, nbatches = ctx.profile()
+    ctx.set_profiling(False)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    frames_total = world * B * a.steps
+    fps = frames_total / dt_max
+    rec_h = rec.cpu().numpy()
+    md_h = md.cpu().numpy()
+    assert rec_h[0] == 0 and rec_h[-1] > 0 and nbatches == a.steps
+
+    result = None
+    if rank == 0:
+        k_ms = sums[0] / max(nbatches, 1)
+        achieved = B * N * 2 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        key = "%dx%d_b%d_ppm%d_d%d_s%d" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(key, {}).get("reduce_kernel_hbm_bytes_per_launch")
+        result = {
+            "metric": "frames/sec + GB/s in, 4096x4096 uint16 @1% sparsity, 1/2/4/8 GPU",
+            "value": round(fps, 1), "unit": "frames/s", "gb_per_s_in": round(fps * N * 2 / 1e9, 1),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt_max / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {
+                "workload": "%dx%d uint16, %.2f%% sparsity, L1 + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
+                    a.ny, a.nx, a.sparsity_ppm / 1e4, {2: "LZ4 frame", 0: "reduce-only pieces"}.get(a.scheme, str(a.scheme)),
+                    a.depth, B, S),
+                "parallelism": "dp%d (contiguous frame blocks per rank, metadata all-gather per step)" % world,
+                "record_bytes_per_frame": round(float(rec_h[-1]) / B, 1),
+            },
+            "roofline": {"bound": "hbm", "kernel": "k_reduce_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": B * N * 2,
+                         "whole_path_frac": round(fps / world * N * 2 / 1e9 / HBM_PEAK_GBS, 4)},
+            "stage_ms_per_step": {"reduce": round(sums[0] / nbatches, 4), "scan": round(sums[1] / nbatches, 4),
+                                  "bitmap_codec": round(sums[2] / nbatches, 4),
+                                  "layout_assemble": round(sums[3] / nbatches, 4), "total": round(sums[4] / nbatches, 4)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            ns = min(32, S)
+            frames_h = stack[:ns].cpu().numpy().view(np.uint16)
+            thr_h = dark.cpu().numpy().view(np.uint16)
+            result["cpu_baseline"] = cpu_baseline(frames_h, thr_h, a.depth, a.scheme)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,7 +71,8 @@ rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth, uint32_t
 int rc_ctx_destroy(rc_ctx *ctx);
 
 /* Use a caller-provided hipStream_t (passed as void*) instead of the ctx's own stream, e.g. torch's current
- * stream so that caller-side events bracket the kernels.  NULL restores the ctx's own stream. */
+ * stream so that caller-side events bracket the kernels.  NULL restores the ctx's own stream (so the legacy null
+ * stream, whose handle is 0, cannot be selected: use a created stream). */
 int rc_ctx_set_stream(rc_ctx *ctx, void *hip_stream);
 
 /* thr = calibration frame + epsilon in uint16 arithmetic (wraps mod 2^16 like NumPy 2):
@@ -123,6 +124,12 @@ int rc_get_binary_map(rc_ctx *ctx, uint32_t i, uint8_t *bitmap_out);
  *       + frame_pixel_intensity_compression_time (assemble kernel)   [4] whole batch (frame_time * n)
  * Only filled by the synchronous entry point. */
 int rc_get_stage_ms(rc_ctx *ctx, float ms[5]);
+
+/* Stage timing of the ASYNCHRONOUS path: with profiling on, every rc_reduce_compress_batch_async brackets its stages
+ * with HIP events on the ctx's stream; rc_ctx_sync folds them into running sums (same 5 slots as rc_get_stage_ms).
+ * rc_ctx_set_profiling also clears the sums.  Used by bench.py to measure the dominant kernel inside the timed region. */
+int rc_ctx_set_profiling(rc_ctx *ctx, int on);
+int rc_ctx_get_profile(rc_ctx *ctx, double sum_ms[5], uint64_t *batches);
 
 /* ---- seam 2: compressor backend -----------------------------------------------------------------------
  * compress()/de_compress() of pyrecode/recode_compressors.py:82-120 / :40-79 for the device codecs.

@@ -40,6 +40,8 @@ SIGNATURES = {
     "rc_ctx_sync": (C.c_int, [C.c_void_p]),
     "rc_get_binary_map": (C.c_int, [C.c_void_p, C.c_uint32, _u8p]),
     "rc_get_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rc_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "rc_ctx_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "rc_compress": (C.c_int, [C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rc_decompress": (C.c_int, [C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rc_compress_bound": (C.c_uint64, [C.c_uint32, C.c_uint64]),
@@ -135,9 +137,9 @@ class ReduceContext:
         return self._h
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().rc_ctx_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:  # _lib is None during interpreter shutdown
+            _lib.rc_ctx_destroy(h)
 
     __del__ = close
 
@@ -178,6 +180,15 @@ class ReduceContext:
         out = np.empty(self.bitmap_bytes, np.uint8)
         check(lib().rc_get_binary_map(self._h, i, ptr(out)), "rc_get_binary_map")
         return out
+
+    def set_profiling(self, on=True):
+        check(lib().rc_ctx_set_profiling(self._h, 1 if on else 0))
+
+    def profile(self):
+        """(sum_ms[5], batches) accumulated by the asynchronous path since set_profiling()."""
+        s, n = (C.c_double * 5)(), C.c_uint64(0)
+        check(lib().rc_ctx_get_profile(self._h, s, C.byref(n)))
+        return list(s), n.value
 
     def stage_ms(self):
         ms = (C.c_float * 5)()

@@ -8,6 +8,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/recode_hip.h"
 #include "rc_expand.h"
@@ -86,6 +87,12 @@ struct rc_ctx {
     rc::BatchStatus *h_status = nullptr;  // pinned
     hipEvent_t ev[5] = {};
     float stage_ms[5] = {};
+    // optional per-enqueue stage events for the asynchronous path (rc_ctx_set_profiling)
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_ev;   // 5 events per enqueued batch, in enqueue order
+    size_t prof_used = 0;              // events consumed since the last rc_ctx_sync
+    double prof_sum_ms[5] = {};
+    uint64_t prof_batches = 0;
 };
 
 // ---- library ---------------------------------------------------------------------------------------------
@@ -220,6 +227,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RC_OK;
@@ -280,19 +288,32 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     rp.level = c->level; rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
     rp.frame_bytes = c->sc.N * 2;
     HIP_TRY(hipMemsetAsync(c->sc.status, 0, sizeof(BatchStatus), s));
-    if (timed) HIP_TRY(hipEventRecord(c->ev[0], s));
+    hipEvent_t *ev = nullptr;
+    if (timed) ev = c->ev;
+    else if (c->profiling) {
+        if (c->prof_used + 5 > c->prof_ev.size()) {
+            for (int i = 0; i < 5; ++i) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                c->prof_ev.push_back(e);
+            }
+        }
+        ev = c->prof_ev.data() + c->prof_used;
+        c->prof_used += 5;
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     launch_reduce(c->sc, frames_dev, n, c->level == 1, s);
-    if (timed) HIP_TRY(hipEventRecord(c->ev[1], s));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
     if (c->level == 1) launch_scan_counts(c->sc, n, s);
-    if (timed) HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     if (c->emit == RC_SCHEME_LZ4) {
         launch_lz4_encode_bitmap(c->sc, n, s);
         launch_scan_blocks(c->sc, n, s);
     }
-    if (timed) HIP_TRY(hipEventRecord(c->ev[3], s));
+    if (ev) HIP_TRY(hipEventRecord(ev[3], s));
     launch_layout(c->sc, rp, n, out_cap, rec_off_dev, md_dev, s);
     launch_assemble(c->sc, rp, n, out_dev, rec_off_dev, s);
-    if (timed) HIP_TRY(hipEventRecord(c->ev[4], s));
+    if (ev) HIP_TRY(hipEventRecord(ev[4], s));
     HIP_TRY(hipGetLastError());
     c->last_n = n;
     return RC_OK;
@@ -321,6 +342,14 @@ RC_EXPORT int rc_ctx_sync(rc_ctx *c)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->h_status, c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t b = 0; b + 5 <= c->prof_used; b += 5) {  // fold the finished batches' stage events into the sums
+        float ms;
+        for (int i = 0; i < 4; ++i)
+            if (hipEventElapsedTime(&ms, c->prof_ev[b + i], c->prof_ev[b + i + 1]) == hipSuccess) c->prof_sum_ms[i] += ms;
+        if (hipEventElapsedTime(&ms, c->prof_ev[b], c->prof_ev[b + 4]) == hipSuccess) c->prof_sum_ms[4] += ms;
+        ++c->prof_batches;
+    }
+    c->prof_used = 0;
     if (c->h_status->code != 0) {
         char msg[96];
         snprintf(msg, sizeof msg, "%s (frame %u of the batch)", rc_strerror(c->h_status->code), c->h_status->frame);
@@ -375,6 +404,22 @@ RC_EXPORT int rc_get_binary_map(rc_ctx *c, uint32_t i, uint8_t *bitmap_out)
     int r = copy_out(bitmap_out, c->sc.bitmap + (uint64_t)i * c->sc.nb_stride, c->sc.nb, c->stream);
     if (r != RC_OK) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return RC_OK;
+}
+
+RC_EXPORT int rc_ctx_set_profiling(rc_ctx *c, int on)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    c->profiling = on != 0;
+    for (double &v : c->prof_sum_ms) v = 0;
+    c->prof_batches = 0;
+    return RC_OK;
+}
+RC_EXPORT int rc_ctx_get_profile(rc_ctx *c, double sum_ms[5], uint64_t *batches)
+{
+    if (!c || !sum_ms || !batches) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    memcpy(sum_ms, c->prof_sum_ms, sizeof c->prof_sum_ms);
+    *batches = c->prof_batches;
     return RC_OK;
 }
 

@@ -1,5 +1,6 @@
 """Development helper: stage timings of the device-resident pipeline at a given shape (not the bench contract)."""
-import sys, time
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from pyrecode_amd import _lib as hip

@@ -133,7 +133,9 @@ int rc_ctx_get_profile(rc_ctx *ctx, double sum_ms[5], uint64_t *batches);
 
 /* ---- seam 2: compressor backend -----------------------------------------------------------------------
  * compress()/de_compress() of pyrecode/recode_compressors.py:82-120 / :40-79 for the device codecs.
- * Host or device pointers.  *out_n receives the produced byte count.  Uses GPU `RC_DEVICE` (env, default 0). */
+ * Host or device pointers.  *out_n receives the produced byte count; rc_decompress also sets it to the required size
+ * when it returns RC_ERR_OUT_TOO_SMALL (dst may then be NULL with dst_cap 0: a size query).
+ * Uses GPU `RC_DEVICE` (env, default 0). */
 int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap,
                 uint64_t *out_n);
 int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n);
@@ -143,7 +145,8 @@ uint64_t rc_compress_bound(uint32_t scheme, uint64_t n);
  * get_frame_sparse -> _unpack_frame_sparse (pyrecode.cpp:95-119, c_extensions/reader.h:10-68): for every set bit of
  * the bitmap in row-major order write (row, col, val) as three uint64; level 1: val = next d-bit LSB-first field
  * of pixvals; other levels: val = 1.  out must hold 3 * popcount(bitmap) uint64 (the reference sizes it
- * nx*ny*3, recode_reader.py:111-115); out_cap_triplets bounds it.  Returns nnz >= 0 or a negative rc_status. */
+ * nx*ny*3, recode_reader.py:111-115); out_cap_triplets bounds it.  Returns nnz >= 0 or a negative rc_status.
+ * out == NULL with out_cap_triplets == 0 is a counting call: returns popcount(bitmap) and writes nothing. */
 int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_depth, const uint8_t *bitmap,
                                const uint8_t *pixvals, uint64_t pixvals_bytes, uint64_t *out,
                                uint64_t out_cap_triplets, uint32_t reduction_level);

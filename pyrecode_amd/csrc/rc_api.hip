@@ -489,7 +489,7 @@ RC_EXPORT int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_
                                          const uint8_t *pixvals, uint64_t pixvals_bytes, uint64_t *out,
                                          uint64_t out_cap_triplets, uint32_t reduction_level)
 {
-    if (!bitmap || !out || nx == 0 || ny == 0) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
+    if (!bitmap || nx == 0 || ny == 0 || (!out && out_cap_triplets)) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
     if (reduction_level == 1 && (bit_depth == 0 || bit_depth > 64)) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..64");
     if (reduction_level == 1 && !pixvals && pixvals_bytes) return fail(RC_ERR_BAD_ARG, "pixvals is NULL");
     std::lock_guard<std::mutex> lock(g_util.mu);
@@ -514,6 +514,7 @@ RC_EXPORT int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_
     HIP_TRY(hipMemcpyAsync(u.h_scalar, nnz_dev, 8, hipMemcpyDeviceToHost, u.stream));
     HIP_TRY(hipStreamSynchronize(u.stream));
     const uint64_t nnz = *u.h_scalar;
+    if (!out) return (int64_t)nnz;  // counting call
     if (nnz > out_cap_triplets) return fail(RC_ERR_OUT_TOO_SMALL, "out holds fewer triplets than the bitmap has set bits");
     if (reduction_level == 1 && (nnz * bit_depth + 7) / 8 > pixvals_bytes)
         return fail(RC_ERR_CORRUPT, "pixvals shorter than popcount(bitmap) * bit_depth bits");
@@ -587,16 +588,158 @@ RC_EXPORT int rc_bit_unpack(const uint8_t *packed, uint64_t packed_bytes, uint64
 }
 
 // ---- seam 2 ----------------------------------------------------------------------------------------------------
+static int lz4_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
+{
+    using namespace rc;
+    Util &u = g_util;
+    if (n >= (1ull << 32)) return fail(RC_ERR_BAD_ARG, "rc_compress: input must be < 4 GiB");
+    if (n == 0) {  // empty frame: header + EndMark
+        const uint32_t h = lz4f_descriptor(0x40);
+        const uint8_t f[11] = {0x04, 0x22, 0x4D, 0x18, (uint8_t)h, (uint8_t)(h >> 8), (uint8_t)(h >> 16), 0, 0, 0, 0};
+        if (dst_cap < 11) return fail(RC_ERR_OUT_TOO_SMALL, "rc_compress: dst too small");
+        HIP_TRY(hipMemcpy(dst, f, 11, is_device_ptr(dst) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+        *out_n = 11;
+        return RC_OK;
+    }
+    Scratch sc;
+    sc.ntiles = (uint32_t)((n + TILE_BM - 1) / TILE_BM);
+    sc.nb = n;
+    sc.nb_stride = (uint64_t)sc.ntiles * TILE_BM;
+    const uint8_t *d_src = nullptr;
+    int r = stage_in(src, n, u.a, u.a_cap, d_src, sc.nb_stride - n + 16);
+    if (r != RC_OK) return r;
+    sc.bitmap = const_cast<uint8_t *>(d_src);
+    const uint64_t T = sc.ntiles;
+    r = ensure(u.w, u.w_cap, T * BLK_SLOT + T * 8 + 64);
+    if (r != RC_OK) return r;
+    sc.blk_slots = u.w;
+    sc.blk_size = reinterpret_cast<uint32_t *>(u.w + T * BLK_SLOT);
+    sc.blk_off = sc.blk_size + T;
+    sc.frame_cbytes = sc.blk_off + T;
+    launch_lz4_encode_bitmap(sc, 1, u.stream);
+    launch_scan_blocks(sc, 1, u.stream);
+    HIP_TRY(hipMemcpyAsync(u.h_scalar, sc.frame_cbytes, 4, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    const uint64_t total = 7ull + *reinterpret_cast<uint32_t *>(u.h_scalar) + 4;
+    if (total > dst_cap) return fail(RC_ERR_OUT_TOO_SMALL, "rc_compress: dst too small (see rc_compress_bound)");
+    uint8_t *d_out = dst;
+    const bool out_host = !is_device_ptr(dst);
+    if (out_host) {
+        r = ensure(u.o, u.o_cap, total);
+        if (r != RC_OK) return r;
+        d_out = u.o;
+    }
+    launch_lz4f_gather(sc, lz4f_descriptor(0x40), d_out, u.stream);
+    HIP_TRY(hipGetLastError());
+    if (out_host) HIP_TRY(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    *out_n = total;
+    return RC_OK;
+}
+
+static int lz4_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
+{
+    using namespace rc;
+    Util &u = g_util;
+    // the frame and block headers are walked on the host (sequential by format, a few bytes per block)
+    std::vector<uint8_t> hsrc;
+    const uint8_t *h = src;
+    if (is_device_ptr(src)) {
+        hsrc.resize(n);
+        HIP_TRY(hipMemcpy(hsrc.data(), src, n, hipMemcpyDeviceToHost));
+        h = hsrc.data();
+    }
+    auto rd32 = [&](uint64_t p) { return (uint32_t)h[p] | ((uint32_t)h[p + 1] << 8) | ((uint32_t)h[p + 2] << 16) | ((uint32_t)h[p + 3] << 24); };
+    if (n < 11 || rd32(0) != 0x184D2204u) return fail(RC_ERR_CORRUPT, "not an LZ4 frame");
+    const uint32_t flg = h[4], bd = h[5];
+    if ((flg >> 6) != 1 || (flg & 2) || (bd & 0x8F) || ((bd >> 4) & 7) < 4) return fail(RC_ERR_CORRUPT, "bad LZ4 frame descriptor");
+    const int linked = !((flg >> 5) & 1), bsum = (flg >> 4) & 1, csize = (flg >> 3) & 1, csum = (flg >> 2) & 1, dict = flg & 1;
+    const uint64_t bmax = 1ull << (8 + 2 * ((bd >> 4) & 7));
+    uint64_t ip = 6 + (csize ? 8 : 0) + (dict ? 4 : 0) + 1;
+    std::vector<Lz4Block> blks;
+    for (;;) {
+        if (ip + 4 > n) return fail(RC_ERR_CORRUPT, "truncated LZ4 frame");
+        uint32_t bs = rd32(ip);
+        ip += 4;
+        if (bs == 0) break;
+        const uint32_t raw = bs >> 31;
+        bs &= 0x7FFFFFFFu;
+        if (bs > bmax || ip + bs > n) return fail(RC_ERR_CORRUPT, "LZ4 block exceeds the frame");
+        blks.push_back(Lz4Block{ip, bs, raw});
+        ip += bs + (bsum ? 4 : 0);
+    }
+    if (csum) ip += 4;
+    if (ip != n) return fail(RC_ERR_CORRUPT, "trailing bytes after the LZ4 frame");
+    const uint32_t nblk = (uint32_t)blks.size();
+    if (nblk == 0) { *out_n = 0; return RC_OK; }
+    const uint8_t *d_src = nullptr;
+    int r = stage_in(src, n, u.a, u.a_cap, d_src);
+    if (r != RC_OK) return r;
+    // work buffer: block table | sizes | offsets | err
+    const uint64_t tab = (uint64_t)nblk * sizeof(Lz4Block), szs = ((uint64_t)nblk * 4 + 7) & ~7ull, offs = (uint64_t)nblk * 8;
+    r = ensure(u.w, u.w_cap, tab + szs + offs + 16);
+    if (r != RC_OK) return r;
+    Lz4Block *d_blks = reinterpret_cast<Lz4Block *>(u.w);
+    uint32_t *d_sizes = reinterpret_cast<uint32_t *>(u.w + tab);
+    uint64_t *d_offs = reinterpret_cast<uint64_t *>(u.w + tab + szs);
+    int *d_err = reinterpret_cast<int *>(u.w + tab + szs + offs);
+    HIP_TRY(hipMemcpyAsync(d_blks, blks.data(), tab, hipMemcpyHostToDevice, u.stream));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 4, u.stream));
+    launch_lz4_decode(d_src, d_blks, nblk, d_sizes, nullptr, nullptr, ~0ull, linked, d_err, u.stream);
+    std::vector<uint32_t> sizes(nblk);
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(sizes.data(), d_sizes, (uint64_t)(linked ? 1 : nblk) * 4, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    if (err) return fail(RC_ERR_CORRUPT, "malformed LZ4 block");
+    std::vector<uint64_t> off(nblk, 0);
+    uint64_t total = 0;
+    if (linked) total = sizes[0];
+    else
+        for (uint32_t b = 0; b < nblk; ++b) {
+            if (sizes[b] > bmax) return fail(RC_ERR_CORRUPT, "LZ4 block decodes beyond its declared maximum");
+            off[b] = total;
+            total += sizes[b];
+        }
+    *out_n = total;  // reported even when dst is too small, so a caller can size its buffer and call again
+    if (total > dst_cap) return fail(RC_ERR_OUT_TOO_SMALL, "rc_decompress: dst too small");
+    if (total == 0) return RC_OK;
+    uint8_t *d_out = dst;
+    const bool out_host = !is_device_ptr(dst);
+    if (out_host) {
+        r = ensure(u.o, u.o_cap, total);
+        if (r != RC_OK) return r;
+        d_out = u.o;
+    }
+    HIP_TRY(hipMemcpyAsync(d_offs, off.data(), offs, hipMemcpyHostToDevice, u.stream));
+    launch_lz4_decode(d_src, d_blks, nblk, nullptr, d_offs, d_out, total, linked, d_err, u.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, u.stream));
+    if (out_host) HIP_TRY(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    if (err) return fail(RC_ERR_CORRUPT, "malformed LZ4 block");
+    return RC_OK;
+}
+
 RC_EXPORT int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap,
                           uint64_t *out_n)
 {
-    (void)level; (void)src; (void)n; (void)dst; (void)dst_cap; (void)out_n; (void)scheme;
-    return fail(RC_ERR_UNSUPPORTED, "rc_compress: scheme not implemented on device");
+    (void)level;  // the device encoders have a single effort level
+    if (!dst || !out_n || (!src && n)) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    if (scheme != RC_SCHEME_LZ4) return fail(RC_ERR_UNSUPPORTED, "rc_compress: compression scheme not implemented on device");
+    std::lock_guard<std::mutex> lock(g_util.mu);
+    int r = util_init();
+    if (r != RC_OK) return r;
+    return lz4_compress(src, n, dst, dst_cap, out_n);
 }
 RC_EXPORT int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
 {
-    (void)src; (void)n; (void)dst; (void)dst_cap; (void)out_n; (void)scheme;
-    return fail(RC_ERR_UNSUPPORTED, "rc_decompress: scheme not implemented on device");
+    if (!src || !out_n || (!dst && dst_cap)) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    if (scheme != RC_SCHEME_LZ4) return fail(RC_ERR_UNSUPPORTED, "rc_decompress: compression scheme not implemented on device");
+    std::lock_guard<std::mutex> lock(g_util.mu);
+    int r = util_init();
+    if (r != RC_OK) return r;
+    return lz4_decompress(src, n, dst, dst_cap, out_n);
 }
 RC_EXPORT uint64_t rc_compress_bound(uint32_t scheme, uint64_t n)
 {

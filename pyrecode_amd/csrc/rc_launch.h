@@ -46,6 +46,11 @@ void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64
 void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off,
                      hipStream_t s);
 // rc_lz4.hip
+struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
 void launch_lz4_encode_bitmap(const Scratch &sc, uint32_t B, hipStream_t s);
+void launch_lz4f_gather(const Scratch &sc, uint32_t hdr3, uint8_t *out, hipStream_t s);
+void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
+                       uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s);
+uint32_t lz4f_descriptor(uint8_t bd);  // rc_reduce.hip: FLG | BD << 8 | HC << 16
 
 }  // namespace rc

@@ -164,6 +164,126 @@ __global__ __launch_bounds__(WG) void k_lz4_bitmap(Scratch sc, uint32_t B)
     for (uint32_t i = lane; i < (nbytes + 3) / 4; i += 64) slot32[1 + i] = payload[i];
 }
 
+// ---- stand-alone LZ4 frame of an arbitrary byte buffer (seam 2: compress(), recode_compressors.py:91) -----------------
+// Blocks were encoded by k_lz4_bitmap with B == 1 (the buffer plays the role of one frame's bitmap); this kernel
+// concatenates them behind the 7-byte frame header and appends the EndMark.  One wavefront per block.
+__global__ __launch_bounds__(WG) void k_lz4f_gather(Scratch sc, uint32_t hdr3, uint8_t *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (t >= sc.ntiles) return;
+    if (t == 0 && lane_id() == 0) {
+        out[0] = 0x04; out[1] = 0x22; out[2] = 0x4D; out[3] = 0x18;
+        out[4] = (uint8_t)hdr3; out[5] = (uint8_t)(hdr3 >> 8); out[6] = (uint8_t)(hdr3 >> 16);
+        uint8_t *e = out + 7 + sc.frame_cbytes[0];
+        e[0] = e[1] = e[2] = e[3] = 0;
+    }
+    const uint8_t *src = sc.blk_slots + (uint64_t)t * BLK_SLOT;
+    uint8_t *dst = out + 7 + sc.blk_off[t];
+    const uint32_t n = sc.blk_size[t];
+    for (uint32_t i = lane_id(); i < n; i += 64) dst[i] = src[i];
+}
+void launch_lz4f_gather(const Scratch &sc, uint32_t hdr3, uint8_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lz4f_gather, dim3((sc.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, s, sc, hdr3, out);
+}
+
+// ---- LZ4 frame decode (seam 2: de_compress(), recode_compressors.py:49) -------------------------------------------------
+// The host walks the frame's block headers (cheap, sequential by format) and hands over a block table; one thread
+// decodes one block.  Independent blocks (what this library writes: 1024 blocks per 4096x4096 bitmap) decode in
+// parallel; a frame with linked blocks (liblz4's default) is decoded by a single thread in block order.
+// pass 1 (sizes != nullptr): decoded size of each block; pass 2: decode to dst + dst_off[b].
+__device__ uint32_t lz4_block_walk(const uint8_t *__restrict__ src, uint32_t n, uint8_t *__restrict__ dst_base, uint64_t op0,
+                                   uint64_t cap, bool write, int *err)
+{
+    uint32_t ip = 0;
+    uint64_t op = op0;
+    while (ip < n) {
+        const uint32_t token = src[ip++];
+        uint32_t lit = token >> 4;
+        if (lit == 15) {
+            uint32_t b;
+            do {
+                if (ip >= n) { *err = 1; return 0; }
+                b = src[ip++];
+                lit += b;
+            } while (b == 255);
+        }
+        if (ip + lit > n || op + lit > cap) { *err = 1; return 0; }
+        if (write)
+            for (uint32_t i = 0; i < lit; ++i) dst_base[op + i] = src[ip + i];
+        ip += lit;
+        op += lit;
+        if (ip >= n) break;
+        if (ip + 2 > n) { *err = 1; return 0; }
+        const uint32_t off = src[ip] | ((uint32_t)src[ip + 1] << 8);
+        ip += 2;
+        uint32_t ml = token & 15;
+        if (ml == 15) {
+            uint32_t b;
+            do {
+                if (ip >= n) { *err = 1; return 0; }
+                b = src[ip++];
+                ml += b;
+            } while (b == 255);
+        }
+        ml += 4;
+        if (off == 0 || off > op || op + ml > cap) { *err = 1; return 0; }
+        if (write)
+            for (uint32_t i = 0; i < ml; ++i) dst_base[op + i] = dst_base[op + i - off];
+        op += ml;
+    }
+    return (uint32_t)(op - op0);
+}
+
+__global__ void k_lz4_decode(const uint8_t *__restrict__ src, const Lz4Block *__restrict__ blks, uint32_t nblk,
+                             uint32_t *__restrict__ sizes, const uint64_t *__restrict__ dst_off, uint8_t *__restrict__ dst,
+                             uint64_t cap, int linked, int *__restrict__ err)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (linked) {
+        if (b != 0) return;
+        uint64_t op = 0;
+        for (uint32_t k = 0; k < nblk; ++k) {
+            const Lz4Block q = blks[k];
+            if (q.raw) {
+                if (op + q.size > cap) { *err = 1; return; }
+                if (dst) for (uint32_t i = 0; i < q.size; ++i) dst[op + i] = src[q.src_off + i];
+                op += q.size;
+            } else {
+                // sizes pass of a linked frame still needs the bytes (matches reach into earlier blocks) -> decode for real
+                op += lz4_block_walk(src + q.src_off, q.size, dst, op, cap, dst != nullptr, err);
+                if (*err) return;
+            }
+        }
+        if (sizes) sizes[0] = (uint32_t)op;
+        return;
+    }
+    if (b >= nblk) return;
+    const Lz4Block q = blks[b];
+    if (sizes) {
+        int e = 0;
+        // an independent block may not reference bytes before its own start: walk with op0 = 0 and an unbounded cap
+        sizes[b] = q.raw ? q.size : lz4_block_walk(src + q.src_off, q.size, nullptr, 0, ~0ull, false, &e);
+        if (e) *err = 1;
+        return;
+    }
+    const uint64_t o = dst_off[b];
+    if (q.raw) {
+        if (o + q.size > cap) { *err = 1; return; }
+        for (uint32_t i = 0; i < q.size; ++i) dst[o + i] = src[q.src_off + i];
+    } else {
+        int e = 0;
+        (void)lz4_block_walk(src + q.src_off, q.size, dst + o, 0, cap - o, true, &e);
+        if (e) *err = 1;
+    }
+}
+void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
+                       uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s)
+{
+    const uint32_t threads = 64, grid = linked ? 1 : (nblk + threads - 1) / threads;
+    hipLaunchKernelGGL(k_lz4_decode, dim3(grid), dim3(threads), 0, s, src, blks, nblk, sizes, dst_off, dst, cap, linked, err);
+}
+
 void launch_lz4_encode_bitmap(const Scratch &sc, uint32_t B, hipStream_t s)
 {
     const dim3 grid((sc.ntiles + WAVES - 1) / WAVES, B), block(WG);

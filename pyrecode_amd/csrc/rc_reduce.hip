@@ -509,7 +509,7 @@ static uint32_t xxh32_small(const uint8_t *p, size_t n)
     h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
     return h;
 }
-static uint32_t lz4f_descriptor(uint8_t bd)
+uint32_t lz4f_descriptor(uint8_t bd)
 {
     const uint8_t desc[2] = {0x60 /* version 01, block-independent, no checksums, no content size */, bd};
     const uint8_t hc = (uint8_t)((xxh32_small(desc, 2) >> 8) & 0xFF);

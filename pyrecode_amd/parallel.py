@@ -1,0 +1,123 @@
+"""Multi-GPU driver pieces: frame ownership, and the merged `.rcN` file written directly after ONE collective.
+
+The reference scales by data parallelism over frames: node i owns the contiguous block [i*ceil(n/T), ...)
+(pyrecode/recode_writer.py:320-322), every node writes its own part file, and the final file is produced afterwards by
+merge_parts' two passes over all part files (pyrecode/recode_reader.py:495-595).  Here one process drives one GPU
+(rank == node_id), frames never cross GPUs, and the merge needs a single exchange step: an all-gather of
+the per-frame metadata rows (<= 12 bytes per frame; RCCL over xGMI when the process group is `nccl`, gloo on CPU).
+From the gathered table every rank derives the global seek table and its own byte offset, and pwrite()s its frame data
+into place.  The result is byte-identical to merge_parts on the same part files (tests/test_parallel_gloo.py).
+"""
+import os
+import struct
+
+import numpy as np
+
+from .recode_reader import ReCoDeReader
+
+
+def frame_block(n_frames, world, rank):
+    """(first frame, frame count) owned by `rank` - the reference's contiguous-block rule (recode_writer.py:320-322)."""
+    per = -(-n_frames // world)
+    lo = rank * per
+    return lo, min(per, max(n_frames - lo, 0))
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return None
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def all_gather_rows(rows):
+    """rows: int64 ndarray [k, w] (k may differ per rank).  Returns the list of every rank's rows, in rank order.
+    One collective for the payload (padded to the largest k) preceded by a tiny one for the counts."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return [rows]
+    import torch
+    world = dist.get_world_size()
+    on_gpu = dist.get_backend() == 'nccl'
+    dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+    w = rows.shape[1]
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev))
+    counts = [int(c.item()) for c in counts]
+    kmax = max(max(counts), 1)
+    mine = torch.zeros((kmax, w), dtype=torch.int64, device=dev)
+    if rows.shape[0]:
+        mine[:rows.shape[0]] = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)).to(dev)
+    gathered = torch.empty((world * kmax, w), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gathered, mine)
+    g = gathered.cpu().numpy().reshape(world, kmax, w)
+    return [g[r, :counts[r]] for r in range(world)]
+
+
+def read_part_records(path):
+    """[(frame_id, [metadata values], data bytes)] of one part file, in file order."""
+    rd = ReCoDeReader(path, is_intermediate=True)
+    rd.open(print_header=False)
+    out = []
+    while True:
+        f = rd.get_next_frame_raw()
+        if f is None:
+            break
+        (fid, body), = f.items()
+        out.append((int(fid), [int(v) for v in body['metadata'].values()], b''.join(body['data'].values())))
+    hdr = rd.get_header()
+    rd.close()
+    return hdr, out
+
+
+def merge_direct(folder_path, base_filename, rank=None, world=None, records=None):
+    """Collective.  Every rank passes (or re-reads from `<base>_part<rank>`) its own records and writes its share of
+    `<base>`; rank 0 also writes the header (copy of part 000's, nz patched) and the metadata table.
+    Layout: reference recode_reader.py:518-592 / SURVEY appendix A."""
+    dist = _dist()
+    if rank is None:
+        rank = dist.get_rank() if dist else 0
+    if world is None:
+        world = dist.get_world_size() if dist else 1
+    part = os.path.join(folder_path, '%s_part%03d' % (base_filename, rank))
+    hdr, recs = read_part_records(part)
+    if records is not None:
+        recs = records
+    n_md = len(recs[0][1]) if recs else 0
+    rows = np.array([[fid, len(data)] + md for fid, md, data in recs], dtype=np.int64).reshape(len(recs), 2 + n_md)
+    if rows.shape[0] == 0:  # width must agree across ranks: derive it from the header's (level, mode)
+        from .structures import ReCoDeStructures
+        h = hdr.as_dict()
+        n_md = len(ReCoDeStructures(h).standard_frame_metadata_structure_for(h['reduction_level'], h['rc_operation_mode']))
+        rows = np.zeros((0, 2 + n_md), dtype=np.int64)
+    per_rank = all_gather_rows(rows)
+    table = np.concatenate(per_rank, axis=0)
+    order = np.argsort(table[:, 0], kind='stable')          # frame-id order (already sorted for contiguous blocks)
+    sizes = table[order, 1]
+    starts = np.concatenate([[0], np.cumsum(sizes)[:-1]]) if len(sizes) else np.zeros(0, np.int64)
+    pos_of = dict(zip(table[order, 0].tolist(), starts.tolist()))
+    nz = table.shape[0]
+    h = hdr.as_dict()
+    head_len = hdr.recode_header_length + int(h['source_header_length'])
+    data_start = head_len + nz * 4 * n_md
+    target = os.path.join(folder_path, base_filename)
+    if rank == 0:
+        with open(os.path.join(folder_path, '%s_part%03d' % (base_filename, 0)), 'rb') as src, open(target, 'wb') as out:
+            out.write(src.read(head_len))
+            for row in table[order]:
+                out.write(struct.pack('<%dI' % n_md, *[int(v) for v in row[2:]]))
+            out.seek(hdr.get_field_position_in_bytes('nz'))
+            out.write(int(nz).to_bytes(hdr.get_definition('nz')['bytes'], 'little'))
+            out.truncate(data_start + int(sizes.sum()))
+    if dist is not None and world > 1:
+        dist.barrier()                                      # the file exists and is sized before anyone pwrite()s
+    fd = os.open(target, os.O_WRONLY)
+    try:
+        for fid, md, data in recs:
+            os.pwrite(fd, data, data_start + pos_of[fid])
+    finally:
+        os.close(fd)
+    if dist is not None and world > 1:
+        dist.barrier()
+    return nz

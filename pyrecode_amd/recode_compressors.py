@@ -1,0 +1,118 @@
+"""Compressor backend dispatch: compress(scheme, level, data, ctx) / de_compress(scheme, data, ctx).
+
+Same two signatures, scheme codes and NotImplementedError behaviour as reference pyrecode/recode_compressors.py
+(:82-120, :40-79, import_checks :123-129).  Schemes with a device codec (rc_scheme_on_device: LZ4 frames today) run
+on the GPU through rc_compress / rc_decompress; the others call the same host library the reference calls.  Inside
+ReCoDeWriter the device codecs never come through here: the batched operator emits finished records.
+"""
+import bz2
+import ctypes as C
+import lzma
+import zlib
+
+import numpy as np
+
+from . import _lib
+
+_compression_scheme_code_map = {0: 'zlib', 1: 'zstandard', 2: 'lz4', 3: 'snappy', 4: 'bzip', 5: 'lzma', 6: 'blosc',
+                                7: 'blosc', 8: 'blosc', 9: 'blosc', 10: 'blosc', 11: 'blosc'}
+_BLOSC_CNAMES = {6: 'zlib', 7: 'zstd', 8: 'lz4', 9: 'snappy', 10: 'blosclz', 11: 'lz4hc'}
+
+
+def _optional(name):
+    try:
+        return __import__(name)
+    except ImportError:
+        return None
+
+
+def _on_device(scheme):
+    return bool(_lib.lib().rc_scheme_on_device(int(scheme)))
+
+
+def _as_u8(data):
+    return np.frombuffer(memoryview(data), dtype=np.uint8)
+
+
+def device_compress(scheme, level, data):
+    src = _as_u8(data)
+    cap = int(_lib.lib().rc_compress_bound(int(scheme), src.size))
+    dst = np.empty(cap, np.uint8)
+    n = C.c_uint64(0)
+    _lib.check(_lib.lib().rc_compress(int(scheme), int(level), src.ctypes.data if src.size else None, src.size,
+                                      dst.ctypes.data, cap, C.byref(n)), "rc_compress")
+    return dst[:n.value].tobytes()
+
+
+def device_decompress(scheme, data, size_hint=0):
+    src = _as_u8(data)
+    n = C.c_uint64(0)
+    cap = int(size_hint) if size_hint else max(4 * src.size, 1 << 16)
+    for _ in range(2):
+        dst = np.empty(max(cap, 1), np.uint8)
+        st = _lib.lib().rc_decompress(int(scheme), src.ctypes.data, src.size, dst.ctypes.data, cap, C.byref(n))
+        if st == _lib.RC_ERR_OUT_TOO_SMALL and n.value > cap:
+            cap = n.value
+            continue
+        _lib.check(st, "rc_decompress")
+        return dst[:n.value].tobytes()
+    _lib.check(st, "rc_decompress")
+
+
+def compress(compression_scheme, compression_level, data, compressor_context):
+    s = compression_scheme
+    if s not in _compression_scheme_code_map:
+        raise NotImplementedError('compression scheme not implemented')
+    if _on_device(s):
+        return device_compress(s, compression_level, data)
+    if s == 0:
+        return zlib.compress(data, compression_level)
+    if s == 1:
+        return compressor_context.compress(data)
+    if s == 3:
+        return _need('snappy').compress(data)
+    if s == 4:
+        return bz2.compress(data, compresslevel=compression_level)
+    if s == 5:
+        return lzma.compress(data, preset=compression_level)
+    blosc = _need('blosc')
+    return blosc.compress(data, clevel=compression_level, cname=_BLOSC_CNAMES[s], shuffle=blosc.BITSHUFFLE)
+
+
+def de_compress(compression_scheme, compressed_data, decompressor_context):
+    s = compression_scheme
+    if s not in _compression_scheme_code_map:
+        raise NotImplementedError('compression scheme not implemented')
+    if _on_device(s):
+        return device_decompress(s, compressed_data)
+    if s == 0:
+        return zlib.decompress(compressed_data)
+    if s == 1:
+        # streaming decode: frames carry no content size (recode_writer.py:177-178)
+        return decompressor_context.decompressobj().decompress(compressed_data)
+    if s == 3:
+        return _need('snappy').decompress(compressed_data)
+    if s == 4:
+        return bz2.decompress(compressed_data)
+    if s == 5:
+        return lzma.decompress(compressed_data)
+    return _need('blosc').decompress(compressed_data, as_bytearray=True)
+
+
+def _need(module):
+    m = _optional(module)
+    if m is None:
+        raise ImportError("For this compression scheme package " + module + " is required.")
+    return m
+
+
+def import_checks(header):
+    """True when the package a file's compression scheme needs on the HOST is importable (device codecs need none)."""
+    s = int(header['compression_scheme'])
+    if _on_device(s) or s in (0, 4, 5):
+        return True
+    module = {1: 'zstandard', 3: 'snappy'}.get(s, 'blosc')
+    if _optional(module) is None:
+        print("For compression code " + str(s) + " package " + _compression_scheme_code_map[s] + " is required.")
+        raise ImportError()
+    return True

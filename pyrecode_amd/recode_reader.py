@@ -1,0 +1,297 @@
+"""ReCoDeReader / merge_parts: the reference's reader API over the HIP sparse-expand and codecs.
+
+Same classes, method names and return shapes as reference pyrecode/recode_reader.py (ReCoDeReader :15-492,
+merge_parts :495-595): get_frame / get_next_frame return {frame_id: {'metadata': {...}, 'data': scipy COO}}.  The
+bitmap + packed-residual expansion runs on the GPU through the c_recode.Reader shim (rc_unpack_frame_sparse);
+decompression goes through recode_compressors.de_compress (device codec or the reference's host library).
+Reference defects that made files unreadable are not reproduced: L3/L4 frames can be read,
+zstd frames are stream-decoded, merge_parts is a plain k-way merge by frame id.
+"""
+import heapq
+import os
+import struct
+
+import numpy as np
+from scipy.sparse import coo_matrix
+
+from . import recode_compressors as compressors
+from . import c_recode
+from .misc import map_dtype
+from .recode_header import ReCoDeHeader
+from .structures import ReCoDeStructures
+
+
+class ReCoDeReader:
+
+    def __init__(self, file, is_intermediate=False):
+        self._source_filename = file
+        self._current_frame_index = 0
+        self._c_reader = c_recode.Reader()
+        self._is_intermediate = 1 if is_intermediate else 0
+        self._file_size = None
+        self._header = None
+        self._frame_metadata = None
+        self._seek_table = None
+        self._rc_header = None
+        self._frame_data_start_position = 0
+        self._sz_frame_metadata = None
+        self._n_elements_frame_metadata = None
+        self._fp = None
+        self._structures = None
+        self._numpy_dtype = None
+        self._decompressor_context = None
+
+    # ---- opening -------------------------------------------------------------------------------------------
+    def open(self, print_header=True):
+        self._load_header(print_header)
+        compressors.import_checks(self._header)
+        self._fp = open(self._source_filename, "rb")
+        self._fp.seek(0, 2)
+        self._file_size = self._fp.tell()
+        self._fp.seek(0, 0)
+        self._initialize()
+        self._create_read_buffers()
+        self._load_seek_table()
+        self._numpy_dtype = map_dtype(self._header['target_dtype'], self._header['target_bit_depth'])
+        if self._header['compression_scheme'] == 1 and not compressors._on_device(1):
+            import zstandard as zstd
+            self._decompressor_context = zstd.ZstdDecompressor()
+
+    def _load_header(self, print_header=True):
+        self._rc_header = ReCoDeHeader()
+        self._rc_header.load(self._source_filename)
+        self._header = self._rc_header.as_dict()
+        if print_header:
+            self._rc_header.print()
+
+    def _md_fields(self):
+        return self._structures.standard_frame_metadata_structure_for(self._header['reduction_level'],
+                                                                      self._header['rc_operation_mode'])
+
+    def _initialize(self):
+        h = self._header
+        self._structures = ReCoDeStructures(h)
+        nsm = list(self._rc_header.non_standard_metadata_sizes.values())
+        self._sz_frame_metadata = self._structures.get_standard_frame_metadata_size(
+            h['reduction_level'], h['rc_operation_mode']) + int(np.sum(nsm))
+        self._n_elements_frame_metadata = len(nsm) + len(self._md_fields())
+        self._frame_data_start_position = self._rc_header.get_frame_data_offset(self._is_intermediate,
+                                                                                self._sz_frame_metadata)
+        return h
+
+    def _create_read_buffers(self):
+        if 'nz' not in self._header:
+            raise ValueError('Attempting to set persistent variables before reading header')
+        self._c_reader.create_buffers(int(self._header["ny"]), int(self._header["nx"]), int(self._header["target_bit_depth"]))
+
+    def _read_metadata_row(self):
+        d = {}
+        for field in self._md_fields():
+            d[field['name']] = np.frombuffer(self._fp.read(field['bytes']), dtype=field['dtype'])[0]
+        return d
+
+    def _load_seek_table(self):
+        """Merged files only: the nz-row metadata table and the cumulative data offsets (reference :127-168)."""
+        if self._is_intermediate:
+            return
+        if 'nz' not in self._header:
+            raise ValueError('Attempting to read seek table before reading header')
+        h = self._header
+        self._fp.seek(self._rc_header.get_frame_data_offset(True, self._sz_frame_metadata), 0)
+        self._frame_metadata = [self._read_metadata_row() for _ in range(int(h['nz']))]
+        sizes = np.array([self._structures.get_frame_data_size(h['reduction_level'], h['rc_operation_mode'], m)
+                          for m in self._frame_metadata], dtype=np.uint64)
+        self._seek_table = np.zeros((int(h['nz']), 2), dtype=np.uint64)
+        self._seek_table[:, 0] = sizes
+        if len(sizes) > 1:
+            self._seek_table[1:, 1] = np.cumsum(sizes[:-1])
+
+    # ---- accessors -----------------------------------------------------------------------------------------
+    def get_header(self):
+        return self._rc_header
+
+    def get_source_header(self):
+        return self._rc_header.source_header
+
+    def get_true_shape(self):
+        return tuple([self._header["nz"], self._header["ny"], self._header["nx"]])
+
+    def get_shape(self):
+        return tuple([self._header["nz"], self._header["ny"], self._header["nx"]])
+
+    def get_dtype(self):
+        return self._header['target_dtype']
+
+    def get_sub_volume(self, slice_z, slice_y, slice_x):
+        raise NotImplementedError
+
+    @property
+    def sz_frame_metadata(self):
+        return self._sz_frame_metadata
+
+    def close(self):
+        self._fp.close()
+
+    def seek_to_frame_data(self):
+        self._frame_data_start_position = self._rc_header.get_frame_data_offset(self._is_intermediate,
+                                                                                self._sz_frame_metadata)
+        self._fp.seek(0, 2)
+        if self._frame_data_start_position <= self._fp.tell():
+            self._fp.seek(self._frame_data_start_position, 0)
+
+    def get_file_position(self):
+        return self._fp.tell()
+
+    def copy_headers_to(self, target_fp, source_header_length):
+        self._fp.seek(0, 0)
+        target_fp.write(self._fp.read(self._rc_header.recode_header_length))
+        target_fp.write(self._fp.read(source_header_length))
+
+    # ---- frame access --------------------------------------------------------------------------------------
+    def _pack(self, key, metadata, sparse):
+        if sparse is None:
+            self._header['nz'] = self._current_frame_index
+            return None
+        return {key: {'metadata': metadata, 'data': sparse}}
+
+    def get_frame(self, z):
+        if self._is_intermediate:
+            raise ValueError("Random acceess is not available for intermediate files")
+        if z >= self._header['nz']:
+            raise ValueError('Requested frame index is greater than number of frames in dataset')
+        self._fp.seek(self._frame_data_start_position + int(self._seek_table[z, 1]), 0)
+        if self._file_size - self._fp.tell() == 0:
+            return self._pack(z, None, None)
+        out = self._pack(z, self._frame_metadata[z], self._get_frame_sparse(self._frame_metadata[z]))
+        if out is not None:
+            self._current_frame_index = z + 1
+        return out
+
+    def _next_header(self):
+        """(frame_id, metadata) of the next frame, or None at the end of an intermediate file."""
+        if self._current_frame_index == 0:
+            self._fp.seek(self._frame_data_start_position, 0)
+        if self._file_size - self._fp.tell() == 0:
+            return None
+        if not self._is_intermediate:
+            if self._current_frame_index >= self._header['nz']:
+                raise ValueError('Requested frame index is greater than number of frames in dataset')
+            return self._current_frame_index, self._frame_metadata[self._current_frame_index]
+        frame_id = np.frombuffer(self._fp.read(4), dtype=np.uint32)[0]
+        return frame_id, self._read_metadata_row()
+
+    def get_next_frame(self):
+        nxt = self._next_header()
+        if nxt is None:
+            return None
+        frame_id, d = nxt
+        out = self._pack(frame_id, d, self._get_frame_sparse(d))
+        if out is not None:
+            self._current_frame_index += 1
+        return out
+
+    def get_next_frame_raw(self, read_data=True):
+        nxt = self._next_header()
+        if nxt is None:
+            return None
+        frame_id, d = nxt
+        raw_d = self._get_frame_raw(d, read_data=read_data)
+        if not read_data:
+            raw_d = self._fp.tell()
+        self._current_frame_index += 1
+        return {frame_id: {'metadata': d, 'data': raw_d}}
+
+    def _stream_sizes(self, md):
+        """(bytes of the binary-map stream, bytes of the value stream or None) as stored in the file."""
+        h = self._header
+        level, mode = h['reduction_level'], h['rc_operation_mode']
+        sz_map = self._structures.binary_image_sz_bytes if mode == 0 else int(md['bytes_in_compressed_binary_map'])
+        if level not in (1, 2):
+            return sz_map, None
+        what = 'pixvals' if level == 1 else 'summary_stats'
+        return sz_map, int(md['bytes_in_%s_%s' % ('packed' if mode == 0 else 'compressed', what)])
+
+    def _get_frame_raw(self, frame_metadata, read_data=True):
+        sz_map, sz_val = self._stream_sizes(frame_metadata)
+
+        def take(n):
+            if read_data:
+                return self._fp.read(n)
+            self._fp.seek(n, 1)
+            return None
+        out = {'binary_map': take(sz_map)}
+        if sz_val is not None:
+            out['pixvals'] = take(sz_val)
+        return out
+
+    def _get_frame_sparse(self, frame_metadata):
+        """Read one frame's streams, decompress if needed, expand on the GPU, wrap as COO (reference :379-471)."""
+        h = self._header
+        level, mode = h['reduction_level'], h['rc_operation_mode']
+        if level == 2:
+            raise NotImplementedError('L2 files: summary statistics are not implemented (non-functional in the reference)')
+        sz_map, sz_val = self._stream_sizes(frame_metadata)
+        binary_map = self._fp.read(sz_map)
+        values = self._fp.read(sz_val) if sz_val is not None else None
+        if mode == 1:
+            scheme = h['compression_scheme']
+            binary_map = compressors.de_compress(scheme, binary_map, self._decompressor_context)
+            if values is not None:
+                values = compressors.de_compress(scheme, values, self._decompressor_context)
+        # size the triplet buffer from the value stream (L1) or ask the library to count (bitmap-only levels)
+        if level == 1:
+            d = int(h['target_bit_depth'])
+            cap = (len(values) * 8) // d
+        else:
+            cap = self._c_reader.count(binary_map)
+        buf = np.empty((max(cap, 1), 3), dtype=np.uint64)
+        n = self._c_reader.get_frame_sparse(level, binary_map, values, buf) if cap else 0
+        if n == 0 and mode == 0:
+            return None  # reference :387-391: an empty reduce-only frame reads as end of data
+        return self._make_coo_frame(n, buf)
+
+    def _make_coo_frame(self, n, buf):
+        d = buf[:n]
+        return coo_matrix((d[:, 2], (d[:, 0], d[:, 1])), shape=(int(self._header['ny']), int(self._header['nx'])),
+                          dtype=self._numpy_dtype)
+
+
+def merge_parts(folder_path, base_filename, num_parts):
+    """Merge `<base>_partNNN` files into `<base>` (reference :495-595): header of part 000 (nz patched), the
+    source header, one metadata row per frame (frame_id dropped), then the frame data blobs in frame-id order."""
+    paths = [os.path.join(folder_path, '%s_part%03d' % (base_filename, i)) for i in range(num_parts)]
+    readers = []
+    for p in paths:
+        r = ReCoDeReader(p, is_intermediate=True)
+        r.open(print_header=False)
+        readers.append(r)
+    first = readers[0]
+    rc_header = first.get_header()
+    header = rc_header.as_dict()
+
+    def stream(idx):
+        r = readers[idx]
+        while True:
+            f = r.get_next_frame_raw()
+            if f is None:
+                return
+            (frame_id, body), = f.items()
+            yield int(frame_id), idx, body
+
+    metadata, blobs = [], []
+    for frame_id, _, body in heapq.merge(*(stream(i) for i in range(num_parts))):
+        metadata.append(body['metadata'])
+        blobs.append(b''.join(body['data'][k] for k in body['data']))
+    with open(os.path.join(folder_path, base_filename), 'wb') as target:
+        with open(paths[0], 'rb') as src:
+            target.write(src.read(rc_header.recode_header_length + int(header['source_header_length'])))
+        for md in metadata:
+            for name, value in md.items():
+                if name != 'frame_id':
+                    target.write(struct.pack('<I', int(value)))
+        for blob in blobs:
+            target.write(blob)
+        target.seek(rc_header.get_field_position_in_bytes('nz'), 0)
+        target.write(len(metadata).to_bytes(rc_header.get_definition('nz')['bytes'], 'little'))
+    for r in readers:
+        r.close()

@@ -1,0 +1,329 @@
+"""ReCoDeWriter: frames in, `.rc<L>_part<NNN>` part file out - the reference's writer API over the HIP hot path.
+
+Keeps the constructor arguments, start()/run()/close(), the per-frame seam `_reduce_compress`, the run-metrics keys, the
+output file names and every byte of the part-file layout of reference pyrecode/recode_writer.py (ctor :26-182,
+start :184-240, run :292-428, _reduce_compress :430-557, close :589-607).  What changed is where the work happens:
+run() hands whole batches of frames to librecode_hip (rc_reduce_compress_batch: threshold, bitmap, compaction,
+d-bit pack and - for schemes with a device codec - compression and record assembly on the GPU) and appends the returned
+records to the part file.  There is no host implementation of those stages here: without the library or a GPU the
+constructor raises.
+"""
+import math
+import os
+import struct
+import warnings
+from datetime import datetime, timedelta
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+from . import recode_compressors as compressors
+from .misc import rc_cfg as rc
+from .params import InitParams, InputParams
+from .recode_header import ReCoDeHeader
+from .structures import ReCoDeStructures
+
+_STAGE_KEYS = ('frame_thresholding_and_counting_time', 'frame_binary_image_packing_time',
+               'frame_pixel_intensity_packing_time', 'frame_binary_image_compression_time',
+               'frame_pixel_intensity_compression_time', 'frame_time')
+
+
+def _read_binary_frames(path, ny, nx, dtype):
+    """Raw headerless stack, reference pyrecode/fileutils.py:1-8."""
+    a = np.fromfile(path, dtype=dtype)
+    return a.reshape((-1, ny, nx))
+
+
+class ReCoDeWriter:
+
+    def __init__(self, image_filename, dark_data=None, dark_filename='', output_directory='', input_params=None,
+                 params_filename='', mode='batch', validation_frame_gap=-1, log_filename='recode.log', run_name='run',
+                 verbosity=0, use_c=False, max_count=-1, chunk_time_in_sec=0, node_id=0, buffer_size_in_frames=10.0,
+                 device_id=None, batch_size=None):
+        """Arguments as in the reference (recode_writer.py:29-66).  Two additions, both optional:
+        device_id   HIP device ordinal (default: LOCAL_RANK, else node_id modulo the visible GPUs)
+        batch_size  frames handed to the GPU per call (default: sized to ~1 GiB of input, at most 64)
+        use_c is accepted for compatibility; the native path is always the HIP library."""
+        self._init_params = InitParams(mode, output_directory, image_filename=image_filename,
+                                       calibration_filename=dark_filename, params_filename=params_filename,
+                                       validation_frame_gap=validation_frame_gap, log_filename=log_filename,
+                                       run_name=run_name, verbosity=verbosity, use_c=use_c)
+        if input_params is None:
+            self._input_params = InputParams()
+            self._input_params.load(Path(self._init_params.params_filename))
+        else:
+            self._input_params = input_params
+        if not self._input_params.validate():
+            raise ValueError('Invalid input params')
+        ip = self._input_params
+        if ip.source_numpy_dtype != np.uint16 or ip.target_numpy_dtype != np.uint16:
+            # same restriction the reference places on its native path (recode_writer.py:85-87)
+            raise ValueError('the HIP path requires source and target dtypes to be unsigned 16-bit')
+        if ip.reduction_level not in (1, 3):
+            raise NotImplementedError('reduction levels 2 and 4 are not implemented on device '
+                                      '(non-functional in the reference as well, SURVEY.md 0.5)')
+
+        self._rc_header = ReCoDeHeader()
+        self._rc_header.create(self._init_params, ip, True)
+        self._rc_header.set('source_header_length', 1024 if ip.source_file_type in (rc.FILE_TYPE_MRC, rc.FILE_TYPE_SEQ) else 0)
+        if verbosity > 0:
+            self._rc_header.print()
+        if not self._rc_header.validate():
+            raise ValueError('Invalid ReCoDe header created')
+        self._header = self._rc_header.as_dict()
+
+        if dark_data is None:
+            if ip.calibration_file_type == rc.FILE_TYPE_BINARY:
+                t = _read_binary_frames(self._init_params.calibration_filename, self._header['ny'], self._header['nx'],
+                                        ip.source_numpy_dtype)
+                t = np.squeeze(t[0]) if t.ndim > 2 else t
+            elif ip.calibration_file_type in (rc.FILE_TYPE_MRC, rc.FILE_TYPE_SEQ):
+                raise NotImplementedError('MRC / SEQ calibration files need the reference em_reader (out of scope); '
+                                          'pass dark_data')
+            else:
+                raise NotImplementedError("No implementation available for loading calibration file of type 'Other'")
+        else:
+            t = dark_data
+        if self._header['ny'] != t.shape[0] or self._header['nx'] != t.shape[1]:
+            raise RuntimeError('Data and Calibration frames have different shapes')
+        self._src_dtype = ip.source_numpy_dtype
+        if t.dtype != self._src_dtype:
+            # reference :131-137 casts after adding epsilon in the dark frame's own dtype; for an integer epsilon
+            # cast-then-add gives the same uint16 frame (floor(x + k) == floor(x) + k), so the sum stays on the device
+            warnings.warn('Calibration data type not same as source. Attempting to cast.')
+            t = t.astype(self._src_dtype)
+        self._calibration_frame = t  # thr = dark + epsilon is formed on the device (rc_set_dark, reference :126-127)
+
+        self._node_id = node_id
+        self._device_id = device_id
+        self._batch_size = batch_size
+        self._buffer_size_in_frames = buffer_size_in_frames
+        self._structures = ReCoDeStructures(self._header)
+        self._intermediate_file_name = self._intermediate_file = None
+        self._validation_file_name = self._validation_file = None
+        self._ctx = None
+        self._is_first_chunk = True
+        self._chunk_offset = self._num_frames_in_part = None
+        self._frame_buffer = None
+        self._vc_roi = {'x_start': None, 'y_start': None, 'nx': None, 'ny': None}
+        self._vc_n_pixels = None
+        self._vc_dose_rate = 0.0
+        self._compressor_context = None
+        if ip.compression_scheme == 1 and not _lib.lib().rc_scheme_on_device(1):
+            import zstandard as zstd
+            self._compressor_context = zstd.ZstdCompressor(level=ip.compression_level, write_content_size=False)
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _pick_device(self):
+        if self._device_id is not None:
+            return int(self._device_id)
+        n = _lib.device_count()
+        if n == 0:
+            raise _lib.RecodeHipError('no GPU visible: ReCoDeWriter has no CPU path')
+        if 'LOCAL_RANK' in os.environ:
+            return int(os.environ['LOCAL_RANK']) % n
+        return self._node_id % n
+
+    def start(self):
+        """Create the part file, write its header, allocate host buffers and the device context."""
+        ip, init = self._input_params, self._init_params
+        base = Path(init.image_filename).stem if init.mode == 'batch' else init.run_name
+        self._intermediate_file_name = os.path.join(
+            init.output_directory, '%s.rc%d_part%03d' % (base, ip.reduction_level, self._node_id))
+        self._intermediate_file = open(self._intermediate_file_name, 'wb')
+        self._rc_header.serialize_to(self._intermediate_file)
+        self._intermediate_file.flush()
+        if init.validation_frame_gap > 0:
+            self._validation_file_name = os.path.join(
+                init.output_directory, '%s_part%03d_validation_frames.bin' % (base, self._node_id))
+            self._validation_file = open(self._validation_file_name, 'wb')
+
+        nx, ny = int(self._header['nx']), int(self._header['ny'])
+        self._frame_sz = nx * ny * np.dtype(self._src_dtype).itemsize
+        self._frame_buffer = bytearray(self._frame_sz)
+        self._n_bytes_in_binary_image = math.ceil(nx * ny / 8)
+        self._buffer_sz = int(np.ceil(self._frame_sz * self._buffer_size_in_frames))
+        self._rct_buffer = bytearray()
+        if self._batch_size is None:
+            self._batch_size = int(max(1, min(64, (1 << 30) // self._frame_sz)))
+        self._ctx = _lib.ReduceContext(nx, ny, ip.source_bit_depth, ip.reduction_level, ip.rc_operation_mode,
+                                       ip.compression_scheme, ip.compression_level, self._pick_device(), self._batch_size)
+        self._ctx.set_dark(np.ascontiguousarray(self._calibration_frame), ip.calibration_threshold_epsilon)
+        self._host_compress = ip.rc_operation_mode == 1 and not self._ctx.on_device_codec
+        self._out = np.empty(self._ctx.out_capacity(self._batch_size), np.uint8)
+        self._chunk_offset = 0
+        self._num_frames_in_part = 0
+        self._vc_roi['nx'], self._vc_roi['ny'] = min(nx, 128), min(ny, 128)
+        self._vc_roi['x_start'] = math.floor((nx - self._vc_roi['nx']) / 2.0)
+        self._vc_roi['y_start'] = math.floor((ny - self._vc_roi['ny']) / 2.0)
+        self._vc_n_pixels = self._vc_roi['nx'] * self._vc_roi['ny']
+
+    def _do_sanity_checks(self, is_first_chunk, data=None):
+        ip = self._input_params
+        if data is None:
+            if ip.source_file_type == rc.FILE_TYPE_BINARY:
+                self._source = None
+                self._source_shape = (self._header['nz'], self._header['ny'], self._header['nx'])
+            elif ip.source_file_type in (rc.FILE_TYPE_MRC, rc.FILE_TYPE_SEQ):
+                raise NotImplementedError('MRC / SEQ sources need the reference em_reader (out of scope); pass data')
+            else:
+                raise NotImplementedError("No implementation available for loading calibration file of type 'Other'")
+        else:
+            self._source = data
+            self._source_shape = data.shape
+        if self._source_shape[1] != self._header['ny']:
+            raise RuntimeError('Expected height does not match height in source file')
+        if self._source_shape[2] != self._header['nx']:
+            raise RuntimeError('Expected width does not match width in source file')
+        if ip.num_frames == -1:
+            self._header['nz'] = self._source_shape[0]
+        elif ip.num_frames > self._source_shape[0]:
+            raise RuntimeError('Number of frames requested in config file is larger than available in source file')
+        else:
+            self._header['nz'] = ip.num_frames
+
+    # ---------------------------------------------------------------------------------------------------------
+    def run(self, data=None):
+        """Process this node's contiguous block of the chunk (reference :311-350) and append its records to the part file."""
+        run_metrics = {}
+        ip, init = self._input_params, self._init_params
+        self._do_sanity_checks(self._is_first_chunk, data)
+        self._is_first_chunk = False
+        if init.mode == 'batch':
+            n_frames_in_chunk = ip.nz
+        elif init.mode == 'stream':
+            n_frames_in_chunk = self._source_shape[0]
+        else:
+            raise ValueError("Invalid input params: mode. Can be 'batch' or 'stream'.")
+        n_frames_per_thread = int(math.ceil(n_frames_in_chunk / float(ip.num_threads)))
+        frame_offset = self._node_id * n_frames_per_thread
+        available_frames = min(n_frames_per_thread, max(n_frames_in_chunk - frame_offset, 0))
+
+        stt = datetime.now()
+        if data is None:
+            stack = _read_binary_frames(init.image_filename, self._header['ny'], self._header['nx'], self._src_dtype)
+            data = stack[frame_offset:frame_offset + available_frames]
+            available_frames = data.shape[0]
+        else:
+            data = data[frame_offset:frame_offset + available_frames]
+        if data.dtype != self._src_dtype:
+            warnings.warn('Source data type either not as specified or does not match params specs. Attempting to cast.')
+            data = data.astype(self._src_dtype)
+        run_metrics['run_data_read_time'] = datetime.now() - stt
+
+        run_start = datetime.now()
+        gap = init.validation_frame_gap
+        for lo in range(0, available_frames, self._batch_size):
+            batch = np.ascontiguousarray(data[lo:lo + self._batch_size])
+            first_id = self._chunk_offset + frame_offset + lo
+            records, metrics = self._reduce_compress_batch(batch, first_id)
+            for rec in records:
+                if self._buffer_sz - len(self._rct_buffer) < len(rec):
+                    self._offload_buffer()
+                self._rct_buffer += rec
+            if gap > 0:
+                for i in range(batch.shape[0]):
+                    if (first_id + i) % gap == 0:
+                        self._validation_file.write(batch[i].tobytes())
+                        run_metrics.setdefault('run_dose_rates', []).append(self._count_validation_frame(i))
+            for key, value in metrics.items():
+                run_metrics[key] = run_metrics[key] + value if key in run_metrics else value
+        self._chunk_offset += n_frames_in_chunk
+        self._num_frames_in_part += available_frames
+        run_metrics['run_time'] = datetime.now() - run_start
+        run_metrics['run_frames'] = available_frames
+        return run_metrics
+
+    def _count_validation_frame(self, i):
+        """Dose-rate estimate on the central ROI of frame i's binary map (reference :402-415)."""
+        import scipy.ndimage as nd
+        nx, ny = int(self._header['nx']), int(self._header['ny'])
+        bits = np.unpackbits(self._ctx.binary_map(i), bitorder='little')[:nx * ny].reshape(ny, nx)
+        r = self._vc_roi
+        roi = bits[r['y_start']:r['y_start'] + r['ny'], r['x_start']:r['x_start'] + r['nx']]
+        _, num_features = nd.label(roi, structure=nd.generate_binary_structure(2, 2))
+        self._vc_dose_rate = num_features / self._vc_n_pixels
+        return self._vc_dose_rate
+
+    def _reduce_compress_batch(self, frames, first_frame_id):
+        """n frames -> list of n record byte strings + metrics summed over the batch (device stage times)."""
+        n = frames.shape[0]
+        t0 = datetime.now()
+        out, rec, md = self._ctx.reduce_compress_batch(frames, first_frame_id, out=self._out)
+        ms = self._ctx.stage_ms()
+        zero = timedelta(0)
+        metrics = {
+            'frame_thresholding_and_counting_time': timedelta(milliseconds=ms[0] + ms[1]),
+            'frame_binary_image_packing_time': zero,  # fused into the thresholding kernel
+            'frame_pixel_intensity_packing_time': timedelta(milliseconds=ms[3]),
+            'frame_binary_image_compression_time': timedelta(milliseconds=ms[2]),
+            'frame_pixel_intensity_compression_time': zero,  # fused into record assembly
+        }
+        records = [out[int(rec[i]):int(rec[i + 1])] for i in range(n)]
+        if self._host_compress:
+            records = [self._host_compress_record(r.tobytes(), metrics) for r in records]
+        else:
+            records = [r.tobytes() for r in records]
+        metrics['frame_time'] = datetime.now() - t0
+        return records, metrics
+
+    def _host_compress_record(self, r, metrics):
+        """Schemes without a device codec: the GPU delivered the mode-0 record; run the reference's own library call on
+        the two streams (recode_writer.py:503-525) and re-frame."""
+        h, nb = self._header, self._n_bytes_in_binary_image
+        scheme, level = h['compression_scheme'], h['compression_level']
+        t0 = datetime.now()
+        if h['reduction_level'] == 1:
+            fid, npk = struct.unpack_from('<II', r, 0)
+            cb = compressors.compress(scheme, level, r[8:8 + nb], self._compressor_context)
+            t1 = datetime.now()
+            cp = compressors.compress(scheme, level, r[8 + nb:8 + nb + npk], self._compressor_context)
+            metrics['frame_pixel_intensity_compression_time'] += datetime.now() - t1
+            out = struct.pack('<IIII', fid, len(cb), len(cp), npk) + cb + cp
+        else:
+            fid, = struct.unpack_from('<I', r, 0)
+            cb = compressors.compress(scheme, level, r[4:4 + nb], self._compressor_context)
+            t1 = datetime.now()
+            out = struct.pack('<II', fid, len(cb)) + cb
+        metrics['frame_binary_image_compression_time'] += t1 - t0
+        if len(out) > self._frame_sz:
+            raise ValueError('Buffer size smaller than compressed data size')
+        return out
+
+    def _reduce_compress(self, frame, absolute_frame_index, _statistics=None, _centroiding_scheme=None):
+        """The reference's per-frame seam (recode_writer.py:430-557): record bytes land in self._frame_buffer[:length];
+        returns (length, metrics, binary_frame)."""
+        records, metrics = self._reduce_compress_batch(np.ascontiguousarray(frame)[None], int(absolute_frame_index))
+        rec = records[0]
+        self._frame_buffer[:len(rec)] = rec
+        nx, ny = int(self._header['nx']), int(self._header['ny'])
+        binary = np.unpackbits(self._ctx.binary_map(0), bitorder='little')[:nx * ny].reshape(ny, nx).astype(bool)
+        return len(rec), metrics, binary
+
+    def close(self):
+        self._offload_buffer()
+        self._rc_header.update('nz', self._num_frames_in_part)
+        self._intermediate_file.seek(0)
+        self._rc_header.serialize_to(self._intermediate_file)
+        self._intermediate_file.close()
+        if self._init_params.validation_frame_gap > 0:
+            self._validation_file.close()
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def _offload_buffer(self):
+        self._intermediate_file.write(self._rct_buffer)
+        self._intermediate_file.flush()
+        self._rct_buffer = bytearray()
+
+
+def print_run_metrics(run_metrics):
+    for key in run_metrics:
+        if key.startswith('frame_'):
+            print(key, "\t", run_metrics[key] / run_metrics['run_frames'], "\t", run_metrics[key] / run_metrics['frame_time'])
+        elif key == 'run_dose_rates':
+            print(key, "\t", run_metrics[key], "\t", 'Avg.=', np.mean(run_metrics[key]))
+        else:
+            print(key, "\t", run_metrics[key])

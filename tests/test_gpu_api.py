@@ -1,0 +1,227 @@
+"""-m gpu: the reference-shaped Python API (ReCoDeWriter / ReCoDeReader / merge_parts / compressors / c_recode.Reader)
+running on the HIP library, against files the reference itself wrote and against the oracle."""
+import ctypes as C
+import ctypes.util
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_npz, synth_frames
+
+pytestmark = pytest.mark.gpu
+FILES = os.path.join(GOLDEN, "files")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    oracle.lib()
+    return oracle
+
+
+def _params(tmp_path, g, **over):
+    from pyrecode_amd.params import InputParams
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    cfg.update(over)
+    p = tmp_path / "params.txt"
+    p.write_text("".join("%s = %d\n" % kv for kv in cfg.items()))
+    ip = InputParams()
+    ip.load(str(p))
+    return ip, cfg
+
+
+def _write_parts(tmp_path, base, dark, frames, nodes, g, batch_size=None, **over):
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    metrics = []
+    for node in range(nodes):
+        ip, cfg = _params(tmp_path, g, **over)
+        w = ReCoDeWriter(base, dark_data=dark, output_directory=str(tmp_path), input_params=ip, mode="batch",
+                         validation_frame_gap=-1, node_id=node, batch_size=batch_size)
+        w.start()
+        metrics.append(w.run(frames))
+        w.close()
+    return cfg, metrics
+
+
+@pytest.mark.parametrize("tag,level,nodes", [("l1z12", 1, 3), ("l1z16", 1, 2), ("l1ro16", 1, 2), ("l3z", 3, 2)])
+def test_writer_reproduces_reference_files_byte_for_byte(tag, level, nodes, tmp_path):
+    """zlib / reduce-only configs: GPU reduce + pack, host zlib exactly as the reference calls it -> identical files."""
+    from pyrecode_amd.recode_reader import merge_parts
+    from pyrecode_amd import parallel
+    g = load_npz("g3_%s.npz" % tag)
+    base = "g3_" + tag
+    cfg, metrics = _write_parts(tmp_path, base, g["dark"], g["frames"], nodes, g, batch_size=2)
+    for node in range(nodes):
+        fn = "%s.rc%d_part%03d" % (base, level, node)
+        assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
+    assert sum(m["run_frames"] for m in metrics) == g["frames"].shape[0]
+    for key in ("frame_thresholding_and_counting_time", "frame_binary_image_packing_time", "frame_time", "run_time"):
+        assert key in metrics[0]
+    merged = "%s.rc%d" % (base, level)
+    want = open(os.path.join(FILES, merged), "rb").read()
+    merge_parts(str(tmp_path), merged, nodes)
+    assert (tmp_path / merged).read_bytes() == want
+    os.remove(tmp_path / merged)
+    recs = []
+    for node in range(nodes):
+        recs += parallel.read_part_records(os.path.join(tmp_path, "%s_part%03d" % (merged, node)))[1]
+    parallel.merge_direct(str(tmp_path), merged, rank=0, world=1, records=recs)
+    assert (tmp_path / merged).read_bytes() == want
+
+
+@pytest.mark.parametrize("tag", ["l1z12", "l1z16", "l1ro16"])
+def test_reader_decodes_reference_files(tag):
+    from pyrecode_amd.recode_reader import ReCoDeReader
+    g = load_npz("g3_%s.npz" % tag)
+    frames, dark = g["frames"], g["dark"]
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    thr = (dark + np.uint16(cfg["calibration_threshold_epsilon"])).astype(np.uint16)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16)
+    if g["decoded"].size:
+        assert np.array_equal(want, g["decoded"])  # what the reference's own reader returned
+    rd = ReCoDeReader(os.path.join(FILES, "g3_%s.rc1" % tag), is_intermediate=False)
+    rd.open(print_header=False)
+    for z in (3, 0, frames.shape[0] - 1, 1):  # random access
+        f = rd.get_frame(z)
+        assert list(f.keys()) == [z]
+        coo = f[z]["data"]
+        assert coo.dtype == np.uint16 and coo.shape == frames.shape[1:]
+        assert np.array_equal(np.asarray(coo.todense()), want[z])
+        assert np.all(np.diff(coo.row.astype(np.int64) * coo.shape[1] + coo.col) > 0)  # row-major order
+    rd.close()
+    part = ReCoDeReader(os.path.join(FILES, "g3_%s.rc1_part001" % tag), is_intermediate=True)
+    part.open(print_header=False)
+    n = 0
+    while True:
+        f = part.get_next_frame()
+        if f is None:
+            break
+        (fid, body), = f.items()
+        assert np.array_equal(np.asarray(body["data"].todense()), want[fid])
+        n += 1
+    assert n == part.get_header().as_dict()["nz"]
+    part.close()
+
+
+def test_l3_files_are_readable():
+    from pyrecode_amd.recode_reader import ReCoDeReader
+    g = load_npz("g3_l3z.npz")
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    thr = (g["dark"] + np.uint16(cfg["calibration_threshold_epsilon"])).astype(np.uint16)
+    rd = ReCoDeReader(os.path.join(FILES, "g3_l3z.rc3"), is_intermediate=False)
+    rd.open(print_header=False)
+    for z in range(g["frames"].shape[0]):
+        coo = rd.get_frame(z)[z]["data"]
+        assert np.array_equal(np.asarray(coo.todense()) != 0, g["frames"][z] > thr)
+    rd.close()
+
+
+@pytest.mark.parametrize("depth,eps,nodes", [(12, 0, 3), (16, 5, 2)])
+def test_lz4_write_read_round_trip(depth, eps, nodes, tmp_path):
+    """Config-2 shape of flow (L1 + LZ4 on device) at a test size: write parts, merge, read back, compare with the oracle's
+    residual image; part files also decode through the oracle's LZ4 decoder (done in test_gpu_parity)."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, nz = 300, 420, 7
+    dark, frames = synth_frames(77 + depth, nz, ny, nx, 0.02, depth)
+    g = load_npz("g3_l1z12.npz")
+    over = dict(num_rows=ny, num_cols=nx, num_frames=nz, num_threads=nodes, compression_scheme=2,
+                source_bit_depth=depth, target_bit_depth=depth, calibration_threshold_epsilon=eps)
+    _write_parts(tmp_path, "rt", dark, frames, nodes, g, batch_size=3, **over)
+    merge_parts(str(tmp_path), "rt.rc1", nodes)
+    thr = (dark + np.uint16(eps)).astype(np.uint16)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16)
+    rd = ReCoDeReader(str(tmp_path / "rt.rc1"), is_intermediate=False)
+    rd.open(print_header=False)
+    assert rd.get_shape() == (nz, ny, nx)
+    for z in range(nz):
+        f = rd.get_next_frame()
+        assert np.array_equal(np.asarray(f[z]["data"].todense()), want[z])
+        md = f[z]["metadata"]
+        assert md["bytes_in_packed_pixvals"] == (int((want[z] > 0).sum()) * depth + 7) // 8
+    rd.close()
+
+
+def test_validation_frames_and_dose_rate(tmp_path):
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    import scipy.ndimage as nd
+    ny, nx, nz = 200, 256, 6
+    dark, frames = synth_frames(5, nz, ny, nx, 0.01, 12)
+    g = load_npz("g3_l1z12.npz")
+    ip, _ = _params(tmp_path, g, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=1)
+    w = ReCoDeWriter("val", dark_data=dark, output_directory=str(tmp_path), input_params=ip, validation_frame_gap=2, node_id=0)
+    w.start()
+    m = w.run(frames)
+    w.close()
+    raw = np.fromfile(tmp_path / "val_part000_validation_frames.bin", dtype=np.uint16).reshape(-1, ny, nx)
+    assert np.array_equal(raw, frames[::2])
+    want = []
+    for z in range(0, nz, 2):
+        roi = (frames[z] > dark)[36:164, 64:192]
+        want.append(nd.label(roi, structure=nd.generate_binary_structure(2, 2))[1] / (128 * 128))
+    assert m["run_dose_rates"] == want
+
+
+def test_per_frame_seam_reduce_compress(tmp_path, orc):
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    g = load_npz("g3_l1z12.npz")
+    ip, cfg = _params(tmp_path, g, num_threads=1)
+    w = ReCoDeWriter("seam", dark_data=g["dark"], output_directory=str(tmp_path), input_params=ip, node_id=0)
+    w.start()
+    thr = orc.threshold(g["dark"], cfg["calibration_threshold_epsilon"])
+    n, metrics, binary = w._reduce_compress(g["frames"][2], 41)
+    want, _ = orc.l1_record(g["frames"][2], thr, 12, 41, mode=1)
+    assert bytes(w._frame_buffer[:n]) == want
+    assert binary.dtype == bool and np.array_equal(binary, g["frames"][2] > thr)
+    w.close()
+
+
+def test_compressor_seam_on_device(orc):
+    from pyrecode_amd import recode_compressors as rcmp
+    rng = np.random.default_rng(4)
+    sparse = np.where(rng.random(70000) < 0.05, rng.integers(1, 256, 70000), 0).astype(np.uint8).tobytes()
+    noise = rng.integers(0, 256, 5000).astype(np.uint8).tobytes()
+    for data in (sparse, noise, b"", b"\x00" * 1, b"\x00" * 100000, b"abc" * 7, bytes(2048), bytes(2049)):
+        c = rcmp.compress(2, 1, data, None)
+        assert orc.lz4f_decode(c, len(data) + 8) == data
+        assert rcmp.de_compress(2, c, None) == data
+    assert len(rcmp.compress(2, 1, b"\x00" * 100000, None)) < 1500  # 49 blocks x (4 + 25) + 11
+    # streams written by stock liblz4 (linked 64 KiB blocks, what lz4.frame.compress produces) must decode too
+    name = ctypes.util.find_library("lz4")
+    if name:
+        L = C.CDLL(name)
+        L.LZ4F_compressFrameBound.restype = C.c_size_t
+        L.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+        L.LZ4F_compressFrame.restype = C.c_size_t
+        L.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        for data in (sparse * 3, noise):
+            cap = L.LZ4F_compressFrameBound(len(data), None)
+            dst = C.create_string_buffer(cap)
+            n = L.LZ4F_compressFrame(dst, cap, data, len(data), None)
+            assert rcmp.de_compress(2, dst.raw[:n], None) == data
+    with pytest.raises(ValueError):
+        rcmp.de_compress(2, b"\x04\x22\x4d\x18\x60\x40\x82" + b"\x05\x00\x00\x00" + b"\xff" * 5 + b"\x00" * 4, None)
+
+
+def test_c_recode_reader_shim(orc):
+    from pyrecode_amd import c_recode
+    rng = np.random.default_rng(8)
+    ny, nx, d = 50, 70, 12
+    binary = rng.random((ny, nx)) < 0.1
+    vals = rng.integers(1, 4096, int(binary.sum())).astype(np.uint16)
+    bitmap = np.packbits(binary.ravel(), bitorder="little").tobytes()
+    r = c_recode.Reader()
+    assert r.create_buffers(ny, nx, d) == 1
+    packed = memoryview(bytearray((vals.size * d + 7) // 8))
+    r.bit_pack_pixel_intensities(len(packed), vals.size, d, memoryview(bytearray(vals.tobytes())), packed)
+    assert bytes(packed) == orc.bit_pack(vals, d).tobytes()
+    buf = memoryview(bytearray(ny * nx * 3 * 8))  # sized like the reference does (recode_reader.py:111-115)
+    n = r.get_frame_sparse(1, bitmap, bytes(packed), buf)
+    assert n == vals.size
+    trip = np.frombuffer(buf, np.uint64, count=n * 3).reshape(n, 3)
+    assert np.array_equal(trip, orc.unpack_frame_sparse(nx, ny, d, np.frombuffer(bitmap, np.uint8), np.frombuffer(packed, np.uint8), 1))
+    out = memoryview(bytearray(8 * vals.size))
+    assert r.bit_unpack_pixel_intensities(vals.size, bytes(packed), out) == vals.size
+    assert np.array_equal(np.frombuffer(out, np.uint64), vals.astype(np.uint64))
+    assert r.count(bitmap) == vals.size

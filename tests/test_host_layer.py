@@ -1,0 +1,204 @@
+"""CPU: the host-side mirror of the reference interface (header, structures, params, reader parsing, merge_parts) against
+files written by the reference itself, and the C-ABI library's symbol table.  No compute entry point is called."""
+import os
+import re
+import shutil
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO, load_npz
+
+FILES = os.path.join(GOLDEN, "files")
+CASES = [("l1z12", 1, 3), ("l1z16", 1, 2), ("l1ro16", 1, 2), ("l3z", 3, 2)]
+
+
+def test_library_exports_every_declared_symbol():
+    from pyrecode_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "recode_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared and declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()  # resolves every symbol; raises AttributeError on a mismatch
+    assert L.rc_abi_version() == 1
+    assert L.rc_scheme_on_device(2) == 1 and L.rc_scheme_on_device(0) == 0
+    assert L.rc_strerror(-5).decode() == "Buffer size smaller than compressed data size"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from pyrecode_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.RecodeHipError, match="no CPU path"):
+        _lib.ReduceContext(64, 64, 12)
+    out = np.zeros(8, np.uint8)
+    vals = np.arange(4, dtype=np.uint16)
+    with pytest.raises(_lib.RecodeHipError):
+        _lib.check(_lib.lib().rc_bit_pack(vals.ctypes.data, 4, 12, out.ctypes.data, 6))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "pyrecode_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "librecode_oracle" not in text, f
+
+
+@pytest.mark.parametrize("tag,level,nodes", CASES)
+def test_header_roundtrip_and_offsets(tag, level, nodes):
+    from pyrecode_amd.recode_header import ReCoDeHeader
+    path = os.path.join(FILES, "g3_%s.rc%d_part000" % (tag, level))
+    raw = open(path, "rb").read(512)
+    h = ReCoDeHeader()
+    h.load(path)
+    assert h.recode_header_length == 512 and h.to_bytes() == raw
+    d = h.as_dict()
+    # SURVEY §8f-N3 offsets
+    assert struct.unpack_from("<Q", raw, 0)[0] == 158966344846346 == d["uid"]
+    assert (raw[8], raw[9], raw[10], raw[11], raw[12], raw[13]) == (0, 2, 1, level, d["rc_operation_mode"], 1)
+    assert struct.unpack_from("<III", raw, 15) == (d["nx"], d["ny"], d["nz"])
+    assert h.get_field_position_in_bytes("nz") == 23 and h.get_field_position_in_bytes("source_file_name") == 37
+    assert h.get_field_position_in_bytes("source_bit_depth") == 258 and raw[258] == d["source_bit_depth"]
+    assert d["source_file_name"] == ("g3_" + tag).ljust(100)
+    assert h.get_frame_data_offset(True, 12) == 512 and h.get_frame_data_offset(False, 12) == 512 + 12 * d["nz"]
+
+
+@pytest.mark.parametrize("tag,level,nodes", CASES)
+def test_header_create_matches_reference_bytes(tag, level, nodes, tmp_path):
+    from pyrecode_amd.params import InitParams, InputParams
+    from pyrecode_amd.recode_header import ReCoDeHeader
+    g = load_npz("g3_%s.npz" % tag)
+    cfg = tmp_path / "p.txt"
+    cfg.write_text("".join("%s = %d\n" % (k, int(v)) for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"])))
+    ip = InputParams()
+    ip.load(str(cfg))
+    assert ip.validate()
+    init = InitParams("batch", str(tmp_path), image_filename="g3_" + tag)
+    h = ReCoDeHeader()
+    h.create(init, ip, True)
+    h.set("source_header_length", 0)
+    assert h.validate()
+    # the part header's nz is rewritten at close() with the frames that node wrote
+    ref = open(os.path.join(FILES, "g3_%s.rc%d_part000" % (tag, level)), "rb").read(512)
+    h.update("nz", struct.unpack_from("<I", ref, 23)[0])
+    assert h.to_bytes() == ref
+
+
+def test_params_file_of_the_reference_test_loads():
+    from pyrecode_amd.params import InputParams
+    ip = InputParams()
+    ip.load(os.path.join(FILES, "recode_params_minimal_read_write_test.txt"))
+    ip.source_data_type = 0
+    ip.target_data_type = 0
+    assert ip.validate()
+    assert (ip.nx, ip.ny, ip.nz, ip.num_threads) == (512, 512, 9, 3)
+    assert (ip.reduction_level, ip.rc_operation_mode, ip.compression_scheme, ip.compression_level) == (1, 1, 0, 1)
+    assert ip.source_bit_depth == 12 and ip.source_numpy_dtype is np.uint16
+    bad = InputParams()
+    with pytest.raises(AssertionError, match="Unknown parameter"):
+        bad._param_map.pop("num_rows")
+        bad.load(os.path.join(FILES, "recode_params_minimal_read_write_test.txt"))
+
+
+def test_structures_match_reference_layout():
+    from pyrecode_amd.structures import ReCoDeStructures
+    s = ReCoDeStructures({"nx": 53, "ny": 37})
+    assert s.binary_image_sz_bytes == 246
+    assert [f["name"] for f in s.standard_frame_metadata_structure_for(1, 1)] == [
+        "bytes_in_compressed_binary_map", "bytes_in_compressed_pixvals", "bytes_in_packed_pixvals"]
+    assert s.get_standard_frame_metadata_size(1, 1) == 12 and s.get_standard_frame_metadata_size(1, 0) == 4
+    assert s.get_standard_frame_metadata_size(3, 1) == 4 and s.get_standard_frame_metadata_size(3, 0) == 0
+    md = {"bytes_in_compressed_binary_map": 10, "bytes_in_compressed_pixvals": 20, "bytes_in_packed_pixvals": 99}
+    assert s.get_frame_data_size(1, 1, md) == 30
+    assert s.get_frame_data_size(1, 0, {"bytes_in_packed_pixvals": 7}) == 246 + 7
+    assert s.get_frame_data_size(3, 0, {}) == 246 and s.get_frame_data_size(4, 1, md) == 10
+
+
+@pytest.mark.parametrize("tag,level,nodes", CASES)
+def test_merge_parts_reproduces_reference_merged_file(tag, level, nodes, tmp_path):
+    from pyrecode_amd.recode_reader import merge_parts
+    base = "g3_%s.rc%d" % (tag, level)
+    for i in range(nodes):
+        shutil.copy(os.path.join(FILES, "%s_part%03d" % (base, i)), tmp_path)
+    merge_parts(str(tmp_path), base, nodes)
+    assert (tmp_path / base).read_bytes() == open(os.path.join(FILES, base), "rb").read()
+
+
+@pytest.mark.parametrize("tag,level,nodes", CASES)
+def test_reader_raw_access_and_seek_table(tag, level, nodes):
+    from pyrecode_amd.recode_reader import ReCoDeReader
+    g = load_npz("g3_%s.npz" % tag)
+    nz = g["frames"].shape[0]
+    base = os.path.join(FILES, "g3_%s.rc%d" % (tag, level))
+    rd = ReCoDeReader(base, is_intermediate=False)
+    rd.open(print_header=False)
+    assert rd.get_shape() == (nz, g["frames"].shape[1], g["frames"].shape[2])
+    merged = open(base, "rb").read()
+    start = 512 + nz * rd.sz_frame_metadata
+    pieces = []
+    for z in range(nz):
+        f = rd.get_next_frame_raw()
+        (fid, body), = f.items()
+        assert fid == z
+        blob = b"".join(body["data"].values())
+        assert merged[start + int(rd._seek_table[z, 1]):start + int(rd._seek_table[z, 1]) + len(blob)] == blob
+        pieces.append(blob)
+    assert b"".join(pieces) == merged[start:]
+    rd.close()
+    # intermediate file: frame ids follow the contiguous-block rule; EOF -> None
+    part = ReCoDeReader(base + "_part001", is_intermediate=True)
+    part.open(print_header=False)
+    ids = []
+    while True:
+        f = part.get_next_frame_raw(read_data=False)
+        if f is None:
+            break
+        ids.append(int(list(f.keys())[0]))
+    per = -(-nz // nodes)
+    assert ids == list(range(per, min(2 * per, nz)))
+    with pytest.raises(ValueError):
+        part.get_frame(0)
+    part.close()
+
+
+def test_writer_constructor_validation(tmp_path):
+    from pyrecode_amd.params import InputParams
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    g = load_npz("g3_l1z12.npz")
+    cfg = tmp_path / "p.txt"
+    cfg.write_text("".join("%s = %d\n" % (k, int(v)) for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"])))
+
+    def params(**over):
+        ip = InputParams()
+        ip.load(str(cfg))
+        for k, v in over.items():
+            ip._param_map[k] = v
+        return ip
+    with pytest.raises(RuntimeError, match="different shapes"):
+        ReCoDeWriter("x", dark_data=np.zeros((3, 3), np.uint16), output_directory=str(tmp_path), input_params=params())
+    with pytest.raises(ValueError, match="Invalid input params"):
+        ReCoDeWriter("x", dark_data=g["dark"], output_directory=str(tmp_path), input_params=params(reduction_level=7))
+    with pytest.raises(ValueError, match="Invalid initialization parameters"):
+        ReCoDeWriter("x", dark_data=g["dark"], output_directory="", input_params=params())
+    with pytest.raises(NotImplementedError):
+        ReCoDeWriter("x", dark_data=g["dark"], output_directory=str(tmp_path), input_params=params(reduction_level=2))
+    w = ReCoDeWriter("x", dark_data=g["dark"], output_directory=str(tmp_path), input_params=params())
+    assert w._header["nx"] == 56 and w._header["is_intermediate"] is True
+
+
+def test_compressor_seam_host_schemes_and_errors():
+    from pyrecode_amd import recode_compressors as rcmp
+    data = bytes(range(256)) * 8
+    for scheme in (0, 4, 5):
+        c = rcmp.compress(scheme, 1, data, None)
+        assert rcmp.de_compress(scheme, c, None) == data
+    import zlib
+    assert rcmp.compress(0, 1, data, None) == zlib.compress(data, 1)
+    with pytest.raises(NotImplementedError):
+        rcmp.compress(12, 1, data, None)
+    with pytest.raises(NotImplementedError):
+        rcmp.de_compress(99, data, None)
+    assert rcmp.import_checks({"compression_scheme": 0}) and rcmp.import_checks({"compression_scheme": 2})

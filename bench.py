@@ -144,6 +144,7 @@ def main():
     op_mode = 1
     ctx = hip.ReduceContext(a.nx, a.ny, a.depth, 1, op_mode, a.scheme, 1, local, max_batch=B)
     ctx.set_dark(dark.data_ptr(), 0)  # eps = 0 -> thr = dark
+    ctx.keep_binary_maps(False)       # no validation frames in this workload: records only (recode_writer.py:402-415)
     out_cap = B * (N // 2)  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
     out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     rec = torch.empty(B + 1, dtype=torch.int64, device=dev)

@@ -116,6 +116,10 @@ int rc_ctx_sync(rc_ctx *ctx);
 /* Packed binary map (ceil(nx*ny/8) bytes, LSB-first) of frame i of the most recent batch: what the third element
  * of _reduce_compress's return value carries for validation frames (recode_writer.py:386,402-415,557). */
 int rc_get_binary_map(rc_ctx *ctx, uint32_t i, uint8_t *bitmap_out);
+/* The reference only consumes binary_frame for validation frames (recode_writer.py:402-415).  With a device codec the
+ * raw maps are an extra HBM write; a caller that never asks for them can switch that off (default: kept).  Without a
+ * device codec the raw map is part of the record and always produced. */
+int rc_ctx_keep_binary_maps(rc_ctx *ctx, int on);
 
 /* Per-stage device time of the most recent batch in milliseconds (HIP events), keyed like the reference's
  * run metrics (recode_writer.py:451,457,479,506,512,555):

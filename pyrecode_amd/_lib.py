@@ -39,6 +39,7 @@ SIGNATURES = {
     "rc_reduce_compress_batch_async": (C.c_int, [C.c_void_p, _u16p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u64p, _u32p]),
     "rc_ctx_sync": (C.c_int, [C.c_void_p]),
     "rc_get_binary_map": (C.c_int, [C.c_void_p, C.c_uint32, _u8p]),
+    "rc_ctx_keep_binary_maps": (C.c_int, [C.c_void_p, C.c_int]),
     "rc_get_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rc_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rc_ctx_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -180,6 +181,9 @@ class ReduceContext:
         out = np.empty(self.bitmap_bytes, np.uint8)
         check(lib().rc_get_binary_map(self._h, i, ptr(out)), "rc_get_binary_map")
         return out
+
+    def keep_binary_maps(self, on=True):
+        check(lib().rc_ctx_keep_binary_maps(self._h, 1 if on else 0))
 
     def set_profiling(self, on=True):
         check(lib().rc_ctx_set_profiling(self._h, 1 if on else 0))

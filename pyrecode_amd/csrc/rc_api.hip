@@ -77,6 +77,7 @@ struct rc_ctx {
     uint32_t emit = 0;  // 0: mode-0 record pieces, 2: LZ4 frames
     rc::Scratch sc;
     bool thr_set = false;
+    bool keep_bitmap = true;  // also store the raw binary maps when a device codec is active (rc_get_binary_map)
     uint32_t last_n = 0;
     // staging for host callers
     uint16_t *d_frames = nullptr; uint64_t d_frames_cap = 0;
@@ -302,15 +303,11 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
         c->prof_used += 5;
     }
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    launch_reduce(c->sc, frames_dev, n, c->level == 1, s);
+    launch_reduce(c->sc, frames_dev, n, c->level == 1, c->emit, c->keep_bitmap || c->emit == 0, s);
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    if (c->level == 1) launch_scan_counts(c->sc, n, s);
+    launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
-    if (c->emit == RC_SCHEME_LZ4) {
-        launch_lz4_encode_bitmap(c->sc, n, s);
-        launch_scan_blocks(c->sc, n, s);
-    }
-    if (ev) HIP_TRY(hipEventRecord(ev[3], s));
+    if (ev) HIP_TRY(hipEventRecord(ev[3], s));  // (bitmap codec is fused into the reduce kernel)
     launch_layout(c->sc, rp, n, out_cap, rec_off_dev, md_dev, s);
     launch_assemble(c->sc, rp, n, out_dev, rec_off_dev, s);
     if (ev) HIP_TRY(hipEventRecord(ev[4], s));
@@ -400,6 +397,7 @@ RC_EXPORT int rc_get_binary_map(rc_ctx *c, uint32_t i, uint8_t *bitmap_out)
 {
     if (!c || !bitmap_out) return fail(RC_ERR_BAD_ARG, "NULL argument");
     if (i >= c->last_n) return fail(RC_ERR_BAD_ARG, "frame index outside the most recent batch");
+    if (!c->keep_bitmap && c->emit != 0) return fail(RC_ERR_BAD_ARG, "binary maps are not kept (rc_ctx_keep_binary_maps(ctx, 0))");
     HIP_TRY(hipSetDevice(c->device));
     int r = copy_out(bitmap_out, c->sc.bitmap + (uint64_t)i * c->sc.nb_stride, c->sc.nb, c->stream);
     if (r != RC_OK) return r;
@@ -420,6 +418,13 @@ RC_EXPORT int rc_ctx_get_profile(rc_ctx *c, double sum_ms[5], uint64_t *batches)
     if (!c || !sum_ms || !batches) return fail(RC_ERR_BAD_ARG, "NULL argument");
     memcpy(sum_ms, c->prof_sum_ms, sizeof c->prof_sum_ms);
     *batches = c->prof_batches;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_ctx_keep_binary_maps(rc_ctx *c, int on)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    c->keep_bitmap = on != 0;
     return RC_OK;
 }
 
@@ -616,8 +621,8 @@ static int lz4_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t d
     sc.blk_size = reinterpret_cast<uint32_t *>(u.w + T * BLK_SLOT);
     sc.blk_off = sc.blk_size + T;
     sc.frame_cbytes = sc.blk_off + T;
-    launch_lz4_encode_bitmap(sc, 1, u.stream);
-    launch_scan_blocks(sc, 1, u.stream);
+    launch_lz4_encode_buffer(sc, u.stream);
+    launch_scans(sc, 1, false, true, u.stream);
     HIP_TRY(hipMemcpyAsync(u.h_scalar, sc.frame_cbytes, 4, hipMemcpyDeviceToHost, u.stream));
     HIP_TRY(hipStreamSynchronize(u.stream));
     const uint64_t total = 7ull + *reinterpret_cast<uint32_t *>(u.h_scalar) + 4;

@@ -6,16 +6,17 @@
 namespace rc {
 
 // ---- geometry -----------------------------------------------------------------------------------
-// A frame of N = nx*ny uint16 pixels is cut, in row-major (linear) order, into tiles of TILE_PX pixels.
-// One 256-thread workgroup owns one tile position for several consecutive frames.  Inside a tile a
-// "group" is 512 consecutive pixels = one 16-byte load per lane of one wavefront (64 lanes x 8 px);
-// wave w of the workgroup owns groups [w*R, (w+1)*R).  8 pixels per lane == exactly one bitmap byte.
+// A frame of N = nx*ny uint16 pixels is cut, in row-major (linear) order, into tiles of TILE_PX pixels, one tile per
+// WAVEFRONT: a "group" is 512 consecutive pixels = one 16-byte load per lane (64 lanes x 8 px), a tile is R groups.
+// 8 pixels per lane == exactly one bitmap byte, so a tile is TILE_BM = 512 bitmap bytes == one LZ4 / zstd block.
+// Everything a tile produces (bitmap bytes, residuals, encoded block) is wave-local: no barrier, no cross-wave LDS.
+// A 256-thread workgroup covers WAVES consecutive tiles and keeps them for several consecutive frames.
 constexpr int WG = 256;                    // threads per workgroup (4 wavefronts of 64)
 constexpr int WAVES = WG / 64;
 constexpr int R = 8;                       // 16-byte loads per lane per frame-tile
 constexpr int GROUP_PX = 64 * 8;           // 512
-constexpr int TILE_PX = WG * R * 8;        // 16384 pixels = 32 KiB of uint16
-constexpr int TILE_BM = TILE_PX / 8;       // 2048 bitmap bytes per tile == one LZ4 / zstd block
+constexpr int TILE_PX = R * GROUP_PX;      // 4096 pixels = 8 KiB of uint16
+constexpr int TILE_BM = TILE_PX / 8;       // 512 bitmap bytes per tile
 constexpr int BLK_SLOT = TILE_BM + 16;     // per-tile scratch slot for an encoded block (4-byte size word + payload)
 
 // ---- wavefront primitives (64 lanes) ------------------------------------------------------------------
@@ -39,6 +40,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
     x += dpp_zero<0x143, 0xC>(x);   // row_bcast:31 -> rows 2 and 3
     return x;
 }
+
+// value of lane-1 (lane 0 gets 0) / lane+1 (lane 63 gets 0): one DPP move each
+__device__ __forceinline__ uint32_t wave_prev(uint32_t x) { return dpp_zero<0x138>(x); }  // wave_shr:1
+__device__ __forceinline__ uint32_t wave_next(uint32_t x) { return dpp_zero<0x130>(x); }  // wave_shl:1
 
 __device__ __forceinline__ uint32_t wave_last(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
 

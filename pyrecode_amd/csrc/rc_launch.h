@@ -38,16 +38,16 @@ struct RecordParams {
 
 // rc_reduce.hip
 void launch_threshold(const uint16_t *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s);
-void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, hipStream_t s);
-void launch_scan_counts(const Scratch &sc, uint32_t B, hipStream_t s);
-void launch_scan_blocks(const Scratch &sc, uint32_t B, hipStream_t s);
+void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, uint32_t codec, bool keep_bitmap,
+                   hipStream_t s);
+void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);
 void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
                    uint32_t *md, hipStream_t s);
 void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off,
                      hipStream_t s);
 // rc_lz4.hip
 struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
-void launch_lz4_encode_bitmap(const Scratch &sc, uint32_t B, hipStream_t s);
+void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s);  // sc.bitmap = the buffer, sc.nb = its length
 void launch_lz4f_gather(const Scratch &sc, uint32_t hdr3, uint8_t *out, hipStream_t s);
 void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
                        uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s);

@@ -1,0 +1,151 @@
+// rc_lz4_block.h - LZ4 block encoder for one 512-byte block held by one wavefront.
+//
+// Replaces the reference's `lz4.frame.compress(data, compression_level, store_size=False)` on the packed binary map
+// (pyrecode/recode_compressors.py:91, called from recode_writer.py:503-505).  The reference pins no compressed bytes for
+// this scheme: the contract is a valid LZ4 frame that any stock decoder expands to the bit-exact input.
+// Format: lz4_Block_format.md / lz4_Frame_format.md (v1.6.x).
+//
+// Encoder (no hash table - the input is a sparse bitmap, > 90 % zero bytes at the target sparsity):
+//   every run of >= 5 zero bytes becomes  [literal 0x00][match offset=1, length=run-1]  (an overlapping copy, the format's
+//   RLE idiom); everything else is literals.  Two phases, both wave-local:
+//   1. position-major, 8 positions per lane: zero-byte mask, run detection by shift/AND arithmetic on a 24-bit window
+//      (own 8 bits + 8-bit halos from the neighbour lanes via DPP), giving per lane the bits "match start" and "first
+//      literal of a sequence"; their ranks (one packed DPP scan) index two small LDS tables of positions.
+//   2. sequence-major, one sequence per lane (a 512-byte block has at most 86): literal run [FL[k], MS[k]) and match
+//      [MS[k], FL[k+1]) come from the tables; encoded sizes are prefix-summed with one DPP scan; each lane writes its
+//      token, length bytes, literals (copied from the LDS image of the block) and offset into the LDS staging block,
+//      which is flushed with coalesced dword stores.
+//   Work is therefore proportional to the number of sequences (about 40 per block at 1 % sparsity), not to 512.
+//   Block-end rules (last 5 bytes literal, last match starts >= 12 bytes before the end) are met by never matching
+//   inside the last 12 bytes.  A block that would not shrink is stored raw.
+#pragma once
+#include "rc_device.h"
+
+namespace rc {
+
+constexpr int LZ4_BLK = TILE_BM;       // 512
+constexpr int LZ4_MAXSEQ = LZ4_BLK / 5 + 2;
+
+// wave-private LDS working set of the encoder
+struct __attribute__((aligned(16))) Lz4Lds {
+    uint8_t raw[LZ4_BLK];              // block image in position order
+    uint8_t out[LZ4_BLK + 16];         // encoded payload staging
+    uint16_t ms[LZ4_MAXSEQ + 2];       // position of the k-th match start
+    uint16_t fl[LZ4_MAXSEQ + 2];       // position of the k-th sequence start (first literal)
+};
+
+// bit j (0..3) set iff byte j of x is zero (exact, no borrow artefacts)
+__device__ __forceinline__ uint32_t zero_bytes4(uint32_t x)
+{
+    const uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 in every zero byte
+    return (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+__device__ __forceinline__ uint32_t lz4_ext(uint32_t x) { return (x >= 15u ? 1u : 0u) + (x >= 270u ? 1u : 0u); }  // x <= 512
+// LZ4 length extension bytes for a field whose value is 15 + r, r <= 497 (lengths never exceed the 512-byte block)
+__device__ __forceinline__ uint32_t lz4_emit_len(uint8_t *out, uint32_t o, uint32_t r)
+{
+    if (r >= 255) { out[o++] = 255; r -= 255; }
+    out[o++] = (uint8_t)r;
+    return o;
+}
+
+// Wave-collective.  Precondition: L.raw holds the block in position order (written by this wavefront) and `own` is this
+// lane's 8 bytes raw[8*lane .. 8*lane+8), little-endian.  n: valid bytes (1..512).
+// Returns the compressed size (wave-uniform); the payload is in L.out[0..size) only when size < n.
+__device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, Lz4Lds &L)
+{
+    const int lane = lane_id();
+    const int base = 8 * lane;
+    // ---- phase 1: per-lane masks over the 8 owned positions -------------------------------------------------------
+    const uint32_t z = zero_bytes4((uint32_t)own) | (zero_bytes4((uint32_t)(own >> 32)) << 4);
+    auto below = [&](int lim) -> uint32_t {  // mask of own positions p < lim
+        const int rel = lim - base;
+        return rel >= 8 ? 0xFFu : (rel <= 0 ? 0u : ((1u << rel) - 1u));
+    };
+    const uint32_t valid = below((int)n);
+    const uint32_t zeff = z & below((int)n - 12);  // never match inside the last 12 bytes
+    const uint32_t W = wave_prev(zeff) | (zeff << 8) | (wave_next(zeff) << 16);
+    const uint32_t R5 = W & (W >> 1) & (W >> 2) & (W >> 3) & (W >> 4);       // bit i: window positions i..i+4 all zero
+    const uint32_t Q = R5 | (R5 << 1) | (R5 << 2) | (R5 << 3) | (R5 << 4);   // inside a zero run of length >= 5
+    const uint32_t Mw = Q & (Q << 1);                                        // ... and not the run's first byte
+    const uint32_t m = (Mw >> 8) & 0xFFu;                                    // own positions produced by a match
+    const uint32_t after = ((m << 1) | ((Mw >> 7) & 1u)) & 0xFFu;            // bit j: position j-1 is a match position
+    uint32_t fl = ~m & valid & (after | (lane == 0 ? 1u : 0u));              // first literal of a sequence
+    uint32_t ms = m & ~after;                                                // first position of a match
+    // ranks of this lane's starts among all starts of the block
+    const uint32_t cnt = (uint32_t)__builtin_popcount(ms) | ((uint32_t)__builtin_popcount(fl) << 10);
+    const uint32_t inc = wave_incl_scan(cnt);
+    const uint32_t tot = wave_last(inc);
+    const uint32_t nm = tot & 0x3FFu;  // matches; sequences = nm + 1 (the last one has literals only)
+    uint32_t kms = (inc - cnt) & 0x3FFu, kfl = ((inc - cnt) >> 10) & 0x3FFu;
+    for (; ms; ms &= ms - 1) L.ms[kms++] = (uint16_t)(base + __builtin_ctz(ms));
+    for (; fl; fl &= fl - 1) L.fl[kfl++] = (uint16_t)(base + __builtin_ctz(fl));
+
+    // ---- phase 2: one sequence per lane ------------------------------------------------------------------------------
+    uint32_t carry = 0, total = 0;
+    uint32_t seq_o[2], seq_fs[2], seq_ll[2], seq_ml4[2];  // at most 2 rounds of 64 sequences (86 max)
+    const uint32_t nrounds = (nm + 64) / 64;              // ceil((nm + 1) / 64)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        seq_ll[rd] = 0xFFFFFFFFu;  // "no sequence"
+        if ((uint32_t)rd < nrounds) {
+            const uint32_t k = rd * 64 + lane;
+            uint32_t size = 0;
+            if (k <= nm) {
+                const uint32_t fs = L.fl[k];
+                const uint32_t q = k < nm ? L.ms[k] : n;
+                const uint32_t ll = q - fs;
+                size = 1 + lz4_ext(ll) + ll;
+                uint32_t ml4 = 0xFFFFu;  // final sequence: no match
+                if (k < nm) {
+                    ml4 = (uint32_t)L.fl[k + 1] - q - 4u;
+                    size += 2 + lz4_ext(ml4);
+                }
+                seq_fs[rd] = fs; seq_ll[rd] = ll; seq_ml4[rd] = ml4;
+            }
+            const uint32_t sinc = wave_incl_scan(size);
+            seq_o[rd] = carry + sinc - size;
+            carry += wave_last(sinc);
+        }
+    }
+    total = carry;
+    if (total >= n) return total;  // would not shrink: caller stores the block raw
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        if ((uint32_t)rd < nrounds && seq_ll[rd] != 0xFFFFFFFFu) {
+            uint32_t o = seq_o[rd];
+            const uint32_t ll = seq_ll[rd], ml4 = seq_ml4[rd], fs = seq_fs[rd];
+            L.out[o++] = (uint8_t)((min(ll, 15u) << 4) | (ml4 == 0xFFFFu ? 0u : min(ml4, 15u)));
+            if (ll >= 15) o = lz4_emit_len(L.out, o, ll - 15);
+            for (uint32_t i = 0; i < ll; ++i) L.out[o + i] = L.raw[fs + i];
+            o += ll;
+            if (ml4 != 0xFFFFu) {
+                L.out[o++] = 1;  // offset 1, little-endian
+                L.out[o++] = 0;
+                if (ml4 >= 15) o = lz4_emit_len(L.out, o, ml4 - 15);
+            }
+        }
+    }
+    return total;
+}
+
+// Wave-collective: write the block to its slot = [u32 LZ4F block word][payload]; returns slot bytes used.
+__device__ __forceinline__ uint32_t lz4_store_block(uint8_t *slot, uint64_t own, uint32_t n, uint32_t csize, const Lz4Lds &L)
+{
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(slot);
+    const int lane = lane_id();
+    if (csize >= n) {  // stored block: bit 31 of the size word
+        if (lane == 0) slot32[0] = n | 0x80000000u;
+        if ((uint32_t)(8 * lane) < n) {
+            slot32[1 + 2 * lane] = (uint32_t)own;
+            slot32[2 + 2 * lane] = (uint32_t)(own >> 32);
+        }
+        return 4 + n;
+    }
+    if (lane == 0) slot32[0] = csize;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(L.out);
+    for (uint32_t i = lane; i < (csize + 3) / 4; i += 64) slot32[1 + i] = p[i];
+    return 4 + csize;
+}
+
+}  // namespace rc

@@ -7,7 +7,10 @@
 //   A4 LSB-first bitmap                         pyrecode/recode_writer.py:622-634
 //   A5 LSB-first d-bit pack                     pyrecode/recode_writer.py:637-652
 //   A7 record assembly                          pyrecode/recode_writer.py:485-494,518-525,546-550,559-574
+#include <cstdlib>
+
 #include "rc_launch.h"
+#include "rc_lz4_block.h"
 
 namespace rc {
 
@@ -68,25 +71,37 @@ __device__ __forceinline__ u32x4 load8(const uint16_t *__restrict__ base, uint64
     }
 }
 
-// Workgroup `id` owns tile position id / ngroups for frames [g*BZ, g*BZ+BZ) with g = id % ngroups: workgroups that
-// share a threshold tile are adjacent in dispatch order, so the tile is fetched from HBM once per batch and
-// served from L2 / Infinity Cache to the other frame groups.  The threshold stays in registers for BZ frames.
-template <int BZ, bool ALIGNED, bool LEVEL1>
+// Workgroup id -> (tile block, frame group).  A tile block is WAVES consecutive tiles (one per wavefront); a frame group
+// is BZ consecutive frames.  The threshold tile stays in registers for the BZ frames.  The ngroups workgroups that share
+// a tile block get ids that are congruent mod 8 and adjacent within that residue class: the dispatcher deals
+// workgroups round-robin over the 8 XCDs, so they meet in ONE XCD's L2 at about the same time and the threshold is
+// fetched from HBM once per batch (placement affects speed only, never results).
+//
+// Per frame and wavefront, with NO barrier and no cross-wave traffic:
+//   8 x 16-byte nontemporal loads per lane -> saturating subtract (residual and mask in one op) -> 8-bit mask per lane
+//   -> bitmap bytes transposed through wave-private LDS (8 contiguous bytes per lane)
+//   -> [LEVEL1] DPP prefix sums of the popcounts, residuals stored from registers into the tile's slot
+//   -> [CODEC 2] the 512-byte bitmap block is LZ4-encoded in place (rc_lz4_block.h) and written to its slot
+//   -> [KEEP_BITMAP] the raw bitmap bytes are stored as well (rc_get_binary_map / mode-0 records)
+template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP>
 __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
-                                                       uint32_t B, uint32_t ngroups, uint8_t *__restrict__ bitmap,
-                                                       uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
-                                                       uint32_t *__restrict__ tile_cnt)
+                                                       uint32_t B, uint32_t ngroups, uint64_t nb,
+                                                       uint8_t *__restrict__ bitmap, uint64_t nb_stride,
+                                                       uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
+                                                       uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_bm[2][TILE_BM];
-    __shared__ uint32_t s_wtot[2][WAVES];
+    __shared__ Lz4Lds s_lz[CODEC ? WAVES : 1];                                                  // codec working set
+    __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : WAVES][CODEC ? 16 : TILE_BM];  // transpose only
 
-    const uint32_t tile = blockIdx.x / ngroups;
-    const uint32_t grp = blockIdx.x % ngroups;
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t grp = j % ngroups;
+    const uint32_t tblock = (j / ngroups) * 8u + xcd;
     const int lane = lane_id();
-    const int w = threadIdx.x >> 6;
-    const uint64_t tile_px0 = (uint64_t)tile * TILE_PX;
-    const uint64_t lane_px0 = tile_px0 + (uint64_t)(w * R) * GROUP_PX + (uint64_t)lane * 8;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t tile = tblock * WAVES + w;
+    if (tile >= ntiles) return;  // whole wavefront leaves; nothing below synchronises across wavefronts
+    const uint64_t lane_px0 = (uint64_t)tile * TILE_PX + (uint64_t)lane * 8;
 
     u32x4 t[R];
 #pragma unroll
@@ -99,41 +114,30 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
 #pragma unroll
         for (int r = 0; r < R; ++r) x[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
     }
+    const uint32_t n_blk = (uint32_t)min((uint64_t)TILE_BM, nb - (uint64_t)tile * TILE_BM);  // bitmap bytes of this tile
 
 #pragma unroll 1
     for (int z = 0; z < BZ; ++z) {
         const uint32_t f = f0 + z;
         if (f >= B) break;
-        const int buf = z & 1;
+        const uint64_t ft = (uint64_t)f * ntiles + tile;
 
-        // residuals (saturating subtract) and the 8-bit mask of this lane's 8 pixels, per group
+        // residuals (saturating subtract, in place) and the 8-bit mask of this lane's 8 pixels, per group
         uint32_t m8[R];
-        u32x4 res[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            u32x4 d;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = pk_sub_sat_u16(x[r][j], t[r][j]);
-            res[r] = d;
+            for (int k = 0; k < 4; ++k) x[r][k] = pk_sub_sat_u16(x[r][k], t[r][k]);
             const uint32_t one = 0x00010001u;
-            const uint32_t M = pk_min_u16(d[0], one) | (pk_min_u16(d[1], one) << 2) | (pk_min_u16(d[2], one) << 4) |
-                               (pk_min_u16(d[3], one) << 6);  // pixel 2j -> bit 2j, pixel 2j+1 -> bit 16+2j
+            const uint32_t M = pk_min_u16(x[r][0], one) | (pk_min_u16(x[r][1], one) << 2) | (pk_min_u16(x[r][2], one) << 4) |
+                               (pk_min_u16(x[r][3], one) << 6);  // pixel 2k -> bit 2k, pixel 2k+1 -> bit 16+2k
             m8[r] = (M | (M >> 15)) & 0xFFu;
         }
-        // prefetch the next frame of this tile while the current one is compacted
-        if (z + 1 < BZ && f + 1 < B) {
-            const uint16_t *fr = frames + (uint64_t)(f + 1) * N;
-#pragma unroll
-            for (int r = 0; r < R; ++r) x[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) s_bm[buf][(w * R + r) * 64 + lane] = (uint8_t)m8[r];
-
-        uint32_t excl[R];
-        uint32_t wave_total = 0;
         if (LEVEL1) {
             // exclusive prefix of the per-lane popcounts in (group, lane) order: three groups per packed scan
-            // (each field <= 512 needs 10 bits)
+            // (each field <= 512 needs 10 bits); residuals are stored as soon as their group's offsets are known
+            uint32_t wave_total = 0;
+            uint16_t *slot = pix_slots + ft * TILE_PX;
 #pragma unroll
             for (int r0 = 0; r0 < R; r0 += 3) {
                 uint32_t pk = 0;
@@ -146,139 +150,185 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     if (r0 + k < R) {
-                        excl[r0 + k] = wave_total + ((exc >> (10 * k)) & 0x3FFu);
+                        const int r = r0 + k;
+                        // sparse regime: a lane rarely owns more than one set pixel per group, so walk the set bits
+                        // (one wave iteration per "k-th set pixel of any lane") instead of 8 predicated stores
+                        uint32_t m = m8[r];
+                        uint32_t o = wave_total + ((exc >> (10 * k)) & 0x3FFu);
+                        while (m) {
+                            const uint32_t i = (uint32_t)__builtin_ctz(m);
+                            m &= m - 1;
+                            const uint32_t lo = (i & 4u) ? x[r][2] : x[r][0], hi = (i & 4u) ? x[r][3] : x[r][1];
+                            const uint32_t d = (i & 2u) ? hi : lo;
+                            slot[o++] = (uint16_t)((i & 1u) ? (d >> 16) : d);
+                        }
                         wave_total += (tot >> (10 * k)) & 0x3FFu;
                     }
             }
-            if (lane == 0) s_wtot[buf][w] = wave_total;
+            if (lane == 0) tile_cnt[ft] = wave_total;
         }
-        __syncthreads();
-
-        // bitmap: 8 contiguous bytes per thread, coalesced
-        {
-            const u32x2 b = *reinterpret_cast<const u32x2 *>(&s_bm[buf][threadIdx.x * 8]);
-            uint8_t *dst = bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM + threadIdx.x * 8;
-            *reinterpret_cast<u32x2 *>(dst) = b;
+        // the residual registers are free now: fetch the next frame of this tile while the bitmap is encoded
+        if (z + 1 < BZ && f + 1 < B) {
+            const uint16_t *fr = frames + (uint64_t)(f + 1) * N;
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
         }
-        if (LEVEL1) {
-            uint32_t base = 0, total = 0;
+        if (KEEP_BITMAP || CODEC) {
+            // transpose through wave-private LDS: byte (r, lane) -> position r*64 + lane; 8 contiguous bytes per lane out
+            uint8_t *bm = CODEC ? s_lz[w].raw : s_bm[w];
 #pragma unroll
-            for (int i = 0; i < WAVES; ++i) {
-                const uint32_t v = s_wtot[buf][i];
-                if (i < w) base += v;
-                total += v;
-            }
-            if (threadIdx.x == 0) tile_cnt[(uint64_t)f * ntiles + tile] = total;
-            uint16_t *slot = pix_slots + ((uint64_t)f * ntiles + tile) * TILE_PX + base;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t m = m8[r];
-                if (m) {
-                    uint32_t o = excl[r];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (m & (1u << i)) {
-                            const uint32_t d = res[r][i >> 1];
-                            slot[o++] = (uint16_t)((i & 1) ? (d >> 16) : (d & 0xFFFFu));
-                        }
-                    }
-                }
+            for (int r = 0; r < R; ++r) bm[r * 64 + lane] = (uint8_t)m8[r];
+            const u32x2 own = *reinterpret_cast<const u32x2 *>(&bm[lane * 8]);
+            if (KEEP_BITMAP)
+                *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = own;
+            if (CODEC == 2) {
+                const uint64_t bytes = (uint64_t)own[0] | ((uint64_t)own[1] << 32);
+                const uint32_t csize = lz4_encode_block(bytes, n_blk, s_lz[w]);
+                const uint32_t used = lz4_store_block(blk_slots + ft * BLK_SLOT, bytes, n_blk, csize, s_lz[w]);
+                if (lane == 0) blk_size[ft] = used;
             }
         }
     }
 }
 
-void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, hipStream_t s)
+static int reduce_bz()
 {
-    constexpr int BZ = 4;
+    static const int bz = [] {
+        const char *e = getenv("RC_BZ");
+        const int v = e ? atoi(e) : 4;
+        return (v == 2 || v == 8) ? v : 4;
+    }();
+    return bz;
+}
+
+template <int BZ, bool AL, bool L1, int CODEC, bool KEEP>
+static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, hipStream_t s)
+{
     const uint32_t ngroups = (B + BZ - 1) / BZ;
-    const dim3 grid(sc.ntiles * ngroups), block(WG);
-    const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
-#define RC_LAUNCH(AL, L1)                                                                                          \
-    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1>), grid, block, 0, s, frames, sc.thr, sc.N, sc.ntiles, B, ngroups, \
-                       sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt)
-    if (aligned) {
-        if (level1) RC_LAUNCH(true, true); else RC_LAUNCH(true, false);
+    const uint32_t ntb = (sc.ntiles + WAVES - 1) / WAVES;
+    const uint32_t grid = ((ntb + 7) / 8) * 8 * ngroups;
+    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N, sc.ntiles, B,
+                       ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size);
+}
+template <int BZ, bool AL>
+static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, uint32_t codec, bool keep,
+                            hipStream_t s)
+{
+    if (codec == 2) {
+        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 2, true>(sc, frames, B, s); else launch_reduce_t<BZ, AL, true, 2, false>(sc, frames, B, s); }
+        else        { if (keep) launch_reduce_t<BZ, AL, false, 2, true>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 2, false>(sc, frames, B, s); }
     } else {
-        if (level1) RC_LAUNCH(false, true); else RC_LAUNCH(false, false);
+        if (level1) launch_reduce_t<BZ, AL, true, 0, true>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 0, true>(sc, frames, B, s);
     }
-#undef RC_LAUNCH
+}
+void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, uint32_t codec, bool keep_bitmap,
+                   hipStream_t s)
+{
+    const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
+    const int bz = reduce_bz();
+    if (aligned) {
+        if (bz == 8) launch_reduce_a<8, true>(sc, frames, B, level1, codec, keep_bitmap, s);
+        else if (bz == 2) launch_reduce_a<2, true>(sc, frames, B, level1, codec, keep_bitmap, s);
+        else launch_reduce_a<4, true>(sc, frames, B, level1, codec, keep_bitmap, s);
+    } else {
+        launch_reduce_a<4, false>(sc, frames, B, level1, codec, keep_bitmap, s);
+    }
 }
 
 // ---- per-frame scans over tiles ---------------------------------------------------------------------------
-// One workgroup per frame: exclusive prefix of in[f][0..ntiles) -> off, row total -> total[f]; optionally
-// next[f][t] = smallest t' > t with in[f][t'] > 0 (ntiles if none).
-template <bool WITH_NEXT>
-__global__ __launch_bounds__(WG) void k_scan_rows(const uint32_t *__restrict__ in, uint32_t *__restrict__ off,
-                                                    uint32_t *__restrict__ total, uint32_t *__restrict__ next,
-                                                    uint32_t ntiles, const BatchStatus *__restrict__ st)
+// One 1024-thread workgroup per frame, 4 consecutive entries per thread and round:
+//   tile_off = exclusive prefix of tile_cnt, frame_nnz = its total, tile_next[t] = smallest t' > t with tile_cnt[t'] > 0
+//   blk_off  = exclusive prefix of blk_size, frame_cbytes = its total              (only when a device codec ran)
+constexpr int SCAN_T = 1024, SCAN_W = SCAN_T / 64;
+
+__device__ __forceinline__ uint32_t scan1024_excl(uint32_t v, uint32_t *sm, uint32_t *total)
 {
-    __shared__ uint32_t sm[WAVES + 1];
-    __shared__ uint32_t s_carry;
-    const uint32_t f = blockIdx.x;
-    const uint32_t *row = in + (uint64_t)f * ntiles;
-    uint32_t *orow = off + (uint64_t)f * ntiles;
-    uint32_t carry = 0;
-    for (uint32_t t0 = 0; t0 < ntiles; t0 += WG) {
-        const uint32_t t = t0 + threadIdx.x;
-        const uint32_t v = t < ntiles ? row[t] : 0;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan(v, sm, &tot);
-        if (t < ntiles) orow[t] = carry + ex;
-        carry += tot;
+    const int w = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane_id() == 63) sm[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_W; ++i) {
+        const uint32_t x = sm[i];
+        if (i < w) base += x;
+        tot += x;
     }
-    if (threadIdx.x == 0) total[f] = carry;
-    if (WITH_NEXT) {
-        // suffix pass, chunks from the end: next non-empty tile index
-        uint32_t *nrow = next + (uint64_t)f * ntiles;
-        if (threadIdx.x == 0) s_carry = ntiles;
-        __syncthreads();
-        const uint32_t nchunks = (ntiles + WG - 1) / WG;
-        for (uint32_t c = nchunks; c-- > 0;) {
-            const uint32_t t = c * WG + threadIdx.x;
-            const uint32_t v = t < ntiles ? row[t] : 0;
-            // candidate = own index if non-empty else "infinite"; suffix-min over lanes to the right (exclusive)
-            uint32_t cand = v ? t : 0xFFFFFFFFu;
-            // inclusive suffix-min inside the wave via shuffles
-            uint32_t m = cand;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_down(m, d);
-                if (lane_id() + d < 64) m = min(m, y);
-            }
-            const int w = threadIdx.x >> 6;
-            if (lane_id() == 0) sm[w] = m;  // min of the whole wave
-            __syncthreads();
-            uint32_t right = s_carry;  // min over all later chunks
-#pragma unroll
-            for (int i = WAVES - 1; i >= 0; --i)
-                if (i > w) right = min(right, sm[i]);
-            uint32_t excl_in_wave = __shfl_down(m, 1);
-            if (lane_id() == 63) excl_in_wave = 0xFFFFFFFFu;
-            const uint32_t nx = min(excl_in_wave, right);
-            if (t < ntiles) nrow[t] = nx;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t all = s_carry;
-#pragma unroll
-                for (int i = 0; i < WAVES; ++i) all = min(all, sm[i]);
-                s_carry = all;
-            }
-            __syncthreads();
-        }
-    }
-    (void)st;
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
 }
 
-void launch_scan_counts(const Scratch &sc, uint32_t B, hipStream_t s)
+__device__ __forceinline__ void scan_row(const uint32_t *__restrict__ row, uint32_t *__restrict__ orow, uint32_t n,
+                                         uint32_t *__restrict__ total, uint32_t *sm)
 {
-    hipLaunchKernelGGL((k_scan_rows<true>), dim3(B), dim3(WG), 0, s, sc.tile_cnt, sc.tile_off, sc.frame_nnz,
-                       sc.tile_next, sc.ntiles, sc.status);
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += SCAN_T * 4) {
+        const uint32_t t = t0 + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = t + k < n ? row[t + k] : 0;
+        uint32_t tot;
+        uint32_t ex = carry + scan1024_excl(v[0] + v[1] + v[2] + v[3], sm, &tot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (t + k < n) orow[t + k] = ex;
+            ex += v[k];
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
 }
-void launch_scan_blocks(const Scratch &sc, uint32_t B, hipStream_t s)
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_counts, int with_blocks)
 {
-    hipLaunchKernelGGL((k_scan_rows<false>), dim3(B), dim3(WG), 0, s, sc.blk_size, sc.blk_off, sc.frame_cbytes,
-                       (uint32_t *)nullptr, sc.ntiles, sc.status);
+    __shared__ uint32_t sm[SCAN_W];
+    __shared__ uint32_t s_carry;
+    const uint32_t f = blockIdx.x, n = sc.ntiles;
+    const uint64_t fr = (uint64_t)f * n;
+    if (with_blocks) scan_row(sc.blk_size + fr, sc.blk_off + fr, n, sc.frame_cbytes + f, sm);
+    if (!with_counts) return;
+    const uint32_t *row = sc.tile_cnt + fr;
+    scan_row(row, sc.tile_off + fr, n, sc.frame_nnz + f, sm);
+    // suffix pass, rounds from the end: next non-empty tile
+    uint32_t *nrow = sc.tile_next + fr;
+    if (threadIdx.x == 0) s_carry = n;
+    __syncthreads();
+    const uint32_t nrounds = (n + SCAN_T - 1) / SCAN_T;
+    for (uint32_t c = nrounds; c-- > 0;) {
+        const uint32_t t = c * SCAN_T + threadIdx.x;
+        const uint32_t v = t < n ? row[t] : 0;
+        uint32_t m = v ? t : 0xFFFFFFFFu;  // inclusive suffix-min of "own index if non-empty" inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_down(m, d);
+            if (lane_id() + d < 64) m = min(m, y);
+        }
+        const int w = threadIdx.x >> 6;
+        if (lane_id() == 0) sm[w] = m;
+        __syncthreads();
+        uint32_t right = s_carry;  // min over all later rounds
+#pragma unroll
+        for (int i = SCAN_W - 1; i >= 0; --i)
+            if (i > w) right = min(right, sm[i]);
+        uint32_t excl = __shfl_down(m, 1);
+        if (lane_id() == 63) excl = 0xFFFFFFFFu;
+        if (t < n) nrow[t] = min(excl, right);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t all = s_carry;
+#pragma unroll
+            for (int i = 0; i < SCAN_W; ++i) all = min(all, sm[i]);
+            s_carry = all;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s)
+{
+    if (!with_counts && !with_blocks) return;
+    hipLaunchKernelGGL(k_scan_frames, dim3(B), dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
 }
 
 // ---- record layout: sizes, offsets, metadata, status ------------------------------------------------------------
@@ -393,7 +443,9 @@ __device__ __forceinline__ uint32_t pix_fetch(const PixSrc &s, uint32_t v)
 // position of packed-pixel byte b inside the pixel LZ4 frame (stored chunks of 4 MiB)
 __device__ __forceinline__ uint64_t lz4f_stored_pos(uint64_t b) { return LZ4F_HDR + 4 * ((b >> LZ4F_MAXBLK_SHIFT) + 1) + b; }
 
-// One wavefront per (tile, frame): copies the tile's encoded bitmap block (or raw bitmap bytes) to its place in the
+constexpr uint32_t ASM_TPW = 4;  // consecutive tiles handled by one wavefront
+
+// One wavefront per ASM_TPW consecutive tiles of a frame: copies the tile's encoded bitmap block (or raw bitmap bytes) to its place in the
 // record and bit-packs the tile's residuals straight into the record; wave 0 of tile 0 writes the fixed fields.
 __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, uint32_t B, uint8_t *__restrict__ out,
                                                    const uint64_t *__restrict__ rec_off, uint32_t lz4f_hdr_bitmap,
@@ -401,9 +453,9 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
 {
     if (sc.status->code != 0) return;
     const uint32_t f = blockIdx.y;
-    const uint32_t t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint32_t t_first = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * ASM_TPW;
     const int lane = lane_id();
-    if (t >= sc.ntiles) return;
+    if (t_first >= sc.ntiles) return;
     uint8_t *rec = out + rec_off[f];
     const uint64_t frow = (uint64_t)f * sc.ntiles;
     const uint32_t nnz = rp.level == 1 ? sc.frame_nnz[f] : 0;
@@ -421,7 +473,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     }
 
     // fixed fields
-    if (t == 0 && lane == 0) {
+    if (t_first == 0 && lane == 0) {
         store_u32_le(rec, rp.first_frame_id + f);
         if (rp.emit == 0) {
             if (rp.level == 1) store_u32_le(rec + 4, npk);
@@ -450,6 +502,8 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
         }
     }
 
+  const uint32_t t_end = min(t_first + ASM_TPW, sc.ntiles);
+  for (uint32_t t = t_first; t < t_end; ++t) {
     // bitmap stream
     if (rp.emit == 0) {
         const uint64_t b0 = (uint64_t)t * TILE_BM;
@@ -461,9 +515,9 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     }
 
     // packed residuals owned by this tile
-    if (rp.level != 1) return;
+    if (rp.level != 1) continue;
     const uint32_t c = sc.tile_cnt[frow + t];
-    if (c == 0) return;
+    if (c == 0) continue;
     const uint32_t P = sc.tile_off[frow + t];
     uint8_t *pdst = rec + pix_pos;
     const uint32_t d = rp.depth;
@@ -475,7 +529,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
             if (rp.emit == 0) { pdst[b] = (uint8_t)v; pdst[b + 1] = (uint8_t)(v >> 8); }
             else { pdst[lz4f_stored_pos(b)] = (uint8_t)v; pdst[lz4f_stored_pos(b + 1)] = (uint8_t)(v >> 8); }
         }
-        return;
+        continue;
     }
     PixSrc ps{sc.pix_slots + frow * TILE_PX, sc.tile_cnt + frow, sc.tile_next + frow, sc.ntiles, t, P, c, nnz};
     const uint32_t dmask = (1u << d) - 1;
@@ -494,6 +548,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
         }
         pdst[rp.emit == 0 ? b : lz4f_stored_pos(b)] = (uint8_t)acc;
     }
+  }
 }
 
 // xxHash32 of the two descriptor bytes -> LZ4 frame header checksum byte (lz4_Frame_format.md, "HC")
@@ -521,7 +576,8 @@ void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint
 {
     static const uint32_t hdr_bitmap = lz4f_descriptor(0x40);  // 64 KiB max block (blocks are <= 2 KiB)
     static const uint32_t hdr_pix = lz4f_descriptor(0x70);     // 4 MiB max block (stored chunks)
-    const dim3 grid((sc.ntiles + WAVES - 1) / WAVES, B), block(WG);
+    const uint32_t per_wg = WAVES * ASM_TPW;
+    const dim3 grid((sc.ntiles + per_wg - 1) / per_wg, B), block(WG);
     hipLaunchKernelGGL(k_assemble, grid, block, 0, s, sc, rp, B, out, rec_off, hdr_bitmap, hdr_pix);
 }
 

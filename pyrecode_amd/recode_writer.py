@@ -150,6 +150,9 @@ class ReCoDeWriter:
         self._ctx = _lib.ReduceContext(nx, ny, ip.source_bit_depth, ip.reduction_level, ip.rc_operation_mode,
                                        ip.compression_scheme, ip.compression_level, self._pick_device(), self._batch_size)
         self._ctx.set_dark(np.ascontiguousarray(self._calibration_frame), ip.calibration_threshold_epsilon)
+        # raw binary maps are only consumed for validation frames (reference :402-415); skip the extra HBM write otherwise
+        self._keep_maps = init.validation_frame_gap > 0
+        self._ctx.keep_binary_maps(self._keep_maps)
         self._host_compress = ip.rc_operation_mode == 1 and not self._ctx.on_device_codec
         self._out = np.empty(self._ctx.out_capacity(self._batch_size), np.uint8)
         self._chunk_offset = 0
@@ -294,11 +297,13 @@ class ReCoDeWriter:
     def _reduce_compress(self, frame, absolute_frame_index, _statistics=None, _centroiding_scheme=None):
         """The reference's per-frame seam (recode_writer.py:430-557): record bytes land in self._frame_buffer[:length];
         returns (length, metrics, binary_frame)."""
+        self._ctx.keep_binary_maps(True)
         records, metrics = self._reduce_compress_batch(np.ascontiguousarray(frame)[None], int(absolute_frame_index))
         rec = records[0]
         self._frame_buffer[:len(rec)] = rec
         nx, ny = int(self._header['nx']), int(self._header['ny'])
         binary = np.unpackbits(self._ctx.binary_map(0), bitorder='little')[:nx * ny].reshape(ny, nx).astype(bool)
+        self._ctx.keep_binary_maps(self._keep_maps)
         return len(rec), metrics, binary
 
     def close(self):

@@ -137,16 +137,16 @@ static int ctx_alloc(rc_ctx *c)
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipMalloc((void **)&sc.thr, sc.N * 2));
-    HIP_TRY(hipMalloc((void **)&sc.bitmap, B * sc.nb_stride));
+    HIP_TRY(hipMalloc((void **)&sc.bitmap, B * sc.nb_stride + 64));  // + slack: wave_copy reads <= 4 B past a tile
     HIP_TRY(hipMalloc((void **)&sc.tile_cnt, B * T * 4));
     HIP_TRY(hipMalloc((void **)&sc.tile_off, B * T * 4));
     HIP_TRY(hipMalloc((void **)&sc.tile_next, B * T * 4));
     HIP_TRY(hipMalloc((void **)&sc.frame_nnz, B * 4));
     HIP_TRY(hipMalloc((void **)&sc.frame_cbytes, B * 4));
     HIP_TRY(hipMalloc((void **)&sc.status, sizeof(BatchStatus)));
-    if (c->level == 1) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2));
+    if (c->level == 1) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2 + 64));
     if (c->emit != 0) {
-        HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * BLK_SLOT));
+        HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * BLK_SLOT + 64));
         HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
         HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
     }

@@ -412,10 +412,51 @@ __device__ __forceinline__ void store_u32_le(uint8_t *p, uint32_t v)
     p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
 }
 
-// byte copy by one wavefront, arbitrary alignment on both sides
+// ---- wave-cooperative copy of small segments with any destination alignment -----------------------------------------
+// A segment is n bytes at a 4-byte aligned source going to an arbitrarily aligned destination.  The body is written as
+// aligned dwords: destination dword j = source bytes [head + 4j, head + 4j + 4) = byte funnel shift (v_alignbyte_b32) of
+// the source dwords j and j+1, which each lane fetches with ONE 8-byte load; head / tail bytes are stored singly.
+// The load and the store are separate calls so that a caller can keep several segments in flight.
+// Reads at most 8 bytes past src + n (every slot / row / buffer is padded accordingly).
+struct SegLoad { u32x2 v; };
+
+__device__ __forceinline__ SegLoad seg_load(const uint8_t *__restrict__ src, uint32_t n, uint32_t chunk)
+{
+    SegLoad r;
+    const uint32_t j = chunk * 64 + lane_id();
+    r.v = u32x2{0u, 0u};
+    if (4 * j < n + 4) r.v = *reinterpret_cast<const u32x2 *>(src + 4 * j);  // dwords j and j+1 (j == nd holds the tail)
+    return r;
+}
+__device__ __forceinline__ void seg_store(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n, uint32_t chunk,
+                                          const SegLoad &ld)
+{
+    (void)src;
+    const uint32_t lane = lane_id();
+    const uint32_t head = min(n, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
+    const uint32_t n2 = n - head, nd = n2 >> 2, tail = n2 & 3u;
+    const uint32_t j = chunk * 64 + lane;
+    const uint32_t val = __builtin_amdgcn_alignbyte(ld.v[1], ld.v[0], head);  // source bytes [head + 4j, head + 4j + 4)
+    if (j < nd) reinterpret_cast<uint32_t *>(dst + head)[j] = val;
+    if (j == nd && tail) {  // the lane just behind the body holds the tail bytes in `val`
+        uint8_t *t = dst + head + 4 * nd;
+        t[0] = (uint8_t)val;
+        if (tail > 1) t[1] = (uint8_t)(val >> 8);
+        if (tail > 2) t[2] = (uint8_t)(val >> 16);
+    }
+    if (j == 0 && head) {   // lane 0 holds source dword 0 = the head bytes
+        dst[0] = (uint8_t)ld.v[0];
+        if (head > 1) dst[1] = (uint8_t)(ld.v[0] >> 8);
+        if (head > 2) dst[2] = (uint8_t)(ld.v[0] >> 16);
+    }
+}
+// whole segment, one call (used for the rare segments longer than one 256-byte chunk and by simple callers)
 __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n)
 {
-    for (uint32_t i = lane_id(); i < n; i += 64) dst[i] = src[i];
+    for (uint32_t c = 0; c * 256 < n + 4; ++c) {
+        const SegLoad ld = seg_load(src, n, c);
+        seg_store(dst, src, n, c, ld);
+    }
 }
 
 struct PixSrc {
@@ -443,19 +484,23 @@ __device__ __forceinline__ uint32_t pix_fetch(const PixSrc &s, uint32_t v)
 // position of packed-pixel byte b inside the pixel LZ4 frame (stored chunks of 4 MiB)
 __device__ __forceinline__ uint64_t lz4f_stored_pos(uint64_t b) { return LZ4F_HDR + 4 * ((b >> LZ4F_MAXBLK_SHIFT) + 1) + b; }
 
-constexpr uint32_t ASM_TPW = 4;  // consecutive tiles handled by one wavefront
+constexpr uint32_t ASM_TPW = 16;  // tiles per wavefront: their metadata sits one tile per lane (lanes 0..15)
+constexpr int ASM_U = 8;           // segments kept in flight
 
-// One wavefront per ASM_TPW consecutive tiles of a frame: copies the tile's encoded bitmap block (or raw bitmap bytes) to its place in the
-// record and bit-packs the tile's residuals straight into the record; wave 0 of tile 0 writes the fixed fields.
+// One wavefront per ASM_TPW consecutive tiles of a frame.  Lane L fetches tile L's metadata (one coalesced round trip); the
+// wavefront then walks the tiles with wave-uniform (readlane) sizes and offsets, copying each tile's encoded bitmap block
+// (or raw bitmap bytes) and its residuals to their places in the record, ASM_U segments in flight at a time.
+// Residuals with a bit depth that is not a multiple of 8 are bit-packed on the way (byte-granular path).
 __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, uint32_t B, uint8_t *__restrict__ out,
                                                    const uint64_t *__restrict__ rec_off, uint32_t lz4f_hdr_bitmap,
                                                    uint32_t lz4f_hdr_pix)
 {
     if (sc.status->code != 0) return;
     const uint32_t f = blockIdx.y;
-    const uint32_t t_first = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * ASM_TPW;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t t0 = (blockIdx.x * WAVES + w) * ASM_TPW;
     const int lane = lane_id();
-    if (t_first >= sc.ntiles) return;
+    if (t0 >= sc.ntiles) return;
     uint8_t *rec = out + rec_off[f];
     const uint64_t frow = (uint64_t)f * sc.ntiles;
     const uint32_t nnz = rp.level == 1 ? sc.frame_nnz[f] : 0;
@@ -473,7 +518,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     }
 
     // fixed fields
-    if (t_first == 0 && lane == 0) {
+    if (t0 == 0 && lane == 0) {
         store_u32_le(rec, rp.first_frame_id + f);
         if (rp.emit == 0) {
             if (rp.level == 1) store_u32_le(rec + 4, npk);
@@ -502,53 +547,112 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
         }
     }
 
-  const uint32_t t_end = min(t_first + ASM_TPW, sc.ntiles);
-  for (uint32_t t = t_first; t < t_end; ++t) {
-    // bitmap stream
-    if (rp.emit == 0) {
-        const uint64_t b0 = (uint64_t)t * TILE_BM;
-        const uint32_t n = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
-        wave_copy(rec + bitmap_pos + b0, sc.bitmap + (uint64_t)f * sc.nb_stride + b0, n);
-    } else {
-        const uint32_t n = sc.blk_size[frow + t];
-        wave_copy(rec + bitmap_pos + LZ4F_HDR + sc.blk_off[frow + t], sc.blk_slots + (frow + t) * BLK_SLOT, n);
+    // this lane's tile: metadata
+    const uint32_t tl = t0 + lane;
+    const bool have = tl < sc.ntiles;
+    uint32_t bsz = 0, boff = 0, cnt = 0, poff = 0;
+    if (have) {
+        if (rp.emit == 0) {
+            boff = tl * (uint32_t)TILE_BM;
+            bsz = (uint32_t)min((uint64_t)TILE_BM, sc.nb - (uint64_t)tl * TILE_BM);
+        } else {
+            bsz = sc.blk_size[frow + tl];
+            boff = LZ4F_HDR + sc.blk_off[frow + tl];
+        }
+        if (rp.level == 1) {
+            cnt = sc.tile_cnt[frow + tl];
+            poff = sc.tile_off[frow + tl];
+        }
     }
+    const uint32_t ntl = min(ASM_TPW, sc.ntiles - t0);
+    const uint8_t *bsrc0 = rp.emit == 0 ? sc.bitmap + (uint64_t)f * sc.nb_stride + (uint64_t)t0 * TILE_BM
+                                        : sc.blk_slots + (frow + t0) * BLK_SLOT;
+    const uint32_t bstride = rp.emit == 0 ? TILE_BM : BLK_SLOT;
+    uint8_t *bdst0 = rec + bitmap_pos;
 
-    // packed residuals owned by this tile
-    if (rp.level != 1) continue;
-    const uint32_t c = sc.tile_cnt[frow + t];
-    if (c == 0) continue;
-    const uint32_t P = sc.tile_off[frow + t];
+    // ---- bitmap stream: ASM_U tiles in flight -------------------------------------------------------------------------
+    for (uint32_t k0 = 0; k0 < ntl; k0 += ASM_U) {
+        SegLoad ld[ASM_U];
+        uint32_t sz[ASM_U], of[ASM_U];
+#pragma unroll
+        for (int u = 0; u < ASM_U; ++u) {
+            const uint32_t k = min(k0 + u, ntl - 1);
+            sz[u] = k0 + u < ntl ? (uint32_t)__builtin_amdgcn_readlane((int)bsz, (int)k) : 0u;
+            of[u] = (uint32_t)__builtin_amdgcn_readlane((int)boff, (int)k);
+            ld[u] = seg_load(bsrc0 + (uint64_t)k * bstride, sz[u], 0);
+        }
+#pragma unroll
+        for (int u = 0; u < ASM_U; ++u) {
+            const uint32_t k = min(k0 + u, ntl - 1);
+            const uint8_t *src = bsrc0 + (uint64_t)k * bstride;
+            if (sz[u]) seg_store(bdst0 + of[u], src, sz[u], 0, ld[u]);
+            for (uint32_t c = 1; c * 256 < sz[u] + 4; ++c) {  // rare: segment longer than one chunk
+                const SegLoad more = seg_load(src, sz[u], c);
+                seg_store(bdst0 + of[u], src, sz[u], c, more);
+            }
+        }
+    }
+    if (rp.level != 1) return;
+
+    // ---- residuals ---------------------------------------------------------------------------------------------------------
     uint8_t *pdst = rec + pix_pos;
     const uint32_t d = rp.depth;
     if (d == 16) {
-        const uint16_t *src = sc.pix_slots + (frow + t) * TILE_PX;
-        for (uint32_t i = lane; i < c; i += 64) {
-            const uint32_t v = src[i];
-            const uint64_t b = 2ull * (P + i);
-            if (rp.emit == 0) { pdst[b] = (uint8_t)v; pdst[b + 1] = (uint8_t)(v >> 8); }
-            else { pdst[lz4f_stored_pos(b)] = (uint8_t)v; pdst[lz4f_stored_pos(b + 1)] = (uint8_t)(v >> 8); }
+        const uint8_t *psrc0 = reinterpret_cast<const uint8_t *>(sc.pix_slots + (frow + t0) * TILE_PX);
+        for (uint32_t k0 = 0; k0 < ntl; k0 += ASM_U) {
+            SegLoad ld[ASM_U];
+            uint32_t sz[ASM_U];
+            uint64_t b0[ASM_U];
+#pragma unroll
+            for (int u = 0; u < ASM_U; ++u) {
+                const uint32_t k = min(k0 + u, ntl - 1);
+                sz[u] = k0 + u < ntl ? 2u * (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)k) : 0u;
+                b0[u] = 2ull * (uint32_t)__builtin_amdgcn_readlane((int)poff, (int)k);
+                ld[u] = seg_load(psrc0 + (uint64_t)k * (TILE_PX * 2), sz[u], 0);
+            }
+#pragma unroll
+            for (int u = 0; u < ASM_U; ++u) {
+                if (sz[u] == 0) continue;
+                const uint32_t k = min(k0 + u, ntl - 1);
+                const uint8_t *src = psrc0 + (uint64_t)k * (TILE_PX * 2);
+                const uint64_t b1 = b0[u] + sz[u] - 1;
+                if (rp.emit == 0 || (b0[u] >> LZ4F_MAXBLK_SHIFT) == (b1 >> LZ4F_MAXBLK_SHIFT)) {  // contiguous in the record
+                    uint8_t *dst = pdst + (rp.emit == 0 ? b0[u] : lz4f_stored_pos(b0[u]));
+                    seg_store(dst, src, sz[u], 0, ld[u]);
+                    for (uint32_t c = 1; c * 256 < sz[u] + 4; ++c) {
+                        const SegLoad more = seg_load(src, sz[u], c);
+                        seg_store(dst, src, sz[u], c, more);
+                    }
+                } else {  // straddles a stored-chunk header of the pixel frame: byte by byte
+                    for (uint32_t i = lane; i < sz[u]; i += 64) pdst[lz4f_stored_pos(b0[u] + i)] = src[i];
+                }
+            }
         }
-        continue;
+        return;
     }
-    PixSrc ps{sc.pix_slots + frow * TILE_PX, sc.tile_cnt + frow, sc.tile_next + frow, sc.ntiles, t, P, c, nnz};
+    // generic depth: per tile (wave-uniform metadata), lanes over the bytes whose first bit lies in the tile's values
     const uint32_t dmask = (1u << d) - 1;
-    const uint64_t b_lo = ((uint64_t)P * d + 7) >> 3;
-    const uint64_t b_hi = ((uint64_t)(P + c) * d + 7) >> 3;  // exclusive: bytes whose first bit lies in this tile's values
-    for (uint64_t b = b_lo + lane; b < b_hi; b += 64) {
-        const uint64_t bit0 = b * 8;
-        uint32_t v = (uint32_t)(bit0 / d);
-        const uint32_t o = (uint32_t)(bit0 - (uint64_t)v * d);
-        uint32_t acc = (pix_fetch(ps, v) & dmask) >> o;
-        uint32_t filled = d - o;
-        while (filled < 8) {
-            ++v;
-            acc |= (pix_fetch(ps, v) & dmask) << filled;
-            filled += d;
+    for (uint32_t k = 0; k < ntl; ++k) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)k);
+        if (c == 0) continue;
+        const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)poff, (int)k);
+        PixSrc ps{sc.pix_slots + frow * TILE_PX, sc.tile_cnt + frow, sc.tile_next + frow, sc.ntiles, t0 + k, P, c, nnz};
+        const uint64_t b_lo = ((uint64_t)P * d + 7) >> 3;
+        const uint64_t b_hi = ((uint64_t)(P + c) * d + 7) >> 3;
+        for (uint64_t b = b_lo + lane; b < b_hi; b += 64) {
+            const uint64_t bit0 = b * 8;
+            uint32_t v = (uint32_t)(bit0 / d);
+            const uint32_t o = (uint32_t)(bit0 - (uint64_t)v * d);
+            uint32_t acc = (pix_fetch(ps, v) & dmask) >> o;
+            uint32_t filled = d - o;
+            while (filled < 8) {
+                ++v;
+                acc |= (pix_fetch(ps, v) & dmask) << filled;
+                filled += d;
+            }
+            pdst[rp.emit == 0 ? b : lz4f_stored_pos(b)] = (uint8_t)acc;
         }
-        pdst[rp.emit == 0 ? b : lz4f_stored_pos(b)] = (uint8_t)acc;
     }
-  }
 }
 
 // xxHash32 of the two descriptor bytes -> LZ4 frame header checksum byte (lz4_Frame_format.md, "HC")

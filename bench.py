@@ -5,7 +5,8 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
 
   step      one pass of the hot path over one batch of B synthetic frames per GPU, inputs resident in HBM:
-            rc_reduce_compress_batch_async = reduce kernel -> scans -> bitmap codec -> record layout -> assembly,
+            rc_reduce_compress_batch_async = reduce kernel (LZ4 bitmap encoder fused in) -> scans -> record layout ->
+            assembly (zstd: its block encoder runs as a kernel of its own after the reduce kernel),
             records + offsets + metadata left in HBM; for N > 1 followed by the path's one exchange step, the
             RCCL all-gather of the per-frame metadata (12 B / frame).
   workload  BASELINE.json configs[1]: 4096x4096 uint16, 1 % sparsity, L1 + LZ4 (d = 16 primary; --depth 12 secondary).
@@ -125,7 +126,8 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (any world size)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     L = hip.lib()
@@ -149,7 +151,7 @@ def main():
     out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
     md = torch.empty((B, 3), dtype=torch.int32, device=dev)
-    md_all = torch.empty((world * B, 3), dtype=torch.int32, device=dev) if world > 1 else None
+    md_all = torch.empty((world * B, 3), dtype=torch.int32, device=dev) if use_dist else None
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -158,12 +160,12 @@ def main():
     def step(i):
         lo = (i % nb) * B
         ctx.enqueue(stack[lo].data_ptr(), B, lo, out.data_ptr(), out_cap, rec.data_ptr(), md.data_ptr())
-        if world > 1:
+        if use_dist:  # the path's one exchange step: every rank learns every frame's sizes
             dist.all_gather_into_tensor(md_all, md)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -183,7 +185,7 @@ def main():
     ctx.set_profiling(False)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
     frames_total = world * B * a.steps
@@ -208,7 +210,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {
                 "workload": "%dx%d uint16, %.2f%% sparsity, L1 + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
-                    a.ny, a.nx, a.sparsity_ppm / 1e4, {2: "LZ4 frame", 0: "reduce-only pieces"}.get(a.scheme, str(a.scheme)),
+                    a.ny, a.nx, a.sparsity_ppm / 1e4, {2: "LZ4 frame", 1: "zstd frame", 0: "reduce-only pieces"}.get(a.scheme, str(a.scheme)),
                     a.depth, B, S),
                 "parallelism": "dp%d (contiguous frame blocks per rank, metadata all-gather per step)" % world,
                 "record_bytes_per_frame": round(float(rec_h[-1]) / B, 1),
@@ -217,8 +219,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": B * N * 2,
                          "whole_path_frac": round(fps / world * N * 2 / 1e9 / HBM_PEAK_GBS, 4)},
-            "stage_ms_per_step": {"reduce": round(sums[0] / nbatches, 4), "scan": round(sums[1] / nbatches, 4),
-                                  "bitmap_codec": round(sums[2] / nbatches, 4),
+            "stage_ms_per_step": {"reduce": round(sums[0] / nbatches, 4), "bitmap_codec_kernel": round(sums[1] / nbatches, 4),
+                                  "scan": round(sums[2] / nbatches, 4),
                                   "layout_assemble": round(sums[3] / nbatches, 4), "total": round(sums[4] / nbatches, 4)},
         }
         if world == 1 and not a.no_cpu_baseline:
@@ -229,7 +231,9 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
+        if rank == 0:  # the gathered table must hold this rank's own rows at its block
+            assert torch.equal(md_all[:B].cpu(), md.cpu())
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

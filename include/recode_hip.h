@@ -123,9 +123,11 @@ int rc_ctx_keep_binary_maps(rc_ctx *ctx, int on);
 
 /* Per-stage device time of the most recent batch in milliseconds (HIP events), keyed like the reference's
  * run metrics (recode_writer.py:451,457,479,506,512,555):
- *   [0] frame_thresholding_and_counting_time + frame_binary_image_packing_time (fused reduce kernel)
- *   [1] scans / record layout   [2] frame_binary_image_compression_time   [3] frame_pixel_intensity_packing_time
- *       + frame_pixel_intensity_compression_time (assemble kernel)   [4] whole batch (frame_time * n)
+ *   [0] frame_thresholding_and_counting_time + frame_binary_image_packing_time (fused reduce kernel; with LZ4 the
+ *       bitmap compression is fused in here as well)
+ *   [1] frame_binary_image_compression_time when the codec is a kernel of its own (zstd)   [2] per-frame scans
+ *   [3] record layout + frame_pixel_intensity_packing_time + frame_pixel_intensity_compression_time (assemble kernel)
+ *   [4] whole batch (frame_time * n)
  * Only filled by the synchronous entry point. */
 int rc_get_stage_ms(rc_ctx *ctx, float ms[5]);
 

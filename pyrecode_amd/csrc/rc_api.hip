@@ -85,6 +85,7 @@ struct rc_ctx {
     uint16_t *d_dark = nullptr;   uint64_t d_dark_cap = 0;
     uint64_t *d_rec_off = nullptr;
     uint32_t *d_md = nullptr;
+    void *d_ztab = nullptr;               // zstd FSE tables (emit == 1)
     rc::BatchStatus *h_status = nullptr;  // pinned
     hipEvent_t ev[5] = {};
     float stage_ms[5] = {};
@@ -125,7 +126,7 @@ RC_EXPORT int rc_device_count(int *count)
     *count = n;
     return RC_OK;
 }
-RC_EXPORT int rc_scheme_on_device(uint32_t scheme) { return scheme == RC_SCHEME_LZ4 ? 1 : 0; }
+RC_EXPORT int rc_scheme_on_device(uint32_t scheme) { return (scheme == RC_SCHEME_LZ4 || scheme == RC_SCHEME_ZSTD) ? 1 : 0; }
 
 // ---- seam 1 --------------------------------------------------------------------------------------------------
 static int ctx_alloc(rc_ctx *c)
@@ -149,6 +150,12 @@ static int ctx_alloc(rc_ctx *c)
         HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * BLK_SLOT + 64));
         HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
         HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
+    }
+    if (c->emit == RC_SCHEME_ZSTD) {
+        std::vector<uint8_t> tab(zstd_tables_bytes());
+        zstd_tables_host(tab.data());
+        HIP_TRY(hipMalloc(&c->d_ztab, tab.size()));
+        HIP_TRY(hipMemcpy(c->d_ztab, tab.data(), tab.size(), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc((void **)&c->d_rec_off, (B + 1) * 8));
     HIP_TRY(hipMalloc((void **)&c->d_md, B * 3 * 4));
@@ -222,7 +229,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     rc::Scratch &sc = c->sc;
     void *bufs[] = {sc.thr, sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
                     sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.status, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
-                    c->d_md};
+                    c->d_md, c->d_ztab};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -303,11 +310,14 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
         c->prof_used += 5;
     }
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    launch_reduce(c->sc, frames_dev, n, c->level == 1, c->emit, c->keep_bitmap || c->emit == 0, s);
+    // LZ4 is fused into the reduce kernel; zstd encodes the raw bitmaps in a kernel of its own (one lane per block)
+    const bool fused = c->emit == RC_SCHEME_LZ4;
+    launch_reduce(c->sc, frames_dev, n, c->level == 1, fused ? c->emit : 0u, c->keep_bitmap || !fused, s);
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);
+    if (c->emit == RC_SCHEME_ZSTD) launch_zstd_encode_blocks(c->sc, n, c->d_ztab, s);
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
-    if (ev) HIP_TRY(hipEventRecord(ev[3], s));  // (bitmap codec is fused into the reduce kernel)
+    launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);
+    if (ev) HIP_TRY(hipEventRecord(ev[3], s));
     launch_layout(c->sc, rp, n, out_cap, rec_off_dev, md_dev, s);
     launch_assemble(c->sc, rp, n, out_dev, rec_off_dev, s);
     if (ev) HIP_TRY(hipEventRecord(ev[4], s));
@@ -397,7 +407,7 @@ RC_EXPORT int rc_get_binary_map(rc_ctx *c, uint32_t i, uint8_t *bitmap_out)
 {
     if (!c || !bitmap_out) return fail(RC_ERR_BAD_ARG, "NULL argument");
     if (i >= c->last_n) return fail(RC_ERR_BAD_ARG, "frame index outside the most recent batch");
-    if (!c->keep_bitmap && c->emit != 0) return fail(RC_ERR_BAD_ARG, "binary maps are not kept (rc_ctx_keep_binary_maps(ctx, 0))");
+    if (!c->keep_bitmap && c->emit == RC_SCHEME_LZ4) return fail(RC_ERR_BAD_ARG, "binary maps are not kept (rc_ctx_keep_binary_maps(ctx, 0))");
     HIP_TRY(hipSetDevice(c->device));
     int r = copy_out(bitmap_out, c->sc.bitmap + (uint64_t)i * c->sc.nb_stride, c->sc.nb, c->stream);
     if (r != RC_OK) return r;
@@ -446,6 +456,7 @@ struct Util {
     uint8_t *o = nullptr; uint64_t o_cap = 0;   // output
     uint8_t *w = nullptr; uint64_t w_cap = 0;   // work
     uint64_t *h_scalar = nullptr;               // pinned
+    void *ztab = nullptr;                       // zstd FSE tables
 };
 Util g_util;
 
@@ -726,21 +737,77 @@ static int lz4_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t
     return RC_OK;
 }
 
+static int zstd_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
+{
+    using namespace rc;
+    Util &u = g_util;
+    if (n >= (1ull << 32)) return fail(RC_ERR_BAD_ARG, "rc_compress: input must be < 4 GiB");
+    if (n == 0) {  // a frame needs one block: empty raw block with Last_Block
+        const uint8_t f[9] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x00, 0x01, 0x00, 0x00};
+        if (dst_cap < 9) return fail(RC_ERR_OUT_TOO_SMALL, "rc_compress: dst too small");
+        HIP_TRY(hipMemcpy(dst, f, 9, is_device_ptr(dst) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+        *out_n = 9;
+        return RC_OK;
+    }
+    Scratch sc;
+    sc.ntiles = (uint32_t)((n + TILE_BM - 1) / TILE_BM);
+    sc.nb = n;
+    sc.nb_stride = (uint64_t)sc.ntiles * TILE_BM;
+    const uint8_t *d_src = nullptr;
+    int r = stage_in(src, n, u.a, u.a_cap, d_src, sc.nb_stride - n + 16);
+    if (r != RC_OK) return r;
+    sc.bitmap = const_cast<uint8_t *>(d_src);
+    const uint64_t T = sc.ntiles;
+    r = ensure(u.w, u.w_cap, T * BLK_SLOT + T * 8 + 64);
+    if (r != RC_OK) return r;
+    sc.blk_slots = u.w;
+    sc.blk_size = reinterpret_cast<uint32_t *>(u.w + T * BLK_SLOT);
+    sc.blk_off = sc.blk_size + T;
+    sc.frame_cbytes = sc.blk_off + T;
+    if (!u.ztab) {
+        std::vector<uint8_t> tab(zstd_tables_bytes());
+        zstd_tables_host(tab.data());
+        HIP_TRY(hipMalloc(&u.ztab, tab.size()));
+        HIP_TRY(hipMemcpy(u.ztab, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    }
+    launch_zstd_encode_blocks(sc, 1, u.ztab, u.stream);
+    launch_scans(sc, 1, false, true, u.stream);
+    HIP_TRY(hipMemcpyAsync(u.h_scalar, sc.frame_cbytes, 4, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    const uint64_t total = 6ull + *reinterpret_cast<uint32_t *>(u.h_scalar);
+    if (total > dst_cap) return fail(RC_ERR_OUT_TOO_SMALL, "rc_compress: dst too small (see rc_compress_bound)");
+    uint8_t *d_out = dst;
+    const bool out_host = !is_device_ptr(dst);
+    if (out_host) {
+        r = ensure(u.o, u.o_cap, total);
+        if (r != RC_OK) return r;
+        d_out = u.o;
+    }
+    launch_zstd_gather(sc, d_out, u.stream);
+    HIP_TRY(hipGetLastError());
+    if (out_host) HIP_TRY(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    *out_n = total;
+    return RC_OK;
+}
+
 RC_EXPORT int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap,
                           uint64_t *out_n)
 {
     (void)level;  // the device encoders have a single effort level
     if (!dst || !out_n || (!src && n)) return fail(RC_ERR_BAD_ARG, "NULL argument");
-    if (scheme != RC_SCHEME_LZ4) return fail(RC_ERR_UNSUPPORTED, "rc_compress: compression scheme not implemented on device");
+    if (scheme != RC_SCHEME_LZ4 && scheme != RC_SCHEME_ZSTD)
+        return fail(RC_ERR_UNSUPPORTED, "rc_compress: compression scheme not implemented on device");
     std::lock_guard<std::mutex> lock(g_util.mu);
     int r = util_init();
     if (r != RC_OK) return r;
-    return lz4_compress(src, n, dst, dst_cap, out_n);
+    return scheme == RC_SCHEME_LZ4 ? lz4_compress(src, n, dst, dst_cap, out_n) : zstd_compress(src, n, dst, dst_cap, out_n);
 }
 RC_EXPORT int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
 {
     if (!src || !out_n || (!dst && dst_cap)) return fail(RC_ERR_BAD_ARG, "NULL argument");
-    if (scheme != RC_SCHEME_LZ4) return fail(RC_ERR_UNSUPPORTED, "rc_decompress: compression scheme not implemented on device");
+    if (scheme != RC_SCHEME_LZ4)  // zstd decoding stays with the stock library on the host, like the reference (recode_compressors.py:46)
+        return fail(RC_ERR_UNSUPPORTED, "rc_decompress: compression scheme not implemented on device");
     std::lock_guard<std::mutex> lock(g_util.mu);
     int r = util_init();
     if (r != RC_OK) return r;
@@ -748,9 +815,10 @@ RC_EXPORT int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uin
 }
 RC_EXPORT uint64_t rc_compress_bound(uint32_t scheme, uint64_t n)
 {
-    if (scheme != RC_SCHEME_LZ4) return 0;
     const uint64_t blocks = (n + rc::TILE_BM - 1) / rc::TILE_BM;
-    return 7 + n + 4 * blocks + 4;
+    if (scheme == RC_SCHEME_LZ4) return 7 + n + 4 * blocks + 4;
+    if (scheme == RC_SCHEME_ZSTD) return 9 + n + 3 * blocks;
+    return 0;
 }
 
 // ---- synthetic stacks -------------------------------------------------------------------------------------------

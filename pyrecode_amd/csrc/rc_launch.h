@@ -51,6 +51,11 @@ void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s);  // sc.bitmap =
 void launch_lz4f_gather(const Scratch &sc, uint32_t hdr3, uint8_t *out, hipStream_t s);
 void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
                        uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s);
-uint32_t lz4f_descriptor(uint8_t bd);  // rc_reduce.hip: FLG | BD << 8 | HC << 16
+uint32_t lz4f_descriptor(uint8_t bd);
+// rc_zstd.hip
+void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s);
+void launch_zstd_gather(const Scratch &sc, uint8_t *out, hipStream_t s);
+size_t zstd_tables_bytes();
+void zstd_tables_host(void *dst);  // rc_reduce.hip: FLG | BD << 8 | HC << 16
 
 }  // namespace rc

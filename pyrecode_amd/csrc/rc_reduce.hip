@@ -332,18 +332,29 @@ void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blo
 }
 
 // ---- record layout: sizes, offsets, metadata, status ------------------------------------------------------------
-constexpr uint32_t LZ4F_HDR = 7;                // magic + FLG + BD + HC
-constexpr uint32_t LZ4F_END = 4;                // EndMark
-constexpr uint32_t LZ4F_MAXBLK_SHIFT = 22;      // 4 MiB stored chunks for the pixel stream
+// Framing of the two per-frame streams for the device codecs.  The bitmap stream is [hdr][encoded blocks][end]; the pixel
+// stream is stored ("raw") chunks: [hdr]{[chunk header][<= 2^chunk_shift bytes]}[end].
+//   LZ4 frame  (lz4_Frame_format.md): 7-byte header, 4-byte block words (bit 31 = stored), 4-byte EndMark, 4 MiB chunks
+//   zstd frame (RFC 8878):            6-byte header (magic, descriptor, window), 3-byte block headers, Last_Block bit on the
+//                                     final block instead of an end mark, 128 KiB chunks (Block_Maximum_Size), >= 1 block
+struct FrameFmt { uint32_t hdr, end, chunk_shift, chunk_hdr, min_chunks; };
+__host__ __device__ inline FrameFmt frame_fmt(uint32_t emit)
+{
+    return emit == 1 ? FrameFmt{6, 0, 17, 3, 1} : FrameFmt{7, 4, 22, 4, 0};
+}
 
 __host__ __device__ inline uint32_t packed_bytes(uint32_t nnz, uint32_t depth)
 {
     return depth == 16 ? nnz * 2u : (uint32_t)(((uint64_t)nnz * depth + 7) >> 3);
 }
-__host__ __device__ inline uint32_t lz4f_stored_size(uint32_t n)
+__host__ __device__ inline uint32_t stored_chunks(const FrameFmt &ff, uint32_t n)
 {
-    const uint32_t chunks = (n + (1u << LZ4F_MAXBLK_SHIFT) - 1) >> LZ4F_MAXBLK_SHIFT;
-    return LZ4F_HDR + n + 4 * chunks + LZ4F_END;
+    const uint32_t c = (n + (1u << ff.chunk_shift) - 1) >> ff.chunk_shift;
+    return c < ff.min_chunks ? ff.min_chunks : c;
+}
+__host__ __device__ inline uint32_t stored_size(const FrameFmt &ff, uint32_t n)
+{
+    return ff.hdr + n + ff.chunk_hdr * stored_chunks(ff, n) + ff.end;
 }
 
 __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ frame_nnz,
@@ -368,9 +379,10 @@ __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ fram
             if (rp.level == 1) { sz = 8 + nb + npk; m0 = npk; }
             else sz = 4 + nb;
         } else {  // LZ4 frames (emit == 2)
-            const uint32_t cb = LZ4F_HDR + frame_cbytes[f] + LZ4F_END;
+            const FrameFmt ff = frame_fmt(rp.emit);
+            const uint32_t cb = ff.hdr + frame_cbytes[f] + ff.end;
             if (rp.level == 1) {
-                const uint32_t cp = lz4f_stored_size(npk);
+                const uint32_t cp = stored_size(ff, npk);
                 sz = 16 + (uint64_t)cb + cp; m0 = cb; m1 = cp; m2 = npk;
             } else { sz = 8 + (uint64_t)cb; m0 = cb; }
         }
@@ -481,8 +493,11 @@ __device__ __forceinline__ uint32_t pix_fetch(const PixSrc &s, uint32_t v)
     return 0;
 }
 
-// position of packed-pixel byte b inside the pixel LZ4 frame (stored chunks of 4 MiB)
-__device__ __forceinline__ uint64_t lz4f_stored_pos(uint64_t b) { return LZ4F_HDR + 4 * ((b >> LZ4F_MAXBLK_SHIFT) + 1) + b; }
+// position of packed-pixel byte b inside the pixel stream's frame (stored chunks)
+__device__ __forceinline__ uint64_t stored_pos(const FrameFmt &ff, uint64_t b)
+{
+    return ff.hdr + ff.chunk_hdr * ((b >> ff.chunk_shift) + 1) + b;
+}
 
 constexpr uint32_t ASM_TPW = 16;  // tiles per wavefront: their metadata sits one tile per lane (lanes 0..15)
 constexpr int ASM_U = 8;           // segments kept in flight
@@ -508,11 +523,12 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
 
     uint64_t bitmap_pos, pix_pos;  // record offsets of the bitmap stream and of packed-pixel byte 0's container
     uint32_t cb = 0;
+    const FrameFmt ff = frame_fmt(rp.emit);
     if (rp.emit == 0) {
         bitmap_pos = rp.level == 1 ? 8 : 4;
         pix_pos = bitmap_pos + sc.nb;
     } else {
-        cb = LZ4F_HDR + sc.frame_cbytes[f] + LZ4F_END;
+        cb = ff.hdr + sc.frame_cbytes[f] + ff.end;
         bitmap_pos = rp.level == 1 ? 16 : 8;
         pix_pos = bitmap_pos + cb;
     }
@@ -525,24 +541,40 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
         } else {
             store_u32_le(rec + 4, cb);
             uint8_t *bf = rec + bitmap_pos;
-            store_u32_le(bf, 0x184D2204u);
-            bf[4] = (uint8_t)(lz4f_hdr_bitmap & 0xFF); bf[5] = (uint8_t)((lz4f_hdr_bitmap >> 8) & 0xFF);
-            bf[6] = (uint8_t)((lz4f_hdr_bitmap >> 16) & 0xFF);
-            store_u32_le(bf + cb - LZ4F_END, 0);
+            if (rp.emit == 1) {  // zstd: magic, Frame_Header_Descriptor 0 (no content size, window descriptor follows), 1 KiB window
+                store_u32_le(bf, 0xFD2FB528u);
+                bf[4] = 0; bf[5] = 0x00;
+            } else {
+                store_u32_le(bf, 0x184D2204u);
+                bf[4] = (uint8_t)(lz4f_hdr_bitmap & 0xFF); bf[5] = (uint8_t)((lz4f_hdr_bitmap >> 8) & 0xFF);
+                bf[6] = (uint8_t)((lz4f_hdr_bitmap >> 16) & 0xFF);
+                store_u32_le(bf + cb - ff.end, 0);
+            }
             if (rp.level == 1) {
-                const uint32_t cp = lz4f_stored_size(npk);
+                const uint32_t cp = stored_size(ff, npk);
                 store_u32_le(rec + 8, cp);
                 store_u32_le(rec + 12, npk);
                 uint8_t *pf = rec + pix_pos;
-                store_u32_le(pf, 0x184D2204u);
-                pf[4] = (uint8_t)(lz4f_hdr_pix & 0xFF); pf[5] = (uint8_t)((lz4f_hdr_pix >> 8) & 0xFF);
-                pf[6] = (uint8_t)((lz4f_hdr_pix >> 16) & 0xFF);
-                const uint32_t chunk = 1u << LZ4F_MAXBLK_SHIFT;
-                for (uint32_t k = 0, o = 0; o < npk; ++k, o += chunk) {
-                    const uint32_t len = min(chunk, npk - o);
-                    store_u32_le(pf + LZ4F_HDR + (uint64_t)k * (chunk + 4), len | 0x80000000u);
+                const uint32_t chunk = 1u << ff.chunk_shift, nch = stored_chunks(ff, npk);
+                if (rp.emit == 1) {  // 128 KiB window so that 128 KiB raw blocks are legal
+                    store_u32_le(pf, 0xFD2FB528u);
+                    pf[4] = 0; pf[5] = 7u << 3;
+                    for (uint32_t k = 0; k < nch; ++k) {
+                        const uint32_t o = k * chunk, len = npk > o ? min(chunk, npk - o) : 0u;
+                        const uint32_t h = (k + 1 == nch ? 1u : 0u) | (len << 3);  // Raw_Block
+                        uint8_t *q = pf + ff.hdr + (uint64_t)k * (chunk + 3);
+                        q[0] = (uint8_t)h; q[1] = (uint8_t)(h >> 8); q[2] = (uint8_t)(h >> 16);
+                    }
+                } else {
+                    store_u32_le(pf, 0x184D2204u);
+                    pf[4] = (uint8_t)(lz4f_hdr_pix & 0xFF); pf[5] = (uint8_t)((lz4f_hdr_pix >> 8) & 0xFF);
+                    pf[6] = (uint8_t)((lz4f_hdr_pix >> 16) & 0xFF);
+                    for (uint32_t k = 0; k < nch; ++k) {
+                        const uint32_t o = k * chunk, len = min(chunk, npk - o);
+                        store_u32_le(pf + ff.hdr + (uint64_t)k * (chunk + 4), len | 0x80000000u);
+                    }
+                    store_u32_le(pf + cp - ff.end, 0);
                 }
-                store_u32_le(pf + cp - LZ4F_END, 0);
             }
         }
     }
@@ -557,7 +589,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
             bsz = (uint32_t)min((uint64_t)TILE_BM, sc.nb - (uint64_t)tl * TILE_BM);
         } else {
             bsz = sc.blk_size[frow + tl];
-            boff = LZ4F_HDR + sc.blk_off[frow + tl];
+            boff = ff.hdr + sc.blk_off[frow + tl];
         }
         if (rp.level == 1) {
             cnt = sc.tile_cnt[frow + tl];
@@ -616,15 +648,15 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                 const uint32_t k = min(k0 + u, ntl - 1);
                 const uint8_t *src = psrc0 + (uint64_t)k * (TILE_PX * 2);
                 const uint64_t b1 = b0[u] + sz[u] - 1;
-                if (rp.emit == 0 || (b0[u] >> LZ4F_MAXBLK_SHIFT) == (b1 >> LZ4F_MAXBLK_SHIFT)) {  // contiguous in the record
-                    uint8_t *dst = pdst + (rp.emit == 0 ? b0[u] : lz4f_stored_pos(b0[u]));
+                if (rp.emit == 0 || (b0[u] >> ff.chunk_shift) == (b1 >> ff.chunk_shift)) {  // contiguous in the record
+                    uint8_t *dst = pdst + (rp.emit == 0 ? b0[u] : stored_pos(ff, b0[u]));
                     seg_store(dst, src, sz[u], 0, ld[u]);
                     for (uint32_t c = 1; c * 256 < sz[u] + 4; ++c) {
                         const SegLoad more = seg_load(src, sz[u], c);
                         seg_store(dst, src, sz[u], c, more);
                     }
                 } else {  // straddles a stored-chunk header of the pixel frame: byte by byte
-                    for (uint32_t i = lane; i < sz[u]; i += 64) pdst[lz4f_stored_pos(b0[u] + i)] = src[i];
+                    for (uint32_t i = lane; i < sz[u]; i += 64) pdst[stored_pos(ff, b0[u] + i)] = src[i];
                 }
             }
         }
@@ -650,7 +682,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                 acc |= (pix_fetch(ps, v) & dmask) << filled;
                 filled += d;
             }
-            pdst[rp.emit == 0 ? b : lz4f_stored_pos(b)] = (uint8_t)acc;
+            pdst[rp.emit == 0 ? b : stored_pos(ff, b)] = (uint8_t)acc;
         }
     }
 }

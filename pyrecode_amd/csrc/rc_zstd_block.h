@@ -1,0 +1,447 @@
+// rc_zstd_block.h - Zstandard block encoder for packed binary maps (one 512-byte tile per block), written from the format
+// specification (RFC 8878).  Shared by the HIP kernel (one LANE encodes one block) and by a host-only checker build
+// (tests/zstd_host_check.cpp) that feeds the same bytes to the stock libzstd decoder.
+//
+// Replaces the reference's `ZstdCompressor(level, write_content_size=False).compress(data)` on the packed binary map
+// (pyrecode/recode_writer.py:175-178, recode_compressors.py:88, called from recode_writer.py:503-505).  The reference pins
+// no compressed bytes for this scheme: the contract is a valid zstd frame that the stock decoder expands to
+// the bit-exact input.
+//
+// Block encoding (sparse bitmaps: > 90 % zero bytes at the target sparsity):
+//   all-zero tile        -> RLE block (4 bytes)
+//   otherwise            -> Compressed block: Raw literals + sequences; every run of >= 4 zero bytes is
+//                           [literal 0x00][match: repeat-offset 1, length run-1] (an overlapping copy = RLE).
+//                           Literal lengths and match lengths use the PREDEFINED FSE tables, offsets use RLE mode with
+//                           code 0 (= "repeat offset 1", zero bits per sequence; the frame starts with rep1 = 1 and only
+//                           offset 1 is ever used, and every sequence has >= 1 literal so the code never shifts).
+//   would not shrink     -> Raw block
+#pragma once
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define RC_HD __host__ __device__ __forceinline__
+#else
+#define RC_HD inline
+#endif
+
+namespace rc {
+
+constexpr int ZSTD_BLK = 512;
+constexpr int ZSTD_SLOT_MAX = ZSTD_BLK + 3;  // raw block: 3-byte header + payload
+
+// FSE compression tables of the predefined literal-length and match-length distributions (accuracy log 6).
+struct ZstdTables {
+    uint16_t ll_state[64], ml_state[64];
+    uint32_t ll_dnb[36], ml_dnb[53];   // deltaNbBits
+    int32_t ll_dfs[36], ml_dfs[53];    // deltaFindState
+};
+
+// (host side) FSE_buildCTable of the reference implementation, restated: spread symbols with step (size/2 + size/8 + 3), low-probability
+// (-1) symbols from the top of the table down; state table sorted by symbol; per-symbol transform.
+inline void zstd_build_ctable(const int16_t *norm, int nsym, int table_log, uint16_t *state_table, uint32_t *dnb, int32_t *dfs)
+{
+    const int size = 1 << table_log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint8_t symbol[64];
+    int cumul[64 + 2];
+    int high = size - 1;
+    cumul[0] = 0;
+    for (int u = 1; u <= nsym; ++u) {
+        if (norm[u - 1] == -1) {
+            cumul[u] = cumul[u - 1] + 1;
+            symbol[high--] = (uint8_t)(u - 1);
+        } else {
+            cumul[u] = cumul[u - 1] + norm[u - 1];
+        }
+    }
+    cumul[nsym] = size + 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; ++s)
+        for (int i = 0; i < norm[s]; ++i) {
+            symbol[pos] = (uint8_t)s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    {
+        int c2[64 + 2];
+        for (int i = 0; i <= nsym; ++i) c2[i] = cumul[i];
+        for (int u = 0; u < size; ++u) state_table[c2[symbol[u]]++] = (uint16_t)(size + u);
+    }
+    int total = 0;
+    for (int s = 0; s < nsym; ++s) {
+        const int n = norm[s];
+        if (n == 0) {
+            dnb[s] = (uint32_t)(((table_log + 1) << 16) - (1 << table_log));
+            dfs[s] = 0;
+        } else if (n == -1 || n == 1) {
+            dnb[s] = (uint32_t)((table_log << 16) - (1 << table_log));
+            dfs[s] = total - 1;
+            total++;
+        } else {
+            int hb = 31 - __builtin_clz((unsigned)(n - 1));
+            const int max_bits = table_log - hb;
+            const int min_state_plus = n << max_bits;
+            dnb[s] = (uint32_t)((max_bits << 16) - min_state_plus);
+            dfs[s] = total - n;
+            total += n;
+        }
+    }
+}
+inline void zstd_build_tables(ZstdTables &t)
+{
+    static const int16_t ll[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+    static const int16_t ml[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                   1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+    zstd_build_ctable(ll, 36, 6, t.ll_state, t.ll_dnb, t.ll_dfs);
+    zstd_build_ctable(ml, 53, 6, t.ml_state, t.ml_dnb, t.ml_dfs);
+}
+
+// literal-length / match-length value -> (code, number of extra bits); the extra bits are value - baseline(code)
+RC_HD void zstd_ll_code(uint32_t ll, uint32_t &code, uint32_t &nbits, uint32_t &extra)
+{
+    if (ll < 16) { code = ll; nbits = 0; extra = 0; return; }
+    if (ll < 24) { code = 16 + ((ll - 16) >> 1); nbits = 1; extra = (ll - 16) & 1; return; }
+    if (ll < 32) { code = 20 + ((ll - 24) >> 2); nbits = 2; extra = (ll - 24) & 3; return; }
+    if (ll < 48) { code = 22 + ((ll - 32) >> 3); nbits = 3; extra = (ll - 32) & 7; return; }
+    if (ll < 64) { code = 24; nbits = 4; extra = ll - 48; return; }
+    if (ll < 128) { code = 25; nbits = 6; extra = ll - 64; return; }
+    if (ll < 256) { code = 26; nbits = 7; extra = ll - 128; return; }
+    if (ll < 512) { code = 27; nbits = 8; extra = ll - 256; return; }
+    code = 28; nbits = 9; extra = ll - 512;  // <= 1023; a block holds at most 512 literals
+}
+RC_HD void zstd_ml_code(uint32_t ml, uint32_t &code, uint32_t &nbits, uint32_t &extra)
+{
+    const uint32_t b = ml - 3;  // match length >= 3
+    if (b < 32) { code = b; nbits = 0; extra = 0; return; }
+    if (b < 40) { code = 32 + ((b - 32) >> 1); nbits = 1; extra = (b - 32) & 1; return; }
+    if (b < 48) { code = 36 + ((b - 40) >> 2); nbits = 2; extra = (b - 40) & 3; return; }
+    if (b < 64) { code = 38 + ((b - 48) >> 3); nbits = 3; extra = (b - 48) & 7; return; }
+    if (b < 96) { code = 40 + ((b - 64) >> 4); nbits = 4; extra = (b - 64) & 15; return; }
+    if (b < 128) { code = 42; nbits = 5; extra = b - 96; return; }
+    if (b < 256) { code = 43; nbits = 7; extra = b - 128; return; }
+    code = 44; nbits = 8; extra = b - 256;  // match length <= 514
+}
+
+// backward bit writer of the sequences section: bits accumulate LSB-first, bytes are emitted little-endian
+struct ZstdBits {
+    uint64_t acc;
+    uint32_t n;
+    uint8_t *p;
+};
+RC_HD void zb_add(ZstdBits &b, uint32_t value, uint32_t nbits)
+{
+    b.acc |= (uint64_t)(value & ((1u << nbits) - 1u)) << b.n;
+    b.n += nbits;
+}
+RC_HD void zb_flush(ZstdBits &b)
+{
+    while (b.n >= 8) {
+        *b.p++ = (uint8_t)b.acc;
+        b.acc >>= 8;
+        b.n -= 8;
+    }
+}
+
+struct ZstdSeq { uint16_t ll, ml; };
+
+// Encode one block: src[0..n) -> dst (capacity ZSTD_SLOT_MAX + 8).  `seq` is caller scratch for up to n/4 + 1 sequences.
+// Returns the number of bytes written (block header included).  `last` sets Last_Block.
+RC_HD uint32_t zstd_encode_block(const uint8_t *src, uint32_t n, uint8_t *dst, ZstdSeq *seq, const ZstdTables &T, bool last)
+{
+    const uint32_t lastbit = last ? 1u : 0u;
+    // pass 1: sequences = (literal run, zero run >= 4 minus its first byte); literals are everything not matched
+    uint32_t nseq = 0, nlit = 0, any = 0;
+    {
+        uint32_t i = 0, lit_start = 0;
+        while (i < n) {
+            if (src[i] != 0) { any = 1; ++i; continue; }
+            uint32_t j = i + 1;
+            while (j < n && src[j] == 0) ++j;
+            const uint32_t run = j - i;
+            if (run >= 4) {  // literal zero at i, match of run-1 >= 3 bytes
+                seq[nseq].ll = (uint16_t)(i + 1 - lit_start);
+                seq[nseq].ml = (uint16_t)(run - 1);
+                nlit += i + 1 - lit_start;
+                ++nseq;
+                lit_start = j;
+            }
+            i = j;
+        }
+        nlit += n - lit_start;  // trailing literals (not part of any sequence)
+    }
+    if (!any) {  // RLE block: Block_Size = regenerated size, one byte of content
+        const uint32_t h = lastbit | (1u << 1) | (n << 3);
+        dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16);
+        dst[3] = 0;
+        return 4;
+    }
+    uint8_t *p = dst + 3;
+    // literals section: Raw_Literals_Block, 1-byte header for <= 31 literals else 2-byte (12-bit size)
+    if (nlit < 32) {
+        *p++ = (uint8_t)(nlit << 3);
+    } else {
+        *p++ = (uint8_t)((nlit << 4) | (1u << 2));
+        *p++ = (uint8_t)(nlit >> 4);
+    }
+    {
+        uint32_t i = 0;
+        for (uint32_t s = 0; s < nseq; ++s) {
+            for (uint32_t k = 0; k < seq[s].ll; ++k) *p++ = src[i + k];
+            i += seq[s].ll + seq[s].ml;
+        }
+        while (i < n) *p++ = src[i++];
+    }
+    // sequences section
+    if (nseq < 128) {
+        *p++ = (uint8_t)nseq;
+    } else {
+        *p++ = (uint8_t)(128 + (nseq >> 8));
+        *p++ = (uint8_t)nseq;
+    }
+    if (nseq) {
+        *p++ = (uint8_t)(1u << 4);  // LL predefined (0), OF RLE (1), ML predefined (0)
+        *p++ = 0;                   // the single offset code: 0 = repeat offset 1, no extra bits
+        ZstdBits b{0, 0, p};
+        uint32_t llc, llb, lle, mlc, mlb, mle;
+        zstd_ll_code(seq[nseq - 1].ll, llc, llb, lle);
+        zstd_ml_code(seq[nseq - 1].ml, mlc, mlb, mle);
+        // initial states from the LAST sequence (FSE_initCState2)
+        uint32_t st_ml, st_ll;
+        {
+            const uint32_t nb = (T.ml_dnb[mlc] + (1u << 15)) >> 16;
+            const uint32_t v = (nb << 16) - T.ml_dnb[mlc];
+            st_ml = T.ml_state[(int32_t)(v >> nb) + T.ml_dfs[mlc]];
+        }
+        {
+            const uint32_t nb = (T.ll_dnb[llc] + (1u << 15)) >> 16;
+            const uint32_t v = (nb << 16) - T.ll_dnb[llc];
+            st_ll = T.ll_state[(int32_t)(v >> nb) + T.ll_dfs[llc]];
+        }
+        zb_add(b, lle, llb);
+        zb_add(b, mle, mlb);
+        zb_flush(b);  // (offset: 0 extra bits)
+        for (uint32_t s = nseq - 1; s-- > 0;) {
+            zstd_ll_code(seq[s].ll, llc, llb, lle);
+            zstd_ml_code(seq[s].ml, mlc, mlb, mle);
+            {   // FSE_encodeSymbol: offset state has 0 bits (RLE), then match length, then literal length
+                const uint32_t nb = (st_ml + T.ml_dnb[mlc]) >> 16;
+                zb_add(b, st_ml, nb);
+                st_ml = T.ml_state[(int32_t)(st_ml >> nb) + T.ml_dfs[mlc]];
+            }
+            {
+                const uint32_t nb = (st_ll + T.ll_dnb[llc]) >> 16;
+                zb_add(b, st_ll, nb);
+                st_ll = T.ll_state[(int32_t)(st_ll >> nb) + T.ll_dfs[llc]];
+            }
+            zb_flush(b);
+            zb_add(b, lle, llb);
+            zb_add(b, mle, mlb);
+            zb_flush(b);
+        }
+        zb_add(b, st_ml, 6);  // FSE_flushCState: match length, (offset: 0 bits), literal length
+        zb_add(b, st_ll, 6);
+        zb_add(b, 1, 1);      // end mark
+        zb_flush(b);
+        if (b.n) { *b.p++ = (uint8_t)b.acc; }
+        p = b.p;
+    }
+    const uint32_t content = (uint32_t)(p - (dst + 3));
+    if (content >= n) {  // would not shrink: Raw block
+        const uint32_t h = lastbit | (0u << 1) | (n << 3);
+        dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16);
+        for (uint32_t i = 0; i < n; ++i) dst[3 + i] = src[i];
+        return 3 + n;
+    }
+    const uint32_t h = lastbit | (2u << 1) | (content << 3);
+    dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16);
+    return 3 + content;
+}
+
+// ---- streaming form for the GPU: no sequence array, three passes over the block, dword fast path for zero words ------
+// Output goes through a byte sink that stores aligned dwords (the slot is 16-byte aligned) and never writes at or past
+// `cap`; the position keeps counting so the caller still learns the size.
+struct ZstdSink {
+    uint32_t *d32;   // slot base
+    uint32_t acc;    // bytes not yet stored (little-endian)
+    uint32_t pos;    // bytes put so far
+    uint32_t cap;    // multiple of 4
+};
+RC_HD void zs_put(ZstdSink &k, uint32_t byte)
+{
+    k.acc |= (byte & 0xFFu) << (8 * (k.pos & 3u));
+    ++k.pos;
+    if ((k.pos & 3u) == 0) {
+        if (k.pos <= k.cap) k.d32[(k.pos >> 2) - 1] = k.acc;
+        k.acc = 0;
+    }
+}
+RC_HD void zs_finish(ZstdSink &k)
+{
+    if ((k.pos & 3u) && ((k.pos + 3u) & ~3u) <= k.cap) k.d32[k.pos >> 2] = k.acc;
+}
+struct ZstdBitsS { uint64_t acc; uint32_t n; };
+RC_HD void zbs_add(ZstdBitsS &b, uint32_t value, uint32_t nbits)
+{
+    b.acc |= (uint64_t)(value & ((1u << nbits) - 1u)) << b.n;
+    b.n += nbits;
+}
+RC_HD void zbs_flush(ZstdBitsS &b, ZstdSink &k)
+{
+    while (b.n >= 8) {
+        zs_put(k, (uint32_t)b.acc);
+        b.acc >>= 8;
+        b.n -= 8;
+    }
+}
+
+struct alignas(16) ZW4 { uint32_t v[4]; };
+
+struct ZstdFse {
+    uint32_t st_ml, st_ll;
+    bool first;
+};
+// one sequence, in REVERSE order of appearance (the last sequence of the block comes first)
+RC_HD void zstd_put_sequence(ZstdFse &f, ZstdBitsS &b, ZstdSink &k, const ZstdTables &T, uint32_t ll, uint32_t ml)
+{
+    uint32_t llc, llb, lle, mlc, mlb, mle;
+    zstd_ll_code(ll, llc, llb, lle);
+    zstd_ml_code(ml, mlc, mlb, mle);
+    if (f.first) {  // FSE_initCState2
+        f.first = false;
+        uint32_t nb = (T.ml_dnb[mlc] + (1u << 15)) >> 16;
+        uint32_t v = (nb << 16) - T.ml_dnb[mlc];
+        f.st_ml = T.ml_state[(int32_t)(v >> nb) + T.ml_dfs[mlc]];
+        nb = (T.ll_dnb[llc] + (1u << 15)) >> 16;
+        v = (nb << 16) - T.ll_dnb[llc];
+        f.st_ll = T.ll_state[(int32_t)(v >> nb) + T.ll_dfs[llc]];
+    } else {        // FSE_encodeSymbol: (offset: 0 bits), match length, literal length
+        uint32_t nb = (f.st_ml + T.ml_dnb[mlc]) >> 16;
+        zbs_add(b, f.st_ml, nb);
+        f.st_ml = T.ml_state[(int32_t)(f.st_ml >> nb) + T.ml_dfs[mlc]];
+        nb = (f.st_ll + T.ll_dnb[llc]) >> 16;
+        zbs_add(b, f.st_ll, nb);
+        f.st_ll = T.ll_state[(int32_t)(f.st_ll >> nb) + T.ll_dfs[llc]];
+        zbs_flush(b, k);
+    }
+    zbs_add(b, lle, llb);
+    zbs_add(b, mle, mlb);
+    zbs_flush(b, k);
+}
+
+// src32: the block, 16-byte aligned, readable up to the next multiple of 16 past n.  slot: 16-byte aligned, slot_cap bytes
+// (multiple of 4, >= n + 4).  Returns bytes used in the slot (3-byte block header included).
+RC_HD uint32_t zstd_encode_block_stream(const uint32_t *src32, uint32_t n, uint8_t *slot, uint32_t slot_cap, const ZstdTables &T,
+                                        bool last)
+{
+    const uint32_t lastbit = last ? 1u : 0u;
+    const uint32_t nw = (n + 3) >> 2, ng = (nw + 3) >> 2;
+    const ZW4 *src128 = reinterpret_cast<const ZW4 *>(src32);  // 16-byte loads; the block is readable to a multiple of 16
+    // pass 0: count literals and sequences
+    uint32_t nlit = 0, nseq = 0, any = 0, zrun = 0;
+    for (uint32_t g = 0; g < ng; ++g) {
+      const ZW4 q = src128[g];
+      for (uint32_t jw = 0; jw < 4; ++jw) {
+        const uint32_t w = 4 * g + jw;
+        if (w >= nw) break;
+        const uint32_t x = q.v[jw];
+        const uint32_t nbytes = n - 4 * w >= 4 ? 4u : n - 4 * w;
+        if (x == 0 && nbytes == 4) { zrun += 4; continue; }
+        for (uint32_t kk = 0; kk < nbytes; ++kk) {
+            const uint32_t bt = (x >> (8 * kk)) & 0xFFu;
+            if (bt == 0) { ++zrun; continue; }
+            any = 1;
+            if (zrun >= 4) { ++nseq; ++nlit; } else nlit += zrun;
+            zrun = 0;
+            ++nlit;
+        }
+      }
+    }
+    if (zrun >= 4) { ++nseq; ++nlit; } else nlit += zrun;
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(slot);
+    if (!any) {  // RLE block
+        slot32[0] = lastbit | (1u << 1) | (n << 3);  // 4th byte (the repeated byte) = 0
+        return 4;
+    }
+    ZstdSink k{slot32, 0, 3, slot_cap};  // 3 placeholder bytes for the block header
+    if (nlit < 32) zs_put(k, nlit << 3);
+    else { zs_put(k, (nlit << 4) | (1u << 2)); zs_put(k, nlit >> 4); }
+    // pass A: literals
+    zrun = 0;
+    for (uint32_t g = 0; g < ng; ++g) {
+      const ZW4 q = src128[g];
+      for (uint32_t jw = 0; jw < 4; ++jw) {
+        const uint32_t w = 4 * g + jw;
+        if (w >= nw) break;
+        const uint32_t x = q.v[jw];
+        const uint32_t nbytes = n - 4 * w >= 4 ? 4u : n - 4 * w;
+        if (x == 0 && nbytes == 4) { zrun += 4; continue; }
+        for (uint32_t kk = 0; kk < nbytes; ++kk) {
+            const uint32_t bt = (x >> (8 * kk)) & 0xFFu;
+            if (bt == 0) { ++zrun; continue; }
+            if (zrun >= 4) zs_put(k, 0);
+            else for (; zrun; --zrun) zs_put(k, 0);
+            zrun = 0;
+            zs_put(k, bt);
+        }
+      }
+    }
+    if (zrun >= 4) zs_put(k, 0);
+    else for (; zrun; --zrun) zs_put(k, 0);
+    // sequences section
+    if (nseq < 128) zs_put(k, nseq);
+    else { zs_put(k, 128 + (nseq >> 8)); zs_put(k, nseq); }
+    if (nseq) {
+        zs_put(k, 1u << 4);  // LL predefined, OF RLE, ML predefined
+        zs_put(k, 0);        // offset code 0: repeat offset 1
+        // pass B: backward scan; a sequence is complete when the qualifying run BEFORE it has been seen
+        ZstdFse f{0, 0, true};
+        ZstdBitsS b{0, 0};
+        uint32_t L = 0, pend_ml = 0;
+        bool have = false;
+        zrun = 0;
+        for (uint32_t g = ng; g-- > 0;) {
+          const ZW4 q = src128[g];
+          for (uint32_t jw = 4; jw-- > 0;) {
+            const uint32_t w = 4 * g + jw;
+            if (w >= nw) continue;
+            const uint32_t x = q.v[jw];
+            const uint32_t nbytes = n - 4 * w >= 4 ? 4u : n - 4 * w;
+            if (x == 0 && nbytes == 4) { zrun += 4; continue; }
+            for (uint32_t kk = nbytes; kk-- > 0;) {
+                const uint32_t bt = (x >> (8 * kk)) & 0xFFu;
+                if (bt == 0) { ++zrun; continue; }
+                if (zrun >= 4) {
+                    if (have) zstd_put_sequence(f, b, k, T, L + 1, pend_ml);
+                    have = true; pend_ml = zrun - 1; L = 0;
+                } else L += zrun;
+                zrun = 0;
+                ++L;  // the non-zero byte itself
+            }
+          }
+        }
+        if (zrun >= 4) {
+            if (have) zstd_put_sequence(f, b, k, T, L + 1, pend_ml);
+            have = true; pend_ml = zrun - 1; L = 0;
+        } else L += zrun;
+        if (have) zstd_put_sequence(f, b, k, T, L + 1, pend_ml);
+        zbs_add(b, f.st_ml, 6);
+        zbs_add(b, f.st_ll, 6);
+        zbs_add(b, 1, 1);
+        zbs_flush(b, k);
+        if (b.n) zs_put(k, (uint32_t)b.acc);
+    }
+    const uint32_t content = k.pos - 3;
+    if (content >= n) {  // would not shrink (or overflowed the slot): Raw block
+        ZstdSink r{slot32, 0, 0, slot_cap};
+        const uint32_t h = lastbit | (0u << 1) | (n << 3);
+        zs_put(r, h); zs_put(r, h >> 8); zs_put(r, h >> 16);
+        for (uint32_t i = 0; i < n; ++i) zs_put(r, src32[i >> 2] >> (8 * (i & 3)));
+        zs_finish(r);
+        return 3 + n;
+    }
+    zs_finish(k);
+    const uint32_t h = lastbit | (2u << 1) | (content << 3);
+    slot[0] = (uint8_t)h; slot[1] = (uint8_t)(h >> 8); slot[2] = (uint8_t)(h >> 16);
+    return 3 + content;
+}
+
+}  // namespace rc

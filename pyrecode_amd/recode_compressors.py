@@ -27,7 +27,52 @@ def _optional(name):
 
 
 def _on_device(scheme):
+    """True when the GPU library ENCODES this scheme itself (LZ4 frames, zstd frames)."""
     return bool(_lib.lib().rc_scheme_on_device(int(scheme)))
+
+
+_DEVICE_DECODERS = (2,)  # LZ4 frames are also decoded on the GPU; zstd frames are decoded by the stock library on the host
+
+
+def _zstd_host_decompress(data, decompressor_context=None):
+    """Stream-decode a zstd frame without a content-size field (what both the reference and this library write,
+    recode_writer.py:177-178) with the stock decoder: the `zstandard` package when installed (the reference's own
+    dependency), else libzstd through ctypes.  Host library call, like reference recode_compressors.py:46."""
+    zs = _optional('zstandard')
+    if zs is not None:
+        ctx = decompressor_context if hasattr(decompressor_context, 'decompressobj') else zs.ZstdDecompressor()
+        return ctx.decompressobj().decompress(bytes(data))
+    import ctypes.util
+    name = ctypes.util.find_library('zstd')
+    if not name:
+        raise ImportError("For compression code 1 package zstandard (or libzstd) is required.")
+    L = C.CDLL(name)
+
+    class Buf(C.Structure):
+        _fields_ = [('p', C.c_void_p), ('size', C.c_size_t), ('pos', C.c_size_t)]
+    L.ZSTD_createDStream.restype = C.c_void_p
+    L.ZSTD_freeDStream.argtypes = [C.c_void_p]
+    L.ZSTD_decompressStream.restype = C.c_size_t
+    L.ZSTD_decompressStream.argtypes = [C.c_void_p, C.POINTER(Buf), C.POINTER(Buf)]
+    L.ZSTD_isError.argtypes = [C.c_size_t]
+    src = (C.c_char * len(data)).from_buffer_copy(bytes(data)) if len(data) else (C.c_char * 1)()
+    zds = L.ZSTD_createDStream()
+    out, chunk = bytearray(), C.create_string_buffer(1 << 20)
+    ib = Buf(C.addressof(src), len(data), 0)
+    try:
+        while True:
+            ob = Buf(C.addressof(chunk), len(chunk), 0)
+            r = L.ZSTD_decompressStream(zds, C.byref(ob), C.byref(ib))
+            if L.ZSTD_isError(r):
+                raise ValueError("libzstd rejected the stream")
+            out += chunk.raw[:ob.pos]
+            if r == 0 and ib.pos == ib.size:
+                break
+            if ib.pos == ib.size and ob.pos < ob.size:
+                raise ValueError("truncated zstd frame")
+    finally:
+        L.ZSTD_freeDStream(zds)
+    return bytes(out)
 
 
 def _as_u8(data):
@@ -83,13 +128,12 @@ def de_compress(compression_scheme, compressed_data, decompressor_context):
     s = compression_scheme
     if s not in _compression_scheme_code_map:
         raise NotImplementedError('compression scheme not implemented')
-    if _on_device(s):
+    if s in _DEVICE_DECODERS:
         return device_decompress(s, compressed_data)
     if s == 0:
         return zlib.decompress(compressed_data)
     if s == 1:
-        # streaming decode: frames carry no content size (recode_writer.py:177-178)
-        return decompressor_context.decompressobj().decompress(compressed_data)
+        return _zstd_host_decompress(compressed_data, decompressor_context)
     if s == 3:
         return _need('snappy').decompress(compressed_data)
     if s == 4:
@@ -109,9 +153,15 @@ def _need(module):
 def import_checks(header):
     """True when the package a file's compression scheme needs on the HOST is importable (device codecs need none)."""
     s = int(header['compression_scheme'])
-    if _on_device(s) or s in (0, 4, 5):
+    if s in _DEVICE_DECODERS or s in (0, 4, 5):
         return True
-    module = {1: 'zstandard', 3: 'snappy'}.get(s, 'blosc')
+    if s == 1:
+        import ctypes.util
+        if _optional('zstandard') is None and not ctypes.util.find_library('zstd'):
+            print("For compression code 1 package zstandard is required.")
+            raise ImportError()
+        return True
+    module = {3: 'snappy'}.get(s, 'blosc')
     if _optional(module) is None:
         print("For compression code " + str(s) + " package " + _compression_scheme_code_map[s] + " is required.")
         raise ImportError()

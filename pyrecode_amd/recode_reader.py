@@ -53,9 +53,9 @@ class ReCoDeReader:
         self._create_read_buffers()
         self._load_seek_table()
         self._numpy_dtype = map_dtype(self._header['target_dtype'], self._header['target_bit_depth'])
-        if self._header['compression_scheme'] == 1 and not compressors._on_device(1):
+        if self._header['compression_scheme'] == 1 and compressors._optional('zstandard') is not None:
             import zstandard as zstd
-            self._decompressor_context = zstd.ZstdDecompressor()
+            self._decompressor_context = zstd.ZstdDecompressor()  # (the reference builds a ZstdCompressor here)
 
     def _load_header(self, print_header=True):
         self._rc_header = ReCoDeHeader()

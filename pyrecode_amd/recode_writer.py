@@ -257,10 +257,10 @@ class ReCoDeWriter:
         ms = self._ctx.stage_ms()
         zero = timedelta(0)
         metrics = {
-            'frame_thresholding_and_counting_time': timedelta(milliseconds=ms[0] + ms[1]),
+            'frame_thresholding_and_counting_time': timedelta(milliseconds=ms[0] + ms[2]),
             'frame_binary_image_packing_time': zero,  # fused into the thresholding kernel
             'frame_pixel_intensity_packing_time': timedelta(milliseconds=ms[3]),
-            'frame_binary_image_compression_time': timedelta(milliseconds=ms[2]),
+            'frame_binary_image_compression_time': timedelta(milliseconds=ms[1]),  # LZ4: fused into the first
             'frame_pixel_intensity_compression_time': zero,  # fused into record assembly
         }
         records = [out[int(rec[i]):int(rec[i + 1])] for i in range(n)]

@@ -118,15 +118,15 @@ def test_l3_files_are_readable():
     rd.close()
 
 
-@pytest.mark.parametrize("depth,eps,nodes", [(12, 0, 3), (16, 5, 2)])
-def test_lz4_write_read_round_trip(depth, eps, nodes, tmp_path):
+@pytest.mark.parametrize("depth,eps,nodes,scheme", [(12, 0, 3, 2), (16, 5, 2, 2), (12, 1, 2, 1), (16, 0, 3, 1)])
+def test_device_codec_write_read_round_trip(depth, eps, nodes, scheme, tmp_path):
     """Config-2 shape of flow (L1 + LZ4 on device) at a test size: write parts, merge, read back, compare with the oracle's
     residual image; part files also decode through the oracle's LZ4 decoder (done in test_gpu_parity)."""
     from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
     ny, nx, nz = 300, 420, 7
     dark, frames = synth_frames(77 + depth, nz, ny, nx, 0.02, depth)
     g = load_npz("g3_l1z12.npz")
-    over = dict(num_rows=ny, num_cols=nx, num_frames=nz, num_threads=nodes, compression_scheme=2,
+    over = dict(num_rows=ny, num_cols=nx, num_frames=nz, num_threads=nodes, compression_scheme=scheme,
                 source_bit_depth=depth, target_bit_depth=depth, calibration_threshold_epsilon=eps)
     _write_parts(tmp_path, "rt", dark, frames, nodes, g, batch_size=3, **over)
     merge_parts(str(tmp_path), "rt.rc1", nodes)
@@ -202,6 +202,11 @@ def test_compressor_seam_on_device(orc):
             assert rcmp.de_compress(2, dst.raw[:n], None) == data
     with pytest.raises(ValueError):
         rcmp.de_compress(2, b"\x04\x22\x4d\x18\x60\x40\x82" + b"\x05\x00\x00\x00" + b"\xff" * 5 + b"\x00" * 4, None)
+    # zstd: encoded on the GPU, decoded by the stock library
+    for data in (sparse, noise, b"", b"\x00", b"\x00" * 100000, b"abc" * 7, bytes(512), bytes(513)):
+        c = rcmp.compress(1, 1, data, None)
+        assert rcmp.de_compress(1, c, None) == data
+    assert len(rcmp.compress(1, 1, b"\x00" * 100000, None)) < 1000
 
 
 def test_c_recode_reader_shim(orc):

@@ -1,0 +1,129 @@
+"""-m gpu: BASELINE.json's full frame sizes.  The oracle's C restatement handles a 4096x4096 frame in ~10 ms, so the full
+frames are compared bit-for-bit (not just through properties); on top come the size-independent properties: write -> read
+round trip equals where(frame > thr, frame - thr, 0), popcount(bitmap) == nnz == bytes_in_packed_pixvals * 8 // d, metadata
+equals stream lengths, and the device generator equals its host mirror."""
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from pyrecode_amd import _lib as hip, synth
+    from oracle import oracle as orc
+    orc.lib()
+    if hip.device_count() == 0:
+        pytest.fail("no GPU visible")
+    return torch, hip, synth, orc
+
+
+def _device_stack(torch, hip, seed, n_frames, N, ppm):
+    dark = torch.empty(N, dtype=torch.int16, device="cuda")
+    frames = torch.empty((n_frames, N), dtype=torch.int16, device="cuda")
+    hip.check(hip.lib().rc_synth_dark(0, seed, N, dark.data_ptr()))
+    hip.check(hip.lib().rc_synth_frames(0, seed, 0, n_frames, N, ppm, dark.data_ptr(), frames.data_ptr()))
+    return dark, frames
+
+
+def _decode(orc, scheme, stream, cap):
+    if scheme == 2:
+        return orc.lz4f_decode(stream, cap)
+    from pyrecode_amd.recode_compressors import _zstd_host_decompress
+    return _zstd_host_decompress(stream)
+
+
+@pytest.mark.parametrize("depth,ppm,scheme", [(16, 10000, 2), (12, 10000, 2), (16, 1000, 2), (16, 10000, 1), (12, 1000, 1)])
+def test_4096_device_codec_records_full_oracle_compare(env, depth, ppm, scheme):
+    """configs[1] / configs[2] (and d = 12 / 0.1 % variants): 4096x4096 uint16, L1 + LZ4 or zstd, device-resident in and out."""
+    torch, hip, synth, orc = env
+    ny = nx = 4096
+    N, B = ny * nx, 6
+    dark_d, frames_d = _device_stack(torch, hip, 7, B, N, ppm)
+    ctx = hip.ReduceContext(nx, ny, depth, 1, 1, scheme, 1, 0, max_batch=B)
+    ctx.set_dark(dark_d.data_ptr(), 0)
+    cap = B * (N // 2)
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    rec = torch.empty(B + 1, dtype=torch.int64, device="cuda")
+    md = torch.empty((B, 3), dtype=torch.int32, device="cuda")
+    ctx.enqueue(frames_d.data_ptr(), B, 1000, out.data_ptr(), cap, rec.data_ptr(), md.data_ptr())
+    ctx.sync()
+    rec_h, md_h = rec.cpu().numpy(), md.cpu().numpy()
+    out_h = out[:int(rec_h[-1])].cpu().numpy()
+    thr = dark_d.cpu().numpy().view(np.uint16)
+    frames = frames_d.cpu().numpy().view(np.uint16)
+    # generator: device == host mirror (one frame is enough at this size; small sizes are covered elsewhere)
+    assert np.array_equal(thr, synth.dark_frame(7, N))
+    assert np.array_equal(frames[2], synth.frames(7, 2, 1, N, ppm, thr)[0])
+    for z in range(B):
+        r = out_h[int(rec_h[z]):int(rec_h[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        assert fid == 1000 + z and (cb, cp, npk) == tuple(int(v) for v in md_h[z]) and len(r) == 16 + cb + cp
+        bitmap, packed, nnz = orc.reduce_frame_l1(frames[z], thr, depth)
+        assert npk == packed.size == (nnz * depth + 7) // 8
+        assert _decode(orc, scheme, r[16:16 + cb], bitmap.size + 8) == bitmap.tobytes()
+        assert _decode(orc, scheme, r[16 + cb:], packed.size + 8) == packed.tobytes()
+        assert int(np.unpackbits(bitmap).sum()) == nnz
+        assert abs(nnz / N - ppm / 1e6) < 2e-4
+    ctx.close()
+
+
+def test_direct_electron_size_reduce_only_and_round_trip(env):
+    """configs[4] shape: 11520x8184 uint16, 5 % sparsity, d = 12; reduce-only records vs the oracle, then the reader-side
+    expand must give back where(frame > thr, frame - thr, 0)."""
+    torch, hip, synth, orc = env
+    ny, nx, depth = 8184, 11520, 12
+    N, B = ny * nx, 2
+    dark_d, frames_d = _device_stack(torch, hip, 11, B, N, 50000)
+    ctx = hip.ReduceContext(nx, ny, depth, 1, 0, 0, 1, 0, max_batch=B)
+    ctx.set_dark(dark_d.data_ptr(), 3)
+    thr = (dark_d.cpu().numpy().view(np.uint16) + np.uint16(3)).astype(np.uint16)
+    frames = frames_d.cpu().numpy().view(np.uint16)
+    out, rec, md = ctx.reduce_compress_batch(frames.reshape(B, ny, nx), first_frame_id=0)
+    nb = (N + 7) // 8
+    for z in range(B):
+        r = out[int(rec[z]):int(rec[z + 1])]
+        bitmap, packed, nnz = orc.reduce_frame_l1(frames[z], thr, depth)
+        assert struct.unpack_from("<II", r[:8].tobytes(), 0) == (z, packed.size)
+        assert np.array_equal(r[8:8 + nb], bitmap)
+        assert np.array_equal(r[8 + nb:], packed)
+        # expand (reader side) and compare the dense residual image
+        trip = np.empty((nnz, 3), np.uint64)
+        got = hip.lib().rc_unpack_frame_sparse(nx, ny, depth, hip.ptr(bitmap), hip.ptr(packed), packed.size, hip.ptr(trip), nnz, 1)
+        assert got == nnz
+        dense = np.zeros(N, np.uint16)
+        dense[(trip[:, 0] * nx + trip[:, 1]).astype(np.int64)] = trip[:, 2].astype(np.uint16)
+        want = np.where(frames[z] > thr, frames[z] - thr, 0).astype(np.uint16)
+        assert np.array_equal(dense, want)
+    ctx.close()
+
+
+def test_4096_host_buffer_path_and_pcie_inclusive_rate(env, capsys):
+    """The synchronous entry point with pageable host frames (what ReCoDeWriter.run uses): same records as the device-resident
+    path; prints the PCIe-inclusive rate quoted in DESIGN.md (not bench.py's value)."""
+    import time
+    torch, hip, synth, orc = env
+    ny = nx = 4096
+    N, B = ny * nx, 16
+    dark_d, frames_d = _device_stack(torch, hip, 3, B, N, 10000)
+    frames = frames_d.cpu().numpy().view(np.uint16).reshape(B, ny, nx)
+    ctx = hip.ReduceContext(nx, ny, 16, 1, 1, 2, 1, 0, max_batch=B)
+    ctx.set_dark(dark_d.data_ptr(), 0)
+    out, rec, md = ctx.reduce_compress_batch(frames, 0)           # warm-up + staging allocation
+    t0 = time.perf_counter()
+    out, rec, md = ctx.reduce_compress_batch(frames, 0, out=out)
+    dt = time.perf_counter() - t0
+    thr = dark_d.cpu().numpy().view(np.uint16)
+    for z in (0, B - 1):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        _, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        bitmap, packed, nnz = orc.reduce_frame_l1(frames[z].ravel(), thr, 16)
+        assert orc.lz4f_decode(r[16:16 + cb], bitmap.size + 8) == bitmap.tobytes()
+        assert orc.lz4f_decode(r[16 + cb:], packed.size + 8) == packed.tobytes()
+    with capsys.disabled():
+        print("\n[pcie-inclusive] %d frames 4096x4096 from pageable host memory: %.1f frames/s (%.2f GB/s in)" % (
+            B, B / dt, B * N * 2 / dt / 1e9))
+    ctx.close()

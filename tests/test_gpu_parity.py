@@ -66,6 +66,11 @@ def _check_lz4(orc, stream, expect):
         assert sysd == expect
 
 
+def _zstd_system_decode(data):
+    from pyrecode_amd.recode_compressors import _zstd_host_decompress
+    return _zstd_host_decompress(data)
+
+
 SHAPES = [  # ny, nx, sparsity, depth, eps
     (37, 53, 0.10, 12, 0),      # N not a multiple of 8 -> scalar-load path, ragged last bitmap byte
     (40, 56, 0.05, 12, 7),
@@ -116,7 +121,27 @@ def test_lz4_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode,scheme", [(0, 0), (1, 2), (1, 0)])
+@pytest.mark.parametrize("ny,nx,s,d,eps", SHAPES)
+def test_zstd_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
+    """scheme 1: each stream must be a zstd frame that the STOCK libzstd expands to the bit-exact payload."""
+    dark, frames = synth_frames(31 + nx, 4, ny, nx, s, d)
+    thr = orc.threshold(dark, eps)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 1, 1, 0, max_batch=4)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=3)
+    for z in range(frames.shape[0]):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        assert fid == 3 + z and (cb, cp, npk) == tuple(int(v) for v in md[z]) and len(r) == 16 + cb + cp
+        binary, pix = orc.binarize_l1(frames[z], thr)
+        assert _zstd_system_decode(r[16:16 + cb]) == orc.pack_binary_frame(binary).tobytes()
+        packed = orc.bit_pack(pix, d).tobytes()
+        assert npk == len(packed) and _zstd_system_decode(r[16 + cb:]) == packed
+        assert np.array_equal(ctx.binary_map(z), orc.pack_binary_frame(binary))
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode,scheme", [(0, 0), (1, 2), (1, 0), (1, 1)])
 def test_l3_records(hip, orc, mode, scheme):
     ny, nx = 200, 333
     dark, frames = synth_frames(5, 3, ny, nx, 0.03, 12)
@@ -130,7 +155,10 @@ def test_l3_records(hip, orc, mode, scheme):
         if ctx.on_device_codec:
             fid, cb = struct.unpack_from("<II", r, 0)
             assert fid == z and cb == md[z, 0] and len(r) == 8 + cb
-            _check_lz4(orc, r[8:], bitmap)
+            if scheme == 2:
+                _check_lz4(orc, r[8:], bitmap)
+            else:
+                assert _zstd_system_decode(r[8:]) == bitmap
         else:  # mode-0 record: the host layer compresses for schemes without a device codec
             assert r == struct.pack("<I", z) + bitmap
     ctx.close()

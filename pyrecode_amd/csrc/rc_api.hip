@@ -91,6 +91,7 @@ struct rc_ctx {
     float stage_ms[5] = {};
     // optional per-enqueue stage events for the asynchronous path (rc_ctx_set_profiling)
     bool profiling = false;
+    bool profile_all = getenv("RC_PROFILE_ALL_STAGES") != nullptr;
     std::vector<hipEvent_t> prof_ev;   // 5 events per enqueued batch, in enqueue order
     size_t prof_used = 0;              // events consumed since the last rc_ctx_sync
     double prof_sum_ms[5] = {};
@@ -313,11 +314,14 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     // LZ4 is fused into the reduce kernel; zstd encodes the raw bitmaps in a kernel of its own (one lane per block)
     const bool fused = c->emit == RC_SCHEME_LZ4;
     launch_reduce(c->sc, frames_dev, n, c->level == 1, fused ? c->emit : 0u, c->keep_bitmap || !fused, s);
+    // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
+    // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
+    const bool all_ev = ev && (timed || c->profile_all);
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
     if (c->emit == RC_SCHEME_ZSTD) launch_zstd_encode_blocks(c->sc, n, c->d_ztab, s);
-    if (ev) HIP_TRY(hipEventRecord(ev[2], s));
+    if (all_ev) HIP_TRY(hipEventRecord(ev[2], s));
     launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);
-    if (ev) HIP_TRY(hipEventRecord(ev[3], s));
+    if (all_ev) HIP_TRY(hipEventRecord(ev[3], s));
     launch_layout(c->sc, rp, n, out_cap, rec_off_dev, md_dev, s);
     launch_assemble(c->sc, rp, n, out_dev, rec_off_dev, s);
     if (ev) HIP_TRY(hipEventRecord(ev[4], s));
@@ -351,6 +355,9 @@ RC_EXPORT int rc_ctx_sync(rc_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t b = 0; b + 5 <= c->prof_used; b += 5) {  // fold the finished batches' stage events into the sums
         float ms;
+        if (!c->profile_all) {
+            if (hipEventElapsedTime(&ms, c->prof_ev[b], c->prof_ev[b + 1]) == hipSuccess) c->prof_sum_ms[0] += ms;
+        } else
         for (int i = 0; i < 4; ++i)
             if (hipEventElapsedTime(&ms, c->prof_ev[b + i], c->prof_ev[b + i + 1]) == hipSuccess) c->prof_sum_ms[i] += ms;
         if (hipEventElapsedTime(&ms, c->prof_ev[b], c->prof_ev[b + 4]) == hipSuccess) c->prof_sum_ms[4] += ms;

@@ -71,19 +71,103 @@ __device__ __forceinline__ u32x4 load8(const uint16_t *__restrict__ base, uint64
     }
 }
 
+// One frame of one tile: x holds the 8 loaded groups of this lane (destroyed), xn receives the prefetch of `next`.
+// TMODE: 0 threshold in registers (t), 1 threshold in wave-private LDS (tl), 2 threshold re-read from L2 (thr pointer).
+template <bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE>
+__device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], const uint16_t *__restrict__ next, bool have_next,
+                                                 const u32x4 (&t)[TMODE == 0 ? R : 1], const u32x4 *__restrict__ tl,
+                                                 const uint16_t *__restrict__ thr, uint64_t lane_px0, uint64_t N, uint32_t f,
+                                                 uint32_t tile, uint64_t ft, uint32_t n_blk, int w, uint8_t *__restrict__ bitmap,
+                                                 uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
+                                                 uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ blk_slots,
+                                                 uint32_t *__restrict__ blk_size, Lz4Lds *s_lz, uint8_t *s_bm)
+{
+    const int lane = lane_id();
+    // residuals (saturating subtract, in place) and the 8-bit mask of this lane's 8 pixels, per group
+    uint32_t m8[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const u32x4 tt = TMODE == 0 ? t[TMODE == 0 ? r : 0]
+                       : TMODE == 1 ? tl[r * 64 + lane]
+                                    : load8<ALIGNED, false>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[r][k] = pk_sub_sat_u16(x[r][k], tt[k]);
+        const uint32_t one = 0x00010001u;
+        const uint32_t M = pk_min_u16(x[r][0], one) | (pk_min_u16(x[r][1], one) << 2) | (pk_min_u16(x[r][2], one) << 4) |
+                           (pk_min_u16(x[r][3], one) << 6);  // pixel 2k -> bit 2k, pixel 2k+1 -> bit 16+2k
+        m8[r] = (M | (M >> 15)) & 0xFFu;
+    }
+    // this frame's data has arrived (the subtract above consumed it): start the NEXT frame's loads now, into the other
+    // register set, so that they fly during the whole compaction + encoding of this frame
+    if (have_next) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) xn[r] = load8<ALIGNED, true>(next, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
+    }
+    if (LEVEL1) {
+        // exclusive prefix of the per-lane popcounts in (group, lane) order: three groups per packed scan (each field
+        // <= 512 needs 10 bits); residuals are stored as soon as their group's offsets are known
+        uint32_t wave_total = 0;
+        uint16_t *slot = pix_slots + ft * TILE_PX;
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += 3) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (r0 + k < R) pk |= (uint32_t)__builtin_popcount(m8[r0 + k]) << (10 * k);
+            const uint32_t inc = wave_incl_scan(pk);
+            const uint32_t tot = wave_last(inc);
+            const uint32_t exc = inc - pk;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (r0 + k < R) {
+                    const int r = r0 + k;
+                    // sparse regime: a lane rarely owns more than one set pixel per group, so walk the set bits (one
+                    // wave iteration per "k-th set pixel of any lane") instead of 8 predicated stores
+                    uint32_t m = m8[r];
+                    uint32_t o = wave_total + ((exc >> (10 * k)) & 0x3FFu);
+                    while (m) {
+                        const uint32_t i = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        const uint32_t lo = (i & 4u) ? x[r][2] : x[r][0], hi = (i & 4u) ? x[r][3] : x[r][1];
+                        const uint32_t d = (i & 2u) ? hi : lo;
+                        slot[o++] = (uint16_t)((i & 1u) ? (d >> 16) : d);
+                    }
+                    wave_total += (tot >> (10 * k)) & 0x3FFu;
+                }
+        }
+        if (lane == 0) tile_cnt[ft] = wave_total;
+    }
+    if (KEEP_BITMAP || CODEC) {
+        // transpose through wave-private LDS: byte (r, lane) -> position r*64 + lane; 8 contiguous bytes per lane out
+        uint8_t *bm = CODEC ? s_lz->raw : s_bm;
+#pragma unroll
+        for (int r = 0; r < R; ++r) bm[r * 64 + lane] = (uint8_t)m8[r];
+        const u32x2 own = *reinterpret_cast<const u32x2 *>(&bm[lane * 8]);
+        if (KEEP_BITMAP)
+            *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = own;
+        if (CODEC == 2) {
+            const uint64_t bytes = (uint64_t)own[0] | ((uint64_t)own[1] << 32);
+            const uint32_t csize = lz4_encode_block(bytes, n_blk, *s_lz);
+            const uint32_t used = lz4_store_block(blk_slots + ft * BLK_SLOT, bytes, n_blk, csize, *s_lz);
+            if (lane == 0) blk_size[ft] = used;
+        }
+    }
+}
+
 // Workgroup id -> (tile block, frame group).  A tile block is WAVES consecutive tiles (one per wavefront); a frame group
-// is BZ consecutive frames.  The threshold tile stays in registers for the BZ frames.  The ngroups workgroups that share
-// a tile block get ids that are congruent mod 8 and adjacent within that residue class: the dispatcher deals
-// workgroups round-robin over the 8 XCDs, so they meet in ONE XCD's L2 at about the same time and the threshold is
-// fetched from HBM once per batch (placement affects speed only, never results).
+// is BZ consecutive frames.  The threshold tile is fetched once per workgroup and kept (registers or wave-private LDS)
+// for the BZ frames.  The ngroups workgroups that share a tile block get ids that are congruent mod 8 and adjacent within
+// that residue class: the dispatcher deals workgroups round-robin over the 8 XCDs, so they meet in ONE XCD's L2 at about
+// the same time and the threshold is fetched from HBM once per batch (placement affects speed only, never results).
 //
-// Per frame and wavefront, with NO barrier and no cross-wave traffic:
-//   8 x 16-byte nontemporal loads per lane -> saturating subtract (residual and mask in one op) -> 8-bit mask per lane
-//   -> bitmap bytes transposed through wave-private LDS (8 contiguous bytes per lane)
+// Per frame and wavefront, with NO barrier and no cross-wave traffic (reduce_one_frame):
+//   8 x 16-byte nontemporal loads per lane, issued ONE FRAME AHEAD into the second register set
+//   -> saturating subtract (residual and mask in one op) -> 8-bit mask per lane
 //   -> [LEVEL1] DPP prefix sums of the popcounts, residuals stored from registers into the tile's slot
+//   -> bitmap bytes transposed through wave-private LDS (8 contiguous bytes per lane)
 //   -> [CODEC 2] the 512-byte bitmap block is LZ4-encoded in place (rc_lz4_block.h) and written to its slot
-//   -> [KEEP_BITMAP] the raw bitmap bytes are stored as well (rc_get_binary_map / mode-0 records)
-template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP>
+//   -> [KEEP_BITMAP] the raw bitmap bytes are stored as well (rc_get_binary_map / mode-0 records / zstd input)
+template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE>
 __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
@@ -93,6 +177,7 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
 {
     __shared__ Lz4Lds s_lz[CODEC ? WAVES : 1];                                                  // codec working set
     __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : WAVES][CODEC ? 16 : TILE_BM];  // transpose only
+    __shared__ u32x4 s_thr[TMODE == 1 ? WAVES : 1][TMODE == 1 ? R * 64 : 1];                       // threshold tile per wave
 
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t grp = j % ngroups;
@@ -102,92 +187,43 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
     const uint32_t tile = tblock * WAVES + w;
     if (tile >= ntiles) return;  // whole wavefront leaves; nothing below synchronises across wavefronts
     const uint64_t lane_px0 = (uint64_t)tile * TILE_PX + (uint64_t)lane * 8;
-
-    u32x4 t[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) t[r] = load8<ALIGNED, false>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
-
     const uint32_t f0 = grp * BZ;
-    u32x4 x[R];
-    if (f0 < B) {
+    if (f0 >= B) return;
+
+    u32x4 xa[R], xb[R];
+    {
         const uint16_t *fr = frames + (uint64_t)f0 * N;
 #pragma unroll
-        for (int r = 0; r < R; ++r) x[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
+        for (int r = 0; r < R; ++r) xa[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
     }
-    const uint32_t n_blk = (uint32_t)min((uint64_t)TILE_BM, nb - (uint64_t)tile * TILE_BM);  // bitmap bytes of this tile
-
-#pragma unroll 1
-    for (int z = 0; z < BZ; ++z) {
-        const uint32_t f = f0 + z;
-        if (f >= B) break;
-        const uint64_t ft = (uint64_t)f * ntiles + tile;
-
-        // residuals (saturating subtract, in place) and the 8-bit mask of this lane's 8 pixels, per group
-        uint32_t m8[R];
+    u32x4 t[TMODE == 0 ? R : 1];
+    u32x4 *tl = s_thr[TMODE == 1 ? w : 0];
+    if (TMODE != 2) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[r][k] = pk_sub_sat_u16(x[r][k], t[r][k]);
-            const uint32_t one = 0x00010001u;
-            const uint32_t M = pk_min_u16(x[r][0], one) | (pk_min_u16(x[r][1], one) << 2) | (pk_min_u16(x[r][2], one) << 4) |
-                               (pk_min_u16(x[r][3], one) << 6);  // pixel 2k -> bit 2k, pixel 2k+1 -> bit 16+2k
-            m8[r] = (M | (M >> 15)) & 0xFFu;
+            const u32x4 tv = load8<ALIGNED, false>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
+            if (TMODE == 0) t[TMODE == 0 ? r : 0] = tv; else tl[r * 64 + lane] = tv;
         }
-        if (LEVEL1) {
-            // exclusive prefix of the per-lane popcounts in (group, lane) order: three groups per packed scan
-            // (each field <= 512 needs 10 bits); residuals are stored as soon as their group's offsets are known
-            uint32_t wave_total = 0;
-            uint16_t *slot = pix_slots + ft * TILE_PX;
-#pragma unroll
-            for (int r0 = 0; r0 < R; r0 += 3) {
-                uint32_t pk = 0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (r0 + k < R) pk |= (uint32_t)__builtin_popcount(m8[r0 + k]) << (10 * k);
-                const uint32_t inc = wave_incl_scan(pk);
-                const uint32_t tot = wave_last(inc);
-                const uint32_t exc = inc - pk;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (r0 + k < R) {
-                        const int r = r0 + k;
-                        // sparse regime: a lane rarely owns more than one set pixel per group, so walk the set bits
-                        // (one wave iteration per "k-th set pixel of any lane") instead of 8 predicated stores
-                        uint32_t m = m8[r];
-                        uint32_t o = wave_total + ((exc >> (10 * k)) & 0x3FFu);
-                        while (m) {
-                            const uint32_t i = (uint32_t)__builtin_ctz(m);
-                            m &= m - 1;
-                            const uint32_t lo = (i & 4u) ? x[r][2] : x[r][0], hi = (i & 4u) ? x[r][3] : x[r][1];
-                            const uint32_t d = (i & 2u) ? hi : lo;
-                            slot[o++] = (uint16_t)((i & 1u) ? (d >> 16) : d);
-                        }
-                        wave_total += (tot >> (10 * k)) & 0x3FFu;
-                    }
-            }
-            if (lane == 0) tile_cnt[ft] = wave_total;
-        }
-        // the residual registers are free now: fetch the next frame of this tile while the bitmap is encoded
-        if (z + 1 < BZ && f + 1 < B) {
-            const uint16_t *fr = frames + (uint64_t)(f + 1) * N;
-#pragma unroll
-            for (int r = 0; r < R; ++r) x[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
-        }
-        if (KEEP_BITMAP || CODEC) {
-            // transpose through wave-private LDS: byte (r, lane) -> position r*64 + lane; 8 contiguous bytes per lane out
-            uint8_t *bm = CODEC ? s_lz[w].raw : s_bm[w];
-#pragma unroll
-            for (int r = 0; r < R; ++r) bm[r * 64 + lane] = (uint8_t)m8[r];
-            const u32x2 own = *reinterpret_cast<const u32x2 *>(&bm[lane * 8]);
-            if (KEEP_BITMAP)
-                *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = own;
-            if (CODEC == 2) {
-                const uint64_t bytes = (uint64_t)own[0] | ((uint64_t)own[1] << 32);
-                const uint32_t csize = lz4_encode_block(bytes, n_blk, s_lz[w]);
-                const uint32_t used = lz4_store_block(blk_slots + ft * BLK_SLOT, bytes, n_blk, csize, s_lz[w]);
-                if (lane == 0) blk_size[ft] = used;
-            }
-        }
+    }
+    const uint32_t n_blk = (uint32_t)min((uint64_t)TILE_BM, nb - (uint64_t)tile * TILE_BM);  // bitmap bytes of this tile
+    Lz4Lds *lz = &s_lz[CODEC ? w : 0];
+    uint8_t *bm = s_bm[CODEC ? 0 : w];
+
+#pragma unroll 1
+    for (int z = 0; z < BZ; z += 2) {
+        uint32_t f = f0 + z;
+        if (f >= B) break;
+        bool nxt = z + 1 < BZ && f + 1 < B;
+        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr, lane_px0, N,
+                                                                     f, tile, (uint64_t)f * ntiles + tile, n_blk, w, bitmap,
+                                                                     nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, bm);
+        if (!nxt) break;
+        ++f;
+        nxt = z + 2 < BZ && f + 1 < B;
+        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr, lane_px0, N,
+                                                                     f, tile, (uint64_t)f * ntiles + tile, n_blk, w, bitmap,
+                                                                     nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, bm);
+        if (!nxt) break;
     }
 }
 
@@ -201,14 +237,24 @@ static int reduce_bz()
     return bz;
 }
 
+static int reduce_tmode()  // where the threshold tile lives: 0 registers (default), 1 wave-private LDS, 2 re-read from L2
+{
+    static const int v = [] { const char *e = getenv("RC_THR_MODE"); const int m = e ? atoi(e) : 0; return (m >= 0 && m <= 2) ? m : 0; }();
+    return v;
+}
+
 template <int BZ, bool AL, bool L1, int CODEC, bool KEEP>
 static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, hipStream_t s)
 {
     const uint32_t ngroups = (B + BZ - 1) / BZ;
     const uint32_t ntb = (sc.ntiles + WAVES - 1) / WAVES;
     const uint32_t grid = ((ntb + 7) / 8) * 8 * ngroups;
-    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N, sc.ntiles, B,
-                       ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size);
+#define RC_GO(TM)                                                                                                        \
+    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP, TM>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N, sc.ntiles, \
+                       B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size)
+    const int tm = AL ? reduce_tmode() : 1;  // the scalar-load instantiation exists in one flavour only
+    if (tm == 0) { if (AL) RC_GO(0); } else if (tm == 2) { if (AL) RC_GO(2); } else RC_GO(1);
+#undef RC_GO
 }
 template <int BZ, bool AL>
 static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, uint32_t codec, bool keep,

@@ -1,0 +1,55 @@
+// Development probe: HBM read bandwidth for the access shapes the reduce kernel uses (not part of the product).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__global__ __launch_bounds__(256) void k_read(const u32x4 *__restrict__ p, uint64_t n16, uint32_t *out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256 * 8 + threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint64_t j = i + (uint64_t)r * 256;
+        if (j < n16) { u32x4 v = NT ? __builtin_nontemporal_load(p + j) : p[j]; acc += v; }
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[0] = 1;
+}
+// frame-strided: workgroup b reads tile (b / G) of frames (b % G)*4 .. +4, like k_reduce_tiles' mapping
+__global__ __launch_bounds__(256) void k_read_strided(const u32x4 *__restrict__ p, uint64_t frame16, uint32_t ntb, uint32_t G, uint32_t *out, int mode)
+{
+    uint32_t tb, g;
+    if (mode == 0) { const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3; g = j % G; tb = (j / G) * 8 + xcd; }
+    else { tb = blockIdx.x % ntb; g = blockIdx.x / ntb; }
+    if (tb >= ntb) return;
+    u32x4 acc = {0, 0, 0, 0};
+    for (int z = 0; z < 4; ++z) {
+        const u32x4 *fr = p + (uint64_t)(g * 4 + z) * frame16 + (uint64_t)tb * 2048 + (threadIdx.x >> 6) * 512 + (threadIdx.x & 63);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc += __builtin_nontemporal_load(fr + r * 64);
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[0] = 1;
+}
+int main()
+{
+    const uint64_t bytes = 2ull << 30, n16 = bytes / 16;
+    u32x4 *p; uint32_t *out;
+    hipMalloc(&p, bytes); hipMalloc(&out, 4); hipMemset(p, 1, bytes);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    auto time = [&](auto launch, const char *name) {
+        for (int i = 0; i < 3; ++i) launch();
+        hipEventRecord(a);
+        for (int i = 0; i < 10; ++i) launch();
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("%-40s %.3f ms  %.2f TB/s\n", name, ms / 10, bytes / (ms / 10 * 1e-3) / 1e12);
+    };
+    const uint32_t grid = (uint32_t)(n16 / (256 * 8));
+    time([&] { hipLaunchKernelGGL(k_read<true>, dim3(grid), dim3(256), 0, 0, p, n16, out); }, "linear read, nontemporal");
+    time([&] { hipLaunchKernelGGL(k_read<false>, dim3(grid), dim3(256), 0, 0, p, n16, out); }, "linear read, default policy");
+    const uint64_t frame16 = (32ull << 20) / 16; const uint32_t ntb = 1024, G = 16;
+    time([&] { hipLaunchKernelGGL(k_read_strided, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, out, 0); }, "frame-strided (groups adjacent, xcd)");
+    time([&] { hipLaunchKernelGGL(k_read_strided, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, out, 1); }, "frame-strided (tiles adjacent)");
+    return 0;
+}

@@ -121,3 +121,32 @@ def merge_direct(folder_path, base_filename, rank=None, world=None, records=None
     if dist is not None and world > 1:
         dist.barrier()
     return nz
+
+
+def write_sharded(image_filename, data, dark_data, output_directory, input_params, validation_frame_gap=-1, batch_size=None,
+                  device_id=None, merge=True):
+    """One call per rank (rank == node_id): reduce-compress this rank's contiguous block of `data` on its GPU into
+    `<stem>.rc<L>_part<rank>` with ReCoDeWriter (the reference's per-node flow, recode_server.py:688-723), then build the
+    merged `<stem>.rc<L>` collectively with merge_direct.  `input_params.num_threads` must equal the world size.
+    Returns (run_metrics of this rank, total frames in the merged file or None)."""
+    from pathlib import Path
+
+    from .recode_writer import ReCoDeWriter
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
+    if int(input_params.num_threads) != world:
+        raise ValueError('input_params.num_threads (%s) must equal the number of ranks (%d)' % (input_params.num_threads, world))
+    w = ReCoDeWriter(image_filename, dark_data=dark_data, output_directory=output_directory, input_params=input_params,
+                     mode='batch', validation_frame_gap=validation_frame_gap, node_id=rank, batch_size=batch_size,
+                     device_id=device_id)
+    w.start()
+    metrics = w.run(data)
+    w.close()
+    if dist is not None and world > 1:
+        dist.barrier()  # every part file is complete before anyone reads part 000's header
+    nz = None
+    if merge:
+        base = '%s.rc%d' % (Path(image_filename).stem, int(input_params.reduction_level))
+        nz = merge_direct(output_directory, base, rank=rank, world=world)
+    return metrics, nz

@@ -40,7 +40,7 @@ typedef enum rc_status {
 } rc_status;
 
 /* compression_scheme codes of the reference (recode_compressors.py:3-4, config/README.md). Device codecs:
- * 2 (LZ4 frame), 1 (zstd frame), 8 (blosc1 + lz4 + bitshuffle).  Every other code: the ctx emits the
+ * 2 (LZ4 frame), 1 (zstd frame), 8 (blosc1 chunk: bit-shuffle + LZ4, typesize 8).  Every other code: the ctx emits the
  * reduce-only pieces and the host layer runs the reference's own library call (zlib, bz2, lzma, ...). */
 enum { RC_SCHEME_ZLIB = 0, RC_SCHEME_ZSTD = 1, RC_SCHEME_LZ4 = 2, RC_SCHEME_BLOSC_LZ4 = 8 };
 

@@ -48,6 +48,8 @@ def lib():
         L.orc_reduce_frame_l1.restype = C.c_uint64
         L.orc_lz4f_decode.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
         L.orc_lz4f_decode.restype = C.c_int64
+        L.orc_lz4_block_decode.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
+        L.orc_lz4_block_decode.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -133,6 +135,62 @@ def lz4f_decode(data, cap):
     if n < 0:
         raise ValueError("orc_lz4f_decode: malformed LZ4 frame (code %d)" % n)
     return out[:n].tobytes()
+
+
+def lz4_block_decode(data, cap):
+    data = np.frombuffer(bytes(data), np.uint8)
+    out = np.empty(max(cap, 1), np.uint8)
+    n = lib().orc_lz4_block_decode(_p(data, C.c_uint8), data.size, _p(out, C.c_uint8), cap)
+    if n < 0:
+        raise ValueError("malformed LZ4 block (code %d)" % n)
+    return out[:n].tobytes()
+
+
+def blosc1_decode(chunk):
+    """From-spec decoder of a blosc1 chunk (c-blosc 1.x README_CHUNK_FORMAT.rst / blosc.c blosc_d), LZ4 codec only:
+    16-byte header (version, versionlz, flags, typesize, nbytes, blocksize, cbytes), `memcpyed` chunks, int32 bstarts,
+    per block nsplits x (int32 csize + LZ4 block | stored), then un-shuffle (byte 0x01 / bit 0x04) per block.
+    Reference call site whose inverse this is: pyrecode/recode_compressors.py:61-76 (blosc.decompress)."""
+    c = bytes(chunk)
+    version, versionlz, flags, typesize = c[0], c[1], c[2], c[3]
+    nbytes, blocksize, cbytes = struct.unpack_from("<iii", c, 4)
+    if version != 2 or cbytes != len(c):
+        raise ValueError("bad blosc1 header")
+    if flags & 0x02:
+        if cbytes != 16 + nbytes:
+            raise ValueError("bad memcpyed chunk")
+        return c[16:16 + nbytes]
+    if (flags >> 5) != 1 or versionlz != 1:
+        raise ValueError("not an LZ4 blosc chunk")
+    nblocks = -(-nbytes // blocksize)
+    bstarts = struct.unpack_from("<%di" % nblocks, c, 16)
+    out = bytearray()
+    for b in range(nblocks):
+        bsize = min(blocksize, nbytes - b * blocksize)
+        leftover = bsize != blocksize
+        split = (not (flags & 0x10)) and typesize <= 16 and blocksize // typesize >= 128 and not leftover
+        nsplits = typesize if split else 1
+        neblock = bsize // nsplits
+        pos, tmp = bstarts[b], b""
+        for _ in range(nsplits):
+            csize, = struct.unpack_from("<i", c, pos)
+            pos += 4
+            tmp += c[pos:pos + csize] if csize == neblock else lz4_block_decode(c[pos:pos + csize], neblock)
+            pos += csize
+        if len(tmp) != bsize:
+            raise ValueError("block %d decodes to %d bytes, expected %d" % (b, len(tmp), bsize))
+        a = np.frombuffer(tmp, np.uint8)
+        if flags & 0x04 and bsize >= typesize:       # bit-unshuffle: S elements (multiple of 8), rows of S/8 bytes
+            S = (bsize // typesize) & ~7
+            if S:
+                rows = np.unpackbits(a[:S * typesize].reshape(typesize * 8, S // 8), axis=1, bitorder="little")  # [row r][elem i]
+                bits = rows.T.reshape(S, typesize, 8)                                                        # [elem][byte k][bit b]
+                a = np.concatenate([np.packbits(bits, axis=2, bitorder="little").reshape(-1), a[S * typesize:]])
+        elif flags & 0x01 and typesize > 1:         # byte-unshuffle
+            ne = bsize // typesize
+            a = np.concatenate([a[:ne * typesize].reshape(typesize, ne).T.reshape(-1), a[ne * typesize:]])
+        out += a.tobytes()
+    return bytes(out)
 
 
 # ---- record / file assembly (A7, appendix A of SURVEY.md) ----------------------------------------

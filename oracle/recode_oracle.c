@@ -237,6 +237,12 @@ static int64_t lz4_block_decode(const uint8_t *src, uint64_t n, uint8_t *dst_bas
     return (int64_t)(op - dst_pos);
 }
 
+/* raw LZ4 block (no frame), as stored inside blosc1 chunks; returns decoded bytes or negative */
+ORC_API int64_t orc_lz4_block_decode(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap)
+{
+    return lz4_block_decode(src, n, dst, 0, dst_cap);
+}
+
 ORC_API int64_t orc_lz4f_decode(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap)
 {
     if (n < 7) return -1;

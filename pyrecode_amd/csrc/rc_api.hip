@@ -7,6 +7,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -127,7 +128,10 @@ RC_EXPORT int rc_device_count(int *count)
     *count = n;
     return RC_OK;
 }
-RC_EXPORT int rc_scheme_on_device(uint32_t scheme) { return (scheme == RC_SCHEME_LZ4 || scheme == RC_SCHEME_ZSTD) ? 1 : 0; }
+RC_EXPORT int rc_scheme_on_device(uint32_t scheme)
+{
+    return (scheme == RC_SCHEME_LZ4 || scheme == RC_SCHEME_ZSTD || scheme == RC_SCHEME_BLOSC_LZ4) ? 1 : 0;
+}
 
 // ---- seam 1 --------------------------------------------------------------------------------------------------
 static int ctx_alloc(rc_ctx *c)
@@ -319,6 +323,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     const bool all_ev = ev && (timed || c->profile_all);
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
     if (c->emit == RC_SCHEME_ZSTD) launch_zstd_encode_blocks(c->sc, n, c->d_ztab, s);
+    if (c->emit == RC_SCHEME_BLOSC_LZ4) launch_blosc_encode_blocks(c->sc, n, s);
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], s));
     launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], s));
@@ -798,11 +803,65 @@ static int zstd_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t 
     return RC_OK;
 }
 
+static int blosc_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
+{
+    using namespace rc;
+    Util &u = g_util;
+    if (n >= (1ull << 31) - 16) return fail(RC_ERR_BAD_ARG, "rc_compress: a blosc1 chunk holds < 2 GiB");
+    if (n == 0) {  // header only, "memcpyed"
+        const uint8_t f[16] = {2, 1, 0x36, 8, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 0, 0};
+        if (dst_cap < 16) return fail(RC_ERR_OUT_TOO_SMALL, "rc_compress: dst too small");
+        HIP_TRY(hipMemcpy(dst, f, 16, is_device_ptr(dst) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+        *out_n = 16;
+        return RC_OK;
+    }
+    Scratch sc;
+    sc.ntiles = (uint32_t)((n + TILE_BM - 1) / TILE_BM);
+    sc.nb = n;
+    sc.nb_stride = (uint64_t)sc.ntiles * TILE_BM;
+    const uint8_t *d_src = nullptr;
+    int r = stage_in(src, n, u.a, u.a_cap, d_src, sc.nb_stride - n + 16);
+    if (r != RC_OK) return r;
+    sc.bitmap = const_cast<uint8_t *>(d_src);
+    const uint64_t T = sc.ntiles;
+    r = ensure(u.w, u.w_cap, T * BLK_SLOT + T * 8 + 64);
+    if (r != RC_OK) return r;
+    sc.blk_slots = u.w;
+    sc.blk_size = reinterpret_cast<uint32_t *>(u.w + T * BLK_SLOT);
+    sc.blk_off = sc.blk_size + T;
+    sc.frame_cbytes = sc.blk_off + T;
+    launch_blosc_encode_blocks(sc, 1, u.stream);
+    launch_scans(sc, 1, false, true, u.stream);
+    HIP_TRY(hipMemcpyAsync(u.h_scalar, sc.frame_cbytes, 4, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    const uint64_t total = 16ull + 4ull * T + *reinterpret_cast<uint32_t *>(u.h_scalar);
+    if (total > dst_cap) return fail(RC_ERR_OUT_TOO_SMALL, "rc_compress: dst too small (see rc_compress_bound)");
+    uint8_t *d_out = dst;
+    const bool out_host = !is_device_ptr(dst);
+    if (out_host) {
+        r = ensure(u.o, u.o_cap, total);
+        if (r != RC_OK) return r;
+        d_out = u.o;
+    }
+    launch_blosc_gather(sc, d_out, u.stream);
+    HIP_TRY(hipGetLastError());
+    if (out_host) HIP_TRY(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    *out_n = total;
+    return RC_OK;
+}
+
 RC_EXPORT int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap,
                           uint64_t *out_n)
 {
     (void)level;  // the device encoders have a single effort level
     if (!dst || !out_n || (!src && n)) return fail(RC_ERR_BAD_ARG, "NULL argument");
+    if (scheme == RC_SCHEME_BLOSC_LZ4) {
+        std::lock_guard<std::mutex> lock(g_util.mu);
+        int r = util_init();
+        if (r != RC_OK) return r;
+        return blosc_compress(src, n, dst, dst_cap, out_n);
+    }
     if (scheme != RC_SCHEME_LZ4 && scheme != RC_SCHEME_ZSTD)
         return fail(RC_ERR_UNSUPPORTED, "rc_compress: compression scheme not implemented on device");
     std::lock_guard<std::mutex> lock(g_util.mu);
@@ -810,21 +869,115 @@ RC_EXPORT int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, u
     if (r != RC_OK) return r;
     return scheme == RC_SCHEME_LZ4 ? lz4_compress(src, n, dst, dst_cap, out_n) : zstd_compress(src, n, dst, dst_cap, out_n);
 }
+// blosc1 chunk with the LZ4 codec (what rc_compress(8) and python-blosc's cname='lz4' write): header and block table are
+// walked on the host, the LZ4 blocks are decoded on the GPU into an image of the shuffled chunk, a second kernel unshuffles.
+static int blosc_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
+{
+    using namespace rc;
+    Util &u = g_util;
+    std::vector<uint8_t> hsrc;
+    const uint8_t *h = src;
+    if (is_device_ptr(src)) {
+        hsrc.resize(n);
+        HIP_TRY(hipMemcpy(hsrc.data(), src, n, hipMemcpyDeviceToHost));
+        h = hsrc.data();
+    }
+    auto rd32 = [&](uint64_t p) { return (uint32_t)h[p] | ((uint32_t)h[p + 1] << 8) | ((uint32_t)h[p + 2] << 16) | ((uint32_t)h[p + 3] << 24); };
+    if (n < 16 || h[0] != 2) return fail(RC_ERR_CORRUPT, "not a blosc1 chunk");
+    const uint32_t flags = h[2], typesize = h[3] ? h[3] : 1;
+    const uint64_t nbytes = rd32(4), blocksize = rd32(8), cbytes = rd32(12);
+    if (cbytes != n || nbytes >= (1ull << 31)) return fail(RC_ERR_CORRUPT, "blosc1 header disagrees with the chunk length");
+    *out_n = nbytes;
+    if (nbytes > dst_cap) return fail(RC_ERR_OUT_TOO_SMALL, "rc_decompress: dst too small");
+    if (nbytes == 0) return RC_OK;
+    if (flags & 0x02) {  // memcpyed
+        if (n != 16 + nbytes) return fail(RC_ERR_CORRUPT, "bad memcpyed blosc1 chunk");
+        HIP_TRY(hipMemcpy(dst, src + 16, nbytes, hipMemcpyDefault));
+        return RC_OK;
+    }
+    if ((flags >> 5) != 1) return fail(RC_ERR_UNSUPPORTED, "blosc1 chunk: only the LZ4 codec is decoded on device");
+    if (blocksize == 0 || blocksize > nbytes) return fail(RC_ERR_CORRUPT, "bad blosc1 blocksize");
+    const uint64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    if (16 + 4 * nblocks > n) return fail(RC_ERR_CORRUPT, "truncated blosc1 chunk");
+    std::vector<Lz4Block> blks;
+    std::vector<uint64_t> offs;
+    std::vector<uint32_t> want;
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        const uint64_t bsize = std::min<uint64_t>(blocksize, nbytes - b * blocksize);
+        const bool leftover = bsize != blocksize;
+        const bool split = !(flags & 0x10) && typesize <= 16 && blocksize / typesize >= 128 && !leftover;  // blosc.c blosc_d
+        const uint32_t nsplits = split ? typesize : 1;
+        const uint64_t neblock = bsize / nsplits;
+        uint64_t pos = rd32(16 + 4 * b);
+        for (uint32_t j = 0; j < nsplits; ++j) {
+            if (pos + 4 > n) return fail(RC_ERR_CORRUPT, "blosc1 block table points outside the chunk");
+            const uint32_t cs = rd32(pos);
+            pos += 4;
+            if (pos + cs > n || cs > neblock + neblock / 255 + 16) return fail(RC_ERR_CORRUPT, "blosc1 block exceeds the chunk");
+            blks.push_back(Lz4Block{pos, cs, cs == neblock ? 1u : 0u});
+            offs.push_back(b * blocksize + j * neblock);
+            want.push_back((uint32_t)neblock);
+            pos += cs;
+        }
+    }
+    const uint32_t nb = (uint32_t)blks.size();
+    const uint8_t *d_src = nullptr;
+    int r = stage_in(src, n, u.a, u.a_cap, d_src);
+    if (r != RC_OK) return r;
+    const uint64_t tab = (uint64_t)nb * sizeof(Lz4Block), szs = ((uint64_t)nb * 4 + 7) & ~7ull, ofs = (uint64_t)nb * 8;
+    r = ensure(u.w, u.w_cap, tab + szs + ofs + 16);
+    if (r != RC_OK) return r;
+    r = ensure(u.b, u.b_cap, nbytes + 16);  // image of the shuffled chunk
+    if (r != RC_OK) return r;
+    Lz4Block *d_blks = reinterpret_cast<Lz4Block *>(u.w);
+    uint32_t *d_sizes = reinterpret_cast<uint32_t *>(u.w + tab);
+    uint64_t *d_offs = reinterpret_cast<uint64_t *>(u.w + tab + szs);
+    int *d_err = reinterpret_cast<int *>(u.w + tab + szs + ofs);
+    HIP_TRY(hipMemcpyAsync(d_blks, blks.data(), tab, hipMemcpyHostToDevice, u.stream));
+    HIP_TRY(hipMemcpyAsync(d_offs, offs.data(), ofs, hipMemcpyHostToDevice, u.stream));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 4, u.stream));
+    launch_lz4_decode(d_src, d_blks, nb, d_sizes, nullptr, nullptr, ~0ull, 0, d_err, u.stream);  // sizes only: must equal the split size
+    std::vector<uint32_t> sizes(nb);
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(sizes.data(), d_sizes, (uint64_t)nb * 4, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    if (err) return fail(RC_ERR_CORRUPT, "malformed LZ4 block inside the blosc1 chunk");
+    for (uint32_t i = 0; i < nb; ++i)
+        if (sizes[i] != want[i]) return fail(RC_ERR_CORRUPT, "blosc1 block decodes to the wrong size");
+    launch_lz4_decode(d_src, d_blks, nb, nullptr, d_offs, u.b, nbytes, 0, d_err, u.stream);
+    uint8_t *d_out = dst;
+    const bool out_host = !is_device_ptr(dst);
+    if (out_host) {
+        r = ensure(u.o, u.o_cap, nbytes);
+        if (r != RC_OK) return r;
+        d_out = u.o;
+    }
+    launch_blosc_unshuffle(u.b, d_out, nbytes, (uint32_t)blocksize, typesize, (flags & 0x04) ? 4u : ((flags & 0x01) ? 1u : 0u), u.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, u.stream));
+    if (out_host) HIP_TRY(hipMemcpyAsync(dst, d_out, nbytes, hipMemcpyDeviceToHost, u.stream));
+    HIP_TRY(hipStreamSynchronize(u.stream));
+    if (err) return fail(RC_ERR_CORRUPT, "malformed LZ4 block inside the blosc1 chunk");
+    return RC_OK;
+}
+
 RC_EXPORT int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
 {
     if (!src || !out_n || (!dst && dst_cap)) return fail(RC_ERR_BAD_ARG, "NULL argument");
-    if (scheme != RC_SCHEME_LZ4)  // zstd decoding stays with the stock library on the host, like the reference (recode_compressors.py:46)
+    if (scheme != RC_SCHEME_LZ4 && scheme != RC_SCHEME_BLOSC_LZ4)  // zstd decoding stays with the stock library on the host, like the reference (recode_compressors.py:46)
         return fail(RC_ERR_UNSUPPORTED, "rc_decompress: compression scheme not implemented on device");
     std::lock_guard<std::mutex> lock(g_util.mu);
     int r = util_init();
     if (r != RC_OK) return r;
-    return lz4_decompress(src, n, dst, dst_cap, out_n);
+    return scheme == RC_SCHEME_LZ4 ? lz4_decompress(src, n, dst, dst_cap, out_n) : blosc_decompress(src, n, dst, dst_cap, out_n);
 }
 RC_EXPORT uint64_t rc_compress_bound(uint32_t scheme, uint64_t n)
 {
     const uint64_t blocks = (n + rc::TILE_BM - 1) / rc::TILE_BM;
     if (scheme == RC_SCHEME_LZ4) return 7 + n + 4 * blocks + 4;
     if (scheme == RC_SCHEME_ZSTD) return 9 + n + 3 * blocks;
+    if (scheme == RC_SCHEME_BLOSC_LZ4) return 16 + n + 8 * blocks;
     return 0;
 }
 

@@ -52,6 +52,11 @@ void launch_lz4f_gather(const Scratch &sc, uint32_t hdr3, uint8_t *out, hipStrea
 void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
                        uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s);
 uint32_t lz4f_descriptor(uint8_t bd);
+// rc_blosc.hip
+void launch_blosc_encode_blocks(const Scratch &sc, uint32_t B, hipStream_t s);
+void launch_blosc_gather(const Scratch &sc, uint8_t *out, hipStream_t s);
+void launch_blosc_unshuffle(const uint8_t *in, uint8_t *out, uint64_t nbytes, uint32_t blocksize, uint32_t typesize,
+                            uint32_t shuffle, hipStream_t s);
 // rc_zstd.hip
 void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s);
 void launch_zstd_gather(const Scratch &sc, uint8_t *out, hipStream_t s);

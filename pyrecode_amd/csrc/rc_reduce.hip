@@ -383,10 +383,17 @@ void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blo
 //   LZ4 frame  (lz4_Frame_format.md): 7-byte header, 4-byte block words (bit 31 = stored), 4-byte EndMark, 4 MiB chunks
 //   zstd frame (RFC 8878):            6-byte header (magic, descriptor, window), 3-byte block headers, Last_Block bit on the
 //                                     final block instead of an end mark, 128 KiB chunks (Block_Maximum_Size), >= 1 block
+//   blosc1 chunk (scheme 8):          bitmap: 16-byte header + int32 bstarts[ntiles] + blocks; pixels: 16-byte header with the
+//                                     "memcpyed" flag + the bytes (what c-blosc itself emits for incompressible input)
 struct FrameFmt { uint32_t hdr, end, chunk_shift, chunk_hdr, min_chunks; };
 __host__ __device__ inline FrameFmt frame_fmt(uint32_t emit)
 {
-    return emit == 1 ? FrameFmt{6, 0, 17, 3, 1} : FrameFmt{7, 4, 22, 4, 0};
+    return emit == 1 ? FrameFmt{6, 0, 17, 3, 1} : emit == 8 ? FrameFmt{16, 0, 31, 0, 0} : FrameFmt{7, 4, 22, 4, 0};
+}
+// bytes in front of the encoded bitmap blocks
+__host__ __device__ inline uint32_t bitmap_hdr(const FrameFmt &ff, uint32_t emit, uint32_t ntiles)
+{
+    return emit == 8 ? 16u + 4u * ntiles : ff.hdr;
 }
 
 __host__ __device__ inline uint32_t packed_bytes(uint32_t nnz, uint32_t depth)
@@ -405,7 +412,7 @@ __host__ __device__ inline uint32_t stored_size(const FrameFmt &ff, uint32_t n)
 
 __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ frame_nnz,
                                                  const uint32_t *__restrict__ frame_cbytes, RecordParams rp, uint64_t nb,
-                                                 uint32_t B, uint64_t out_cap, uint64_t *__restrict__ rec_off,
+                                                 uint32_t ntiles, uint32_t B, uint64_t out_cap, uint64_t *__restrict__ rec_off,
                                                  uint32_t *__restrict__ md, BatchStatus *__restrict__ st)
 {
     __shared__ uint64_t s_part[WG];
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ fram
             else sz = 4 + nb;
         } else {  // LZ4 frames (emit == 2)
             const FrameFmt ff = frame_fmt(rp.emit);
-            const uint32_t cb = ff.hdr + frame_cbytes[f] + ff.end;
+            const uint32_t cb = bitmap_hdr(ff, rp.emit, ntiles) + frame_cbytes[f] + ff.end;
             if (rp.level == 1) {
                 const uint32_t cp = stored_size(ff, npk);
                 sz = 16 + (uint64_t)cb + cp; m0 = cb; m1 = cp; m2 = npk;
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ fram
 void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
                    uint32_t *md, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(WG), 0, s, sc.frame_nnz, sc.frame_cbytes, rp, sc.nb, B, out_cap,
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(WG), 0, s, sc.frame_nnz, sc.frame_cbytes, rp, sc.nb, sc.ntiles, B, out_cap,
                        rec_off, md, sc.status);
 }
 
@@ -570,11 +577,12 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     uint64_t bitmap_pos, pix_pos;  // record offsets of the bitmap stream and of packed-pixel byte 0's container
     uint32_t cb = 0;
     const FrameFmt ff = frame_fmt(rp.emit);
+    const uint32_t bhdr = bitmap_hdr(ff, rp.emit, sc.ntiles);
     if (rp.emit == 0) {
         bitmap_pos = rp.level == 1 ? 8 : 4;
         pix_pos = bitmap_pos + sc.nb;
     } else {
-        cb = ff.hdr + sc.frame_cbytes[f] + ff.end;
+        cb = bhdr + sc.frame_cbytes[f] + ff.end;
         bitmap_pos = rp.level == 1 ? 16 : 8;
         pix_pos = bitmap_pos + cb;
     }
@@ -590,6 +598,11 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
             if (rp.emit == 1) {  // zstd: magic, Frame_Header_Descriptor 0 (no content size, window descriptor follows), 1 KiB window
                 store_u32_le(bf, 0xFD2FB528u);
                 bf[4] = 0; bf[5] = 0x00;
+            } else if (rp.emit == 8) {  // blosc1 header: version 2, LZ4 format version 1, bit-shuffle | not split | LZ4, typesize 8
+                bf[0] = 2; bf[1] = 1; bf[2] = 0x34; bf[3] = 8;
+                store_u32_le(bf + 4, (uint32_t)sc.nb);
+                store_u32_le(bf + 8, (uint32_t)min((uint64_t)TILE_BM, sc.nb));
+                store_u32_le(bf + 12, cb);
             } else {
                 store_u32_le(bf, 0x184D2204u);
                 bf[4] = (uint8_t)(lz4f_hdr_bitmap & 0xFF); bf[5] = (uint8_t)((lz4f_hdr_bitmap >> 8) & 0xFF);
@@ -602,7 +615,12 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                 store_u32_le(rec + 12, npk);
                 uint8_t *pf = rec + pix_pos;
                 const uint32_t chunk = 1u << ff.chunk_shift, nch = stored_chunks(ff, npk);
-                if (rp.emit == 1) {  // 128 KiB window so that 128 KiB raw blocks are legal
+                if (rp.emit == 8) {  // blosc1 header with the "memcpyed" flag: the packed residuals follow unchanged
+                    pf[0] = 2; pf[1] = 1; pf[2] = 0x36; pf[3] = 8;
+                    store_u32_le(pf + 4, npk);
+                    store_u32_le(pf + 8, npk);
+                    store_u32_le(pf + 12, 16 + npk);
+                } else if (rp.emit == 1) {  // 128 KiB window so that 128 KiB raw blocks are legal
                     store_u32_le(pf, 0xFD2FB528u);
                     pf[4] = 0; pf[5] = 7u << 3;
                     for (uint32_t k = 0; k < nch; ++k) {
@@ -635,7 +653,8 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
             bsz = (uint32_t)min((uint64_t)TILE_BM, sc.nb - (uint64_t)tl * TILE_BM);
         } else {
             bsz = sc.blk_size[frow + tl];
-            boff = ff.hdr + sc.blk_off[frow + tl];
+            boff = bhdr + sc.blk_off[frow + tl];
+            if (rp.emit == 8) store_u32_le(rec + bitmap_pos + 16 + 4 * (uint64_t)tl, boff);  // bstarts[tl]: offset from the chunk start
         }
         if (rp.level == 1) {
             cnt = sc.tile_cnt[frow + tl];

@@ -31,7 +31,7 @@ def _on_device(scheme):
     return bool(_lib.lib().rc_scheme_on_device(int(scheme)))
 
 
-_DEVICE_DECODERS = (2,)  # LZ4 frames are also decoded on the GPU; zstd frames are decoded by the stock library on the host
+_DEVICE_DECODERS = (2, 8)  # LZ4 frames and blosc1-LZ4 chunks are also DEcoded on the GPU; zstd frames by the stock library on the host
 
 
 def _zstd_host_decompress(data, decompressor_context=None):

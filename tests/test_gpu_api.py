@@ -118,7 +118,7 @@ def test_l3_files_are_readable():
     rd.close()
 
 
-@pytest.mark.parametrize("depth,eps,nodes,scheme", [(12, 0, 3, 2), (16, 5, 2, 2), (12, 1, 2, 1), (16, 0, 3, 1)])
+@pytest.mark.parametrize("depth,eps,nodes,scheme", [(12, 0, 3, 2), (16, 5, 2, 2), (12, 1, 2, 1), (16, 0, 3, 1), (12, 2, 2, 8), (16, 0, 3, 8)])
 def test_device_codec_write_read_round_trip(depth, eps, nodes, scheme, tmp_path):
     """Config-2 shape of flow (L1 + LZ4 on device) at a test size: write parts, merge, read back, compare with the oracle's
     residual image; part files also decode through the oracle's LZ4 decoder (done in test_gpu_parity)."""
@@ -207,6 +207,19 @@ def test_compressor_seam_on_device(orc):
         c = rcmp.compress(1, 1, data, None)
         assert rcmp.de_compress(1, c, None) == data
     assert len(rcmp.compress(1, 1, b"\x00" * 100000, None)) < 1000
+    # blosc1 (bit-shuffle + LZ4): encoded and decoded on the GPU; the from-spec decoder of the oracle must agree
+    for data in (sparse, noise, b"", b"\x01", b"\x00" * 100000, b"abc" * 7, bytes(512), bytes(513), sparse[:700], noise[:64], noise[:63]):
+        c = rcmp.compress(8, 1, data, None)
+        assert orc.blosc1_decode(c) == data
+        assert rcmp.de_compress(8, c, None) == data
+    # a chunk laid out the way python-blosc would for a small array (byte shuffle, split streams, stored) built by hand
+    import struct
+    arr = rng.integers(0, 256, 128 * 8, dtype=np.uint8)           # 128 elements of typesize 8 -> blocksize/typesize >= 128: split
+    sh = arr.reshape(128, 8).T.reshape(-1).tobytes()              # byte shuffle
+    body = b"".join(struct.pack("<i", 128) + sh[j * 128:(j + 1) * 128] for j in range(8))
+    chunk = bytes([2, 1, 0x21, 8]) + struct.pack("<iii", arr.size, arr.size, 16 + 4 + len(body)) + struct.pack("<i", 20) + body
+    assert orc.blosc1_decode(chunk) == arr.tobytes()
+    assert rcmp.de_compress(8, chunk, None) == arr.tobytes()
 
 
 def test_c_recode_reader_shim(orc):

@@ -141,7 +141,29 @@ def test_zstd_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode,scheme", [(0, 0), (1, 2), (1, 0), (1, 1)])
+@pytest.mark.parametrize("ny,nx,s,d,eps", SHAPES)
+def test_blosc_lz4_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
+    """scheme 8: each stream must be a blosc1 chunk (bit-shuffle + LZ4, typesize 8) that the from-spec decoder in the
+    oracle expands to the bit-exact payload (no stock blosc in the image: this codec's parity is unpinned)."""
+    dark, frames = synth_frames(41 + nx, 3, ny, nx, s, d)
+    thr = orc.threshold(dark, eps)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 8, 1, 0, max_batch=3)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=9)
+    for z in range(frames.shape[0]):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        assert fid == 9 + z and (cb, cp, npk) == tuple(int(v) for v in md[z]) and len(r) == 16 + cb + cp
+        binary, pix = orc.binarize_l1(frames[z], thr)
+        chunk = r[16:16 + cb]
+        assert chunk[:4] == bytes([2, 1, 0x34, 8])
+        assert orc.blosc1_decode(chunk) == orc.pack_binary_frame(binary).tobytes()
+        packed = orc.bit_pack(pix, d).tobytes()
+        assert npk == len(packed) and orc.blosc1_decode(r[16 + cb:]) == packed
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode,scheme", [(0, 0), (1, 2), (1, 0), (1, 1), (1, 8)])
 def test_l3_records(hip, orc, mode, scheme):
     ny, nx = 200, 333
     dark, frames = synth_frames(5, 3, ny, nx, 0.03, 12)
@@ -157,6 +179,8 @@ def test_l3_records(hip, orc, mode, scheme):
             assert fid == z and cb == md[z, 0] and len(r) == 8 + cb
             if scheme == 2:
                 _check_lz4(orc, r[8:], bitmap)
+            elif scheme == 8:
+                assert orc.blosc1_decode(r[8:]) == bitmap
             else:
                 assert _zstd_system_decode(r[8:]) == bitmap
         else:  # mode-0 record: the host layer compresses for schemes without a device codec

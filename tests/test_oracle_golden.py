@@ -144,3 +144,25 @@ def test_against_reference_c_loops_when_built():
         got = orc.unpack_frame_sparse(nx, ny, d, bitmap, pk, 1)
         assert n == vals.size == got.shape[0]
         assert np.array_equal(got, buf[:n])
+
+
+def test_blosc1_from_spec_decoder_on_a_hand_built_chunk():
+    """A chunk assembled by hand from the format description: bit-shuffled stored blocks, typesize 8, plus a memcpyed one."""
+    import struct
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 256, 512 + 200, dtype=np.uint8)
+    blocks = []
+    for lo in (0, 512):
+        blk = data[lo:lo + 512]
+        S = (blk.size // 8) & ~7
+        bits = np.unpackbits(blk[:S * 8].reshape(S, 8), axis=1, bitorder="little")          # [elem][bit r]
+        rows = np.packbits(bits.T, axis=1, bitorder="little").reshape(-1)                   # [row r][S/8 bytes]
+        sh = np.concatenate([rows, blk[S * 8:]]).tobytes()
+        blocks.append(struct.pack("<i", len(sh)) + sh)                                      # csize == size -> stored
+    tab = 16 + 8
+    bstarts = [tab, tab + len(blocks[0])]
+    body = struct.pack("<2i", *bstarts) + b"".join(blocks)
+    chunk = bytes([2, 1, 0x34, 8]) + struct.pack("<iii", data.size, 512, 16 + len(body)) + body
+    assert orc.blosc1_decode(chunk) == data.tobytes()
+    mem = bytes([2, 1, 0x36, 8]) + struct.pack("<iii", 5, 5, 21) + b"hello"
+    assert orc.blosc1_decode(mem) == b"hello"

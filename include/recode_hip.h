@@ -36,7 +36,9 @@ typedef enum rc_status {
                                      (recode_compressors.py:78-79,119-120) */
     RC_ERR_RECORD_TOO_LARGE = -5, /* a record exceeds the raw frame size; python: ValueError('Buffer size smaller
                                      than compressed data size') (recode_writer.py:565-566) */
-    RC_ERR_CORRUPT = -6           /* malformed compressed stream / bitmap-vs-pixvals mismatch on the read side */
+    RC_ERR_CORRUPT = -6,          /* malformed compressed stream / bitmap-vs-pixvals mismatch on the read side */
+    RC_ERR_WORKSPACE = -7         /* reduction level 2: more foreground pixels in the batch than the ctx's workspace holds
+                                     (sized for 12.5 % mean density); python: ValueError */
 } rc_status;
 
 /* compression_scheme codes of the reference (recode_compressors.py:3-4, config/README.md). Device codecs:
@@ -59,7 +61,8 @@ int rc_scheme_on_device(uint32_t scheme);        /* 1 if rc_reduce_compress_batc
  *
  *   nx, ny            frame shape (header fields nx, ny; recode_header.py:66-67)
  *   src_bit_depth     source_bit_depth: pixvals are bit-packed when it is not a multiple of 8 (recode_writer.py:463-475)
- *   reduction_level   1 (binary map + residuals) or 3 (binary map only); 2/4 -> RC_ERR_UNSUPPORTED this round
+ *   reduction_level   1 (binary map + residuals), 2 (binary map + one statistic per 8-connected component, see
+ *                     rc_ctx_set_l2_statistics) or 3 (binary map only); 4 -> RC_ERR_UNSUPPORTED
  *   op_mode           rc_operation_mode: 0 reduce only, 1 reduce + compress (recode_writer.py:482,497)
  *   scheme, clevel    compression_scheme / compression_level (recode_writer.py:503-511)
  *   device_id         HIP device ordinal
@@ -69,6 +72,12 @@ rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth, uint32_t
                       uint32_t op_mode, uint32_t scheme, uint32_t clevel, int device_id, uint32_t max_batch,
                       int *status);
 int rc_ctx_destroy(rc_ctx *ctx);
+
+/* Reduction level 2 only: which statistic of the RAW frame values each connected component contributes (header field
+ * L2_statistics, recode_writer.py:358-365): 0 or 1 = maximum, 2 = sum (mod 2^16 in the uint16 source dtype).
+ * Components are listed in scipy.ndimage.label order, i.e. by their first pixel in row-major order
+ * (recode_writer.py:443-446, utils/converters.py:262-297 - restated by intent, the reference's own code cannot run). */
+int rc_ctx_set_l2_statistics(rc_ctx *ctx, uint32_t l2_statistics);
 
 /* Use a caller-provided hipStream_t (passed as void*) instead of the ctx's own stream, e.g. torch's current
  * stream so that caller-side events bracket the kernels.  NULL restores the ctx's own stream (so the legacy null

@@ -19,6 +19,7 @@ RC_ERR_DEVICE = -3
 RC_ERR_UNSUPPORTED = -4
 RC_ERR_RECORD_TOO_LARGE = -5
 RC_ERR_CORRUPT = -6
+RC_ERR_WORKSPACE = -7
 
 # every symbol include/recode_hip.h declares: (restype, argtypes)
 _u8p, _u16p, _u32p, _u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses: host or device
@@ -40,6 +41,7 @@ SIGNATURES = {
     "rc_ctx_sync": (C.c_int, [C.c_void_p]),
     "rc_get_binary_map": (C.c_int, [C.c_void_p, C.c_uint32, _u8p]),
     "rc_ctx_keep_binary_maps": (C.c_int, [C.c_void_p, C.c_int]),
+    "rc_ctx_set_l2_statistics": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rc_get_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rc_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rc_ctx_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -95,7 +97,7 @@ def check(status, what=""):
     msg = "%s%s: %s" % (what + ": " if what else "", lib().rc_strerror(status).decode(), last_error())
     if status == RC_ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
-    if status in (RC_ERR_BAD_ARG, RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL, RC_ERR_CORRUPT):
+    if status in (RC_ERR_BAD_ARG, RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL, RC_ERR_CORRUPT, RC_ERR_WORKSPACE):
         raise ValueError(msg)
     raise RecodeHipError(msg)
 
@@ -181,6 +183,9 @@ class ReduceContext:
         out = np.empty(self.bitmap_bytes, np.uint8)
         check(lib().rc_get_binary_map(self._h, i, ptr(out)), "rc_get_binary_map")
         return out
+
+    def set_l2_statistics(self, code):
+        check(lib().rc_ctx_set_l2_statistics(self._h, int(code)), "rc_ctx_set_l2_statistics")
 
     def keep_binary_maps(self, on=True):
         check(lib().rc_ctx_keep_binary_maps(self._h, 1 if on else 0))

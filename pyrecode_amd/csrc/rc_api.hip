@@ -87,6 +87,8 @@ struct rc_ctx {
     uint64_t *d_rec_off = nullptr;
     uint32_t *d_md = nullptr;
     void *d_ztab = nullptr;               // zstd FSE tables (emit == 1)
+    rc::L2Work l2;                        // level 2 workspace
+    uint32_t l2_sum = 0;                  // L2_statistics: 0/1 max, 2 sum
     rc::BatchStatus *h_status = nullptr;  // pinned
     hipEvent_t ev[5] = {};
     float stage_ms[5] = {};
@@ -112,6 +114,7 @@ RC_EXPORT const char *rc_strerror(int status)
     case RC_ERR_UNSUPPORTED: return "not implemented on device";
     case RC_ERR_RECORD_TOO_LARGE: return "Buffer size smaller than compressed data size";
     case RC_ERR_CORRUPT: return "corrupt input stream";
+    case RC_ERR_WORKSPACE: return "level-2 workspace exceeded (too many foreground pixels in the batch)";
     default: return "unknown status";
     }
 }
@@ -150,7 +153,19 @@ static int ctx_alloc(rc_ctx *c)
     HIP_TRY(hipMalloc((void **)&sc.frame_nnz, B * 4));
     HIP_TRY(hipMalloc((void **)&sc.frame_cbytes, B * 4));
     HIP_TRY(hipMalloc((void **)&sc.status, sizeof(BatchStatus)));
-    if (c->level == 1) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2 + 64));
+    if (c->level != 3) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2 + 64));
+    if (c->level == 2) {  // compact-pixel workspace: 12.5 % mean foreground over the batch (RC_ERR_WORKSPACE beyond that)
+        L2Work &w = c->l2;
+        w.cap = std::max<uint64_t>(B * sc.N / 8, 1ull << 16);
+        if (w.cap > 0xFFFFFFF0ull) w.cap = 0xFFFFFFF0ull;
+        w.words_per_frame = T * (TILE_PX / 64);
+        HIP_TRY(hipMalloc((void **)&w.pos, w.cap * 4));
+        HIP_TRY(hipMalloc((void **)&w.val, w.cap * 2));
+        HIP_TRY(hipMalloc((void **)&w.parent, w.cap * 4));
+        HIP_TRY(hipMalloc((void **)&w.stat, w.cap * 4));
+        HIP_TRY(hipMalloc((void **)&w.word_rank, B * w.words_per_frame * 4));
+        HIP_TRY(hipMalloc((void **)&w.frame_base, (B + 1) * 8));
+    }
     if (c->emit != 0) {
         HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * BLK_SLOT + 64));
         HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
@@ -186,8 +201,8 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
         *status = fail(RC_ERR_BAD_ARG, "nx*ny must be < 2^32");
         return nullptr;
     }
-    if (reduction_level != 1 && reduction_level != 3) {
-        *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 2 and 4 are not implemented on device");
+    if (reduction_level < 1 || reduction_level > 3) {
+        *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 4 (centroiding) is not implemented on device");
         return nullptr;
     }
     if (src_bit_depth < 9 || src_bit_depth > 16) {
@@ -234,7 +249,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     rc::Scratch &sc = c->sc;
     void *bufs[] = {sc.thr, sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
                     sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.status, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
-                    c->d_md, c->d_ztab};
+                    c->d_md, c->d_ztab, c->l2.pos, c->l2.val, c->l2.parent, c->l2.stat, c->l2.word_rank, c->l2.frame_base};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -288,7 +303,7 @@ RC_EXPORT uint32_t rc_md_fields(const rc_ctx *c)
 {
     if (!c) return 0;
     const bool comp = c->emit != 0;
-    if (c->level == 1) return comp ? 3 : 1;
+    if (c->level != 3) return comp ? 3 : 1;
     return comp ? 1 : 0;
 }
 
@@ -298,7 +313,8 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     using namespace rc;
     hipStream_t s = c->stream;
     RecordParams rp;
-    rp.level = c->level; rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
+    rp.level = c->level == 3 ? 3u : 1u;  // level 2 records are framed exactly like level 1 (statistics in place of residuals)
+    rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
     rp.frame_bytes = c->sc.N * 2;
     HIP_TRY(hipMemsetAsync(c->sc.status, 0, sizeof(BatchStatus), s));
     hipEvent_t *ev = nullptr;
@@ -315,9 +331,14 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
         c->prof_used += 5;
     }
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    // LZ4 is fused into the reduce kernel; zstd encodes the raw bitmaps in a kernel of its own (one lane per block)
-    const bool fused = c->emit == RC_SCHEME_LZ4;
-    launch_reduce(c->sc, frames_dev, n, c->level == 1, fused ? c->emit : 0u, c->keep_bitmap || !fused, s);
+    // LZ4 is fused into the reduce kernel (levels 1 and 3); zstd / blosc / level 2 encode the raw bitmaps in a kernel of their own
+    const bool fused = c->emit == RC_SCHEME_LZ4 && c->level != 2;
+    launch_reduce(c->sc, frames_dev, n, c->level, fused ? c->emit : 0u, c->keep_bitmap || !fused, s);
+    if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
+        launch_scans(c->sc, n, true, false, s);
+        launch_l2(c->sc, c->l2, n, c->nx, c->l2_sum, s);
+    }
+    if (c->emit == RC_SCHEME_LZ4 && !fused) launch_lz4_encode_frames(c->sc, n, s);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);
@@ -325,7 +346,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     if (c->emit == RC_SCHEME_ZSTD) launch_zstd_encode_blocks(c->sc, n, c->d_ztab, s);
     if (c->emit == RC_SCHEME_BLOSC_LZ4) launch_blosc_encode_blocks(c->sc, n, s);
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], s));
-    launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);
+    launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);  // (level 2: k_l2_emit has already described its value list)
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], s));
     launch_layout(c->sc, rp, n, out_cap, rec_off_dev, md_dev, s);
     launch_assemble(c->sc, rp, n, out_dev, rec_off_dev, s);
@@ -419,7 +440,7 @@ RC_EXPORT int rc_get_binary_map(rc_ctx *c, uint32_t i, uint8_t *bitmap_out)
 {
     if (!c || !bitmap_out) return fail(RC_ERR_BAD_ARG, "NULL argument");
     if (i >= c->last_n) return fail(RC_ERR_BAD_ARG, "frame index outside the most recent batch");
-    if (!c->keep_bitmap && c->emit == RC_SCHEME_LZ4) return fail(RC_ERR_BAD_ARG, "binary maps are not kept (rc_ctx_keep_binary_maps(ctx, 0))");
+    if (!c->keep_bitmap && c->emit == RC_SCHEME_LZ4 && c->level != 2) return fail(RC_ERR_BAD_ARG, "binary maps are not kept (rc_ctx_keep_binary_maps(ctx, 0))");
     HIP_TRY(hipSetDevice(c->device));
     int r = copy_out(bitmap_out, c->sc.bitmap + (uint64_t)i * c->sc.nb_stride, c->sc.nb, c->stream);
     if (r != RC_OK) return r;
@@ -440,6 +461,13 @@ RC_EXPORT int rc_ctx_get_profile(rc_ctx *c, double sum_ms[5], uint64_t *batches)
     if (!c || !sum_ms || !batches) return fail(RC_ERR_BAD_ARG, "NULL argument");
     memcpy(sum_ms, c->prof_sum_ms, sizeof c->prof_sum_ms);
     *batches = c->prof_batches;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_ctx_set_l2_statistics(rc_ctx *c, uint32_t l2_statistics)
+{
+    if (!c || l2_statistics > 2) return fail(RC_ERR_BAD_ARG, "l2_statistics must be 0, 1 (max) or 2 (sum)");
+    c->l2_sum = l2_statistics == 2 ? 1u : 0u;
     return RC_OK;
 }
 

@@ -1,0 +1,197 @@
+// rc_l2.hip - reduction level 2: one summary statistic per connected component of the binary map.
+//
+// Reference intent (the reference's own L2 path cannot run): pyrecode/recode_writer.py:443-446
+//   labeled, n = scipy.ndimage.label(binary_frame, structure=ones((3,3)))      8-connectivity, labels in raster order of each
+//   stats = get_summary_stats_nb(labeled, frame, 0, dtype, 'max' | 'sum')      component's first pixel; statistic of the RAW
+//   (pyrecode/utils/converters.py:262-297)                                     frame values, cast to the source dtype
+// The record then carries the full binary map and the statistics where L1 carries the residuals (recode_writer.py:461-525).
+//
+// Device formulation - everything works on the COMPACTED list of set pixels (about 1 % of the frame), never on a label image:
+//   k_l2_index   wave per tile: global compact index of every set pixel (frame base + tile prefix + rank), its linear position
+//                and raw value; a rank directory (compact index of the first set pixel at/after each 64-pixel word)
+//   k_l2_union   thread per set pixel: union-find with the smaller compact index as root over the W, NW, N, NE neighbours
+//                (neighbour -> compact index through the rank directory + a popcount); atomicMin links, path halving
+//   k_l2_stats   thread per set pixel: full find, atomicMax / atomicAdd of the raw value into the root's accumulator
+//   k_l2_emit    workgroup per frame: roots in compact order ARE the components in scipy's label order (a root is its
+//                component's first pixel in raster order): prefix-count the roots, write their statistics as a contiguous
+//                uint16 list into the frame's value slots and describe it as full pseudo-tiles, so that record layout,
+//                bit-packing and compression run exactly as for L1.
+#include "rc_launch.h"
+
+namespace rc {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t *__restrict__ parent, uint32_t x)
+{
+    uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        const uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+__device__ __forceinline__ void uf_union(uint32_t *__restrict__ parent, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a > b) { const uint32_t t = a; a = b; b = t; }   // a < b: hang b's root under a
+        const uint32_t old = atomicMin(&parent[b], a);
+        if (old == b) return;                                // b was still a root: linked
+        b = old;                                             // somebody re-parented b meanwhile: retry from there
+    }
+}
+
+// grid (ceil(ntiles/WAVES), B).  Lane L of the tile's wave owns bitmap word L of the tile (64 pixels).
+__global__ __launch_bounds__(WG) void k_l2_index(Scratch sc, L2Work w, uint32_t B)
+{
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
+    if (t >= sc.ntiles) return;
+    const uint64_t frow = (uint64_t)f * sc.ntiles;
+    const u32x2 v = reinterpret_cast<const u32x2 *>(sc.bitmap + (uint64_t)f * sc.nb_stride + (uint64_t)t * TILE_BM)[lane];
+    uint64_t bits = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(bits);
+    const uint32_t inc = wave_incl_scan(cnt);
+    const uint32_t rank0 = inc - cnt;                               // set pixels of this tile before this word
+    const uint64_t base = (uint64_t)w.frame_base[f] + sc.tile_off[frow + t];
+    const uint64_t g0 = base + rank0;
+    w.word_rank[(uint64_t)f * w.words_per_frame + (uint64_t)t * 64 + lane] = (uint32_t)min(g0, (uint64_t)0xFFFFFFFFu);
+    const uint16_t *slot = sc.pix_slots + (frow + t) * TILE_PX;
+    const uint32_t px0 = t * (uint32_t)TILE_PX + (uint32_t)lane * 64u;
+    for (uint32_t j = 0; bits; bits &= bits - 1, ++j) {
+        const uint64_t g = g0 + j;
+        if (g >= w.cap) break;                                       // workspace exceeded: k_l2_emit reports it
+        w.pos[g] = px0 + (uint32_t)__builtin_ctzll(bits);
+        w.val[g] = slot[rank0 + j];
+        w.parent[g] = (uint32_t)g;
+        w.stat[g] = 0;
+    }
+}
+
+// compact index of the set pixel at linear position k of frame f (caller has checked the bit)
+__device__ __forceinline__ bool l2_neighbour(const Scratch &sc, const L2Work &w, uint32_t f, uint32_t k, uint32_t &g)
+{
+    const uint8_t *bm = sc.bitmap + (uint64_t)f * sc.nb_stride;
+    const u32x2 v = reinterpret_cast<const u32x2 *>(bm)[k >> 6];
+    const uint64_t word = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    if (!((word >> (k & 63)) & 1ull)) return false;
+    g = w.word_rank[(uint64_t)f * w.words_per_frame + (k >> 6)] + (uint32_t)__builtin_popcountll(word & ((1ull << (k & 63)) - 1ull));
+    return true;
+}
+
+// grid (L2_GRID, B), grid-stride over the frame's set pixels
+__global__ __launch_bounds__(WG) void k_l2_union(Scratch sc, L2Work w, uint32_t nx)
+{
+    const uint32_t f = blockIdx.y;
+    const uint64_t base = w.frame_base[f];
+    const uint32_t n = sc.frame_nnz[f];
+    if (base + n > w.cap) return;
+    for (uint32_t c = blockIdx.x * WG + threadIdx.x; c < n; c += gridDim.x * WG) {
+        const uint32_t g = (uint32_t)(base + c);
+        const uint32_t k = w.pos[g];
+        const uint32_t row = k / nx, col = k - row * nx;
+        uint32_t h;
+        if (col > 0 && l2_neighbour(sc, w, f, k - 1, h)) uf_union(w.parent, g, h);                 // W
+        if (row > 0) {
+            const uint32_t up = k - nx;
+            if (l2_neighbour(sc, w, f, up, h)) uf_union(w.parent, g, h);                           // N
+            if (col > 0 && l2_neighbour(sc, w, f, up - 1, h)) uf_union(w.parent, g, h);            // NW
+            if (col + 1 < nx && l2_neighbour(sc, w, f, up + 1, h)) uf_union(w.parent, g, h);       // NE
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_l2_stats(Scratch sc, L2Work w, uint32_t use_sum)
+{
+    const uint32_t f = blockIdx.y;
+    const uint64_t base = w.frame_base[f];
+    const uint32_t n = sc.frame_nnz[f];
+    if (base + n > w.cap) return;
+    for (uint32_t c = blockIdx.x * WG + threadIdx.x; c < n; c += gridDim.x * WG) {
+        const uint32_t g = (uint32_t)(base + c);
+        const uint32_t r = uf_find(w.parent, g);
+        w.parent[g] = r;  // flattened: k_l2_emit only asks "is g its own root"
+        if (use_sum) atomicAdd(&w.stat[r], (uint32_t)w.val[g]);
+        else atomicMax(&w.stat[r], (uint32_t)w.val[g]);
+    }
+}
+
+constexpr int L2_T = 1024, L2_W = L2_T / 64;
+// one workgroup per frame
+__global__ __launch_bounds__(L2_T) void k_l2_emit(Scratch sc, L2Work w)
+{
+    __shared__ uint32_t sm[L2_W];
+    const uint32_t f = blockIdx.x;
+    const uint64_t base = w.frame_base[f];
+    const uint32_t n = sc.frame_nnz[f];
+    const uint64_t frow = (uint64_t)f * sc.ntiles;
+    uint16_t *vals = sc.pix_slots + frow * TILE_PX;  // the frame's value slots, reused as ONE contiguous list
+    uint32_t ncomp = 0;
+    if (base + n > w.cap) {
+        if (threadIdx.x == 0) { sc.status->code = -7; sc.status->frame = f; }  // RC_ERR_WORKSPACE
+    } else {
+        for (uint32_t c0 = 0; c0 < n; c0 += L2_T) {
+            const uint32_t c = c0 + threadIdx.x;
+            uint32_t isroot = 0, g = 0;
+            if (c < n) {
+                g = (uint32_t)(base + c);
+                isroot = w.parent[g] == g;
+            }
+            // block exclusive scan of the root flags
+            const int wv = threadIdx.x >> 6;
+            const uint32_t inc = wave_incl_scan(isroot);
+            if (lane_id() == 63) sm[wv] = inc;
+            __syncthreads();
+            uint32_t before = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < L2_W; ++i) {
+                const uint32_t x = sm[i];
+                if (i < wv) before += x;
+                tot += x;
+            }
+            __syncthreads();
+            if (isroot) vals[ncomp + before + inc - 1] = (uint16_t)w.stat[g];
+            ncomp += tot;
+        }
+    }
+    // describe the list as full pseudo-tiles of TILE_PX values
+    for (uint32_t t = threadIdx.x; t < sc.ntiles; t += L2_T) {
+        const uint32_t lo = min(t * (uint32_t)TILE_PX, ncomp);
+        const uint32_t hi = min((t + 1) * (uint32_t)TILE_PX, ncomp);
+        sc.tile_off[frow + t] = lo;
+        sc.tile_cnt[frow + t] = hi - lo;
+        sc.tile_next[frow + t] = (t + 1) * (uint32_t)TILE_PX < ncomp ? t + 1 : sc.ntiles;
+    }
+    if (threadIdx.x == 0) sc.frame_nnz[f] = ncomp;
+}
+
+// exclusive prefix of frame_nnz over the frames of the batch -> frame_base[0..B]; single workgroup
+__global__ __launch_bounds__(WG) void k_l2_bases(const uint32_t *__restrict__ frame_nnz, uint64_t *__restrict__ frame_base, uint32_t B)
+{
+    __shared__ uint64_t part[WG];
+    const uint32_t per = (B + WG - 1) / WG, lo = threadIdx.x * per, hi = min(lo + per, B);
+    uint64_t s = 0;
+    for (uint32_t f = lo; f < hi; ++f) s += frame_nnz[f];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    uint64_t base = 0;
+    for (uint32_t i = 0; i < threadIdx.x; ++i) base += part[i];
+    for (uint32_t f = lo; f < hi; ++f) { frame_base[f] = base; base += frame_nnz[f]; }
+    if (threadIdx.x == WG - 1) frame_base[B] = base;
+}
+
+void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_l2_bases, dim3(1), dim3(WG), 0, s, sc.frame_nnz, w.frame_base, B);
+    hipLaunchKernelGGL(k_l2_index, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc, w, B);
+    hipLaunchKernelGGL(k_l2_union, dim3(128, B), dim3(WG), 0, s, sc, w, nx);
+    hipLaunchKernelGGL(k_l2_stats, dim3(128, B), dim3(WG), 0, s, sc, w, use_sum);
+    hipLaunchKernelGGL(k_l2_emit, dim3(B), dim3(L2_T), 0, s, sc, w);
+}
+
+}  // namespace rc

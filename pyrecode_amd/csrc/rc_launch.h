@@ -28,6 +28,17 @@ struct Scratch {
     BatchStatus *status = nullptr;     // [1]
 };
 
+// workspace of reduction level 2 (connected-component statistics), indexed by the batch-global compact pixel index
+struct L2Work {
+    uint32_t *pos = nullptr;         // [cap] linear pixel position inside its frame
+    uint16_t *val = nullptr;         // [cap] raw frame value
+    uint32_t *parent = nullptr;      // [cap] union-find parent (smaller index wins)
+    uint32_t *stat = nullptr;        // [cap] per-root accumulator
+    uint32_t *word_rank = nullptr;   // [B][words_per_frame] compact index of the first set pixel at/after each 64-pixel word
+    uint64_t *frame_base = nullptr;  // [B+1] compact index of each frame's first set pixel
+    uint64_t cap = 0, words_per_frame = 0;
+};
+
 struct RecordParams {
     uint32_t level;        // 1 or 3
     uint32_t emit;         // 0 = raw pieces (mode-0 record), 2 = LZ4 frames, 1 = zstd frames, 8 = blosc-lz4
@@ -38,8 +49,11 @@ struct RecordParams {
 
 // rc_reduce.hip
 void launch_threshold(const uint16_t *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s);
-void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, uint32_t codec, bool keep_bitmap,
+// level: 1 residuals, 2 raw values of the set pixels (input of launch_l2), 3 bitmap only
+void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
                    hipStream_t s);
+// rc_l2.hip
+void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s);
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);
 void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
                    uint32_t *md, hipStream_t s);
@@ -48,6 +62,7 @@ void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint
 // rc_lz4.hip
 struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
 void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s);  // sc.bitmap = the buffer, sc.nb = its length
+void launch_lz4_encode_frames(const Scratch &sc, uint32_t B, hipStream_t s);  // the raw bitmaps of B frames (unfused path)
 void launch_lz4f_gather(const Scratch &sc, uint32_t hdr3, uint8_t *out, hipStream_t s);
 void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
                        uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s);

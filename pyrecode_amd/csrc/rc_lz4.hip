@@ -23,21 +23,26 @@ __global__ __launch_bounds__(WG) void k_lz4_buffer(Scratch sc)
 {
     __shared__ Lz4Lds s_lz[WAVES];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    const uint32_t t = blockIdx.x * WAVES + w;
+    const uint32_t t = blockIdx.x * WAVES + w, f = blockIdx.y;
     if (t >= sc.ntiles) return;
     const uint64_t b0 = (uint64_t)t * TILE_BM;
     const uint32_t n = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = reinterpret_cast<const u32x2 *>(sc.bitmap + b0)[lane];  // the buffer is padded to whole blocks
+    const u32x2 v = reinterpret_cast<const u32x2 *>(sc.bitmap + (uint64_t)f * sc.nb_stride + b0)[lane];  // rows are padded to whole blocks
     reinterpret_cast<u32x2 *>(s_lz[w].raw)[lane] = v;
     const uint64_t own = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
     const uint32_t csize = lz4_encode_block(own, n, s_lz[w]);
-    const uint32_t used = lz4_store_block(sc.blk_slots + (uint64_t)t * BLK_SLOT, own, n, csize, s_lz[w]);
-    if (lane == 0) sc.blk_size[t] = used;
+    const uint64_t ft = (uint64_t)f * sc.ntiles + t;
+    const uint32_t used = lz4_store_block(sc.blk_slots + ft * BLK_SLOT, own, n, csize, s_lz[w]);
+    if (lane == 0) sc.blk_size[ft] = used;
 }
 void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s)
 {
     hipLaunchKernelGGL(k_lz4_buffer, dim3((sc.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, s, sc);
+}
+void launch_lz4_encode_frames(const Scratch &sc, uint32_t B, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lz4_buffer, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc);
 }
 
 // ---- stand-alone LZ4 frame of an arbitrary byte buffer (seam 2: compress(), recode_compressors.py:91) -----------------

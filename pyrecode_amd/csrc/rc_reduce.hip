@@ -73,7 +73,7 @@ __device__ __forceinline__ u32x4 load8(const uint16_t *__restrict__ base, uint64
 
 // One frame of one tile: x holds the 8 loaded groups of this lane (destroyed), xn receives the prefetch of `next`.
 // TMODE: 0 threshold in registers (t), 1 threshold in wave-private LDS (tl), 2 threshold re-read from L2 (thr pointer).
-template <bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE>
+template <bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
 __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], const uint16_t *__restrict__ next, bool have_next,
                                                  const u32x4 (&t)[TMODE == 0 ? R : 1], const u32x4 *__restrict__ tl,
                                                  const uint16_t *__restrict__ thr, uint64_t lane_px0, uint64_t N, uint32_t f,
@@ -129,7 +129,13 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                         const uint32_t i = (uint32_t)__builtin_ctz(m);
                         m &= m - 1;
                         const uint32_t lo = (i & 4u) ? x[r][2] : x[r][0], hi = (i & 4u) ? x[r][3] : x[r][1];
-                        const uint32_t d = (i & 2u) ? hi : lo;
+                        uint32_t d = (i & 2u) ? hi : lo;
+                        if (RAWVAL) {  // level 2 keeps the raw frame value: residual + threshold (TMODE 0 only)
+                            const uint32_t tlo = (i & 4u) ? t[TMODE == 0 ? r : 0][2] : t[TMODE == 0 ? r : 0][0];
+                            const uint32_t thi = (i & 4u) ? t[TMODE == 0 ? r : 0][3] : t[TMODE == 0 ? r : 0][1];
+                            const uint32_t td = (i & 2u) ? thi : tlo;
+                            d = ((d & 0xFFFFu) + (td & 0xFFFFu)) | ((d & 0xFFFF0000u) + (td & 0xFFFF0000u));
+                        }
                         slot[o++] = (uint16_t)((i & 1u) ? (d >> 16) : d);
                     }
                     wave_total += (tot >> (10 * k)) & 0x3FFu;
@@ -167,7 +173,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 //   -> bitmap bytes transposed through wave-private LDS (8 contiguous bytes per lane)
 //   -> [CODEC 2] the 512-byte bitmap block is LZ4-encoded in place (rc_lz4_block.h) and written to its slot
 //   -> [KEEP_BITMAP] the raw bitmap bytes are stored as well (rc_get_binary_map / mode-0 records / zstd input)
-template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE>
+template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
 __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
@@ -214,13 +220,13 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
         uint32_t f = f0 + z;
         if (f >= B) break;
         bool nxt = z + 1 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr, lane_px0, N,
+        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr, lane_px0, N,
                                                                      f, tile, (uint64_t)f * ntiles + tile, n_blk, w, bitmap,
                                                                      nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, bm);
         if (!nxt) break;
         ++f;
         nxt = z + 2 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr, lane_px0, N,
+        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr, lane_px0, N,
                                                                      f, tile, (uint64_t)f * ntiles + tile, n_blk, w, bitmap,
                                                                      nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, bm);
         if (!nxt) break;
@@ -243,41 +249,44 @@ static int reduce_tmode()  // where the threshold tile lives: 0 registers (defau
     return v;
 }
 
-template <int BZ, bool AL, bool L1, int CODEC, bool KEEP>
+template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW>
 static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, hipStream_t s)
 {
     const uint32_t ngroups = (B + BZ - 1) / BZ;
     const uint32_t ntb = (sc.ntiles + WAVES - 1) / WAVES;
     const uint32_t grid = ((ntb + 7) / 8) * 8 * ngroups;
-#define RC_GO(TM)                                                                                                        \
-    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP, TM>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N, sc.ntiles, \
-                       B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size)
-    const int tm = AL ? reduce_tmode() : 1;  // the scalar-load instantiation exists in one flavour only
-    if (tm == 0) { if (AL) RC_GO(0); } else if (tm == 2) { if (AL) RC_GO(2); } else RC_GO(1);
+#define RC_GO(TM)                                                                                                           \
+    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP, TM, RAW>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N,         \
+                       sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size)
+    // the scalar-load instantiation and the raw-value (level 2) one exist with the threshold in registers only
+    const int tm = (AL && !RAW) ? reduce_tmode() : 0;
+    if (tm == 1) { if (AL && !RAW) RC_GO(1); } else if (tm == 2) { if (AL && !RAW) RC_GO(2); } else RC_GO(0);
 #undef RC_GO
 }
 template <int BZ, bool AL>
-static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, uint32_t codec, bool keep,
+static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep,
                             hipStream_t s)
 {
+    if (level == 2) { launch_reduce_t<BZ, AL, true, 0, true, true>(sc, frames, B, s); return; }
+    const bool level1 = level == 1;
     if (codec == 2) {
-        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 2, true>(sc, frames, B, s); else launch_reduce_t<BZ, AL, true, 2, false>(sc, frames, B, s); }
-        else        { if (keep) launch_reduce_t<BZ, AL, false, 2, true>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 2, false>(sc, frames, B, s); }
+        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 2, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, true, 2, false, false>(sc, frames, B, s); }
+        else        { if (keep) launch_reduce_t<BZ, AL, false, 2, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 2, false, false>(sc, frames, B, s); }
     } else {
-        if (level1) launch_reduce_t<BZ, AL, true, 0, true>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 0, true>(sc, frames, B, s);
+        if (level1) launch_reduce_t<BZ, AL, true, 0, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 0, true, false>(sc, frames, B, s);
     }
 }
-void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, bool level1, uint32_t codec, bool keep_bitmap,
+void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
                    hipStream_t s)
 {
     const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
     const int bz = reduce_bz();
     if (aligned) {
-        if (bz == 8) launch_reduce_a<8, true>(sc, frames, B, level1, codec, keep_bitmap, s);
-        else if (bz == 2) launch_reduce_a<2, true>(sc, frames, B, level1, codec, keep_bitmap, s);
-        else launch_reduce_a<4, true>(sc, frames, B, level1, codec, keep_bitmap, s);
+        if (bz == 8) launch_reduce_a<8, true>(sc, frames, B, level, codec, keep_bitmap, s);
+        else if (bz == 2) launch_reduce_a<2, true>(sc, frames, B, level, codec, keep_bitmap, s);
+        else launch_reduce_a<4, true>(sc, frames, B, level, codec, keep_bitmap, s);
     } else {
-        launch_reduce_a<4, false>(sc, frames, B, level1, codec, keep_bitmap, s);
+        launch_reduce_a<4, false>(sc, frames, B, level, codec, keep_bitmap, s);
     }
 }
 

@@ -149,10 +149,16 @@ class ReCoDeReader:
 
     # ---- frame access --------------------------------------------------------------------------------------
     def _pack(self, key, metadata, sparse):
+        stats = None
+        if isinstance(sparse, tuple):  # level 2: (binary map as COO, summary statistics)
+            sparse, stats = sparse
         if sparse is None:
             self._header['nz'] = self._current_frame_index
             return None
-        return {key: {'metadata': metadata, 'data': sparse}}
+        d = {'metadata': metadata, 'data': sparse}
+        if stats is not None:
+            d['summary_stats'] = stats
+        return {key: d}
 
     def get_frame(self, z):
         if self._is_intermediate:
@@ -228,8 +234,6 @@ class ReCoDeReader:
         """Read one frame's streams, decompress if needed, expand on the GPU, wrap as COO (reference :379-471)."""
         h = self._header
         level, mode = h['reduction_level'], h['rc_operation_mode']
-        if level == 2:
-            raise NotImplementedError('L2 files: summary statistics are not implemented (non-functional in the reference)')
         sz_map, sz_val = self._stream_sizes(frame_metadata)
         binary_map = self._fp.read(sz_map)
         values = self._fp.read(sz_val) if sz_val is not None else None
@@ -239,16 +243,25 @@ class ReCoDeReader:
             if values is not None:
                 values = compressors.de_compress(scheme, values, self._decompressor_context)
         # size the triplet buffer from the value stream (L1) or ask the library to count (bitmap-only levels)
+        d = int(h['target_bit_depth'])
         if level == 1:
-            d = int(h['target_bit_depth'])
             cap = (len(values) * 8) // d
         else:
             cap = self._c_reader.count(binary_map)
         buf = np.empty((max(cap, 1), 3), dtype=np.uint64)
-        n = self._c_reader.get_frame_sparse(level, binary_map, values, buf) if cap else 0
+        n = self._c_reader.get_frame_sparse(level, binary_map, values if level == 1 else None, buf) if cap else 0
         if n == 0 and mode == 0:
-            return None  # reference :387-391: an empty reduce-only frame reads as end of data
-        return self._make_coo_frame(n, buf)
+            return (None, None) if level == 2 else None  # reference :387-391: an empty reduce-only frame reads as end of data
+        coo = self._make_coo_frame(n, buf)
+        if level != 2:
+            return coo
+        # level 2: the value stream holds one statistic per connected component, in scipy label order (reference :473-481,
+        # whose count formula and unpacker are defective - SURVEY appendix B; the intended semantics are implemented)
+        n_stats = (len(values) * 8) // d
+        stats = np.zeros(max(n_stats, 1), dtype=np.uint64)
+        if n_stats:
+            self._c_reader.bit_unpack_pixel_intensities(n_stats, values, stats)
+        return coo, stats[:n_stats].astype(self._numpy_dtype)
 
     def _make_coo_frame(self, n, buf):
         d = buf[:n]

@@ -60,8 +60,8 @@ class ReCoDeWriter:
         if ip.source_numpy_dtype != np.uint16 or ip.target_numpy_dtype != np.uint16:
             # same restriction the reference places on its native path (recode_writer.py:85-87)
             raise ValueError('the HIP path requires source and target dtypes to be unsigned 16-bit')
-        if ip.reduction_level not in (1, 3):
-            raise NotImplementedError('reduction levels 2 and 4 are not implemented on device '
+        if ip.reduction_level not in (1, 2, 3):
+            raise NotImplementedError('reduction level 4 (centroiding) is not implemented on device '
                                       '(non-functional in the reference as well, SURVEY.md 0.5)')
 
         self._rc_header = ReCoDeHeader()
@@ -150,6 +150,8 @@ class ReCoDeWriter:
         self._ctx = _lib.ReduceContext(nx, ny, ip.source_bit_depth, ip.reduction_level, ip.rc_operation_mode,
                                        ip.compression_scheme, ip.compression_level, self._pick_device(), self._batch_size)
         self._ctx.set_dark(np.ascontiguousarray(self._calibration_frame), ip.calibration_threshold_epsilon)
+        if ip.reduction_level == 2:
+            self._ctx.set_l2_statistics(ip.L2_statistics)  # 0/1 max, 2 sum (reference :358-365)
         # raw binary maps are only consumed for validation frames (reference :402-415); skip the extra HBM write otherwise
         self._keep_maps = init.validation_frame_gap > 0
         self._ctx.keep_binary_maps(self._keep_maps)
@@ -277,7 +279,7 @@ class ReCoDeWriter:
         h, nb = self._header, self._n_bytes_in_binary_image
         scheme, level = h['compression_scheme'], h['compression_level']
         t0 = datetime.now()
-        if h['reduction_level'] == 1:
+        if h['reduction_level'] in (1, 2):
             fid, npk = struct.unpack_from('<II', r, 0)
             cb = compressors.compress(scheme, level, r[8:8 + nb], self._compressor_context)
             t1 = datetime.now()

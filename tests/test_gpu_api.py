@@ -295,3 +295,27 @@ def test_two_rank_sharded_write_and_direct_merge(tmp_path):
     for z in (0, 4, 5, 8):
         assert np.array_equal(np.asarray(rd.get_frame(z)[z]["data"].todense()), want[z])
     rd.close()
+
+
+def test_l2_write_read_round_trip(tmp_path):
+    """Level 2 through the reference-shaped API: ReCoDeWriter(reduction_level=2) -> merge -> ReCoDeReader returns the binary map
+    plus 'summary_stats' (one value per 8-connected component, scipy label order)."""
+    import scipy.ndimage as nd
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, nz = 120, 200, 5
+    dark, frames = synth_frames(9, nz, ny, nx, 0.08, 12)
+    g = load_npz("g3_l1z12.npz")
+    over = dict(num_rows=ny, num_cols=nx, num_frames=nz, num_threads=2, compression_scheme=2, reduction_level=2, l2_statistics=2)
+    _write_parts(tmp_path, "l2", dark, frames, 2, g, batch_size=2, **over)
+    merge_parts(str(tmp_path), "l2.rc2", 2)
+    rd = ReCoDeReader(str(tmp_path / "l2.rc2"))
+    rd.open(print_header=False)
+    for z in range(nz):
+        f = rd.get_frame(z)[z]
+        binary = frames[z] > dark
+        assert np.array_equal(np.asarray(f["data"].todense()) != 0, binary)
+        labels, n = nd.label(binary, structure=np.ones((3, 3), int))
+        want = (np.asarray(nd.sum(frames[z].astype(np.int64), labels, np.arange(1, n + 1)), np.int64) & 0xFFF).astype(np.uint16)
+        assert np.array_equal(f["summary_stats"], want)   # 12-bit fields: bits above the depth are dropped by the packer
+        assert f["metadata"]["bytes_in_packed_summary_stats"] == (n * 12 + 7) // 8
+    rd.close()

@@ -127,3 +127,36 @@ def test_4096_host_buffer_path_and_pcie_inclusive_rate(env, capsys):
         print("\n[pcie-inclusive] %d frames 4096x4096 from pageable host memory: %.1f frames/s (%.2f GB/s in)" % (
             B, B / dt, B * N * 2 / dt / 1e9))
     ctx.close()
+
+
+def test_4096_l2_blosc_config4(env):
+    """configs[3]: 4096x4096 uint16, 0.1 % sparsity, L2 (component maxima) + blosc-lz4.  No oracle exists in the reference for
+    L2: the checker is the stated intent, scipy.ndimage.label (8-connectivity) + per-label maximum of the raw frame."""
+    import scipy.ndimage as nd
+    torch, hip, synth, orc = env
+    ny = nx = 4096
+    N, B = ny * nx, 3
+    dark_d, frames_d = _device_stack(torch, hip, 21, B, N, 1000)
+    ctx = hip.ReduceContext(nx, ny, 12, 2, 1, 8, 1, 0, max_batch=B)
+    ctx.set_dark(dark_d.data_ptr(), 0)
+    ctx.set_l2_statistics(1)
+    cap = B * (N // 4)
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    rec = torch.empty(B + 1, dtype=torch.int64, device="cuda")
+    md = torch.empty((B, 3), dtype=torch.int32, device="cuda")
+    ctx.enqueue(frames_d.data_ptr(), B, 0, out.data_ptr(), cap, rec.data_ptr(), md.data_ptr())
+    ctx.sync()
+    rec_h = rec.cpu().numpy()
+    out_h = out[:int(rec_h[-1])].cpu().numpy()
+    thr = dark_d.cpu().numpy().view(np.uint16).reshape(ny, nx)
+    frames = frames_d.cpu().numpy().view(np.uint16).reshape(B, ny, nx)
+    for z in range(B):
+        r = out_h[int(rec_h[z]):int(rec_h[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        binary = frames[z] > thr
+        labels, n = nd.label(binary, structure=np.ones((3, 3), int))
+        vals = np.asarray(nd.maximum(frames[z].astype(np.int64), labels, np.arange(1, n + 1)), np.int64).astype(np.uint16)
+        assert orc.blosc1_decode(r[16:16 + cb]) == orc.pack_binary_frame(binary).tobytes()
+        assert npk == (n * 12 + 7) // 8
+        assert orc.blosc1_decode(r[16 + cb:]) == orc.bit_pack(vals, 12).tobytes()
+    ctx.close()

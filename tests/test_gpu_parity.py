@@ -302,3 +302,56 @@ def test_synth_generator_host_device_identical(hip):
     assert np.array_equal(fr_d.cpu().numpy().view(np.uint16), synth.frames(42, 5, 3, N, 10000, dark_h))
     frac = (fr_d.cpu().numpy().view(np.uint16) > dark_h).mean()
     assert 0.008 < frac < 0.012
+
+
+# ---- reduction level 2: specification by intent, checked against scipy.ndimage.label + numpy -----------------
+def _l2_expected(frame, thr, stat):
+    import scipy.ndimage as nd
+    binary = frame > thr
+    labels, n = nd.label(binary, structure=np.ones((3, 3), int))        # recode_writer.py:443 (8-connectivity, raster label order)
+    idx = np.arange(1, n + 1)
+    f = frame.astype(np.int64)
+    vals = nd.maximum(f, labels, idx) if stat in (0, 1) else nd.sum(f, labels, idx)
+    return binary, (np.asarray(vals, np.int64) & 0xFFFF).astype(np.uint16) if n else np.zeros(0, np.uint16)
+
+
+@pytest.mark.parametrize("ny,nx,s,d,stat,scheme,mode", [
+    (64, 64, 0.05, 16, 1, 0, 0), (129, 127, 0.10, 12, 0, 0, 0), (37, 53, 0.20, 12, 2, 0, 0), (200, 300, 0.30, 16, 2, 2, 1),
+    (256, 1024, 0.02, 12, 1, 2, 1), (100, 300, 0.45, 16, 0, 1, 1), (128, 128, 0.62, 14, 2, 8, 1), (96, 160, 0.0, 12, 1, 2, 1)])
+def test_l2_summary_statistics(hip, orc, ny, nx, s, d, stat, scheme, mode):
+    dark, frames = synth_frames(77 + ny + stat, 3, ny, nx, s, d)
+    if s > 0.4:  # blobs: make components large and snaky so that unions have real work
+        rng = np.random.default_rng(5)
+        frames[1, :, ::2] = (dark[:, ::2] + 5).astype(np.uint16)
+        frames[2, ny // 2, :] = (dark[ny // 2, :] + rng.integers(1, 100, nx)).astype(np.uint16)
+    thr = orc.threshold(dark, 1)
+    ctx = hip.ReduceContext(nx, ny, d, 2, mode, scheme, 1, 0, max_batch=3)
+    ctx.set_dark(dark, 1)
+    ctx.set_l2_statistics(stat)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+    for z in range(frames.shape[0]):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        binary, vals = _l2_expected(frames[z], thr, stat)
+        bitmap = orc.pack_binary_frame(binary).tobytes()
+        packed = orc.bit_pack(vals, d).tobytes()
+        if mode == 0:
+            assert r == struct.pack("<II", z, len(packed)) + bitmap + packed, "frame %d" % z
+        else:
+            fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+            assert fid == z and npk == len(packed) and len(r) == 16 + cb + cp
+            dec = {2: lambda b, n: orc.lz4f_decode(b, n + 8), 1: lambda b, n: _zstd_system_decode(b), 8: lambda b, n: orc.blosc1_decode(b)}[scheme]
+            assert dec(r[16:16 + cb], len(bitmap)) == bitmap
+            assert dec(r[16 + cb:], len(packed)) == packed
+    ctx.close()
+
+
+def test_l2_workspace_overflow_is_reported(hip):
+    ny, nx = 256, 256
+    frames = np.full((4, ny, nx), 1000, np.uint16)   # every pixel set in every frame: > 12.5 % mean density
+    ctx = hip.ReduceContext(nx, ny, 16, 2, 0, 0, 1, 0, max_batch=4)
+    ctx.set_threshold(np.zeros((ny, nx), np.uint16))
+    with pytest.raises(ValueError, match="workspace"):
+        ctx.reduce_compress_batch(frames, 0)
+    out, rec, md = ctx.reduce_compress_batch(frames[:1] * 0, 0)   # the ctx stays usable
+    assert md[0, 0] == 0
+    ctx.close()

@@ -160,3 +160,44 @@ def test_4096_l2_blosc_config4(env):
         assert npk == (n * 12 + 7) // 8
         assert orc.blosc1_decode(r[16 + cb:]) == orc.bit_pack(vals, 12).tobytes()
     ctx.close()
+
+
+def test_direct_electron_size_zstd_write_read_config5(env, tmp_path):
+    """configs[4]: 11520x8184 uint16, 5 % sparsity, L1 + zstd, through the reference-shaped API with 2 writers (the contiguous
+    block rule), direct merge, and a round trip through ReCoDeReader that must be bit-exact."""
+    torch, hip, synth, orc = env
+    from pyrecode_amd.params import InputParams
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    from pyrecode_amd.recode_reader import ReCoDeReader
+    from pyrecode_amd import parallel
+    ny, nx, depth, nz = 8184, 11520, 12, 3
+    N = ny * nx
+    dark_d, frames_d = _device_stack(torch, hip, 13, nz, N, 50000)
+    dark = dark_d.cpu().numpy().view(np.uint16).reshape(ny, nx)
+    frames = frames_d.cpu().numpy().view(np.uint16).reshape(nz, ny, nx)
+    del frames_d
+    cfg = dict(l4_centroiding=0, source_file_type=0, num_frames=nz, source_header_length=0, calibration_frame_offset=0,
+               compression_scheme=1, calibration_file_type=0, compression_level=1, l2_statistics=0,
+               calibration_threshold_epsilon=0, frame_offset=0, num_threads=2, rc_operation_mode=1, num_calibration_frames=1,
+               reduction_level=1, keep_calibration_data=1, source_bit_depth=depth, target_bit_depth=depth, keep_part_files=0,
+               num_rows=ny, num_cols=nx, source_data_type=0, target_data_type=0)
+    pf = tmp_path / "p.txt"
+    pf.write_text("".join("%s = %d\n" % kv for kv in cfg.items()))
+    for node in range(2):
+        ip = InputParams()
+        ip.load(str(pf))
+        w = ReCoDeWriter("de", dark_data=dark, output_directory=str(tmp_path), input_params=ip, node_id=node, batch_size=2)
+        w.start()
+        w.run(frames)
+        w.close()
+    recs = []
+    for node in range(2):
+        recs += parallel.read_part_records(str(tmp_path / ("de.rc1_part%03d" % node)))[1]
+    assert parallel.merge_direct(str(tmp_path), "de.rc1", rank=0, world=1, records=recs) == nz
+    rd = ReCoDeReader(str(tmp_path / "de.rc1"))
+    rd.open(print_header=False)
+    for z in (2, 0):
+        got = np.asarray(rd.get_frame(z)[z]["data"].todense())
+        want = np.where(frames[z] > dark, frames[z] - dark, 0).astype(np.uint16)
+        assert np.array_equal(got, want)
+    rd.close()

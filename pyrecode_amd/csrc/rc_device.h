@@ -17,7 +17,7 @@ constexpr int R = 8;                       // 16-byte loads per lane per frame-t
 constexpr int GROUP_PX = 64 * 8;           // 512
 constexpr int TILE_PX = R * GROUP_PX;      // 4096 pixels = 8 KiB of uint16
 constexpr int TILE_BM = TILE_PX / 8;       // 512 bitmap bytes per tile
-constexpr int BLK_SLOT = TILE_BM + 16;     // per-tile scratch slot for an encoded block (4-byte size word + payload)
+constexpr int BLK_SLOT = TILE_BM + 128;    // per-tile scratch slot for an encoded block (4-byte size word + payload), 5 x 128-byte lines
 
 // ---- wavefront primitives (64 lanes) ------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

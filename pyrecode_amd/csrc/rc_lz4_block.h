@@ -142,9 +142,11 @@ __device__ __forceinline__ uint32_t lz4_store_block(uint8_t *slot, uint64_t own,
         }
         return 4 + n;
     }
-    if (lane == 0) slot32[0] = csize;
+    // [size word][payload] written as whole 128-byte lines (slots are 128-byte aligned, BLK_SLOT is a multiple of 128): the
+    // bytes behind the payload are unused slot space, and partial-line writes cost a read-modify-write at the memory side
     const uint32_t *p = reinterpret_cast<const uint32_t *>(L.out);
-    for (uint32_t i = lane; i < (csize + 3) / 4; i += 64) slot32[1 + i] = p[i];
+    const uint32_t ndw = ((1u + (csize + 3) / 4) + 31u) & ~31u;
+    for (uint32_t i = lane; i < ndw; i += 64) slot32[i] = i == 0 ? csize : p[i - 1];
     return 4 + csize;
 }
 

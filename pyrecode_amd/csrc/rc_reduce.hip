@@ -71,16 +71,60 @@ __device__ __forceinline__ u32x4 load8(const uint16_t *__restrict__ base, uint64
     }
 }
 
+// Results of one (tile, frame) that are still sitting in wave-private LDS / registers, waiting to be written out.
+// Stores are issued one frame LATE, right behind the next frame's loads: the `s_waitcnt vmcnt(0)` in front of a frame's first
+// use of its data then only meets operations that were issued a whole frame of compute earlier.  (gfx9 counts loads and stores
+// on ONE in-order counter; with the stores issued just before the wait, their full write latency was exposed on every frame:
+// measured 0.49 ms -> 0.37 ms for this kernel with the stores removed, 0.30 ms being the pure read time.)
+struct Pending {
+    bool valid;
+    uint64_t ft;        // frame * ntiles + tile
+    uint32_t f;
+    uint32_t cnt;       // residuals staged in LDS
+    uint32_t csize;     // LZ4 payload bytes staged in LDS (>= n_blk: store raw)
+    u32x2 own;          // this lane's 8 bitmap bytes (raw-block fallback / raw bitmap store)
+};
+
+struct __attribute__((aligned(16))) WaveStage {
+    uint16_t pix[TILE_PX];  // compacted residuals of the tile, row-major
+};
+
+template <bool LEVEL1, int CODEC, bool KEEP_BITMAP>
+__device__ __forceinline__ void flush_pending(const Pending &p, uint32_t tile, uint32_t n_blk, uint8_t *__restrict__ bitmap,
+                                              uint64_t nb_stride, uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
+                                              uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, const Lz4Lds *lz,
+                                              const WaveStage *st)
+{
+    if (!p.valid) return;
+    const int lane = lane_id();
+    if (LEVEL1) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(pix_slots + p.ft * TILE_PX);   // slots are 8 KiB aligned
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(st->pix);
+        // whole 128-byte lines only (the tail of the last line is unused slot space): partial-line writes cost a
+        // read-modify-write at the memory side
+        const uint32_t ndw = (((p.cnt + 1) >> 1) + 31u) & ~31u;
+        for (uint32_t i = lane; i < ndw; i += 64) dst[i] = src[i];
+        if (lane == 0) tile_cnt[p.ft] = p.cnt;
+    }
+    if (KEEP_BITMAP) *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)p.f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = p.own;
+    if (CODEC == 2) {
+        const uint64_t bytes = (uint64_t)p.own[0] | ((uint64_t)p.own[1] << 32);
+        const uint32_t used = lz4_store_block(blk_slots + p.ft * BLK_SLOT, bytes, n_blk, p.csize, *lz);
+        if (lane == 0) blk_size[p.ft] = used;
+    }
+}
+
 // One frame of one tile: x holds the 8 loaded groups of this lane (destroyed), xn receives the prefetch of `next`.
 // TMODE: 0 threshold in registers (t), 1 threshold in wave-private LDS (tl), 2 threshold re-read from L2 (thr pointer).
 template <bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
 __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], const uint16_t *__restrict__ next, bool have_next,
                                                  const u32x4 (&t)[TMODE == 0 ? R : 1], const u32x4 *__restrict__ tl,
                                                  const uint16_t *__restrict__ thr, uint64_t lane_px0, uint64_t N, uint32_t f,
-                                                 uint32_t tile, uint64_t ft, uint32_t n_blk, int w, uint8_t *__restrict__ bitmap,
+                                                 uint32_t tile, uint64_t ft, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
                                                  uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ blk_slots,
-                                                 uint32_t *__restrict__ blk_size, Lz4Lds *s_lz, uint8_t *s_bm)
+                                                 uint32_t *__restrict__ blk_size, Lz4Lds *s_lz, uint8_t *s_bm, WaveStage *st,
+                                                 Pending &pend)
 {
     const int lane = lane_id();
     // residuals (saturating subtract, in place) and the 8-bit mask of this lane's 8 pixels, per group
@@ -98,16 +142,20 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
         m8[r] = (M | (M >> 15)) & 0xFFu;
     }
     // this frame's data has arrived (the subtract above consumed it): start the NEXT frame's loads now, into the other
-    // register set, so that they fly during the whole compaction + encoding of this frame
+    // register set, so that they fly during the whole compaction + encoding of this frame ...
     if (have_next) {
 #pragma unroll
         for (int r = 0; r < R; ++r) xn[r] = load8<ALIGNED, true>(next, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
     }
+    pend.valid = true;
+    pend.ft = ft;
+    pend.f = f;
+    pend.cnt = 0;
+    pend.csize = 0;
     if (LEVEL1) {
         // exclusive prefix of the per-lane popcounts in (group, lane) order: three groups per packed scan (each field
-        // <= 512 needs 10 bits); residuals are stored as soon as their group's offsets are known
+        // <= 512 needs 10 bits); residuals are compacted into the wave's LDS stage as soon as their group's offsets are known
         uint32_t wave_total = 0;
-        uint16_t *slot = pix_slots + ft * TILE_PX;
 #pragma unroll
         for (int r0 = 0; r0 < R; r0 += 3) {
             uint32_t pk = 0;
@@ -136,28 +184,26 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                             const uint32_t td = (i & 2u) ? thi : tlo;
                             d = ((d & 0xFFFFu) + (td & 0xFFFFu)) | ((d & 0xFFFF0000u) + (td & 0xFFFF0000u));
                         }
-                        slot[o++] = (uint16_t)((i & 1u) ? (d >> 16) : d);
+                        st->pix[o++] = (uint16_t)((i & 1u) ? (d >> 16) : d);
                     }
                     wave_total += (tot >> (10 * k)) & 0x3FFu;
                 }
         }
-        if (lane == 0) tile_cnt[ft] = wave_total;
+        pend.cnt = wave_total;
     }
     if (KEEP_BITMAP || CODEC) {
         // transpose through wave-private LDS: byte (r, lane) -> position r*64 + lane; 8 contiguous bytes per lane out
         uint8_t *bm = CODEC ? s_lz->raw : s_bm;
 #pragma unroll
         for (int r = 0; r < R; ++r) bm[r * 64 + lane] = (uint8_t)m8[r];
-        const u32x2 own = *reinterpret_cast<const u32x2 *>(&bm[lane * 8]);
-        if (KEEP_BITMAP)
-            *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = own;
+        pend.own = *reinterpret_cast<const u32x2 *>(&bm[lane * 8]);
         if (CODEC == 2) {
-            const uint64_t bytes = (uint64_t)own[0] | ((uint64_t)own[1] << 32);
-            const uint32_t csize = lz4_encode_block(bytes, n_blk, *s_lz);
-            const uint32_t used = lz4_store_block(blk_slots + ft * BLK_SLOT, bytes, n_blk, csize, *s_lz);
-            if (lane == 0) blk_size[ft] = used;
+            const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
+            pend.csize = lz4_encode_block(bytes, n_blk, *s_lz);
         }
     }
+    flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st);
+    pend.valid = false;
 }
 
 // Workgroup id -> (tile block, frame group).  A tile block is WAVES consecutive tiles (one per wavefront); a frame group
@@ -169,10 +215,10 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 // Per frame and wavefront, with NO barrier and no cross-wave traffic (reduce_one_frame):
 //   8 x 16-byte nontemporal loads per lane, issued ONE FRAME AHEAD into the second register set
 //   -> saturating subtract (residual and mask in one op) -> 8-bit mask per lane
-//   -> [LEVEL1] DPP prefix sums of the popcounts, residuals stored from registers into the tile's slot
+//   -> [LEVEL1] DPP prefix sums of the popcounts, residuals compacted into the wave's LDS stage
 //   -> bitmap bytes transposed through wave-private LDS (8 contiguous bytes per lane)
-//   -> [CODEC 2] the 512-byte bitmap block is LZ4-encoded in place (rc_lz4_block.h) and written to its slot
-//   -> [KEEP_BITMAP] the raw bitmap bytes are stored as well (rc_get_binary_map / mode-0 records / zstd input)
+//   -> [CODEC 2] the 512-byte bitmap block is LZ4-encoded in LDS (rc_lz4_block.h)
+//   -> all global stores (residuals, encoded block, raw bitmap, counts) are issued ONE FRAME LATE, coalesced (flush_pending)
 template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
 __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
@@ -184,6 +230,7 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
     __shared__ Lz4Lds s_lz[CODEC ? WAVES : 1];                                                  // codec working set
     __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : WAVES][CODEC ? 16 : TILE_BM];  // transpose only
     __shared__ u32x4 s_thr[TMODE == 1 ? WAVES : 1][TMODE == 1 ? R * 64 : 1];                       // threshold tile per wave
+    __shared__ WaveStage s_stage[LEVEL1 ? WAVES : 1];                                           // compacted residuals
 
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t grp = j % ngroups;
@@ -214,23 +261,30 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
     const uint32_t n_blk = (uint32_t)min((uint64_t)TILE_BM, nb - (uint64_t)tile * TILE_BM);  // bitmap bytes of this tile
     Lz4Lds *lz = &s_lz[CODEC ? w : 0];
     uint8_t *bm = s_bm[CODEC ? 0 : w];
+    WaveStage *st = &s_stage[LEVEL1 ? w : 0];
+    Pending pend;
+    pend.valid = false;
+    pend.ft = 0; pend.f = 0; pend.cnt = 0; pend.csize = 0; pend.own = u32x2{0u, 0u};
 
 #pragma unroll 1
     for (int z = 0; z < BZ; z += 2) {
         uint32_t f = f0 + z;
         if (f >= B) break;
         bool nxt = z + 1 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr, lane_px0, N,
-                                                                     f, tile, (uint64_t)f * ntiles + tile, n_blk, w, bitmap,
-                                                                     nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, bm);
+        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr,
+                                                                             lane_px0, N, f, tile, (uint64_t)f * ntiles + tile, n_blk,
+                                                                             bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
+                                                                             blk_size, lz, bm, st, pend);
         if (!nxt) break;
         ++f;
         nxt = z + 2 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr, lane_px0, N,
-                                                                     f, tile, (uint64_t)f * ntiles + tile, n_blk, w, bitmap,
-                                                                     nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, bm);
+        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr,
+                                                                             lane_px0, N, f, tile, (uint64_t)f * ntiles + tile, n_blk,
+                                                                             bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
+                                                                             blk_size, lz, bm, st, pend);
         if (!nxt) break;
     }
+    flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st);
 }
 
 static int reduce_bz()

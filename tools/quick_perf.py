@@ -22,11 +22,12 @@ ctx.keep_binary_maps(bool(keep))
 cap = B * (N // 2 + 4096)
 out = torch.empty(cap, dtype=torch.uint8, device="cuda")
 recn = np.zeros(B + 1, np.uint64); mdn = np.zeros((B, 3), np.uint32)
-best = None
-for it in range(6):
+runs = []
+for it in range(24):
     hip.check(L.rc_reduce_compress_batch(ctx.handle, frames.data_ptr(), B, 0, out.data_ptr(), cap, recn.ctypes.data, mdn.ctypes.data))
-    ms = ctx.stage_ms()
-    if it >= 2 and (best is None or ms[4] < best[4]):
-        best = ms
-print("shape %dx%d B=%d ppm=%d d=%d scheme=%d level=%d keep=%d: stage ms [reduce, codec, scan, layout+assemble, total] = %s  -> %.0f frames/s, reduce %.2f TB/s" %
-      (ny, nx, B, ppm, d, scheme, level, keep, ["%.3f" % v for v in best], B / best[4] * 1e3, B * N * 2 / best[0] / 1e9))
+    if it >= 4:
+        runs.append(ctx.stage_ms())
+runs = np.array(runs)
+med, best = np.median(runs, axis=0), runs.min(axis=0)
+print("shape %dx%d B=%d ppm=%d d=%d scheme=%d level=%d keep=%d: median ms [reduce, codec, scan, layout+assemble, total] = %s (min reduce %.3f total %.3f) -> %.0f frames/s, reduce %.2f TB/s" %
+      (ny, nx, B, ppm, d, scheme, level, keep, ["%.3f" % v for v in med], best[0], best[4], B / med[4] * 1e3, B * N * 2 / med[0] / 1e9))

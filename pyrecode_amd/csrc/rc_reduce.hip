@@ -616,7 +616,6 @@ __device__ __forceinline__ uint64_t stored_pos(const FrameFmt &ff, uint64_t b)
 }
 
 constexpr uint32_t ASM_TPW = 16;  // tiles per wavefront: their metadata sits one tile per lane (lanes 0..15)
-constexpr int ASM_U = 8;           // segments kept in flight
 
 // One wavefront per ASM_TPW consecutive tiles of a frame.  Lane L fetches tile L's metadata (one coalesced round trip); the
 // wavefront then walks the tiles with wave-uniform (readlane) sizes and offsets, copying each tile's encoded bitmap block
@@ -706,89 +705,116 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
         }
     }
 
-    // this lane's tile: metadata
-    const uint32_t tl = t0 + lane;
-    const bool have = tl < sc.ntiles;
-    uint32_t bsz = 0, boff = 0, cnt = 0, poff = 0;
-    if (have) {
-        if (rp.emit == 0) {
-            boff = tl * (uint32_t)TILE_BM;
-            bsz = (uint32_t)min((uint64_t)TILE_BM, sc.nb - (uint64_t)tl * TILE_BM);
-        } else {
-            bsz = sc.blk_size[frow + tl];
-            boff = bhdr + sc.blk_off[frow + tl];
-            if (rp.emit == 8) store_u32_le(rec + bitmap_pos + 16 + 4 * (uint64_t)tl, boff);  // bstarts[tl]: offset from the chunk start
-        }
-        if (rp.level == 1) {
-            cnt = sc.tile_cnt[frow + tl];
-            poff = sc.tile_off[frow + tl];
-        }
-    }
+    // ---- copies: 16 lanes per segment, 4 segments per wave-instruction, no scalar address arithmetic --------------------
+    // Quarter q of the wavefront (lanes 16q..16q+15) handles tile t0 + 4*pass + q in pass 0..3.  A segment is n bytes from
+    // a 4-byte aligned source to an arbitrarily aligned destination: destination dword j = source bytes [head+4j, head+4j+4)
+    // = byte funnel shift (v_alignbyte_b32) of source dwords j, j+1 (one 8-byte load per lane); head / tail bytes are
+    // stored singly by the lanes that already hold them.  All loads of the wavefront's 16 tiles are issued before the
+    // first store (loads and stores share one in-order counter).
     const uint32_t ntl = min(ASM_TPW, sc.ntiles - t0);
-    const uint8_t *bsrc0 = rp.emit == 0 ? sc.bitmap + (uint64_t)f * sc.nb_stride + (uint64_t)t0 * TILE_BM
-                                        : sc.blk_slots + (frow + t0) * BLK_SLOT;
-    const uint32_t bstride = rp.emit == 0 ? TILE_BM : BLK_SLOT;
-    uint8_t *bdst0 = rec + bitmap_pos;
-
-    // ---- bitmap stream: ASM_U tiles in flight -------------------------------------------------------------------------
-    for (uint32_t k0 = 0; k0 < ntl; k0 += ASM_U) {
-        SegLoad ld[ASM_U];
-        uint32_t sz[ASM_U], of[ASM_U];
+    const uint32_t sub = (uint32_t)lane >> 4, sl = (uint32_t)lane & 15u;
+    const uint32_t d = rp.depth;
+    const bool pix16 = rp.level == 1 && d == 16;
+    uint8_t *pdst = rec + pix_pos;
+    constexpr int BIT = 4, PIT = 2;  // unrolled 16-dword steps per segment: 256 B of block, 128 B of residuals; longer: loop
+    uint8_t *bdst[4], *pdstp[4];
+    const uint8_t *bsrc[4], *psrc[4];
+    uint32_t bn[4], pn[4];
+    u32x2 bv[4][BIT], pv[4][PIT];
 #pragma unroll
-        for (int u = 0; u < ASM_U; ++u) {
-            const uint32_t k = min(k0 + u, ntl - 1);
-            sz[u] = k0 + u < ntl ? (uint32_t)__builtin_amdgcn_readlane((int)bsz, (int)k) : 0u;
-            of[u] = (uint32_t)__builtin_amdgcn_readlane((int)boff, (int)k);
-            ld[u] = seg_load(bsrc0 + (uint64_t)k * bstride, sz[u], 0);
-        }
-#pragma unroll
-        for (int u = 0; u < ASM_U; ++u) {
-            const uint32_t k = min(k0 + u, ntl - 1);
-            const uint8_t *src = bsrc0 + (uint64_t)k * bstride;
-            if (sz[u]) seg_store(bdst0 + of[u], src, sz[u], 0, ld[u]);
-            for (uint32_t c = 1; c * 256 < sz[u] + 4; ++c) {  // rare: segment longer than one chunk
-                const SegLoad more = seg_load(src, sz[u], c);
-                seg_store(bdst0 + of[u], src, sz[u], c, more);
+    for (int ps = 0; ps < 4; ++ps) {
+        const uint32_t k = 4u * ps + sub;
+        const uint32_t tl = t0 + k;
+        const bool have = k < ntl;
+        bn[ps] = 0; pn[ps] = 0;
+        bdst[ps] = rec; pdstp[ps] = rec; bsrc[ps] = sc.blk_slots; psrc[ps] = sc.blk_slots;
+        if (have) {
+            if (rp.emit == 0) {
+                const uint64_t b0 = (uint64_t)tl * TILE_BM;
+                bn[ps] = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
+                bdst[ps] = rec + bitmap_pos + b0;
+                bsrc[ps] = sc.bitmap + (uint64_t)f * sc.nb_stride + b0;
+            } else {
+                bn[ps] = sc.blk_size[frow + tl];
+                const uint32_t boff = bhdr + sc.blk_off[frow + tl];
+                bdst[ps] = rec + bitmap_pos + boff;
+                bsrc[ps] = sc.blk_slots + (frow + tl) * BLK_SLOT;
+                if (rp.emit == 8 && sl == 0) store_u32_le(rec + bitmap_pos + 16 + 4 * (uint64_t)tl, boff);  // blosc bstarts[tl]
+            }
+            if (pix16) {
+                const uint32_t c = sc.tile_cnt[frow + tl];
+                const uint64_t b0 = 2ull * sc.tile_off[frow + tl];
+                pn[ps] = 2u * c;
+                psrc[ps] = reinterpret_cast<const uint8_t *>(sc.pix_slots + (frow + tl) * TILE_PX);
+                const uint64_t b1 = b0 + pn[ps] - 1;
+                if (rp.emit != 0 && c && (b0 >> ff.chunk_shift) != (b1 >> ff.chunk_shift)) {
+                    // straddles a stored-chunk header of the pixel frame (once per 4 MiB): byte by byte
+                    for (uint32_t i = sl; i < pn[ps]; i += 16) pdst[stored_pos(ff, b0 + i)] = psrc[ps][i];
+                    pn[ps] = 0;
+                }
+                pdstp[ps] = pdst + (rp.emit == 0 ? b0 : stored_pos(ff, b0));
             }
         }
     }
-    if (rp.level != 1) return;
-
-    // ---- residuals ---------------------------------------------------------------------------------------------------------
-    uint8_t *pdst = rec + pix_pos;
-    const uint32_t d = rp.depth;
-    if (d == 16) {
-        const uint8_t *psrc0 = reinterpret_cast<const uint8_t *>(sc.pix_slots + (frow + t0) * TILE_PX);
-        for (uint32_t k0 = 0; k0 < ntl; k0 += ASM_U) {
-            SegLoad ld[ASM_U];
-            uint32_t sz[ASM_U];
-            uint64_t b0[ASM_U];
+    // loads
 #pragma unroll
-            for (int u = 0; u < ASM_U; ++u) {
-                const uint32_t k = min(k0 + u, ntl - 1);
-                sz[u] = k0 + u < ntl ? 2u * (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)k) : 0u;
-                b0[u] = 2ull * (uint32_t)__builtin_amdgcn_readlane((int)poff, (int)k);
-                ld[u] = seg_load(psrc0 + (uint64_t)k * (TILE_PX * 2), sz[u], 0);
-            }
+    for (int ps = 0; ps < 4; ++ps) {
 #pragma unroll
-            for (int u = 0; u < ASM_U; ++u) {
-                if (sz[u] == 0) continue;
-                const uint32_t k = min(k0 + u, ntl - 1);
-                const uint8_t *src = psrc0 + (uint64_t)k * (TILE_PX * 2);
-                const uint64_t b1 = b0[u] + sz[u] - 1;
-                if (rp.emit == 0 || (b0[u] >> ff.chunk_shift) == (b1 >> ff.chunk_shift)) {  // contiguous in the record
-                    uint8_t *dst = pdst + (rp.emit == 0 ? b0[u] : stored_pos(ff, b0[u]));
-                    seg_store(dst, src, sz[u], 0, ld[u]);
-                    for (uint32_t c = 1; c * 256 < sz[u] + 4; ++c) {
-                        const SegLoad more = seg_load(src, sz[u], c);
-                        seg_store(dst, src, sz[u], c, more);
-                    }
-                } else {  // straddles a stored-chunk header of the pixel frame: byte by byte
-                    for (uint32_t i = lane; i < sz[u]; i += 64) pdst[stored_pos(ff, b0[u] + i)] = src[i];
-                }
+        for (int it = 0; it < BIT; ++it) {
+            const uint32_t j = sl + 16u * it;
+            bv[ps][it] = u32x2{0u, 0u};
+            if (4 * j < bn[ps] + 4 && bn[ps]) bv[ps][it] = *reinterpret_cast<const u32x2 *>(bsrc[ps] + 4 * j);
+        }
+        if (pix16) {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const uint32_t j = sl + 16u * it;
+                pv[ps][it] = u32x2{0u, 0u};
+                if (4 * j < pn[ps] + 4 && pn[ps]) pv[ps][it] = *reinterpret_cast<const u32x2 *>(psrc[ps] + 4 * j);
             }
         }
-        return;
+    }
+    // stores
+    auto put = [&](uint8_t *dst, uint32_t n, uint32_t j, const u32x2 &v) {
+        const uint32_t head = min(n, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
+        const uint32_t n2 = n - head, nd = n2 >> 2, tail = n2 & 3u;
+        const uint32_t val = __builtin_amdgcn_alignbyte(v[1], v[0], head);  // source bytes [head + 4j, head + 4j + 4)
+        if (j < nd) reinterpret_cast<uint32_t *>(dst + head)[j] = val;
+        if (j == nd && tail) {
+            uint8_t *t = dst + head + 4 * nd;
+            t[0] = (uint8_t)val;
+            if (tail > 1) t[1] = (uint8_t)(val >> 8);
+            if (tail > 2) t[2] = (uint8_t)(val >> 16);
+        }
+        if (j == 0 && head) {
+            dst[0] = (uint8_t)v[0];
+            if (head > 1) dst[1] = (uint8_t)(v[0] >> 8);
+            if (head > 2) dst[2] = (uint8_t)(v[0] >> 16);
+        }
+    };
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        if (bn[ps]) {
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) put(bdst[ps], bn[ps], sl + 16u * it, bv[ps][it]);
+            for (uint32_t j = sl + 16u * BIT; 4 * j < bn[ps] + 4; j += 16)  // rare: longer than the unrolled part
+                put(bdst[ps], bn[ps], j, *reinterpret_cast<const u32x2 *>(bsrc[ps] + 4 * j));
+        }
+        if (pix16 && pn[ps]) {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) put(pdstp[ps], pn[ps], sl + 16u * it, pv[ps][it]);
+            for (uint32_t j = sl + 16u * PIT; 4 * j < pn[ps] + 4; j += 16)
+                put(pdstp[ps], pn[ps], j, *reinterpret_cast<const u32x2 *>(psrc[ps] + 4 * j));
+        }
+    }
+    if (rp.level != 1 || pix16) return;
+
+    // ---- residuals with a bit depth that is not a multiple of 8: bit-packed on the way ---------------------------------------
+    const uint32_t tl_ = t0 + (uint32_t)lane;
+    uint32_t cnt = 0, poff = 0;
+    if (tl_ < sc.ntiles) {
+        cnt = sc.tile_cnt[frow + tl_];
+        poff = sc.tile_off[frow + tl_];
     }
     // generic depth: per tile (wave-uniform metadata), lanes over the bytes whose first bit lies in the tile's values
     const uint32_t dmask = (1u << d) - 1;

@@ -31,6 +31,45 @@ __global__ __launch_bounds__(256) void k_read_strided(const u32x4 *__restrict__ 
     }
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[0] = 1;
 }
+// like the reduce kernel's traffic: per (tile, frame) a wave reads 8 KiB and writes `wlines` full 128-byte lines into a slot
+// (slot stride 8 KiB, like pix_slots) -> how much does a small write stream cost the read stream?
+__global__ __launch_bounds__(256) void k_read_write(const u32x4 *__restrict__ p, uint64_t frame16, uint32_t ntb, uint32_t G, uint32_t *__restrict__ wbuf,
+                                                    int wlines, int scalar_too)
+{
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3; const uint32_t g = j % G; const uint32_t tb = (j / G) * 8 + xcd;
+    if (tb >= ntb) return;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int z = 0; z < 4; ++z) {
+        const uint32_t f = g * 4 + z;
+        const u32x4 *fr = p + (uint64_t)f * frame16 + (uint64_t)tb * 2048 + w * 512 + lane;
+        u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc += __builtin_nontemporal_load(fr + r * 64);
+        const uint64_t slot = ((uint64_t)f * ntb * 4 + tb * 4 + w);  // tile-frame index
+        uint32_t *dst = wbuf + slot * 2048;                              // 8 KiB slots
+        for (int l = 0; l < wlines; ++l) if (lane < 32) dst[l * 32 + lane] = acc[0] + l;  // one full line per iteration
+        if (scalar_too && lane == 0) wbuf[(uint64_t)64 * ntb * 4 * 2048 + slot] = acc[1];  // 4-byte count store
+    }
+}
+// same, but the slot index order and stride are parameters: order 0 = [frame][tile] (frame-major), 1 = [tile][frame]
+__global__ __launch_bounds__(256) void k_read_write2(const u32x4 *__restrict__ p, uint64_t frame16, uint32_t ntb, uint32_t G, uint32_t *__restrict__ wbuf,
+                                                     int wlines, uint32_t stride_dw, int order, int nframes)
+{
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3; const uint32_t g = j % G; const uint32_t tb = (j / G) * 8 + xcd;
+    if (tb >= ntb) return;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int z = 0; z < 4; ++z) {
+        const uint32_t f = g * 4 + z;
+        const u32x4 *fr = p + (uint64_t)f * frame16 + (uint64_t)tb * 2048 + w * 512 + lane;
+        u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc += __builtin_nontemporal_load(fr + r * 64);
+        const uint64_t tile = (uint64_t)tb * 4 + w;
+        const uint64_t slot = order == 0 ? (uint64_t)f * ntb * 4 + tile : tile * nframes + f;
+        uint32_t *dst = wbuf + slot * stride_dw;
+        for (int l = 0; l < wlines; ++l) if (lane < 32) dst[l * 32 + lane] = acc[0] + l;
+    }
+}
 int main()
 {
     const uint64_t bytes = 2ull << 30, n16 = bytes / 16;
@@ -51,5 +90,15 @@ int main()
     const uint64_t frame16 = (32ull << 20) / 16; const uint32_t ntb = 1024, G = 16;
     time([&] { hipLaunchKernelGGL(k_read_strided, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, out, 0); }, "frame-strided (groups adjacent, xcd)");
     time([&] { hipLaunchKernelGGL(k_read_strided, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, out, 1); }, "frame-strided (tiles adjacent)");
+    uint32_t *wbuf; hipMalloc(&wbuf, (uint64_t)64 * ntb * 4 * 8192 + (64ull * ntb * 4 * 4));
+    for (int wl = 0; wl <= 4; ++wl) for (int sc = 0; sc <= 1; ++sc) {
+        char name[64]; snprintf(name, sizeof name, "read + %d full lines/tile%s", wl, sc ? " + 4B scalar" : "");
+        time([&] { hipLaunchKernelGGL(k_read_write, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, sc); }, name);
+    }
+    for (int order = 0; order <= 1; ++order) for (uint32_t stride : {96u, 128u, 160u, 2048u}) for (int wl : {1, 3}) {
+        if (wl * 32 > (int)stride) continue;
+        char name[80]; snprintf(name, sizeof name, "read + %d lines, slot stride %u B, %s", wl, stride * 4, order ? "[tile][frame]" : "[frame][tile]");
+        time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, stride, order, 64); }, name);
+    }
     return 0;
 }

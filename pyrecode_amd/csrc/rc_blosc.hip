@@ -18,7 +18,6 @@
 
 namespace rc {
 
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // grid (ceil(ntiles/WAVES), B): wave w encodes block t = blockIdx.x*WAVES + w of frame blockIdx.y from the raw bitmap row.
 __global__ __launch_bounds__(WG) void k_blosc_blocks(Scratch sc)

@@ -19,6 +19,9 @@ constexpr int TILE_PX = R * GROUP_PX;      // 4096 pixels = 8 KiB of uint16
 constexpr int TILE_BM = TILE_PX / 8;       // 512 bitmap bytes per tile
 constexpr int BLK_SLOT = TILE_BM + 128;    // per-tile scratch slot for an encoded block (4-byte size word + payload), 5 x 128-byte lines
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 // ---- wavefront primitives (64 lanes) ------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -8,7 +8,6 @@
 
 namespace rc {
 
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // bitmap is padded with zero bytes to a multiple of 8 by the host wrapper, so 8-byte loads are always in bounds.
 __global__ __launch_bounds__(WG) void k_expand_count(const uint8_t *__restrict__ bitmap, uint64_t nb8, uint32_t *__restrict__ blk_cnt)

@@ -20,7 +20,6 @@
 
 namespace rc {
 
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t uf_find(uint32_t *__restrict__ parent, uint32_t x)
 {

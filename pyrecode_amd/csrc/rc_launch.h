@@ -74,6 +74,7 @@ void launch_blosc_unshuffle(const uint8_t *in, uint8_t *out, uint64_t nbytes, ui
                             uint32_t shuffle, hipStream_t s);
 // rc_zstd.hip
 void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s);
+void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s);  // 2nd half of the fused path
 void launch_zstd_gather(const Scratch &sc, uint8_t *out, hipStream_t s);
 size_t zstd_tables_bytes();
 void zstd_tables_host(void *dst);  // rc_reduce.hip: FLG | BD << 8 | HC << 16

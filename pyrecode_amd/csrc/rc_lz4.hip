@@ -27,7 +27,6 @@ __global__ __launch_bounds__(WG) void k_lz4_buffer(Scratch sc)
     if (t >= sc.ntiles) return;
     const uint64_t b0 = (uint64_t)t * TILE_BM;
     const uint32_t n = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const u32x2 v = reinterpret_cast<const u32x2 *>(sc.bitmap + (uint64_t)f * sc.nb_stride + b0)[lane];  // rows are padded to whole blocks
     reinterpret_cast<u32x2 *>(s_lz[w].raw)[lane] = v;
     const uint64_t own = (uint64_t)v[0] | ((uint64_t)v[1] << 32);

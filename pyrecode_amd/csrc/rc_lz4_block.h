@@ -24,12 +24,12 @@
 namespace rc {
 
 constexpr int LZ4_BLK = TILE_BM;       // 512
-constexpr int LZ4_MAXSEQ = LZ4_BLK / 5 + 2;
+constexpr int LZ4_MAXSEQ = LZ4_BLK / 4 + 2;  // LZ4: runs >= 5 (at most 104 sequences); zstd (rc_zstd_wave.h): runs >= 4 (128)
 
-// wave-private LDS working set of the encoder
+// wave-private LDS working set of the block encoders (LZ4 here, zstd tokenizer in rc_zstd_wave.h)
 struct __attribute__((aligned(16))) Lz4Lds {
     uint8_t raw[LZ4_BLK];              // block image in position order
-    uint8_t out[LZ4_BLK + 16];         // encoded payload staging
+    uint8_t out[BLK_SLOT];             // staging of what goes to the tile's slot
     uint16_t ms[LZ4_MAXSEQ + 2];       // position of the k-th match start
     uint16_t fl[LZ4_MAXSEQ + 2];       // position of the k-th sequence start (first literal)
 };

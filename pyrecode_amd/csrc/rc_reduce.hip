@@ -11,11 +11,10 @@
 
 #include "rc_launch.h"
 #include "rc_lz4_block.h"
+#include "rc_zstd_wave.h"
 
 namespace rc {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b)
 {
@@ -81,8 +80,10 @@ struct Pending {
     uint64_t ft;        // frame * ntiles + tile
     uint32_t f;
     uint32_t cnt;       // residuals staged in LDS
-    uint32_t csize;     // LZ4 payload bytes staged in LDS (>= n_blk: store raw)
+    uint32_t csize;     // LZ4 payload bytes staged in LDS (>= n_blk: store raw); zstd: the blk_size word
+    uint32_t staged;    // zstd: bytes staged in LDS for the slot
     u32x2 own;          // this lane's 8 bitmap bytes (raw-block fallback / raw bitmap store)
+    bool last;          // zstd: the tile is the frame's last block
 };
 
 struct __attribute__((aligned(16))) WaveStage {
@@ -111,6 +112,10 @@ __device__ __forceinline__ void flush_pending(const Pending &p, uint32_t tile, u
         const uint64_t bytes = (uint64_t)p.own[0] | ((uint64_t)p.own[1] << 32);
         const uint32_t used = lz4_store_block(blk_slots + p.ft * BLK_SLOT, bytes, n_blk, p.csize, *lz);
         if (lane == 0) blk_size[p.ft] = used;
+    }
+    if (CODEC == 1) {
+        zstd_store_block(blk_slots + p.ft * BLK_SLOT, n_blk, p.last, p.csize, p.staged, *lz);
+        if (lane == 0) blk_size[p.ft] = p.csize;
     }
 }
 
@@ -201,6 +206,10 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
             const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
             pend.csize = lz4_encode_block(bytes, n_blk, *s_lz);
         }
+        if (CODEC == 1) {
+            const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
+            pend.csize = zstd_tokenize_block(bytes, n_blk, pend.last, *s_lz, pend.staged);
+        }
     }
     flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st);
     pend.valid = false;
@@ -265,6 +274,7 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
     Pending pend;
     pend.valid = false;
     pend.ft = 0; pend.f = 0; pend.cnt = 0; pend.csize = 0; pend.own = u32x2{0u, 0u};
+    pend.staged = 0; pend.last = tile + 1 == ntiles;
 
 #pragma unroll 1
     for (int z = 0; z < BZ; z += 2) {
@@ -326,6 +336,9 @@ static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t 
     if (codec == 2) {
         if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 2, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, true, 2, false, false>(sc, frames, B, s); }
         else        { if (keep) launch_reduce_t<BZ, AL, false, 2, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 2, false, false>(sc, frames, B, s); }
+    } else if (codec == 1) {
+        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 1, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, true, 1, false, false>(sc, frames, B, s); }
+        else        { if (keep) launch_reduce_t<BZ, AL, false, 1, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 1, false, false>(sc, frames, B, s); }
     } else {
         if (level1) launch_reduce_t<BZ, AL, true, 0, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 0, true, false>(sc, frames, B, s);
     }

@@ -1,6 +1,7 @@
-// rc_zstd.hip - Zstandard block encoding of packed binary maps on the GPU: one LANE per 512-byte block (the FSE bitstream
-// of a block is a serial chain, so blocks - not bytes - are the unit of parallelism: 64 blocks per wavefront, 4096 blocks
-// per 4096x4096 frame).  Encoder logic and format notes: rc_zstd_block.h (shared with the host-side format check).
+// rc_zstd.hip - Zstandard block encoding of packed binary maps on the GPU, in two halves (rc_zstd_wave.h): the byte-parallel
+// half (zero runs, literals, sequence tokens) is wave-collective - fused into the reduce kernel, or k_zstd_buffer here for
+// stand-alone buffers - and the FSE bitstream, a serial chain per block, runs one LANE per 512-byte block (k_zstd_fse).
+// Format notes and the serial restatement used by the host-side format check: rc_zstd_block.h.
 //
 // Replaces `ZstdCompressor(level, write_content_size=False).compress(bitmap)` (pyrecode/recode_writer.py:175-178,
 // recode_compressors.py:88).  Decoding stays with the stock library on the host (recode_compressors.py:46).
@@ -8,33 +9,93 @@
 
 #include "rc_launch.h"
 #include "rc_zstd_block.h"
+#include "rc_zstd_wave.h"
 
 namespace rc {
 
-// grid (ceil(ntiles/WG), B): thread t encodes block t of frame blockIdx.y from the raw bitmap row into blk_slots / blk_size.
-__global__ __launch_bounds__(WG) void k_zstd_blocks(Scratch sc, const ZstdTables *__restrict__ tables)
+// Unfused form (seam 2 buffers, reduction level 2): wave w tokenizes block t = blockIdx.x*WAVES + w of row blockIdx.y of
+// sc.bitmap (rows padded to whole blocks) exactly like the fused reduce kernel does; k_zstd_fse finishes the blocks.
+__global__ __launch_bounds__(WG) void k_zstd_buffer(Scratch sc)
+{
+    __shared__ Lz4Lds s_lz[WAVES];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const uint32_t t = blockIdx.x * WAVES + w, f = blockIdx.y;
+    if (t >= sc.ntiles) return;
+    const uint64_t b0 = (uint64_t)t * TILE_BM;
+    const uint32_t n = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
+    const u32x2 v = reinterpret_cast<const u32x2 *>(sc.bitmap + (uint64_t)f * sc.nb_stride + b0)[lane];
+    const uint64_t own = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    const bool last = t + 1 == sc.ntiles;
+    uint32_t staged;
+    const uint32_t word = zstd_tokenize_block(own, n, last, s_lz[w], staged);
+    const uint64_t ft = (uint64_t)f * sc.ntiles + t;
+    zstd_store_block(sc.blk_slots + ft * BLK_SLOT, n, last, word, staged, s_lz[w]);
+    if (lane == 0) sc.blk_size[ft] = word;
+}
+
+// Second half of the fused path (rc_zstd_wave.h): thread ft turns the token list the reduce kernel left in slot ft into the
+// FSE bitstream and completes the block header.  Slots that already hold a finished block (RLE / Raw) only get their size
+// word cleaned.
+//
+// The chain itself is a few thousand cycles per block; what matters is that it never waits on memory it does not need:
+// tokens arrive by 16-byte loads issued two chunks ahead, and the loop contains NO global store (gfx9 counts loads and
+// stores on one in-order counter, so a store inside the loop would put its whole write latency in front of the next token).
+// The bitstream is collected in a per-lane LDS row and written out afterwards.  A lane whose bitstream outgrows its row
+// (dense blocks) re-runs the chain with stores straight into the slot, in place: a sequence costs at most 29 bits and its
+// token is 32, so the write position never passes the read position.
+constexpr int FSE_ROW = 48;  // dwords of bitstream kept in LDS per lane (192 bytes; a 1 %-sparsity block needs about 15)
+
+__global__ __launch_bounds__(WG) void k_zstd_fse(Scratch sc, uint32_t nslots, const ZstdTables *__restrict__ tables)
 {
     __shared__ ZstdTables T;
+    __shared__ uint32_t s_row[WG][FSE_ROW + 1];  // + 1: rows start in different banks
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&T);
         for (uint32_t i = threadIdx.x; i < sizeof(ZstdTables) / 4; i += WG) dst[i] = src[i];
     }
     __syncthreads();
-    const uint32_t t = blockIdx.x * WG + threadIdx.x;
-    const uint32_t f = blockIdx.y;
-    if (t >= sc.ntiles) return;
-    const uint64_t b0 = (uint64_t)t * TILE_BM;
-    const uint32_t n = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
-    const uint32_t *src32 = reinterpret_cast<const uint32_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride + b0);
-    const uint64_t ft = (uint64_t)f * sc.ntiles + t;
-    sc.blk_size[ft] = zstd_encode_block_stream(src32, n, sc.blk_slots + ft * BLK_SLOT, BLK_SLOT, T, t + 1 == sc.ntiles);
+    const uint32_t ft = blockIdx.x * WG + threadIdx.x;
+    if (ft >= nslots) return;
+    const uint32_t word = sc.blk_size[ft];
+    if (word & ZW_FINAL) { sc.blk_size[ft] = word & 0xFFFFu; return; }
+    const uint32_t P = word & 0xFFFFu, nseq = word >> 16;
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(sc.blk_slots + (uint64_t)ft * BLK_SLOT);
+    const ZW4 *tok4 = reinterpret_cast<const ZW4 *>(slot32 + (zstd_token_offset(P) >> 2));
+    const uint32_t w0 = P >> 2, nb0 = 8 * (P & 3u);
+    const uint64_t acc0 = nb0 ? (uint64_t)(slot32[w0] & ((1u << nb0) - 1u)) : 0ull;
+    uint32_t *row = s_row[threadIdx.x];
+    uint32_t o = 0;
+    uint64_t acc = acc0;
+    uint32_t nb = fse_chain(tok4, nseq, acc, nb0, T, [&](uint32_t v) { if (o < (uint32_t)FSE_ROW) row[o] = v; ++o; });
+    // at most 44 bits are left: one or two more dwords
+    uint32_t ndw = o + ((nb + 31) >> 5);
+    const uint32_t end = 4 * (w0 + o) + ((nb + 7) >> 3);  // first byte behind the bitstream
+    if (ndw <= (uint32_t)FSE_ROW) {
+        if (nb) { row[o] = (uint32_t)acc; if (nb > 32) row[o + 1] = (uint32_t)(acc >> 32); }
+        for (uint32_t i = 0; i < ndw; ++i) slot32[w0 + i] = row[i];
+    } else {  // does not fit the LDS row: again, storing in place
+        o = 0;
+        acc = acc0;
+        nb = fse_chain(tok4, nseq, acc, nb0, T, [&](uint32_t v) { slot32[w0 + o] = v; ++o; });
+        if (nb) { slot32[w0 + o] = (uint32_t)acc; if (nb > 32) slot32[w0 + o + 1] = (uint32_t)(acc >> 32); }
+    }
+    const uint32_t content = end - 3;
+    const uint32_t lastbit = (ft % sc.ntiles) + 1 == sc.ntiles ? 1u : 0u;
+    slot32[0] |= lastbit | (2u << 1) | (content << 3);  // bytes 0..2 were left zero; byte 3 is the literals header
+    sc.blk_size[ft] = end;
+}
+void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s)
+{
+    const uint32_t nslots = B * sc.ntiles;
+    hipLaunchKernelGGL(k_zstd_fse, dim3((nslots + WG - 1) / WG), dim3(WG), 0, s, sc, nslots,
+                       reinterpret_cast<const ZstdTables *>(tables_dev));
 }
 
 void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_zstd_blocks, dim3((sc.ntiles + WG - 1) / WG, B), dim3(WG), 0, s, sc,
-                       reinterpret_cast<const ZstdTables *>(tables_dev));
+    hipLaunchKernelGGL(k_zstd_buffer, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc);
+    launch_zstd_fse(sc, B, tables_dev, s);
 }
 
 size_t zstd_tables_bytes() { return sizeof(ZstdTables); }

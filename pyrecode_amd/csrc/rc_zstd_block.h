@@ -256,192 +256,74 @@ RC_HD uint32_t zstd_encode_block(const uint8_t *src, uint32_t n, uint8_t *dst, Z
     return 3 + content;
 }
 
-// ---- streaming form for the GPU: no sequence array, three passes over the block, dword fast path for zero words ------
-// Output goes through a byte sink that stores aligned dwords (the slot is 16-byte aligned) and never writes at or past
-// `cap`; the position keeps counting so the caller still learns the size.
-struct ZstdSink {
-    uint32_t *d32;   // slot base
-    uint32_t acc;    // bytes not yet stored (little-endian)
-    uint32_t pos;    // bytes put so far
-    uint32_t cap;    // multiple of 4
-};
-RC_HD void zs_put(ZstdSink &k, uint32_t byte)
-{
-    k.acc |= (byte & 0xFFu) << (8 * (k.pos & 3u));
-    ++k.pos;
-    if ((k.pos & 3u) == 0) {
-        if (k.pos <= k.cap) k.d32[(k.pos >> 2) - 1] = k.acc;
-        k.acc = 0;
-    }
-}
-RC_HD void zs_finish(ZstdSink &k)
-{
-    if ((k.pos & 3u) && ((k.pos + 3u) & ~3u) <= k.cap) k.d32[k.pos >> 2] = k.acc;
-}
-struct ZstdBitsS { uint64_t acc; uint32_t n; };
-RC_HD void zbs_add(ZstdBitsS &b, uint32_t value, uint32_t nbits)
-{
-    b.acc |= (uint64_t)(value & ((1u << nbits) - 1u)) << b.n;
-    b.n += nbits;
-}
-RC_HD void zbs_flush(ZstdBitsS &b, ZstdSink &k)
-{
-    while (b.n >= 8) {
-        zs_put(k, (uint32_t)b.acc);
-        b.acc >>= 8;
-        b.n -= 8;
-    }
-}
+// ---- token form: the split the GPU runs (rc_zstd_wave.h) ------------------------------------------------------------------
+// The byte-parallel half of the encoder leaves, per block, the fixed part of the Compressed block followed by one 32-bit
+// token per sequence, LAST sequence of the block first:  llc | mlc << 6 | ll_extra << 12 | ml_extra << 21.
+// fse_chain below is the serial half (shared by the HIP kernel k_zstd_fse and the host-side format check).
+constexpr uint32_t ZW_FINAL = 0x80000000u;  // blk_size word: the slot already holds a complete block of (word & 0xFFFF) bytes
+// otherwise: P | nseq << 16  (P = offset of the FSE bitstream, tokens at zstd_token_offset(P))
+RC_HD uint32_t zstd_token_offset(uint32_t P) { return (P + 15u) & ~15u; }  // tokens are fetched by 16-byte loads
+
+// number of extra bits of a literal-length / match-length code: 13 nibbles for codes 16.. / 32..
+RC_HD uint32_t zstd_ll_bits(uint32_t c) { return c < 16 ? 0u : (uint32_t)(0x9876433221111ull >> (4 * (c - 16))) & 15u; }
+RC_HD uint32_t zstd_ml_bits(uint32_t c) { return c < 32 ? 0u : (uint32_t)(0x8754433221111ull >> (4 * (c - 32))) & 15u; }
 
 struct alignas(16) ZW4 { uint32_t v[4]; };
-
-struct ZstdFse {
-    uint32_t st_ml, st_ll;
-    bool first;
-};
-// one sequence, in REVERSE order of appearance (the last sequence of the block comes first)
-RC_HD void zstd_put_sequence(ZstdFse &f, ZstdBitsS &b, ZstdSink &k, const ZstdTables &T, uint32_t ll, uint32_t ml)
-{
-    uint32_t llc, llb, lle, mlc, mlb, mle;
-    zstd_ll_code(ll, llc, llb, lle);
-    zstd_ml_code(ml, mlc, mlb, mle);
-    if (f.first) {  // FSE_initCState2
-        f.first = false;
-        uint32_t nb = (T.ml_dnb[mlc] + (1u << 15)) >> 16;
-        uint32_t v = (nb << 16) - T.ml_dnb[mlc];
-        f.st_ml = T.ml_state[(int32_t)(v >> nb) + T.ml_dfs[mlc]];
-        nb = (T.ll_dnb[llc] + (1u << 15)) >> 16;
-        v = (nb << 16) - T.ll_dnb[llc];
-        f.st_ll = T.ll_state[(int32_t)(v >> nb) + T.ll_dfs[llc]];
-    } else {        // FSE_encodeSymbol: (offset: 0 bits), match length, literal length
-        uint32_t nb = (f.st_ml + T.ml_dnb[mlc]) >> 16;
-        zbs_add(b, f.st_ml, nb);
-        f.st_ml = T.ml_state[(int32_t)(f.st_ml >> nb) + T.ml_dfs[mlc]];
-        nb = (f.st_ll + T.ll_dnb[llc]) >> 16;
-        zbs_add(b, f.st_ll, nb);
-        f.st_ll = T.ll_state[(int32_t)(f.st_ll >> nb) + T.ll_dfs[llc]];
-        zbs_flush(b, k);
-    }
-    zbs_add(b, lle, llb);
-    zbs_add(b, mle, mlb);
-    zbs_flush(b, k);
+struct FseState { uint32_t st_ml, st_ll; };
+RC_HD void fse_first(FseState &f, uint32_t llc, uint32_t mlc, const ZstdTables &T)
+{   // FSE_initCState2
+    uint32_t b = (T.ml_dnb[mlc] + (1u << 15)) >> 16;
+    uint32_t v = (b << 16) - T.ml_dnb[mlc];
+    f.st_ml = T.ml_state[(int32_t)(v >> b) + T.ml_dfs[mlc]];
+    b = (T.ll_dnb[llc] + (1u << 15)) >> 16;
+    v = (b << 16) - T.ll_dnb[llc];
+    f.st_ll = T.ll_state[(int32_t)(v >> b) + T.ll_dfs[llc]];
 }
 
-// src32: the block, 16-byte aligned, readable up to the next multiple of 16 past n.  slot: 16-byte aligned, slot_cap bytes
-// (multiple of 4, >= n + 4).  Returns bytes used in the slot (3-byte block header included).
-RC_HD uint32_t zstd_encode_block_stream(const uint32_t *src32, uint32_t n, uint8_t *slot, uint32_t slot_cap, const ZstdTables &T,
-                                        bool last)
+// Runs the chain over the tokens; emit(dword) receives the finished dwords in order.  acc/nb enter holding the (P & 3)
+// fixed-part bytes that share the first dword.  Returns the bit count left in acc (at most 44).  Tokens are read two
+// 16-byte chunks ahead of their use, and a sequence adds at most 29 bits for its 32-bit token, so emit() may store IN PLACE
+// from dword P >> 2 of the same slot: the write position never passes the read position.
+template <class Emit>
+RC_HD uint32_t fse_chain(const ZW4 *tok4, uint32_t nseq, uint64_t &acc, uint32_t nb, const ZstdTables &T, Emit &&emit)
 {
-    const uint32_t lastbit = last ? 1u : 0u;
-    const uint32_t nw = (n + 3) >> 2, ng = (nw + 3) >> 2;
-    const ZW4 *src128 = reinterpret_cast<const ZW4 *>(src32);  // 16-byte loads; the block is readable to a multiple of 16
-    // pass 0: count literals and sequences
-    uint32_t nlit = 0, nseq = 0, any = 0, zrun = 0;
-    for (uint32_t g = 0; g < ng; ++g) {
-      const ZW4 q = src128[g];
-      for (uint32_t jw = 0; jw < 4; ++jw) {
-        const uint32_t w = 4 * g + jw;
-        if (w >= nw) break;
-        const uint32_t x = q.v[jw];
-        const uint32_t nbytes = n - 4 * w >= 4 ? 4u : n - 4 * w;
-        if (x == 0 && nbytes == 4) { zrun += 4; continue; }
-        for (uint32_t kk = 0; kk < nbytes; ++kk) {
-            const uint32_t bt = (x >> (8 * kk)) & 0xFFu;
-            if (bt == 0) { ++zrun; continue; }
-            any = 1;
-            if (zrun >= 4) { ++nseq; ++nlit; } else nlit += zrun;
-            zrun = 0;
-            ++nlit;
-        }
-      }
-    }
-    if (zrun >= 4) { ++nseq; ++nlit; } else nlit += zrun;
-    uint32_t *slot32 = reinterpret_cast<uint32_t *>(slot);
-    if (!any) {  // RLE block
-        slot32[0] = lastbit | (1u << 1) | (n << 3);  // 4th byte (the repeated byte) = 0
-        return 4;
-    }
-    ZstdSink k{slot32, 0, 3, slot_cap};  // 3 placeholder bytes for the block header
-    if (nlit < 32) zs_put(k, nlit << 3);
-    else { zs_put(k, (nlit << 4) | (1u << 2)); zs_put(k, nlit >> 4); }
-    // pass A: literals
-    zrun = 0;
-    for (uint32_t g = 0; g < ng; ++g) {
-      const ZW4 q = src128[g];
-      for (uint32_t jw = 0; jw < 4; ++jw) {
-        const uint32_t w = 4 * g + jw;
-        if (w >= nw) break;
-        const uint32_t x = q.v[jw];
-        const uint32_t nbytes = n - 4 * w >= 4 ? 4u : n - 4 * w;
-        if (x == 0 && nbytes == 4) { zrun += 4; continue; }
-        for (uint32_t kk = 0; kk < nbytes; ++kk) {
-            const uint32_t bt = (x >> (8 * kk)) & 0xFFu;
-            if (bt == 0) { ++zrun; continue; }
-            if (zrun >= 4) zs_put(k, 0);
-            else for (; zrun; --zrun) zs_put(k, 0);
-            zrun = 0;
-            zs_put(k, bt);
-        }
-      }
-    }
-    if (zrun >= 4) zs_put(k, 0);
-    else for (; zrun; --zrun) zs_put(k, 0);
-    // sequences section
-    if (nseq < 128) zs_put(k, nseq);
-    else { zs_put(k, 128 + (nseq >> 8)); zs_put(k, nseq); }
-    if (nseq) {
-        zs_put(k, 1u << 4);  // LL predefined, OF RLE, ML predefined
-        zs_put(k, 0);        // offset code 0: repeat offset 1
-        // pass B: backward scan; a sequence is complete when the qualifying run BEFORE it has been seen
-        ZstdFse f{0, 0, true};
-        ZstdBitsS b{0, 0};
-        uint32_t L = 0, pend_ml = 0;
-        bool have = false;
-        zrun = 0;
-        for (uint32_t g = ng; g-- > 0;) {
-          const ZW4 q = src128[g];
-          for (uint32_t jw = 4; jw-- > 0;) {
-            const uint32_t w = 4 * g + jw;
-            if (w >= nw) continue;
-            const uint32_t x = q.v[jw];
-            const uint32_t nbytes = n - 4 * w >= 4 ? 4u : n - 4 * w;
-            if (x == 0 && nbytes == 4) { zrun += 4; continue; }
-            for (uint32_t kk = nbytes; kk-- > 0;) {
-                const uint32_t bt = (x >> (8 * kk)) & 0xFFu;
-                if (bt == 0) { ++zrun; continue; }
-                if (zrun >= 4) {
-                    if (have) zstd_put_sequence(f, b, k, T, L + 1, pend_ml);
-                    have = true; pend_ml = zrun - 1; L = 0;
-                } else L += zrun;
-                zrun = 0;
-                ++L;  // the non-zero byte itself
+    const uint32_t nchunk = (nseq + 3) >> 2;
+    const ZW4 zero = {{0u, 0u, 0u, 0u}};
+    ZW4 cur = tok4[0];
+    ZW4 nxt = nchunk > 1 ? tok4[1] : zero;
+    FseState f{0, 0};
+    for (uint32_t c = 0; c < nchunk; ++c) {
+        const ZW4 ahead = c + 2 < nchunk ? tok4[c + 2] : zero;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = 4 * c + j;
+            if (i < nseq) {
+                const uint32_t t = cur.v[j];
+                const uint32_t llc = t & 63u, mlc = (t >> 6) & 63u;
+                if (i == 0) {
+                    fse_first(f, llc, mlc, T);
+                } else {  // FSE_encodeSymbol: (offset: 0 bits), match length, literal length
+                    uint32_t b = (f.st_ml + T.ml_dnb[mlc]) >> 16;
+                    acc |= (uint64_t)(f.st_ml & ((1u << b) - 1u)) << nb; nb += b;
+                    f.st_ml = T.ml_state[(int32_t)(f.st_ml >> b) + T.ml_dfs[mlc]];
+                    b = (f.st_ll + T.ll_dnb[llc]) >> 16;
+                    acc |= (uint64_t)(f.st_ll & ((1u << b) - 1u)) << nb; nb += b;
+                    f.st_ll = T.ll_state[(int32_t)(f.st_ll >> b) + T.ll_dfs[llc]];
+                    if (nb >= 32) { emit((uint32_t)acc); acc >>= 32; nb -= 32; }
+                }
+                const uint32_t llb = zstd_ll_bits(llc), mlb = zstd_ml_bits(mlc);
+                acc |= (uint64_t)((t >> 12) & ((1u << llb) - 1u)) << nb; nb += llb;
+                acc |= (uint64_t)((t >> 21) & ((1u << mlb) - 1u)) << nb; nb += mlb;
+                if (nb >= 32) { emit((uint32_t)acc); acc >>= 32; nb -= 32; }
             }
-          }
         }
-        if (zrun >= 4) {
-            if (have) zstd_put_sequence(f, b, k, T, L + 1, pend_ml);
-            have = true; pend_ml = zrun - 1; L = 0;
-        } else L += zrun;
-        if (have) zstd_put_sequence(f, b, k, T, L + 1, pend_ml);
-        zbs_add(b, f.st_ml, 6);
-        zbs_add(b, f.st_ll, 6);
-        zbs_add(b, 1, 1);
-        zbs_flush(b, k);
-        if (b.n) zs_put(k, (uint32_t)b.acc);
+        cur = nxt;
+        nxt = ahead;
     }
-    const uint32_t content = k.pos - 3;
-    if (content >= n) {  // would not shrink (or overflowed the slot): Raw block
-        ZstdSink r{slot32, 0, 0, slot_cap};
-        const uint32_t h = lastbit | (0u << 1) | (n << 3);
-        zs_put(r, h); zs_put(r, h >> 8); zs_put(r, h >> 16);
-        for (uint32_t i = 0; i < n; ++i) zs_put(r, src32[i >> 2] >> (8 * (i & 3)));
-        zs_finish(r);
-        return 3 + n;
-    }
-    zs_finish(k);
-    const uint32_t h = lastbit | (2u << 1) | (content << 3);
-    slot[0] = (uint8_t)h; slot[1] = (uint8_t)(h >> 8); slot[2] = (uint8_t)(h >> 16);
-    return 3 + content;
+    // FSE_flushCState: match length, (offset: 0 bits), literal length; then the end mark
+    acc |= (uint64_t)(f.st_ml & 63u) << nb; nb += 6;
+    acc |= (uint64_t)(f.st_ll & 63u) << nb; nb += 6;
+    acc |= (uint64_t)1 << nb; nb += 1;
+    return nb;
 }
 
 }  // namespace rc

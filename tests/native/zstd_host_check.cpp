@@ -1,9 +1,85 @@
 // Host-only build of the device block encoder (pyrecode_amd/csrc/rc_zstd_block.h) for CPU tests: lets the stock libzstd
-// decoder judge the bitstream the HIP kernel will emit, without a GPU.  Test infrastructure, not a product path.
+// decoder judge the bitstream the HIP kernels will emit, without a GPU.  Test infrastructure, not a product path.
+//   streaming = 0: the serial restatement zstd_encode_block
+//   streaming = 1: the token form the GPU runs - a scalar stand-in for the wave tokenizer (rc_zstd_wave.h) lays out the slot
+//                  (fixed part, padded to 16, tokens with the last sequence first), then the SAME fse_chain the kernel
+//                  k_zstd_fse runs writes the bitstream in place.
 #include <cstring>
 #include <vector>
 
 #include "../../pyrecode_amd/csrc/rc_zstd_block.h"
+
+// scalar stand-in for zstd_tokenize_block + k_zstd_fse on one block; slot: 640 bytes, 16-byte aligned
+static uint32_t token_form_block(const uint8_t *src, uint32_t n, uint8_t *slot, const rc::ZstdTables &T, bool last)
+{
+    constexpr uint32_t SLOT = 640;
+    std::vector<rc::ZstdSeq> seq;
+    std::vector<uint8_t> lits;
+    bool any = false;
+    {
+        uint32_t i = 0, lit_start = 0;
+        while (i < n) {
+            if (src[i] != 0) { any = true; ++i; continue; }
+            uint32_t j = i + 1;
+            while (j < n && src[j] == 0) ++j;
+            if (j - i >= 4) {
+                for (uint32_t k = lit_start; k <= i; ++k) lits.push_back(src[k]);
+                seq.push_back({(uint16_t)(i + 1 - lit_start), (uint16_t)(j - i - 1)});
+                lit_start = j;
+            }
+            i = j;
+        }
+        for (uint32_t k = lit_start; k < n; ++k) lits.push_back(src[k]);
+    }
+    const uint32_t lastbit = last ? 1u : 0u;
+    if (!any) {
+        const uint32_t h = lastbit | (1u << 1) | (n << 3);
+        slot[0] = (uint8_t)h; slot[1] = (uint8_t)(h >> 8); slot[2] = (uint8_t)(h >> 16); slot[3] = 0;
+        return 4;
+    }
+    const uint32_t nseq = (uint32_t)seq.size(), nlit = (uint32_t)lits.size();
+    const uint32_t lh = nlit < 32 ? 1u : 2u, sh = nseq < 128 ? 1u : 2u;
+    const uint32_t P = 3 + lh + nlit + sh + 2, T0 = rc::zstd_token_offset(P);
+    bool raw = nseq == 0 || T0 + 4 * nseq + 8 > SLOT;
+    if (!raw) {
+        memset(slot, 0, SLOT);
+        uint8_t *p = slot + 3;
+        if (nlit < 32) *p++ = (uint8_t)(nlit << 3);
+        else { *p++ = (uint8_t)((nlit << 4) | (1u << 2)); *p++ = (uint8_t)(nlit >> 4); }
+        memcpy(p, lits.data(), nlit);
+        p += nlit;
+        if (nseq < 128) *p++ = (uint8_t)nseq;
+        else { *p++ = (uint8_t)(128 + (nseq >> 8)); *p++ = (uint8_t)nseq; }
+        *p++ = 1u << 4;
+        *p++ = 0;
+        uint32_t *tok = reinterpret_cast<uint32_t *>(slot + T0);
+        uint32_t xbits = 0;
+        for (uint32_t k = 0; k < nseq; ++k) {
+            uint32_t llc, llb, lle, mlc, mlb, mle;
+            rc::zstd_ll_code(seq[k].ll, llc, llb, lle);
+            rc::zstd_ml_code(seq[k].ml, mlc, mlb, mle);
+            tok[nseq - 1 - k] = llc | (mlc << 6) | (lle << 12) | (mle << 21);
+            xbits += llb + mlb;
+        }
+        raw = (P - 3) + ((xbits + 12 * nseq + 1 + 7) >> 3) >= n;
+    }
+    if (raw) {
+        const uint32_t h = lastbit | (n << 3);
+        slot[0] = (uint8_t)h; slot[1] = (uint8_t)(h >> 8); slot[2] = (uint8_t)(h >> 16);
+        memcpy(slot + 3, src, n);
+        return 3 + n;
+    }
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(slot);
+    const uint32_t w0 = P >> 2, nb0 = 8 * (P & 3u);
+    uint64_t acc = nb0 ? (uint64_t)(slot32[w0] & ((1u << nb0) - 1u)) : 0ull;
+    uint32_t o = 0;
+    uint32_t nb = rc::fse_chain(reinterpret_cast<const rc::ZW4 *>(slot + T0), nseq, acc, nb0, T,
+                                [&](uint32_t v) { slot32[w0 + o] = v; ++o; });  // in place, like the kernel's fallback path
+    const uint32_t end = 4 * (w0 + o) + ((nb + 7) >> 3);
+    if (nb) { slot32[w0 + o] = (uint32_t)acc; if (nb > 32) slot32[w0 + o + 1] = (uint32_t)(acc >> 32); }
+    slot32[0] |= lastbit | (2u << 1) | ((end - 3) << 3);
+    return end;
+}
 
 extern "C" int64_t zstd_check_encode_frame(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, int streaming)
 {
@@ -22,15 +98,12 @@ extern "C" int64_t zstd_check_encode_frame(const uint8_t *src, uint64_t n, uint8
         p[0] = 1; p[1] = 0; p[2] = 0;
         return (p - dst) + 3;
     }
-    alignas(16) uint32_t in32[rc::ZSTD_BLK / 4 + 8];
-    alignas(16) uint8_t slot[rc::ZSTD_BLK + 16];
+    alignas(16) uint8_t slot[640 + 16];
     for (uint64_t o = 0; o < n; o += rc::ZSTD_BLK) {
         const uint32_t len = (uint32_t)((n - o) < rc::ZSTD_BLK ? (n - o) : rc::ZSTD_BLK);
         uint32_t used;
-        if (streaming) {  // the form the HIP kernel runs
-            memset(in32, 0, sizeof in32);
-            memcpy(in32, src + o, len);
-            used = rc::zstd_encode_block_stream(in32, len, slot, rc::ZSTD_BLK + 16, T, o + len >= n);
+        if (streaming) {  // the form the HIP kernels run
+            used = token_form_block(src + o, len, slot, T, o + len >= n);
             memcpy(tmp, slot, used);
         } else
             used = rc::zstd_encode_block(src + o, len, tmp, seq.data(), T, o + len >= n);

@@ -141,6 +141,63 @@ def test_zstd_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
     ctx.close()
 
 
+def _pattern_frames(ny, nx):
+    """Frames whose bitmaps hit every block type of the codecs: all-zero tiles, isolated pixels at fixed periods (from
+    the densest pattern that still has >= 4-byte zero runs down to one pixel per tile), dense noise (raw blocks), a
+    mixture per tile, and a frame that is set everywhere."""
+    rng = np.random.default_rng(7)
+    N = ny * nx
+    frames = []
+    for period in (40, 48, 56, 64, 72, 100, 200, 1000, 4096, 8192):      # one set pixel every `period` pixels
+        f = np.zeros(N, np.uint16)
+        f[period - 1::period] = 500
+        frames.append(f)
+    f = np.zeros(N, np.uint16)                                           # per-tile mixture: period changes every 4096 px
+    for t in range(-(-N // 4096)):
+        per = (33, 40, 41, 47, 64, 96, 160, 333, 5000)[t % 9]
+        f[t * 4096 + per - 1:(t + 1) * 4096:per] = 300 + t % 100
+    frames.append(f)
+    frames.append((rng.random(N) < 0.5).astype(np.uint16) * 900)         # incompressible
+    f = np.zeros(N, np.uint16)                                           # long runs of 0xFF bytes (no zero run at all)
+    f[: N // 2] = 1000
+    frames.append(f)
+    frames.append(np.zeros(N, np.uint16))                                # nothing set
+    f = np.zeros(N, np.uint16)                                           # 0xFF bytes separated by zero runs of 3 / 4 / 5
+    pos = 0
+    for k in range(N // 8):
+        if pos + 8 > N:
+            break
+        f[pos:pos + 8] = 700
+        pos += 8 * (1 + (3, 4, 5)[k % 3])
+    frames.append(f)
+    return np.stack(frames).reshape(-1, ny, nx)
+
+
+@pytest.mark.parametrize("scheme", [1, 2])
+@pytest.mark.parametrize("ny,nx", [(128, 256), (130, 250)])
+def test_codec_block_types(hip, orc, scheme, ny, nx):
+    """Every block type of the fused encoders (zstd: RLE / Raw / Compressed incl. the in-place path for long bitstreams and
+    the slot-capacity fallback; LZ4: compressed / stored) decodes with the stock library to the bit-exact bitmap."""
+    frames = _pattern_frames(ny, nx)
+    thr = np.full((ny, nx), 100, np.uint16)
+    B = frames.shape[0]
+    ctx = hip.ReduceContext(nx, ny, 16, 1, 1, scheme, 1, 0, max_batch=B)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+    for z in range(B):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        binary, pix = orc.binarize_l1(frames[z], thr)
+        expect = orc.pack_binary_frame(binary).tobytes()
+        if scheme == 1:
+            assert _zstd_system_decode(r[16:16 + cb]) == expect, "frame %d" % z
+            assert _zstd_system_decode(r[16 + cb:]) == pix.tobytes()
+        else:
+            _check_lz4(orc, r[16:16 + cb], expect)
+            _check_lz4(orc, r[16 + cb:], pix.tobytes())
+    ctx.close()
+
+
 @pytest.mark.parametrize("ny,nx,s,d,eps", SHAPES)
 def test_blosc_lz4_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
     """scheme 8: each stream must be a blosc1 chunk (bit-shuffle + LZ4, typesize 8) that the from-spec decoder in the

@@ -39,7 +39,7 @@ def _roundtrip(enc, zstd, data):
     src = np.frombuffer(data, np.uint8) if len(data) else np.zeros(0, np.uint8)
     dst = np.empty(len(data) + len(data) // 64 + 64, np.uint8)
     sizes = []
-    for streaming in (0, 1):  # array form and the streaming form the HIP kernel runs: identical bytes expected
+    for streaming in (0, 1):  # serial restatement, then the token form the HIP kernels run (same fse_chain code)
         n = enc.zstd_check_encode_frame(src.ctypes.data if src.size else None, src.size, dst.ctypes.data, dst.size, streaming)
         assert n > 0
         out = np.empty(len(data) + 16, np.uint8)
@@ -47,8 +47,11 @@ def _roundtrip(enc, zstd, data):
         assert not zstd.ZSTD_isError(r), zstd.ZSTD_getErrorName(r)
         assert r == len(data) and out[:r].tobytes() == data
         sizes.append((n, dst[:n].tobytes()))
-    assert sizes[0] == sizes[1]
-    return sizes[0][0]
+    # same bytes, except that the token form decides "store raw" from an upper bound of the bitstream length (before the
+    # bitstream exists): blocks within a few bytes of not shrinking may be stored raw there and compressed by the serial form
+    if sizes[0] != sizes[1]:
+        assert sizes[0][0] <= sizes[1][0] <= sizes[0][0] * 1.02 + 8
+    return sizes[1][0]
 
 
 @pytest.mark.parametrize("density", [0.0, 0.001, 0.01, 0.077, 0.3, 0.7, 1.0])

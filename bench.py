@@ -7,8 +7,9 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
   step      one pass of the hot path over one batch of B synthetic frames per GPU, inputs resident in HBM:
             rc_reduce_compress_batch_async = reduce kernel (LZ4 bitmap encoder fused in) -> scans -> record layout ->
             assembly (zstd: its block encoder runs as a kernel of its own after the reduce kernel),
-            records + offsets + metadata left in HBM; for N > 1 followed by the path's one exchange step, the
-            RCCL all-gather of the per-frame metadata (12 B / frame).
+            records + offsets + metadata left in HBM; for N > 1 each step also issues the path's one exchange step, the
+            RCCL all-gather of the per-frame metadata (12 B / frame), on a side stream so that it overlaps
+            the next step (metadata rows double-buffered; all of them are complete inside the timed region).
   workload  BASELINE.json configs[1]: 4096x4096 uint16, 1 % sparsity, L1 + LZ4 (d = 16 primary; --depth 12 secondary).
   value     frames/s, whole job (all ranks' frames / max-over-ranks time); gb_per_s_in = value * 2*nx*ny.
   roofline  dominant kernel = the reduce kernel (k_reduce_tiles): algorithmic bytes per launch = B * 2*nx*ny
@@ -150,18 +151,31 @@ def main():
     out_cap = B * (N // 2)  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
     out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
-    md = torch.empty((B, 3), dtype=torch.int32, device=dev)
-    md_all = torch.empty((world * B, 3), dtype=torch.int32, device=dev) if use_dist else None
+    # the metadata rows are double-buffered: the all-gather of step i runs on a side stream while step i+1 computes
+    md2 = [torch.empty((B, 3), dtype=torch.int32, device=dev) for _ in range(2)]
+    md_all2 = [torch.empty((world * B, 3), dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
     stream = torch.cuda.Stream(device=dev)
+    cstream = torch.cuda.Stream(device=dev) if use_dist else None
+    produced = [torch.cuda.Event() for _ in range(2)]
+    gathered = [None, None]
     ctx.set_stream(stream.cuda_stream)
 
     nb = S // B
 
     def step(i):
         lo = (i % nb) * B
-        ctx.enqueue(stack[lo].data_ptr(), B, lo, out.data_ptr(), out_cap, rec.data_ptr(), md.data_ptr())
+        k = i & 1
+        if use_dist and gathered[k] is not None:
+            stream.wait_event(gathered[k])   # md2[k] is rewritten below: its previous gather (step i-2) must have read it
+        ctx.enqueue(stack[lo].data_ptr(), B, lo, out.data_ptr(), out_cap, rec.data_ptr(), md2[k].data_ptr())
         if use_dist:  # the path's one exchange step: every rank learns every frame's sizes
-            dist.all_gather_into_tensor(md_all, md)
+            produced[k].record(stream)
+            with torch.cuda.stream(cstream):
+                cstream.wait_event(produced[k])
+                dist.all_gather_into_tensor(md_all2[k], md2[k])
+                ev = torch.cuda.Event()
+                ev.record(cstream)
+                gathered[k] = ev
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -191,7 +205,7 @@ def main():
     frames_total = world * B * a.steps
     fps = frames_total / dt_max
     rec_h = rec.cpu().numpy()
-    md_h = md.cpu().numpy()
+    md_h = md2[(a.warmup + a.steps - 1) & 1].cpu().numpy()
     assert rec_h[0] == 0 and rec_h[-1] > 0 and nbatches == a.steps
 
     result = None
@@ -212,7 +226,7 @@ def main():
                 "workload": "%dx%d uint16, %.2f%% sparsity, L1 + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
                     a.ny, a.nx, a.sparsity_ppm / 1e4, {2: "LZ4 frame", 1: "zstd frame", 0: "reduce-only pieces"}.get(a.scheme, str(a.scheme)),
                     a.depth, B, S),
-                "parallelism": "dp%d (contiguous frame blocks per rank, metadata all-gather per step)" % world,
+                "parallelism": "dp%d (contiguous frame blocks per rank; per step one RCCL all-gather of the metadata rows, on a side stream under the next step)" % world,
                 "record_bytes_per_frame": round(float(rec_h[-1]) / B, 1),
             },
             "roofline": {"bound": "hbm", "kernel": "k_reduce_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -237,7 +251,8 @@ def main():
         print(json.dumps(result), flush=True)
     if use_dist:
         if rank == 0:  # the gathered table must hold this rank's own rows at its block
-            assert torch.equal(md_all[:B].cpu(), md.cpu())
+            k = (a.warmup + a.steps - 1) & 1
+            assert torch.equal(md_all2[k][:B].cpu(), md2[k].cpu())
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

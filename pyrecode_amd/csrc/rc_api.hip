@@ -315,6 +315,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     RecordParams rp;
     rp.level = c->level == 3 ? 3u : 1u;  // level 2 records are framed exactly like level 1 (statistics in place of residuals)
     rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
+    rp.packed_slots = c->level == 1 ? 1u : 0u;
     rp.frame_bytes = c->sc.N * 2;
     HIP_TRY(hipMemsetAsync(c->sc.status, 0, sizeof(BatchStatus), s));
     hipEvent_t *ev = nullptr;
@@ -334,7 +335,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     // LZ4 is fused into the reduce kernel (levels 1 and 3); zstd / blosc / level 2 encode the raw bitmaps in a kernel of their own
     // zstd: the byte-parallel half (literals, sequence tokens) is fused too, the serial FSE half runs lane-per-block behind it
     const bool fused = (c->emit == RC_SCHEME_LZ4 || c->emit == RC_SCHEME_ZSTD) && c->level != 2;
-    launch_reduce(c->sc, frames_dev, n, c->level, fused ? c->emit : 0u, c->keep_bitmap || !fused, s);
+    launch_reduce(c->sc, frames_dev, n, c->level, fused ? c->emit : 0u, c->keep_bitmap || !fused, c->depth, s);
     if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
         launch_scans(c->sc, n, true, false, s);
         launch_l2(c->sc, c->l2, n, c->nx, c->l2_sum, s);

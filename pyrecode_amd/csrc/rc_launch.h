@@ -43,15 +43,17 @@ struct RecordParams {
     uint32_t level;        // 1 or 3
     uint32_t emit;         // 0 = raw pieces (mode-0 record), 2 = LZ4 frames, 1 = zstd frames, 8 = blosc-lz4
     uint32_t depth;        // source_bit_depth
+    uint32_t packed_slots; // 1: pix_slots hold tile-local packed streams (level 1); 0: uint16 values (level 2 statistics)
     uint32_t first_frame_id;
     uint64_t frame_bytes;  // raw frame size = N * 2 (record upper bound, recode_writer.py:565-566)
 };
 
 // rc_reduce.hip
 void launch_threshold(const uint16_t *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s);
-// level: 1 residuals, 2 raw values of the set pixels (input of launch_l2), 3 bitmap only
+// level: 1 residuals, 2 raw values of the set pixels (input of launch_l2), 3 bitmap only.  depth < 16 (level 1 only):
+// every tile's residuals are left in its slot already bit-packed (tile-local LSB-first stream of depth-bit fields)
 void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
-                   hipStream_t s);
+                   uint32_t depth, hipStream_t s);
 // rc_l2.hip
 void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s);
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);

@@ -84,11 +84,41 @@ struct Pending {
     uint32_t staged;    // zstd: bytes staged in LDS for the slot
     u32x2 own;          // this lane's 8 bitmap bytes (raw-block fallback / raw bitmap store)
     bool last;          // zstd: the tile is the frame's last block
+    uint32_t depth;     // bits per staged value (16 = plain uint16)
 };
 
 struct __attribute__((aligned(16))) WaveStage {
     uint16_t pix[TILE_PX];  // compacted residuals of the tile, row-major
 };
+
+// A5 inside the tile: the cnt compacted values (uint16, in the wave's LDS stage) become the tile-local LSB-first stream of
+// their low d bits, IN PLACE: output dword w needs values >= 32w/d >= 2w, which lie at or behind byte 4w, and all lanes
+// of a step read before any of them writes.  The rest of the last 128-byte line is zeroed (k_assemble ORs across tiles).
+__device__ __forceinline__ void pack_stage(WaveStage *st, uint32_t cnt, uint32_t d)
+{
+    const int lane = lane_id();
+    const uint32_t nbits = cnt * d;
+    const uint32_t ndw = (((nbits + 31) >> 5) + 31u) & ~31u;
+    const uint32_t inv = 0xFFFFFFFFu / d + 1u;  // floor(n / d) = umulhi(n, inv) for n * d < 2^32
+    const uint32_t dmask = (1u << d) - 1u;
+    uint32_t *out = reinterpret_cast<uint32_t *>(st->pix);
+    for (uint32_t w0 = 0; w0 < ndw; w0 += 64) {
+        const uint32_t w = w0 + lane;
+        uint32_t v = __umulhi(32u * w, inv);
+        const uint32_t o = 32u * w - v * d;
+        uint64_t acc = 0;
+        uint32_t filled = 0;
+        if (v < cnt) { acc = (st->pix[v] & dmask) >> o; filled = d - o; ++v; }
+        while (filled < 32 && v < cnt) {
+            acc |= (uint64_t)(st->pix[v] & dmask) << filled;
+            filled += d;
+            ++v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (w < ndw) out[w] = (uint32_t)acc;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 template <bool LEVEL1, int CODEC, bool KEEP_BITMAP>
 __device__ __forceinline__ void flush_pending(const Pending &p, uint32_t tile, uint32_t n_blk, uint8_t *__restrict__ bitmap,
@@ -103,7 +133,7 @@ __device__ __forceinline__ void flush_pending(const Pending &p, uint32_t tile, u
         const uint32_t *src = reinterpret_cast<const uint32_t *>(st->pix);
         // whole 128-byte lines only (the tail of the last line is unused slot space): partial-line writes cost a
         // read-modify-write at the memory side
-        const uint32_t ndw = (((p.cnt + 1) >> 1) + 31u) & ~31u;
+        const uint32_t ndw = (((p.cnt * p.depth + 31) >> 5) + 31u) & ~31u;
         for (uint32_t i = lane; i < ndw; i += 64) dst[i] = src[i];
         if (lane == 0) tile_cnt[p.ft] = p.cnt;
     }
@@ -195,6 +225,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                 }
         }
         pend.cnt = wave_total;
+        if (pend.depth < 16 && wave_total) pack_stage(st, wave_total, pend.depth);
     }
     if (KEEP_BITMAP || CODEC) {
         // transpose through wave-private LDS: byte (r, lane) -> position r*64 + lane; 8 contiguous bytes per lane out
@@ -229,12 +260,12 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 //   -> [CODEC 2] the 512-byte bitmap block is LZ4-encoded in LDS (rc_lz4_block.h)
 //   -> all global stores (residuals, encoded block, raw bitmap, counts) are issued ONE FRAME LATE, coalesced (flush_pending)
 template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
-__global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict__ frames,
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
                                                        uint8_t *__restrict__ bitmap, uint64_t nb_stride,
                                                        uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
-                                                       uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size)
+                                                       uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, uint32_t depth)
 {
     __shared__ Lz4Lds s_lz[CODEC ? WAVES : 1];                                                  // codec working set
     __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : WAVES][CODEC ? 16 : TILE_BM];  // transpose only
@@ -275,6 +306,7 @@ __global__ __launch_bounds__(WG) void k_reduce_tiles(const uint16_t *__restrict_
     pend.valid = false;
     pend.ft = 0; pend.f = 0; pend.cnt = 0; pend.csize = 0; pend.own = u32x2{0u, 0u};
     pend.staged = 0; pend.last = tile + 1 == ntiles;
+    pend.depth = (LEVEL1 && !RAWVAL) ? depth : 16u;
 
 #pragma unroll 1
     for (int z = 0; z < BZ; z += 2) {
@@ -314,14 +346,14 @@ static int reduce_tmode()  // where the threshold tile lives: 0 registers (defau
 }
 
 template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW>
-static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, hipStream_t s)
+static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t depth, hipStream_t s)
 {
     const uint32_t ngroups = (B + BZ - 1) / BZ;
     const uint32_t ntb = (sc.ntiles + WAVES - 1) / WAVES;
     const uint32_t grid = ((ntb + 7) / 8) * 8 * ngroups;
 #define RC_GO(TM)                                                                                                           \
     hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP, TM, RAW>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N,         \
-                       sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size)
+                       sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size, depth)
     // the scalar-load instantiation and the raw-value (level 2) one exist with the threshold in registers only
     const int tm = (AL && !RAW) ? reduce_tmode() : 0;
     if (tm == 1) { if (AL && !RAW) RC_GO(1); } else if (tm == 2) { if (AL && !RAW) RC_GO(2); } else RC_GO(0);
@@ -329,31 +361,32 @@ static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t 
 }
 template <int BZ, bool AL>
 static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep,
-                            hipStream_t s)
+                            uint32_t depth, hipStream_t s)
 {
-    if (level == 2) { launch_reduce_t<BZ, AL, true, 0, true, true>(sc, frames, B, s); return; }
+    if (level == 2) { launch_reduce_t<BZ, AL, true, 0, true, true>(sc, frames, B, depth, s); return; }
     const bool level1 = level == 1;
     if (codec == 2) {
-        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 2, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, true, 2, false, false>(sc, frames, B, s); }
-        else        { if (keep) launch_reduce_t<BZ, AL, false, 2, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 2, false, false>(sc, frames, B, s); }
+        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 2, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, true, 2, false, false>(sc, frames, B, depth, s); }
+        else        { if (keep) launch_reduce_t<BZ, AL, false, 2, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, false, 2, false, false>(sc, frames, B, depth, s); }
     } else if (codec == 1) {
-        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 1, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, true, 1, false, false>(sc, frames, B, s); }
-        else        { if (keep) launch_reduce_t<BZ, AL, false, 1, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 1, false, false>(sc, frames, B, s); }
+        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 1, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, true, 1, false, false>(sc, frames, B, depth, s); }
+        else        { if (keep) launch_reduce_t<BZ, AL, false, 1, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, false, 1, false, false>(sc, frames, B, depth, s); }
     } else {
-        if (level1) launch_reduce_t<BZ, AL, true, 0, true, false>(sc, frames, B, s); else launch_reduce_t<BZ, AL, false, 0, true, false>(sc, frames, B, s);
+        if (level1) launch_reduce_t<BZ, AL, true, 0, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, false, 0, true, false>(sc, frames, B, depth, s);
     }
 }
 void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
-                   hipStream_t s)
+                   uint32_t depth, hipStream_t s)
 {
+    if (depth == 0 || depth > 16) depth = 16;
     const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
     const int bz = reduce_bz();
     if (aligned) {
-        if (bz == 8) launch_reduce_a<8, true>(sc, frames, B, level, codec, keep_bitmap, s);
-        else if (bz == 2) launch_reduce_a<2, true>(sc, frames, B, level, codec, keep_bitmap, s);
-        else launch_reduce_a<4, true>(sc, frames, B, level, codec, keep_bitmap, s);
+        if (bz == 8) launch_reduce_a<8, true>(sc, frames, B, level, codec, keep_bitmap, depth, s);
+        else if (bz == 2) launch_reduce_a<2, true>(sc, frames, B, level, codec, keep_bitmap, depth, s);
+        else launch_reduce_a<4, true>(sc, frames, B, level, codec, keep_bitmap, depth, s);
     } else {
-        launch_reduce_a<4, false>(sc, frames, B, level, codec, keep_bitmap, s);
+        launch_reduce_a<4, false>(sc, frames, B, level, codec, keep_bitmap, depth, s);
     }
 }
 
@@ -727,19 +760,24 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     const uint32_t ntl = min(ASM_TPW, sc.ntiles - t0);
     const uint32_t sub = (uint32_t)lane >> 4, sl = (uint32_t)lane & 15u;
     const uint32_t d = rp.depth;
-    const bool pix16 = rp.level == 1 && d == 16;
+    // residual slots holding a tile-local packed stream of d-bit fields (level 1; uint16 values are the d = 16 case)
+    const bool pixp = rp.level == 1 && (rp.packed_slots || d == 16);
     uint8_t *pdst = rec + pix_pos;
     constexpr int BIT = 4, PIT = 2;  // unrolled 16-dword steps per segment: 256 B of block, 128 B of residuals; longer: loop
     uint8_t *bdst[4], *pdstp[4];
     const uint8_t *bsrc[4], *psrc[4];
-    uint32_t bn[4], pn[4];
+    uint32_t bn[4], pn[4], ps0[4];
+    // a tile owns the stream bytes whose FIRST bit is one of its bits; when its last owned byte is only partly its own
+    // (fin_avail bits), the rest comes from the next non-empty tile(s): that byte is written separately
+    uint32_t fin_avail[4], fin_q[4], fin_next[4], fin_ncnt[4], fin_nfirst[4];
+    uint64_t fin_b[4];
     u32x2 bv[4][BIT], pv[4][PIT];
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const uint32_t k = 4u * ps + sub;
         const uint32_t tl = t0 + k;
         const bool have = k < ntl;
-        bn[ps] = 0; pn[ps] = 0;
+        bn[ps] = 0; pn[ps] = 0; ps0[ps] = 0; fin_avail[ps] = 0; fin_q[ps] = 0; fin_next[ps] = sc.ntiles; fin_b[ps] = 0;
         bdst[ps] = rec; pdstp[ps] = rec; bsrc[ps] = sc.blk_slots; psrc[ps] = sc.blk_slots;
         if (have) {
             if (rp.emit == 0) {
@@ -754,18 +792,35 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                 bsrc[ps] = sc.blk_slots + (frow + tl) * BLK_SLOT;
                 if (rp.emit == 8 && sl == 0) store_u32_le(rec + bitmap_pos + 16 + 4 * (uint64_t)tl, boff);  // blosc bstarts[tl]
             }
-            if (pix16) {
+            if (pixp) {
                 const uint32_t c = sc.tile_cnt[frow + tl];
-                const uint64_t b0 = 2ull * sc.tile_off[frow + tl];
-                pn[ps] = 2u * c;
-                psrc[ps] = reinterpret_cast<const uint8_t *>(sc.pix_slots + (frow + tl) * TILE_PX);
-                const uint64_t b1 = b0 + pn[ps] - 1;
-                if (rp.emit != 0 && c && (b0 >> ff.chunk_shift) != (b1 >> ff.chunk_shift)) {
-                    // straddles a stored-chunk header of the pixel frame (once per 4 MiB): byte by byte
-                    for (uint32_t i = sl; i < pn[ps]; i += 16) pdst[stored_pos(ff, b0 + i)] = psrc[ps][i];
-                    pn[ps] = 0;
+                if (c) {
+                    const uint64_t dbit = (uint64_t)sc.tile_off[frow + tl] * d;  // stream position of the tile's first bit
+                    const uint32_t nbits = c * d;
+                    const uint64_t b_lo = (dbit + 7) >> 3, b_hi = (dbit + nbits + 7) >> 3;
+                    const uint32_t avail = (uint32_t)((dbit + nbits) & 7u);
+                    uint32_t n = (uint32_t)(b_hi - b_lo);
+                    ps0[ps] = (uint32_t)(8 * b_lo - dbit);
+                    psrc[ps] = reinterpret_cast<const uint8_t *>(sc.pix_slots + (frow + tl) * TILE_PX);
+                    if (avail && n) {  // (n == 0: the tile's few bits all live in a byte that an earlier tile owns)
+                        --n;
+                        fin_avail[ps] = avail;
+                        fin_q[ps] = 8 * n + ps0[ps];
+                        fin_b[ps] = b_hi - 1;
+                        fin_next[ps] = sc.tile_next[frow + tl];
+                    }
+                    pn[ps] = n;
+                    if (n && rp.emit != 0 && (b_lo >> ff.chunk_shift) != ((b_lo + n - 1) >> ff.chunk_shift)) {
+                        // straddles a stored-chunk header of the pixel frame (once per 4 MiB): byte by byte
+                        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(psrc[ps]);
+                        for (uint32_t i = sl; i < n; i += 16) {
+                            const uint32_t q = 8 * i + ps0[ps];
+                            pdst[stored_pos(ff, b_lo + i)] = (uint8_t)__builtin_amdgcn_alignbit(s32[(q >> 5) + 1], s32[q >> 5], q & 31u);
+                        }
+                        pn[ps] = 0;
+                    }
+                    pdstp[ps] = pdst + (rp.emit == 0 ? b_lo : stored_pos(ff, b_lo));
                 }
-                pdstp[ps] = pdst + (rp.emit == 0 ? b0 : stored_pos(ff, b0));
             }
         }
     }
@@ -778,20 +833,26 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
             bv[ps][it] = u32x2{0u, 0u};
             if (4 * j < bn[ps] + 4 && bn[ps]) bv[ps][it] = *reinterpret_cast<const u32x2 *>(bsrc[ps] + 4 * j);
         }
-        if (pix16) {
+        if (pixp) {
 #pragma unroll
             for (int it = 0; it < PIT; ++it) {
                 const uint32_t j = sl + 16u * it;
                 pv[ps][it] = u32x2{0u, 0u};
                 if (4 * j < pn[ps] + 4 && pn[ps]) pv[ps][it] = *reinterpret_cast<const u32x2 *>(psrc[ps] + 4 * j);
             }
+            fin_ncnt[ps] = 0; fin_nfirst[ps] = 0;
+            if (fin_avail[ps] && fin_next[ps] < sc.ntiles) {
+                fin_ncnt[ps] = sc.tile_cnt[frow + fin_next[ps]];
+                fin_nfirst[ps] = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + fin_next[ps]) * TILE_PX);
+            }
         }
     }
-    // stores
-    auto put = [&](uint8_t *dst, uint32_t n, uint32_t j, const u32x2 &v) {
+    // stores.  Destination dword j (behind `head` bytes that align it) = source bits [8*head + s0 + 32j, +32) = dwords j, j+1
+    // funnel-shifted (v_alignbit_b32); s0 = 0 for byte-aligned sources (encoded blocks, d = 16)
+    auto put = [&](uint8_t *dst, uint32_t n, uint32_t j, const u32x2 &v, uint32_t s0) {
         const uint32_t head = min(n, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
         const uint32_t n2 = n - head, nd = n2 >> 2, tail = n2 & 3u;
-        const uint32_t val = __builtin_amdgcn_alignbyte(v[1], v[0], head);  // source bytes [head + 4j, head + 4j + 4)
+        const uint32_t val = __builtin_amdgcn_alignbit(v[1], v[0], 8 * head + s0);
         if (j < nd) reinterpret_cast<uint32_t *>(dst + head)[j] = val;
         if (j == nd && tail) {
             uint8_t *t = dst + head + 4 * nd;
@@ -800,29 +861,48 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
             if (tail > 2) t[2] = (uint8_t)(val >> 16);
         }
         if (j == 0 && head) {
-            dst[0] = (uint8_t)v[0];
-            if (head > 1) dst[1] = (uint8_t)(v[0] >> 8);
-            if (head > 2) dst[2] = (uint8_t)(v[0] >> 16);
+            const uint32_t h0 = __builtin_amdgcn_alignbit(v[1], v[0], s0);
+            dst[0] = (uint8_t)h0;
+            if (head > 1) dst[1] = (uint8_t)(h0 >> 8);
+            if (head > 2) dst[2] = (uint8_t)(h0 >> 16);
         }
     };
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         if (bn[ps]) {
 #pragma unroll
-            for (int it = 0; it < BIT; ++it) put(bdst[ps], bn[ps], sl + 16u * it, bv[ps][it]);
+            for (int it = 0; it < BIT; ++it) put(bdst[ps], bn[ps], sl + 16u * it, bv[ps][it], 0);
             for (uint32_t j = sl + 16u * BIT; 4 * j < bn[ps] + 4; j += 16)  // rare: longer than the unrolled part
-                put(bdst[ps], bn[ps], j, *reinterpret_cast<const u32x2 *>(bsrc[ps] + 4 * j));
+                put(bdst[ps], bn[ps], j, *reinterpret_cast<const u32x2 *>(bsrc[ps] + 4 * j), 0);
         }
-        if (pix16 && pn[ps]) {
+        if (pixp && pn[ps]) {
 #pragma unroll
-            for (int it = 0; it < PIT; ++it) put(pdstp[ps], pn[ps], sl + 16u * it, pv[ps][it]);
+            for (int it = 0; it < PIT; ++it) put(pdstp[ps], pn[ps], sl + 16u * it, pv[ps][it], ps0[ps]);
             for (uint32_t j = sl + 16u * PIT; 4 * j < pn[ps] + 4; j += 16)
-                put(pdstp[ps], pn[ps], j, *reinterpret_cast<const u32x2 *>(psrc[ps] + 4 * j));
+                put(pdstp[ps], pn[ps], j, *reinterpret_cast<const u32x2 *>(psrc[ps] + 4 * j), ps0[ps]);
+        }
+        if (pixp && fin_avail[ps] && sl == 0) {
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(psrc[ps]);
+            const uint32_t q = fin_q[ps], avail = fin_avail[ps];
+            uint32_t byte = __builtin_amdgcn_alignbit(s32[(q >> 5) + 1], s32[q >> 5], q & 31u) & ((1u << avail) - 1u);
+            uint32_t got = avail, tt = fin_next[ps], cc = fin_ncnt[ps], first = fin_nfirst[ps];
+            while (tt < sc.ntiles) {  // one round unless the next tile holds fewer than 8 - avail bits (d < 8 only)
+                const uint32_t take = min(8u - got, cc * d);
+                byte |= (first & ((1u << take) - 1u)) << got;
+                got += take;
+                if (got >= 8) break;
+                tt = sc.tile_next[frow + tt];
+                if (tt < sc.ntiles) {
+                    cc = sc.tile_cnt[frow + tt];
+                    first = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + tt) * TILE_PX);
+                }
+            }
+            pdst[rp.emit == 0 ? fin_b[ps] : stored_pos(ff, fin_b[ps])] = (uint8_t)byte;
         }
     }
-    if (rp.level != 1 || pix16) return;
+    if (rp.level != 1 || pixp) return;
 
-    // ---- residuals with a bit depth that is not a multiple of 8: bit-packed on the way ---------------------------------------
+    // ---- uint16 value lists that still need packing (level 2 statistics with d < 16): bit-packed on the way, byte-wise -------
     const uint32_t tl_ = t0 + (uint32_t)lane;
     uint32_t cnt = 0, poff = 0;
     if (tl_ < sc.ntiles) {

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from pyrecode_amd import _lib as hip
+if os.environ.get("RC_AB_LIB"):  # A/B runs on one box: a second build of the library (development only)
+    hip.LIB_PATH = os.path.abspath(os.environ["RC_AB_LIB"])
 
 a = sys.argv[1:]
 ny, nx, B, ppm, d, scheme = (int(v) for v in a[:6])

@@ -661,12 +661,16 @@ __device__ __forceinline__ uint64_t stored_pos(const FrameFmt &ff, uint64_t b)
     return ff.hdr + ff.chunk_hdr * ((b >> ff.chunk_shift) + 1) + b;
 }
 
-constexpr uint32_t ASM_TPW = 16;  // tiles per wavefront: their metadata sits one tile per lane (lanes 0..15)
+// a quarter-wave handles one tile per pass; 2 passes (8 tiles per wavefront) keep the kernel at ~80 VGPRs: measured 44 us
+// against 58 us with 4 passes / 142 VGPRs (latency-bound: resident waves are what counts), 1 pass is no better
+constexpr int ASM_PASSES = 2;
+constexpr uint32_t ASM_TPW = 4 * ASM_PASSES;  // tiles per wavefront
 
-// One wavefront per ASM_TPW consecutive tiles of a frame.  Lane L fetches tile L's metadata (one coalesced round trip); the
-// wavefront then walks the tiles with wave-uniform (readlane) sizes and offsets, copying each tile's encoded bitmap block
-// (or raw bitmap bytes) and its residuals to their places in the record, ASM_U segments in flight at a time.
-// Residuals with a bit depth that is not a multiple of 8 are bit-packed on the way (byte-granular path).
+// One wavefront per ASM_TPW consecutive tiles of a frame, a quarter-wave (16 lanes) per tile and pass: each quarter copies
+// its tile's encoded bitmap block (or raw bitmap bytes) and its residuals to their places in the record.  Residual slots
+// hold tile-local packed streams of d-bit fields (rc_reduce's pack_stage; plain uint16 = the d = 16 case), so the copy is a
+// bit-granular funnel shift; the byte a tile shares with its successor is completed from the successor's first bits.
+// Value lists that are still uint16 and need packing (level-2 statistics with d < 16) take the byte-granular path at the end.
 __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, uint32_t B, uint8_t *__restrict__ out,
                                                    const uint64_t *__restrict__ rec_off, uint32_t lz4f_hdr_bitmap,
                                                    uint32_t lz4f_hdr_pix)
@@ -752,10 +756,10 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     }
 
     // ---- copies: 16 lanes per segment, 4 segments per wave-instruction, no scalar address arithmetic --------------------
-    // Quarter q of the wavefront (lanes 16q..16q+15) handles tile t0 + 4*pass + q in pass 0..3.  A segment is n bytes from
+    // Quarter q of the wavefront (lanes 16q..16q+15) handles tile t0 + 4*pass + q in pass 0..ASM_PASSES-1.  A segment is n bytes from
     // a 4-byte aligned source to an arbitrarily aligned destination: destination dword j = source bytes [head+4j, head+4j+4)
     // = byte funnel shift (v_alignbyte_b32) of source dwords j, j+1 (one 8-byte load per lane); head / tail bytes are
-    // stored singly by the lanes that already hold them.  All loads of the wavefront's 16 tiles are issued before the
+    // stored singly by the lanes that already hold them.  All loads of the wavefront's tiles are issued before the
     // first store (loads and stores share one in-order counter).
     const uint32_t ntl = min(ASM_TPW, sc.ntiles - t0);
     const uint32_t sub = (uint32_t)lane >> 4, sl = (uint32_t)lane & 15u;
@@ -764,16 +768,16 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     const bool pixp = rp.level == 1 && (rp.packed_slots || d == 16);
     uint8_t *pdst = rec + pix_pos;
     constexpr int BIT = 4, PIT = 2;  // unrolled 16-dword steps per segment: 256 B of block, 128 B of residuals; longer: loop
-    uint8_t *bdst[4], *pdstp[4];
-    const uint8_t *bsrc[4], *psrc[4];
-    uint32_t bn[4], pn[4], ps0[4];
+    uint8_t *bdst[ASM_PASSES], *pdstp[ASM_PASSES];
+    const uint8_t *bsrc[ASM_PASSES], *psrc[ASM_PASSES];
+    uint32_t bn[ASM_PASSES], pn[ASM_PASSES], ps0[ASM_PASSES];
     // a tile owns the stream bytes whose FIRST bit is one of its bits; when its last owned byte is only partly its own
     // (fin_avail bits), the rest comes from the next non-empty tile(s): that byte is written separately
-    uint32_t fin_avail[4], fin_q[4], fin_next[4], fin_ncnt[4], fin_nfirst[4];
-    uint64_t fin_b[4];
-    u32x2 bv[4][BIT], pv[4][PIT];
+    uint32_t fin_avail[ASM_PASSES], fin_q[ASM_PASSES], fin_next[ASM_PASSES], fin_ncnt[ASM_PASSES], fin_nfirst[ASM_PASSES];
+    uint64_t fin_b[ASM_PASSES];
+    u32x2 bv[ASM_PASSES][BIT], pv[ASM_PASSES][PIT];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < ASM_PASSES; ++ps) {
         const uint32_t k = 4u * ps + sub;
         const uint32_t tl = t0 + k;
         const bool have = k < ntl;
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     }
     // loads
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < ASM_PASSES; ++ps) {
 #pragma unroll
         for (int it = 0; it < BIT; ++it) {
             const uint32_t j = sl + 16u * it;
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
         }
     };
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < ASM_PASSES; ++ps) {
         if (bn[ps]) {
 #pragma unroll
             for (int it = 0; it < BIT; ++it) put(bdst[ps], bn[ps], sl + 16u * it, bv[ps][it], 0);

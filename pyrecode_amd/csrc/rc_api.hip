@@ -317,7 +317,6 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
     rp.packed_slots = c->level == 1 ? 1u : 0u;
     rp.frame_bytes = c->sc.N * 2;
-    HIP_TRY(hipMemsetAsync(c->sc.status, 0, sizeof(BatchStatus), s));
     hipEvent_t *ev = nullptr;
     if (timed) ev = c->ev;
     else if (c->profiling) {

@@ -265,8 +265,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
                                                        uint8_t *__restrict__ bitmap, uint64_t nb_stride,
                                                        uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
-                                                       uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, uint32_t depth)
+                                                       uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, uint32_t depth,
+                                                       BatchStatus *__restrict__ status)
 {
+    // first kernel of a batch: clears the batch's status word (written later by k_layout / the level-2 kernels)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
     __shared__ Lz4Lds s_lz[CODEC ? WAVES : 1];                                                  // codec working set
     __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : WAVES][CODEC ? 16 : TILE_BM];  // transpose only
     __shared__ u32x4 s_thr[TMODE == 1 ? WAVES : 1][TMODE == 1 ? R * 64 : 1];                       // threshold tile per wave
@@ -353,7 +356,7 @@ static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t 
     const uint32_t grid = ((ntb + 7) / 8) * 8 * ngroups;
 #define RC_GO(TM)                                                                                                           \
     hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP, TM, RAW>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N,         \
-                       sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size, depth)
+                       sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size, depth, sc.status)
     // the scalar-load instantiation and the raw-value (level 2) one exist with the threshold in registers only
     const int tm = (AL && !RAW) ? reduce_tmode() : 0;
     if (tm == 1) { if (AL && !RAW) RC_GO(1); } else if (tm == 2) { if (AL && !RAW) RC_GO(2); } else RC_GO(0);

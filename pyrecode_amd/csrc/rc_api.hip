@@ -331,23 +331,18 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
         c->prof_used += 5;
     }
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    // LZ4 is fused into the reduce kernel (levels 1 and 3); zstd / blosc / level 2 encode the raw bitmaps in a kernel of their own
-    // zstd: the byte-parallel half (literals, sequence tokens) is fused too, the serial FSE half runs lane-per-block behind it
-    const bool fused = (c->emit == RC_SCHEME_LZ4 || c->emit == RC_SCHEME_ZSTD) && c->level != 2;
-    launch_reduce(c->sc, frames_dev, n, c->level, fused ? c->emit : 0u, c->keep_bitmap || !fused, c->depth, s);
+    // every device codec's block encoder runs inside the reduce kernel (LZ4; blosc = bit-shuffle + LZ4; zstd: the
+    // byte-parallel half - literals, sequence tokens - with the serial FSE half lane-per-block behind it)
+    launch_reduce(c->sc, frames_dev, n, c->level, c->emit, c->keep_bitmap || c->emit == 0, c->depth, s);
     if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
         launch_scans(c->sc, n, true, false, s);
         launch_l2(c->sc, c->l2, n, c->nx, c->l2_sum, s);
     }
-    if (c->emit == RC_SCHEME_LZ4 && !fused) launch_lz4_encode_frames(c->sc, n, s);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    if (c->emit == RC_SCHEME_ZSTD) {
-        if (fused) launch_zstd_fse(c->sc, n, c->d_ztab, s); else launch_zstd_encode_blocks(c->sc, n, c->d_ztab, s);
-    }
-    if (c->emit == RC_SCHEME_BLOSC_LZ4) launch_blosc_encode_blocks(c->sc, n, s);
+    if (c->emit == RC_SCHEME_ZSTD) launch_zstd_fse(c->sc, n, c->d_ztab, s);
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], s));
     launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);  // (level 2: k_l2_emit has already described its value list)
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], s));
@@ -443,7 +438,7 @@ RC_EXPORT int rc_get_binary_map(rc_ctx *c, uint32_t i, uint8_t *bitmap_out)
 {
     if (!c || !bitmap_out) return fail(RC_ERR_BAD_ARG, "NULL argument");
     if (i >= c->last_n) return fail(RC_ERR_BAD_ARG, "frame index outside the most recent batch");
-    if (!c->keep_bitmap && (c->emit == RC_SCHEME_LZ4 || c->emit == RC_SCHEME_ZSTD) && c->level != 2) return fail(RC_ERR_BAD_ARG, "binary maps are not kept (rc_ctx_keep_binary_maps(ctx, 0))");
+    if (!c->keep_bitmap && c->emit != 0 && c->level != 2) return fail(RC_ERR_BAD_ARG, "binary maps are not kept (rc_ctx_keep_binary_maps(ctx, 0))");
     HIP_TRY(hipSetDevice(c->device));
     int r = copy_out(bitmap_out, c->sc.bitmap + (uint64_t)i * c->sc.nb_stride, c->sc.nb, c->stream);
     if (r != RC_OK) return r;

@@ -32,20 +32,8 @@ __global__ __launch_bounds__(WG) void k_blosc_blocks(Scratch sc)
     const u32x2 v = reinterpret_cast<const u32x2 *>(sc.bitmap + (uint64_t)f * sc.nb_stride + b0)[lane];  // rows are padded
     const uint64_t elem = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
     Lz4Lds &L = s_lz[w];
-    const uint32_t S = (n >> 3) & ~7u;        // elements taking part in the bit transpose
-    const uint32_t rowb = S >> 3;             // bytes per output row
-    // unshuffled tail [8S, n): copied as is (this lane's bytes 8*lane .. that fall into the tail)
-    reinterpret_cast<u32x2 *>(L.raw)[lane] = v;  // start from a plain copy, then overwrite the shuffled part
-    if (S) {
-        const uint64_t in_s = (uint32_t)lane < S ? elem : 0ull;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) {
-            const uint64_t row = __ballot((in_s >> r) & 1ull);
-            if ((uint32_t)lane < rowb) L.raw[r * rowb + lane] = (uint8_t)(row >> (8 * lane));
-        }
-    }
-    const u32x2 o = reinterpret_cast<const u32x2 *>(L.raw)[lane];
-    const uint64_t own = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+    reinterpret_cast<u32x2 *>(L.raw)[lane] = v;
+    const uint64_t own = bitshuffle_block(elem, n, L);
     const uint32_t csize = lz4_encode_block(own, n, L);
     const uint64_t ft = (uint64_t)f * sc.ntiles + t;
     uint8_t *slot = sc.blk_slots + ft * BLK_SLOT;

@@ -39,10 +39,6 @@ void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s)
 {
     hipLaunchKernelGGL(k_lz4_buffer, dim3((sc.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, s, sc);
 }
-void launch_lz4_encode_frames(const Scratch &sc, uint32_t B, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_lz4_buffer, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc);
-}
 
 // ---- stand-alone LZ4 frame of an arbitrary byte buffer (seam 2: compress(), recode_compressors.py:91) -----------------
 // Blocks were encoded by k_lz4_bitmap with B == 1 (the buffer plays the role of one frame's bitmap); this kernel

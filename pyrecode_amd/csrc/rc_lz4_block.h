@@ -129,6 +129,43 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
     return total;
 }
 
+// blosc1 bit-shuffle of one block with typesize 8 (bitshuffle's bshuf_trans_bit_elem, little-endian bit order): with S
+// elements, output row r (r = 0..63: bit r%8 of byte r/8 of every element) is S/8 bytes whose bit i is that bit of element
+// i; S is the element count rounded down to a multiple of 8, the bytes behind the shuffled part stay as they are
+// (c-blosc's blosc_internal_bitshuffle).  A lane owns one element (its 8 consecutive bytes), so row r is the wave ballot
+// of bit r.  Wave-collective; precondition: L.raw holds the plain block and `elem` is this lane's 8 bytes of it.
+// Leaves the shuffled block in L.raw and returns this lane's 8 bytes of it.
+__device__ __forceinline__ uint64_t bitshuffle_block(uint64_t elem, uint32_t n, Lz4Lds &L)
+{
+    const int lane = lane_id();
+    const uint32_t S = (n >> 3) & ~7u;        // elements taking part in the bit transpose
+    if (S == 0) return elem;
+    uint32_t *raw32 = reinterpret_cast<uint32_t *>(L.raw);
+    const uint32_t pc = (uint32_t)__builtin_popcountll(elem);
+    const bool sparse = S == 64 && __builtin_amdgcn_ballot_w64(pc > 8) == 0;
+    if (sparse) {
+        // the transposed matrix is as sparse as the block: clear it, then every lane ORs its few set bits into place
+        // (bit r of element i -> row r = bytes [8r, 8r+8), bit i of the row)
+        raw32[2 * lane] = 0; raw32[2 * lane + 1] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (uint64_t q = elem; q; q &= q - 1) {
+            const uint32_t r = (uint32_t)__builtin_ctzll(q);
+            __hip_atomic_fetch_or(&raw32[2 * r + ((uint32_t)lane >> 5)], 1u << (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    } else {
+        const uint32_t rowb = S >> 3;         // bytes per output row
+        const uint64_t in_s = (uint32_t)lane < S ? elem : 0ull;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            const uint64_t row = __builtin_amdgcn_ballot_w64(((in_s >> r) & 1ull) != 0);
+            if ((uint32_t)lane < rowb) L.raw[r * rowb + lane] = (uint8_t)(row >> (8 * lane));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t lo = raw32[2 * lane], hi = raw32[2 * lane + 1];
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 // Wave-collective: write the block to its slot = [u32 LZ4F block word][payload]; returns slot bytes used.
 __device__ __forceinline__ uint32_t lz4_store_block(uint8_t *slot, uint64_t own, uint32_t n, uint32_t csize, const Lz4Lds &L)
 {

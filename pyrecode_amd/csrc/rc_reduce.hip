@@ -83,6 +83,7 @@ struct Pending {
     uint32_t csize;     // LZ4 payload bytes staged in LDS (>= n_blk: store raw); zstd: the blk_size word
     uint32_t staged;    // zstd: bytes staged in LDS for the slot
     u32x2 own;          // this lane's 8 bitmap bytes (raw-block fallback / raw bitmap store)
+    uint64_t cown;      // blosc: this lane's 8 bytes of the bit-shuffled block (stored-block fallback)
     bool last;          // zstd: the tile is the frame's last block
     uint32_t depth;     // bits per staged value (16 = plain uint16)
 };
@@ -146,6 +147,14 @@ __device__ __forceinline__ void flush_pending(const Pending &p, uint32_t tile, u
     if (CODEC == 1) {
         zstd_store_block(blk_slots + p.ft * BLK_SLOT, n_blk, p.last, p.csize, p.staged, *lz);
         if (lane == 0) blk_size[p.ft] = p.csize;
+    }
+    if (CODEC == 8) {
+        uint8_t *slot = blk_slots + p.ft * BLK_SLOT;
+        const uint32_t used = lz4_store_block(slot, p.cown, n_blk, p.csize, *lz);
+        if (lane == 0) {
+            if (p.csize >= n_blk) reinterpret_cast<uint32_t *>(slot)[0] = n_blk;  // blosc marks a stored block by csize == size
+            blk_size[p.ft] = used;
+        }
     }
 }
 
@@ -241,6 +250,11 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
             const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
             pend.csize = zstd_tokenize_block(bytes, n_blk, pend.last, *s_lz, pend.staged);
         }
+        if (CODEC == 8) {  // blosc1 block: bit-shuffle (typesize 8), then the LZ4 block encoder
+            const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
+            pend.cown = bitshuffle_block(bytes, n_blk, *s_lz);
+            pend.csize = lz4_encode_block(pend.cown, n_blk, *s_lz);
+        }
     }
     flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st);
     pend.valid = false;
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
     Pending pend;
     pend.valid = false;
     pend.ft = 0; pend.f = 0; pend.cnt = 0; pend.csize = 0; pend.own = u32x2{0u, 0u};
-    pend.staged = 0; pend.last = tile + 1 == ntiles;
+    pend.staged = 0; pend.last = tile + 1 == ntiles; pend.cown = 0;
     pend.depth = (LEVEL1 && !RAWVAL) ? depth : 16u;
 
 #pragma unroll 1
@@ -332,16 +346,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
     flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st);
 }
 
-static int reduce_bz()
-{
-    static const int bz = [] {
-        const char *e = getenv("RC_BZ");
-        const int v = e ? atoi(e) : 4;
-        return (v == 2 || v == 8) ? v : 4;
-    }();
-    return bz;
-}
-
 static int reduce_tmode()  // where the threshold tile lives: 0 registers (default), 1 wave-private LDS, 2 re-read from L2
 {
     static const int v = [] { const char *e = getenv("RC_THR_MODE"); const int m = e ? atoi(e) : 0; return (m >= 0 && m <= 2) ? m : 0; }();
@@ -362,35 +366,37 @@ static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t 
     if (tm == 1) { if (AL && !RAW) RC_GO(1); } else if (tm == 2) { if (AL && !RAW) RC_GO(2); } else RC_GO(0);
 #undef RC_GO
 }
+template <int BZ, bool AL, bool L1, bool RAW>
+static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s)
+{
+    // raw-value (level 2) instantiations always keep the bitmap: the labelling kernels read it
+    if (RAW) keep = true;
+#define RC_CODEC(C)                                                                                          \
+    do {                                                                                                     \
+        if (keep) launch_reduce_t<BZ, AL, L1, C, true, RAW>(sc, frames, B, depth, s);                        \
+        else if (!RAW && C != 0) launch_reduce_t<BZ, AL, L1, C, false, false>(sc, frames, B, depth, s);      \
+    } while (0)
+    if (codec == 2) RC_CODEC(2);
+    else if (codec == 1) RC_CODEC(1);
+    else if (codec == 8) RC_CODEC(8);
+    else launch_reduce_t<BZ, AL, L1, 0, true, RAW>(sc, frames, B, depth, s);
+#undef RC_CODEC
+}
 template <int BZ, bool AL>
 static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep,
                             uint32_t depth, hipStream_t s)
 {
-    if (level == 2) { launch_reduce_t<BZ, AL, true, 0, true, true>(sc, frames, B, depth, s); return; }
-    const bool level1 = level == 1;
-    if (codec == 2) {
-        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 2, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, true, 2, false, false>(sc, frames, B, depth, s); }
-        else        { if (keep) launch_reduce_t<BZ, AL, false, 2, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, false, 2, false, false>(sc, frames, B, depth, s); }
-    } else if (codec == 1) {
-        if (level1) { if (keep) launch_reduce_t<BZ, AL, true, 1, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, true, 1, false, false>(sc, frames, B, depth, s); }
-        else        { if (keep) launch_reduce_t<BZ, AL, false, 1, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, false, 1, false, false>(sc, frames, B, depth, s); }
-    } else {
-        if (level1) launch_reduce_t<BZ, AL, true, 0, true, false>(sc, frames, B, depth, s); else launch_reduce_t<BZ, AL, false, 0, true, false>(sc, frames, B, depth, s);
-    }
+    if (level == 2) launch_reduce_c<BZ, AL, true, true>(sc, frames, B, codec, keep, depth, s);
+    else if (level == 1) launch_reduce_c<BZ, AL, true, false>(sc, frames, B, codec, keep, depth, s);
+    else launch_reduce_c<BZ, AL, false, false>(sc, frames, B, codec, keep, depth, s);
 }
 void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
                    uint32_t depth, hipStream_t s)
 {
     if (depth == 0 || depth > 16) depth = 16;
     const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
-    const int bz = reduce_bz();
-    if (aligned) {
-        if (bz == 8) launch_reduce_a<8, true>(sc, frames, B, level, codec, keep_bitmap, depth, s);
-        else if (bz == 2) launch_reduce_a<2, true>(sc, frames, B, level, codec, keep_bitmap, depth, s);
-        else launch_reduce_a<4, true>(sc, frames, B, level, codec, keep_bitmap, depth, s);
-    } else {
-        launch_reduce_a<4, false>(sc, frames, B, level, codec, keep_bitmap, depth, s);
-    }
+    if (aligned) launch_reduce_a<4, true>(sc, frames, B, level, codec, keep_bitmap, depth, s);
+    else launch_reduce_a<4, false>(sc, frames, B, level, codec, keep_bitmap, depth, s);
 }
 
 // ---- per-frame scans over tiles ---------------------------------------------------------------------------

@@ -184,7 +184,7 @@ def test_writer_constructor_validation(tmp_path):
     with pytest.raises(ValueError, match="Invalid initialization parameters"):
         ReCoDeWriter("x", dark_data=g["dark"], output_directory="", input_params=params())
     with pytest.raises(NotImplementedError):
-        ReCoDeWriter("x", dark_data=g["dark"], output_directory=str(tmp_path), input_params=params(reduction_level=2))
+        ReCoDeWriter("x", dark_data=g["dark"], output_directory=str(tmp_path), input_params=params(reduction_level=4))
     w = ReCoDeWriter("x", dark_data=g["dark"], output_directory=str(tmp_path), input_params=params())
     assert w._header["nx"] == 56 and w._header["is_intermediate"] is True
 

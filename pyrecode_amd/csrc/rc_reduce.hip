@@ -163,8 +163,8 @@ __device__ __forceinline__ void flush_pending(const Pending &p, uint32_t tile, u
 template <bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
 __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], const uint16_t *__restrict__ next, bool have_next,
                                                  const u32x4 (&t)[TMODE == 0 ? R : 1], const u32x4 *__restrict__ tl,
-                                                 const uint16_t *__restrict__ thr, uint64_t lane_px0, uint64_t N, uint32_t f,
-                                                 uint32_t tile, uint64_t ft, uint32_t n_blk, uint8_t *__restrict__ bitmap,
+                                                 const uint16_t *__restrict__ thr, uint64_t lane_px0, uint64_t N, bool full,
+                                                 uint32_t f, uint32_t tile, uint64_t ft, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
                                                  uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ blk_slots,
                                                  uint32_t *__restrict__ blk_size, Lz4Lds *s_lz, uint8_t *s_bm, WaveStage *st,
@@ -188,8 +188,14 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
     // this frame's data has arrived (the subtract above consumed it): start the NEXT frame's loads now, into the other
     // register set, so that they fly during the whole compaction + encoding of this frame ...
     if (have_next) {
+        if (ALIGNED && full) {  // the whole tile lies inside the frame (all tiles but possibly a frame's last): no predication
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(next + lane_px0);
 #pragma unroll
-        for (int r = 0; r < R; ++r) xn[r] = load8<ALIGNED, true>(next, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
+            for (int r = 0; r < R; ++r) xn[r] = __builtin_nontemporal_load(p + r * (GROUP_PX / 8));
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) xn[r] = load8<ALIGNED, true>(next, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
+        }
     }
     pend.valid = true;
     pend.ft = ft;
@@ -220,15 +226,18 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                     while (m) {
                         const uint32_t i = (uint32_t)__builtin_ctz(m);
                         m &= m - 1;
-                        const uint32_t lo = (i & 4u) ? x[r][2] : x[r][0], hi = (i & 4u) ? x[r][3] : x[r][1];
-                        uint32_t d = (i & 2u) ? hi : lo;
+                        // pixel i = halfword i of the lane's 16 bytes: v_perm_b32 picks halfword (i & 3) of a register pair
+                        // (selector bytes 2j, 2j+1, then two constant-zero bytes), one select between the pairs
+                        const uint32_t sel = 0x0c0c0100u + (i & 3u) * 0x0202u;
+                        const uint32_t p01 = __builtin_amdgcn_perm(x[r][1], x[r][0], sel);
+                        const uint32_t p23 = __builtin_amdgcn_perm(x[r][3], x[r][2], sel);
+                        uint32_t d = (i & 4u) ? p23 : p01;
                         if (RAWVAL) {  // level 2 keeps the raw frame value: residual + threshold (TMODE 0 only)
-                            const uint32_t tlo = (i & 4u) ? t[TMODE == 0 ? r : 0][2] : t[TMODE == 0 ? r : 0][0];
-                            const uint32_t thi = (i & 4u) ? t[TMODE == 0 ? r : 0][3] : t[TMODE == 0 ? r : 0][1];
-                            const uint32_t td = (i & 2u) ? thi : tlo;
-                            d = ((d & 0xFFFFu) + (td & 0xFFFFu)) | ((d & 0xFFFF0000u) + (td & 0xFFFF0000u));
+                            const uint32_t q01 = __builtin_amdgcn_perm(t[TMODE == 0 ? r : 0][1], t[TMODE == 0 ? r : 0][0], sel);
+                            const uint32_t q23 = __builtin_amdgcn_perm(t[TMODE == 0 ? r : 0][3], t[TMODE == 0 ? r : 0][2], sel);
+                            d += (i & 4u) ? q23 : q01;
                         }
-                        st->pix[o++] = (uint16_t)((i & 1u) ? (d >> 16) : d);
+                        st->pix[o++] = (uint16_t)d;
                     }
                     wave_total += (tot >> (10 * k)) & 0x3FFu;
                 }
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
     const uint64_t lane_px0 = (uint64_t)tile * TILE_PX + (uint64_t)lane * 8;
     const uint32_t f0 = grp * BZ;
     if (f0 >= B) return;
+    const bool full = (uint64_t)(tile + 1) * TILE_PX <= N;  // wave-uniform
 
     u32x4 xa[R], xb[R];
     {
@@ -331,14 +341,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
         if (f >= B) break;
         bool nxt = z + 1 < BZ && f + 1 < B;
         reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr,
-                                                                             lane_px0, N, f, tile, (uint64_t)f * ntiles + tile, n_blk,
+                                                                             lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
                                                                              blk_size, lz, bm, st, pend);
         if (!nxt) break;
         ++f;
         nxt = z + 2 < BZ && f + 1 < B;
         reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr,
-                                                                             lane_px0, N, f, tile, (uint64_t)f * ntiles + tile, n_blk,
+                                                                             lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
                                                                              blk_size, lz, bm, st, pend);
         if (!nxt) break;

@@ -92,13 +92,14 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
             const uint32_t k = rd * 64 + lane;
             uint32_t size = 0;
             if (k <= nm) {
-                const uint32_t fs = L.fl[k];
-                const uint32_t q = k < nm ? L.ms[k] : n;
+                // three table reads issued together (one LDS round trip); entries behind the tables' ends are never used
+                const uint32_t fs = L.fl[k], msk = L.ms[k], fnext = L.fl[k + 1];
+                const uint32_t q = k < nm ? msk : n;
                 const uint32_t ll = q - fs;
                 size = 1 + lz4_ext(ll) + ll;
                 uint32_t ml4 = 0xFFFFu;  // final sequence: no match
                 if (k < nm) {
-                    ml4 = (uint32_t)L.fl[k + 1] - q - 4u;
+                    ml4 = fnext - q - 4u;
                     size += 2 + lz4_ext(ml4);
                 }
                 seq_fs[rd] = fs; seq_ll[rd] = ll; seq_ml4[rd] = ml4;
@@ -117,7 +118,20 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
             const uint32_t ll = seq_ll[rd], ml4 = seq_ml4[rd], fs = seq_fs[rd];
             L.out[o++] = (uint8_t)((min(ll, 15u) << 4) | (ml4 == 0xFFFFu ? 0u : min(ml4, 15u)));
             if (ll >= 15) o = lz4_emit_len(L.out, o, ll - 15);
-            for (uint32_t i = 0; i < ll; ++i) L.out[o + i] = L.raw[fs + i];
+            // literals: 4 bytes per step from two aligned dwords of the block image (one LDS round trip per step; a
+            // byte-by-byte copy pays one per byte, and the longest literal run of the block sets the trip count)
+            {
+                const uint32_t *raw32 = reinterpret_cast<const uint32_t *>(L.raw);
+                for (uint32_t i = 0; i < ll; i += 4) {
+                    const uint32_t a = (fs + i) >> 2;
+                    const uint32_t v = __builtin_amdgcn_alignbyte(raw32[a + 1], raw32[a], (fs + i) & 3u);  // (a + 1 may be L.out[0..3]: unused bytes)
+                    const uint32_t rem = ll - i;
+                    L.out[o + i] = (uint8_t)v;
+                    if (rem > 1) L.out[o + i + 1] = (uint8_t)(v >> 8);
+                    if (rem > 2) L.out[o + i + 2] = (uint8_t)(v >> 16);
+                    if (rem > 3) L.out[o + i + 3] = (uint8_t)(v >> 24);
+                }
+            }
             o += ll;
             if (ml4 != 0xFFFFu) {
                 L.out[o++] = 1;  // offset 1, little-endian

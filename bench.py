@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--stack", type=int, default=256, help="distinct frames resident per GPU")
     ap.add_argument("--ny", type=int, default=4096)
@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=16)
     ap.add_argument("--scheme", type=int, default=2, help="2 = LZ4 (headline), 0 = reduce-only pieces")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="plain stream order: a batch's reduce kernel waits for the previous batch's records")
     return ap.parse_args()
 
 
@@ -156,9 +157,9 @@ def main():
     md_all2 = [torch.empty((world * B, 3), dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
     stream = torch.cuda.Stream(device=dev)
     cstream = torch.cuda.Stream(device=dev) if use_dist else None
-    produced = [torch.cuda.Event() for _ in range(2)]
     gathered = [None, None]
     ctx.set_stream(stream.cuda_stream)
+    ctx.set_pipelined(not a.no_pipeline)  # batch i+1's reduce kernel may overlap batch i's scans / layout / assembly
 
     nb = S // B
 
@@ -169,9 +170,8 @@ def main():
             stream.wait_event(gathered[k])   # md2[k] is rewritten below: its previous gather (step i-2) must have read it
         ctx.enqueue(stack[lo].data_ptr(), B, lo, out.data_ptr(), out_cap, rec.data_ptr(), md2[k].data_ptr())
         if use_dist:  # the path's one exchange step: every rank learns every frame's sizes
-            produced[k].record(stream)
             with torch.cuda.stream(cstream):
-                cstream.wait_event(produced[k])
+                ctx.wait_results(cstream.cuda_stream)   # the collective's stream waits for this batch's metadata rows
                 dist.all_gather_into_tensor(md_all2[k], md2[k])
                 ev = torch.cuda.Event()
                 ev.record(cstream)

@@ -122,6 +122,16 @@ int rc_reduce_compress_batch_async(rc_ctx *ctx, const uint16_t *frames_dev, uint
                                    uint8_t *out_dev, uint64_t out_cap, uint64_t *rec_offsets_dev, uint32_t *md_dev);
 int rc_ctx_sync(rc_ctx *ctx);
 
+/* Pipelining across batches (off by default).  A batch is two stages: the reduce kernel on the ctx's stream, then scans,
+ * record layout and assembly on an internal stream, over one of two scratch sets.  Off: the ctx's stream waits for the
+ * records before anything enqueued later - plain stream order.  On: it does not, so the next batch's reduce kernel
+ * overlaps this batch's second stage (small latency-bound kernels that leave most of the GPU idle); a consumer of out /
+ * rec_offsets / md orders itself behind the most recent batch with rc_ctx_wait_results(ctx, its_stream) (NULL = the ctx's
+ * stream), or calls rc_ctx_sync.  The caller must not reuse a batch's output buffers before that.
+ * No counterpart in the reference (one frame at a time on one core, recode_writer.py:383-399). */
+int rc_ctx_set_pipelined(rc_ctx *ctx, int on);
+int rc_ctx_wait_results(rc_ctx *ctx, void *hip_stream);
+
 /* Packed binary map (ceil(nx*ny/8) bytes, LSB-first) of frame i of the most recent batch: what the third element
  * of _reduce_compress's return value carries for validation frames (recode_writer.py:386,402-415,557). */
 int rc_get_binary_map(rc_ctx *ctx, uint32_t i, uint8_t *bitmap_out);

@@ -39,6 +39,8 @@ SIGNATURES = {
     "rc_reduce_compress_batch": (C.c_int, [C.c_void_p, _u16p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u64p, _u32p]),
     "rc_reduce_compress_batch_async": (C.c_int, [C.c_void_p, _u16p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u64p, _u32p]),
     "rc_ctx_sync": (C.c_int, [C.c_void_p]),
+    "rc_ctx_set_pipelined": (C.c_int, [C.c_void_p, C.c_int]),
+    "rc_ctx_wait_results": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rc_get_binary_map": (C.c_int, [C.c_void_p, C.c_uint32, _u8p]),
     "rc_ctx_keep_binary_maps": (C.c_int, [C.c_void_p, C.c_int]),
     "rc_ctx_set_l2_statistics": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -178,6 +180,14 @@ class ReduceContext:
 
     def sync(self):
         check(lib().rc_ctx_sync(self._h), "rc_ctx_sync")
+
+    def set_pipelined(self, on=True):
+        """Let the next batch's reduce kernel overlap this batch's scans / layout / assembly (include/recode_hip.h)."""
+        check(lib().rc_ctx_set_pipelined(self._h, 1 if on else 0), "rc_ctx_set_pipelined")
+
+    def wait_results(self, stream_handle=None):
+        """Order `stream_handle` (None: the ctx's stream) behind the most recent batch's records."""
+        check(lib().rc_ctx_wait_results(self._h, C.c_void_p(stream_handle) if stream_handle else None), "rc_ctx_wait_results")
 
     def binary_map(self, i):
         out = np.empty(self.bitmap_bytes, np.uint8)

@@ -76,7 +76,16 @@ struct rc_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint32_t nx = 0, ny = 0, depth = 0, level = 0, op_mode = 0, scheme = 0, clevel = 0, max_batch = 0;
     uint32_t emit = 0;  // 0: mode-0 record pieces, 2: LZ4 frames
-    rc::Scratch sc;
+    // Per-batch scratch exists twice: batch i reduces into sets[i & 1] on `stream`; its scans / layout / assembly (small,
+    // latency-bound kernels that leave most of the GPU idle) run on `pstream` and may overlap the next batch's reduce
+    // kernel (rc_ctx_set_pipelined).  `sc` is the set of the most recent batch (same geometry and threshold in both).
+    rc::Scratch sc, sets[2];
+    int cur = 0;                          // set the NEXT batch uses
+    int last = 0;                         // set of the most recent batch
+    hipStream_t pstream = nullptr;        // carries everything behind the reduce kernel
+    hipEvent_t ev_red[2] = {}, ev_post[2] = {};
+    bool post_pending[2] = {false, false};
+    bool pipelined = false;
     bool thr_set = false;
     bool keep_bitmap = true;  // also store the raw binary maps when a device codec is active (rc_get_binary_map)
     uint32_t last_n = 0;
@@ -137,15 +146,10 @@ RC_EXPORT int rc_scheme_on_device(uint32_t scheme)
 }
 
 // ---- seam 1 --------------------------------------------------------------------------------------------------
-static int ctx_alloc(rc_ctx *c)
+static int alloc_set(rc_ctx *c, rc::Scratch &sc)
 {
     using namespace rc;
-    Scratch &sc = c->sc;
     const uint64_t B = c->max_batch, T = sc.ntiles;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    HIP_TRY(hipMalloc((void **)&sc.thr, sc.N * 2));
     HIP_TRY(hipMalloc((void **)&sc.bitmap, B * sc.nb_stride + 64));  // + slack: wave_copy reads <= 4 B past a tile
     HIP_TRY(hipMalloc((void **)&sc.tile_cnt, B * T * 4));
     HIP_TRY(hipMalloc((void **)&sc.tile_off, B * T * 4));
@@ -154,9 +158,35 @@ static int ctx_alloc(rc_ctx *c)
     HIP_TRY(hipMalloc((void **)&sc.frame_cbytes, B * 4));
     HIP_TRY(hipMalloc((void **)&sc.status, sizeof(BatchStatus)));
     if (c->level != 3) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2 + 64));
+    if (c->emit != 0) {
+        HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * BLK_SLOT + 64));
+        HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
+        HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
+    }
+    HIP_TRY(hipMemset(sc.frame_nnz, 0, B * 4));
+    HIP_TRY(hipMemset(sc.frame_cbytes, 0, B * 4));
+    HIP_TRY(hipMemset(sc.status, 0, sizeof(BatchStatus)));
+    return RC_OK;
+}
+
+static int ctx_alloc(rc_ctx *c)
+{
+    using namespace rc;
+    const uint64_t B = c->max_batch, T = c->sc.ntiles;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipMalloc((void **)&c->sc.thr, c->sc.N * 2));
+    for (Scratch &set : c->sets) {
+        set = c->sc;  // geometry + the shared threshold
+        int r = alloc_set(c, set);
+        if (r != RC_OK) return r;
+    }
+    c->sc = c->sets[0];
     if (c->level == 2) {  // compact-pixel workspace: 12.5 % mean foreground over the batch (RC_ERR_WORKSPACE beyond that)
         L2Work &w = c->l2;
-        w.cap = std::max<uint64_t>(B * sc.N / 8, 1ull << 16);
+        w.cap = std::max<uint64_t>(B * c->sc.N / 8, 1ull << 16);
         if (w.cap > 0xFFFFFFF0ull) w.cap = 0xFFFFFFF0ull;
         w.words_per_frame = T * (TILE_PX / 64);
         HIP_TRY(hipMalloc((void **)&w.pos, w.cap * 4));
@@ -165,11 +195,6 @@ static int ctx_alloc(rc_ctx *c)
         HIP_TRY(hipMalloc((void **)&w.stat, w.cap * 4));
         HIP_TRY(hipMalloc((void **)&w.word_rank, B * w.words_per_frame * 4));
         HIP_TRY(hipMalloc((void **)&w.frame_base, (B + 1) * 8));
-    }
-    if (c->emit != 0) {
-        HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * BLK_SLOT + 64));
-        HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
-        HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
     }
     if (c->emit == RC_SCHEME_ZSTD) {
         std::vector<uint8_t> tab(zstd_tables_bytes());
@@ -180,9 +205,9 @@ static int ctx_alloc(rc_ctx *c)
     HIP_TRY(hipMalloc((void **)&c->d_rec_off, (B + 1) * 8));
     HIP_TRY(hipMalloc((void **)&c->d_md, B * 3 * 4));
     HIP_TRY(hipHostMalloc((void **)&c->h_status, sizeof(BatchStatus), hipHostMallocDefault));
-    HIP_TRY(hipMemset(sc.frame_nnz, 0, B * 4));
-    HIP_TRY(hipMemset(sc.frame_cbytes, 0, B * 4));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : c->ev_red) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : c->ev_post) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return RC_OK;
 }
 
@@ -245,13 +270,23 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
 {
     if (!c) return RC_OK;
     (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->pstream) (void)hipStreamSynchronize(c->pstream);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    rc::Scratch &sc = c->sc;
-    void *bufs[] = {sc.thr, sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
-                    sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.status, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
+    for (rc::Scratch &sc : c->sets) {
+        void *per_set[] = {sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
+                           sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.status};
+        for (void *b : per_set)
+            if (b) (void)hipFree(b);
+    }
+    void *bufs[] = {c->sc.thr, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
                     c->d_md, c->d_ztab, c->l2.pos, c->l2.val, c->l2.parent, c->l2.stat, c->l2.word_rank, c->l2.frame_base};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    hipEvent_t sync_ev[] = {c->ev_red[0], c->ev_red[1], c->ev_post[0], c->ev_post[1]};
+    for (hipEvent_t e : sync_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->pstream) (void)hipStreamDestroy(c->pstream);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -330,25 +365,41 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
         ev = c->prof_ev.data() + c->prof_used;
         c->prof_used += 5;
     }
+    // Two streams, two scratch sets.  The reduce kernel runs on the ctx's stream `s` (behind whatever produced the frames
+    // there); everything after it runs on `pstream`.  Default: `s` then waits for the batch's records, so stream order as
+    // the caller sees it is the plain one.  Pipelined (rc_ctx_set_pipelined): `s` does not wait - the next batch's reduce
+    // kernel overlaps this batch's scans / layout / assembly, and consumers order themselves with rc_ctx_wait_results.
+    const int k = c->cur;
+    c->cur ^= 1;
+    c->last = k;
+    c->sc = c->sets[k];
+    const rc::Scratch &sc = c->sets[k];
+    hipStream_t ps = c->pstream;
+    if (c->post_pending[k]) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));  // the batch two calls ago has left this set
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     // every device codec's block encoder runs inside the reduce kernel (LZ4; blosc = bit-shuffle + LZ4; zstd: the
     // byte-parallel half - literals, sequence tokens - with the serial FSE half lane-per-block behind it)
-    launch_reduce(c->sc, frames_dev, n, c->level, c->emit, c->keep_bitmap || c->emit == 0, c->depth, s);
-    if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
-        launch_scans(c->sc, n, true, false, s);
-        launch_l2(c->sc, c->l2, n, c->nx, c->l2_sum, s);
-    }
+    launch_reduce(sc, frames_dev, n, c->level, c->emit, c->keep_bitmap || c->emit == 0, c->depth, s);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    if (c->emit == RC_SCHEME_ZSTD) launch_zstd_fse(c->sc, n, c->d_ztab, s);
-    if (all_ev) HIP_TRY(hipEventRecord(ev[2], s));
-    launch_scans(c->sc, n, c->level == 1, c->emit != 0, s);  // (level 2: k_l2_emit has already described its value list)
-    if (all_ev) HIP_TRY(hipEventRecord(ev[3], s));
-    launch_layout(c->sc, rp, n, out_cap, rec_off_dev, md_dev, s);
-    launch_assemble(c->sc, rp, n, out_dev, rec_off_dev, s);
-    if (ev) HIP_TRY(hipEventRecord(ev[4], s));
+    HIP_TRY(hipEventRecord(c->ev_red[k], s));
+    HIP_TRY(hipStreamWaitEvent(ps, c->ev_red[k], 0));
+    if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
+        launch_scans(sc, n, true, false, ps);
+        launch_l2(sc, c->l2, n, c->nx, c->l2_sum, ps);
+    }
+    if (c->emit == RC_SCHEME_ZSTD) launch_zstd_fse(sc, n, c->d_ztab, ps);
+    if (all_ev) HIP_TRY(hipEventRecord(ev[2], ps));
+    launch_scans(sc, n, c->level == 1, c->emit != 0, ps);  // (level 2: k_l2_emit has already described its value list)
+    if (all_ev) HIP_TRY(hipEventRecord(ev[3], ps));
+    launch_layout(sc, rp, n, out_cap, rec_off_dev, md_dev, ps);
+    launch_assemble(sc, rp, n, out_dev, rec_off_dev, ps);
+    if (ev) HIP_TRY(hipEventRecord(ev[4], ps));
+    HIP_TRY(hipEventRecord(c->ev_post[k], ps));
+    c->post_pending[k] = true;
+    if (!c->pipelined) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
     HIP_TRY(hipGetLastError());
     c->last_n = n;
     return RC_OK;
@@ -371,11 +422,27 @@ RC_EXPORT int rc_reduce_compress_batch_async(rc_ctx *c, const uint16_t *frames_d
     return enqueue_batch(c, frames_dev, n, first_frame_id, out_dev, out_cap, rec_offsets_dev, md_dev, false);
 }
 
+RC_EXPORT int rc_ctx_set_pipelined(rc_ctx *c, int on)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    c->pipelined = on != 0;
+    return RC_OK;
+}
+RC_EXPORT int rc_ctx_wait_results(rc_ctx *c, void *hip_stream)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->post_pending[c->last])
+        HIP_TRY(hipStreamWaitEvent(hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream, c->ev_post[c->last], 0));
+    return RC_OK;
+}
+
 RC_EXPORT int rc_ctx_sync(rc_ctx *c)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(c->h_status, c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->pstream));
+    HIP_TRY(hipStreamSynchronize(c->pstream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t b = 0; b + 5 <= c->prof_used; b += 5) {  // fold the finished batches' stage events into the sums
         float ms;

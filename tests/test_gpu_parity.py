@@ -412,3 +412,39 @@ def test_l2_workspace_overflow_is_reported(hip):
     out, rec, md = ctx.reduce_compress_batch(frames[:1] * 0, 0)   # the ctx stays usable
     assert md[0, 0] == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("scheme,level", [(2, 1), (1, 1), (8, 2), (0, 1)])
+def test_async_batches_plain_and_pipelined(hip, orc, scheme, level):
+    """Device-resident asynchronous path: several batches enqueued back to back, each into its own output buffers, in
+    plain stream order and in pipelined mode (the next batch's reduce kernel overlaps the previous batch's second
+    stage, two scratch sets): both must give the records of the synchronous call, bit for bit."""
+    import torch
+    ny, nx, d, nb, B = 256, 320, 12, 5, 3
+    dark, frames = synth_frames(77, nb * B, ny, nx, 0.03, d)
+    thr = orc.threshold(dark, 0)
+    ctx = hip.ReduceContext(nx, ny, d, level, 1, scheme, 1, 0, max_batch=B)
+    ctx.set_threshold(thr)
+    expect = []
+    for b in range(nb):
+        out, rec, md = ctx.reduce_compress_batch(frames[b * B:(b + 1) * B], first_frame_id=b * B)
+        expect.append((out[:int(rec[-1])].copy(), rec.copy(), md.copy()))
+    dev = torch.device("cuda", 0)
+    fr_d = torch.from_numpy(frames.view(np.int16)).to(dev)
+    cap = B * ny * nx * 2
+    for pipelined in (False, True):
+        ctx.set_pipelined(pipelined)
+        outs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(nb)]
+        recs = [torch.zeros(B + 1, dtype=torch.int64, device=dev) for _ in range(nb)]
+        mds = [torch.zeros((B, 3), dtype=torch.int32, device=dev) for _ in range(nb)]
+        torch.cuda.synchronize()
+        for b in range(nb):
+            ctx.enqueue(fr_d[b * B].data_ptr(), B, b * B, outs[b].data_ptr(), cap, recs[b].data_ptr(), mds[b].data_ptr())
+        ctx.sync()
+        for b in range(nb):
+            e_out, e_rec, e_md = expect[b]
+            assert np.array_equal(recs[b].cpu().numpy().astype(np.uint64), e_rec.astype(np.uint64))
+            assert np.array_equal(mds[b].cpu().numpy().view(np.uint32), e_md)
+            assert np.array_equal(outs[b][:len(e_out)].cpu().numpy(), e_out), "batch %d pipelined=%s" % (b, pipelined)
+    ctx.set_pipelined(False)
+    ctx.close()

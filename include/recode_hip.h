@@ -116,8 +116,9 @@ int rc_reduce_compress_batch(rc_ctx *ctx, const uint16_t *frames, uint32_t n, ui
                              uint8_t *out, uint64_t out_cap, uint64_t *rec_offsets, uint32_t *md);
 
 /* Asynchronous form for device-resident pipelines: every pointer must be device memory; work is enqueued on the
- * ctx's stream and nothing is read back.  rc_ctx_sync waits for the stream and returns the status the device
- * recorded for the most recent batch (RC_OK, RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL). */
+ * ctx's stream and nothing is read back.  rc_ctx_sync waits for all enqueued batches and returns RC_OK, or the status
+ * of the FIRST batch that failed since the previous sync (RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL,
+ * RC_ERR_WORKSPACE; rc_last_error names the batch and frame); later batches are unaffected by an earlier failure. */
 int rc_reduce_compress_batch_async(rc_ctx *ctx, const uint16_t *frames_dev, uint32_t n, uint32_t first_frame_id,
                                    uint8_t *out_dev, uint64_t out_cap, uint64_t *rec_offsets_dev, uint32_t *md_dev);
 int rc_ctx_sync(rc_ctx *ctx);

@@ -98,7 +98,9 @@ struct rc_ctx {
     void *d_ztab = nullptr;               // zstd FSE tables (emit == 1)
     rc::L2Work l2;                        // level 2 workspace
     uint32_t l2_sum = 0;                  // L2_statistics: 0/1 max, 2 sum
-    rc::BatchStatus *h_status = nullptr;  // pinned
+    rc::BatchStatus *h_status = nullptr;  // pinned: [0] most recent batch, [1] first failed batch since the last sync
+    rc::BatchStatus *d_first_err = nullptr;
+    uint32_t batch_seq = 0;               // batches enqueued since the last rc_ctx_sync
     hipEvent_t ev[5] = {};
     float stage_ms[5] = {};
     // optional per-enqueue stage events for the asynchronous path (rc_ctx_set_profiling)
@@ -178,6 +180,9 @@ static int ctx_alloc(rc_ctx *c)
     HIP_TRY(hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipMalloc((void **)&c->sc.thr, c->sc.N * 2));
+    HIP_TRY(hipMalloc((void **)&c->d_first_err, sizeof(BatchStatus)));
+    HIP_TRY(hipMemset(c->d_first_err, 0, sizeof(BatchStatus)));
+    c->sc.first_err = c->d_first_err;
     for (Scratch &set : c->sets) {
         set = c->sc;  // geometry + the shared threshold
         int r = alloc_set(c, set);
@@ -204,7 +209,7 @@ static int ctx_alloc(rc_ctx *c)
     }
     HIP_TRY(hipMalloc((void **)&c->d_rec_off, (B + 1) * 8));
     HIP_TRY(hipMalloc((void **)&c->d_md, B * 3 * 4));
-    HIP_TRY(hipHostMalloc((void **)&c->h_status, sizeof(BatchStatus), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->h_status, 2 * sizeof(BatchStatus), hipHostMallocDefault));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev_red) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->ev_post) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -279,7 +284,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
         for (void *b : per_set)
             if (b) (void)hipFree(b);
     }
-    void *bufs[] = {c->sc.thr, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
+    void *bufs[] = {c->sc.thr, c->d_first_err, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
                     c->d_md, c->d_ztab, c->l2.pos, c->l2.val, c->l2.parent, c->l2.stat, c->l2.word_rank, c->l2.frame_base};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -395,7 +400,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     launch_scans(sc, n, c->level == 1, c->emit != 0, ps);  // (level 2: k_l2_emit has already described its value list)
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], ps));
     launch_layout(sc, rp, n, out_cap, rec_off_dev, md_dev, ps);
-    launch_assemble(sc, rp, n, out_dev, rec_off_dev, ps);
+    launch_assemble(sc, rp, n, out_dev, rec_off_dev, c->batch_seq++, ps);
     if (ev) HIP_TRY(hipEventRecord(ev[4], ps));
     HIP_TRY(hipEventRecord(c->ev_post[k], ps));
     c->post_pending[k] = true;
@@ -441,9 +446,13 @@ RC_EXPORT int rc_ctx_sync(rc_ctx *c)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(c->h_status, c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->pstream));
+    HIP_TRY(hipMemcpyAsync(&c->h_status[0], c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->pstream));
+    HIP_TRY(hipMemcpyAsync(&c->h_status[1], c->d_first_err, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->pstream));
+    HIP_TRY(hipMemsetAsync(c->d_first_err, 0, sizeof(rc::BatchStatus), c->pstream));
     HIP_TRY(hipStreamSynchronize(c->pstream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t n_batches = c->batch_seq;
+    c->batch_seq = 0;
     for (size_t b = 0; b + 5 <= c->prof_used; b += 5) {  // fold the finished batches' stage events into the sums
         float ms;
         if (!c->profile_all) {
@@ -455,10 +464,14 @@ RC_EXPORT int rc_ctx_sync(rc_ctx *c)
         ++c->prof_batches;
     }
     c->prof_used = 0;
-    if (c->h_status->code != 0) {
-        char msg[96];
-        snprintf(msg, sizeof msg, "%s (frame %u of the batch)", rc_strerror(c->h_status->code), c->h_status->frame);
-        return fail(c->h_status->code, msg);
+    if (c->h_status[1].code != 0) {  // the first batch that failed since the last sync (not only the most recent one)
+        char msg[160];
+        if (n_batches > 1)
+            snprintf(msg, sizeof msg, "%s (frame %u of batch %llu of the %u enqueued since the last sync)", rc_strerror(c->h_status[1].code),
+                     c->h_status[1].frame, (unsigned long long)c->h_status[1].total, n_batches);
+        else
+            snprintf(msg, sizeof msg, "%s (frame %u of the batch)", rc_strerror(c->h_status[1].code), c->h_status[1].frame);
+        return fail(c->h_status[1].code, msg);
     }
     return RC_OK;
 }

@@ -25,7 +25,9 @@ struct Scratch {
     uint32_t *blk_off = nullptr;       // [B][ntiles]               exclusive prefix of blk_size inside the frame
     uint32_t *frame_nnz = nullptr;     // [B]
     uint32_t *frame_cbytes = nullptr;  // [B]                       sum of blk_size
-    BatchStatus *status = nullptr;     // [1]
+    BatchStatus *status = nullptr;     // [1] of this batch
+    BatchStatus *first_err = nullptr;  // [1] shared by both scratch sets: first failed batch since the last rc_ctx_sync
+                                       //     (code, frame, total = number of the batch among those enqueued since then)
 };
 
 // workspace of reduction level 2 (connected-component statistics), indexed by the batch-global compact pixel index
@@ -60,7 +62,7 @@ void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blo
 void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
                    uint32_t *md, hipStream_t s);
 void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off,
-                     hipStream_t s);
+                     uint32_t batch_seq, hipStream_t s);
 // rc_lz4.hip
 struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
 void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s);  // sc.bitmap = the buffer, sc.nb = its length

@@ -692,9 +692,18 @@ constexpr uint32_t ASM_TPW = 4 * ASM_PASSES;  // tiles per wavefront
 // Value lists that are still uint16 and need packing (level-2 statistics with d < 16) take the byte-granular path at the end.
 __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, uint32_t B, uint8_t *__restrict__ out,
                                                    const uint64_t *__restrict__ rec_off, uint32_t lz4f_hdr_bitmap,
-                                                   uint32_t lz4f_hdr_pix)
+                                                   uint32_t lz4f_hdr_pix, uint32_t batch_seq)
 {
-    if (sc.status->code != 0) return;
+    if (sc.status->code != 0) {
+        // last kernel of the batch: remember the first failure across asynchronously enqueued batches (one writer per
+        // batch, batches are ordered on their stream)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && sc.first_err && sc.first_err->code == 0) {
+            sc.first_err->frame = sc.status->frame;
+            sc.first_err->total = batch_seq;
+            sc.first_err->code = sc.status->code;
+        }
+        return;
+    }
     const uint32_t f = blockIdx.y;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t t0 = (blockIdx.x * WAVES + w) * ASM_TPW;
@@ -978,13 +987,13 @@ uint32_t lz4f_descriptor(uint8_t bd)
 }
 
 void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off,
-                     hipStream_t s)
+                     uint32_t batch_seq, hipStream_t s)
 {
     static const uint32_t hdr_bitmap = lz4f_descriptor(0x40);  // 64 KiB max block (blocks are <= 2 KiB)
     static const uint32_t hdr_pix = lz4f_descriptor(0x70);     // 4 MiB max block (stored chunks)
     const uint32_t per_wg = WAVES * ASM_TPW;
     const dim3 grid((sc.ntiles + per_wg - 1) / per_wg, B), block(WG);
-    hipLaunchKernelGGL(k_assemble, grid, block, 0, s, sc, rp, B, out, rec_off, hdr_bitmap, hdr_pix);
+    hipLaunchKernelGGL(k_assemble, grid, block, 0, s, sc, rp, B, out, rec_off, hdr_bitmap, hdr_pix, batch_seq);
 }
 
 }  // namespace rc

@@ -448,3 +448,29 @@ def test_async_batches_plain_and_pipelined(hip, orc, scheme, level):
             assert np.array_equal(outs[b][:len(e_out)].cpu().numpy(), e_out), "batch %d pipelined=%s" % (b, pipelined)
     ctx.set_pipelined(False)
     ctx.close()
+
+
+def test_async_error_is_not_lost_behind_later_batches(hip, orc):
+    """rc_ctx_sync reports the first failed batch since the previous sync, even when good batches followed it."""
+    import torch
+    ny, nx, B = 128, 256, 2
+    dark, frames = synth_frames(5, 3 * B, ny, nx, 0.05, 16)
+    ctx = hip.ReduceContext(nx, ny, 16, 1, 1, 2, 1, 0, max_batch=B)
+    ctx.set_threshold(orc.threshold(dark, 0))
+    dev = torch.device("cuda", 0)
+    fr_d = torch.from_numpy(frames.view(np.int16)).to(dev)
+    cap = B * ny * nx * 2
+    out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    rec = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    md = torch.zeros((B, 3), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for pipelined in (False, True):
+        ctx.set_pipelined(pipelined)
+        ctx.enqueue(fr_d[0].data_ptr(), B, 0, out.data_ptr(), cap, rec.data_ptr(), md.data_ptr())
+        ctx.enqueue(fr_d[B].data_ptr(), B, B, out.data_ptr(), 64, rec.data_ptr(), md.data_ptr())        # capacity far too small
+        ctx.enqueue(fr_d[2 * B].data_ptr(), B, 2 * B, out.data_ptr(), cap, rec.data_ptr(), md.data_ptr())
+        with pytest.raises(ValueError, match="batch 1 of the 3"):
+            ctx.sync()
+        ctx.sync()   # the error has been consumed; the last batch's records are intact
+        assert int(rec.cpu()[0]) == 0 and int(rec.cpu()[-1]) > 0
+    ctx.close()

@@ -1,0 +1,47 @@
+"""The driver's contract for bench.py (one JSON line, the keys it reads), exercised at a few steps so that a change to the
+library cannot silently break the round-end run.  Also through torch.distributed.run with one rank (RCCL path)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _run(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_bench_contract(launcher):
+    args = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--stack", "64", "--no-cpu-baseline"]
+    if launcher == "plain":
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29533"] + args
+    d = _run(cmd)
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["unit"] == "frames/s" and d["dtype"] == "u16"
+    assert d["value"] > 1000 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "workload" in d["config"] and "4096x4096" in d["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_cpu_baseline_leg():
+    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--stack", "64"])
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]

@@ -388,9 +388,10 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);
-    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    HIP_TRY(hipEventRecord(c->ev_red[k], s));
-    HIP_TRY(hipStreamWaitEvent(ps, c->ev_red[k], 0));
+    // (one event behind the reduce kernel: every packet on this stream is a few microseconds between two reduce kernels)
+    hipEvent_t red = ev ? ev[1] : c->ev_red[k];
+    HIP_TRY(hipEventRecord(red, s));
+    HIP_TRY(hipStreamWaitEvent(ps, red, 0));
     if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
         launch_scans(sc, n, true, false, ps);
         launch_l2(sc, c->l2, n, c->nx, c->l2_sum, ps);

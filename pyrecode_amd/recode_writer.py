@@ -19,6 +19,7 @@ import numpy as np
 
 from . import _lib
 from . import recode_compressors as compressors
+from .em_reader import emfile
 from .misc import rc_cfg as rc
 from .params import InitParams, InputParams
 from .recode_header import ReCoDeHeader
@@ -78,9 +79,9 @@ class ReCoDeWriter:
                 t = _read_binary_frames(self._init_params.calibration_filename, self._header['ny'], self._header['nx'],
                                         ip.source_numpy_dtype)
                 t = np.squeeze(t[0]) if t.ndim > 2 else t
-            elif ip.calibration_file_type in (rc.FILE_TYPE_MRC, rc.FILE_TYPE_SEQ):
-                raise NotImplementedError('MRC / SEQ calibration files need the reference em_reader (out of scope); '
-                                          'pass dark_data')
+            elif ip.calibration_file_type in (rc.FILE_TYPE_MRC, rc.FILE_TYPE_SEQ):   # reference :109-113
+                with emfile(self._init_params.calibration_filename, ip.calibration_file_type) as _t:
+                    t = np.array(np.squeeze(_t[0]) if len(_t.shape) > 2 else _t[0])
             else:
                 raise NotImplementedError("No implementation available for loading calibration file of type 'Other'")
         else:
@@ -170,8 +171,13 @@ class ReCoDeWriter:
             if ip.source_file_type == rc.FILE_TYPE_BINARY:
                 self._source = None
                 self._source_shape = (self._header['nz'], self._header['ny'], self._header['nx'])
-            elif ip.source_file_type in (rc.FILE_TYPE_MRC, rc.FILE_TYPE_SEQ):
-                raise NotImplementedError('MRC / SEQ sources need the reference em_reader (out of scope); pass data')
+            elif ip.source_file_type in (rc.FILE_TYPE_MRC, rc.FILE_TYPE_SEQ):   # reference :250-267
+                with emfile(self._init_params.image_filename, ip.source_file_type) as src:
+                    self._source = None
+                    self._source_shape = tuple(int(v) for v in src.shape)
+                    if is_first_chunk:  # the 1024 bytes announced by source_header_length
+                        src.serialize_header(self._intermediate_file)
+                        self._intermediate_file.flush()
             else:
                 raise NotImplementedError("No implementation available for loading calibration file of type 'Other'")
         else:
@@ -206,7 +212,20 @@ class ReCoDeWriter:
         available_frames = min(n_frames_per_thread, max(n_frames_in_chunk - frame_offset, 0))
 
         stt = datetime.now()
-        if data is None:
+        if data is None and ip.source_file_type in (rc.FILE_TYPE_MRC, rc.FILE_TYPE_SEQ):   # reference :329-348
+            with emfile(init.image_filename, ip.source_file_type) as f:
+                try:  # the header's frame count may overstate what the file holds
+                    data = np.array(f[frame_offset:frame_offset + available_frames])
+                except IndexError:
+                    frame_list = []
+                    while len(frame_list) < available_frames:
+                        try:
+                            frame_list.append(np.squeeze(f[frame_offset + len(frame_list)]))
+                        except IndexError:
+                            break
+                    data = np.asarray(frame_list).reshape((-1, self._header['ny'], self._header['nx']))
+                    available_frames = data.shape[0]
+        elif data is None:
             stack = _read_binary_frames(init.image_filename, self._header['ny'], self._header['nx'], self._src_dtype)
             data = stack[frame_offset:frame_offset + available_frames]
             available_frames = data.shape[0]

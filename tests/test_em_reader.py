@@ -1,0 +1,122 @@
+"""pyrecode_amd.em_reader: MRC2014 and Norpix SEQ stacks read from their published layouts.  The files are
+produced here by an independent packer (struct.pack over the documented field offsets), not by the reader's own code.
+mrcfile / pims, which the reference wraps, are absent from the image: parity for these two formats is unpinned."""
+import struct
+
+import numpy as np
+import pytest
+
+from pyrecode_amd.em_reader import MRCReader, SEQReader, emfile
+from pyrecode_amd.misc import rc_cfg as rc
+
+
+def write_mrc(path, stack, mode, big_endian=False, nsymbt=0, nz_header=None):
+    bo = ">" if big_endian else "<"
+    nz, ny, nx = stack.shape
+    words = [0] * 256
+    words[0:4] = [nx, ny, nz if nz_header is None else nz_header, mode]
+    words[7:10] = [nx, ny, nz]
+    words[16:19] = [1, 2, 3]
+    words[23] = nsymbt
+    hdr = bytearray(struct.pack(bo + "256i", *words))
+    hdr[208:212] = b"MAP "
+    hdr[212:216] = bytes([0x11, 0x11, 0, 0]) if big_endian else bytes([0x44, 0x44, 0, 0])
+    with open(path, "wb") as fp:
+        fp.write(hdr)
+        fp.write(bytes(nsymbt))
+        fp.write(stack.astype(stack.dtype.newbyteorder(bo)).tobytes())
+    return bytes(hdr)
+
+
+def write_seq(path, stack, version=5, pad=0):
+    nz, ny, nx = stack.shape
+    item = stack.dtype.itemsize
+    image_bytes = nx * ny * item
+    true_size = image_bytes + 8 + pad
+    hdr = bytearray(1024)
+    hdr[0:4] = struct.pack("<I", 0xFEED)
+    hdr[4:24] = "Norpix seq".encode("utf-16-le")
+    hdr[28:36] = struct.pack("<ii", version, 1024)
+    hdr[548:572] = struct.pack("<6I", nx, ny, 8 * item, 8 * item, image_bytes, 100)
+    hdr[572:584] = struct.pack("<3I", nz, 0, true_size)
+    hdr[584:592] = struct.pack("<d", 400.0)
+    first = 8192 if version >= 5 else 1024
+    with open(path, "wb") as fp:
+        fp.write(hdr)
+        fp.write(bytes(first - 1024))
+        for z in range(nz):
+            fp.write(stack[z].tobytes())
+            fp.write(struct.pack("<IHH", 1700000000 + z, z, 0))
+            fp.write(bytes(pad))
+
+
+@pytest.mark.parametrize("mode,dtype", [(6, np.uint16), (1, np.int16), (0, np.int8), (2, np.float32)])
+@pytest.mark.parametrize("big_endian,nsymbt", [(False, 0), (True, 0), (False, 160)])
+def test_mrc_reader(tmp_path, mode, dtype, big_endian, nsymbt):
+    rng = np.random.default_rng(mode)
+    stack = rng.integers(0, 100, (5, 12, 20)).astype(dtype)
+    p = str(tmp_path / "s.mrc")
+    hdr = write_mrc(p, stack, mode, big_endian, nsymbt)
+    with emfile(p, rc.FILE_TYPE_MRC) as r:
+        assert r.shape == (5, 12, 20) and r.get_true_shape() == (5, 12, 20) and r.dtype.newbyteorder("=") == np.dtype(dtype)
+        assert r.header["mode"] == mode and r.header["nsymbt"] == nsymbt and r.header["map"] == b"MAP "
+        assert np.array_equal(r[3], stack[3:4]) and r[3].shape == (1, 12, 20)
+        assert np.array_equal(r[1:4], stack[1:4])
+        assert np.array_equal(r[0:5, 2:7, 3:9], stack[0:5, 2:7, 3:9])
+        assert np.array_equal(np.concatenate(list(r)), stack)
+        import io
+        b = io.BytesIO()
+        r.serialize_header(b)
+        assert b.getvalue() == hdr
+        with pytest.raises(IndexError):
+            r[5]
+        with pytest.raises(IndexError):
+            r[3:9]
+
+
+def test_mrc_header_overstates_frames(tmp_path):
+    """nz in the header larger than the data present: slicing past the data raises IndexError (what the writer's
+    frame-by-frame fallback relies on, reference recode_writer.py:333-348), single frames still load."""
+    stack = np.arange(3 * 4 * 6, dtype=np.uint16).reshape(3, 4, 6)
+    p = str(tmp_path / "t.mrc")
+    write_mrc(p, stack, 6, nz_header=10)
+    r = MRCReader(p)
+    assert r.shape == (10, 4, 6) and r.get_true_shape() == (3, 4, 6)
+    with pytest.raises(IndexError):
+        r[0:10]
+    assert np.array_equal(r[2][0], stack[2])
+    r.close()
+
+
+@pytest.mark.parametrize("dtype,version,pad", [(np.uint8, 5, 0), (np.int16, 5, 24), (np.int16, 3, 0)])
+def test_seq_reader(tmp_path, dtype, version, pad):
+    rng = np.random.default_rng(3)
+    stack = rng.integers(0, 120, (4, 10, 14)).astype(dtype)
+    p = str(tmp_path / "s.seq")
+    write_seq(p, stack, version, pad)
+    with emfile(p, rc.FILE_TYPE_SEQ) as r:
+        assert r.shape == (4, 10, 14) and r.dtype == np.dtype(dtype)
+        assert r.header["width"] == 14 and r.header["height"] == 10 and r.header["allocated_frames"] == 4
+        assert r.header["name"] == "Norpix seq" and r.header["suggested_frame_rate"] == 400.0
+        assert np.array_equal(r[2], stack[2:3])
+        assert np.array_equal(r[1:4], stack[1:4])
+        assert np.array_equal(r[0:4, 1:5, 2:9], stack[0:4, 1:5, 2:9])
+        import io
+        b = io.BytesIO()
+        r.serialize_header(b)
+        assert b.getvalue() == bytes(1024)
+        with pytest.raises(IndexError):
+            r[4]
+
+
+def test_emfile_rejects_other_types(tmp_path):
+    with pytest.raises(NotImplementedError):
+        emfile("x", rc.FILE_TYPE_BINARY)
+    with pytest.raises(ValueError):
+        emfile("x", 99)
+    with pytest.raises(NotImplementedError):
+        emfile("x", rc.FILE_TYPE_MRC, mode="w")
+    bad = tmp_path / "bad.seq"
+    bad.write_bytes(bytes(2048))
+    with pytest.raises(ValueError):
+        SEQReader(str(bad))

@@ -319,3 +319,59 @@ def test_l2_write_read_round_trip(tmp_path):
         assert np.array_equal(f["summary_stats"], want)   # 12-bit fields: bits above the depth are dropped by the packer
         assert f["metadata"]["bytes_in_packed_summary_stats"] == (n * 12 + 7) // 8
     rd.close()
+
+
+@pytest.mark.parametrize("kind", ["mrc", "seq", "mrc_short"])
+def test_writer_file_mode_mrc_and_seq_sources(kind, tmp_path):
+    """ReCoDeWriter(image_filename=<stack file>, dark_filename=<MRC file>).run() with no in-memory data
+    (reference recode_writer.py:249-267, 327-348): frames and calibration frame come from pyrecode_amd.em_reader, the part
+    files carry the 1024-byte source header that source_header_length announces, and the merged file decodes to the
+    residual images.  "mrc_short": header and params claim 10 frames, the file holds 7 - the frame-by-frame
+    fallback of the reference (:333-348) must load what is there."""
+    from test_em_reader import write_mrc, write_seq
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    from pyrecode_amd.misc import rc_cfg as rc
+    ny, nx, nz, nodes, depth = 96, 160, 7, 2, 12
+    dark, frames = synth_frames(5, nz, ny, nx, 0.03, depth)
+    dark_path = str(tmp_path / "dark.mrc")
+    write_mrc(dark_path, dark[None], 6)
+    if kind.startswith("mrc"):
+        src = str(tmp_path / "stack.mrc")
+        src_hdr = write_mrc(src, frames, 6, nz_header=10 if kind == "mrc_short" else None)
+        ftype = rc.FILE_TYPE_MRC
+    else:
+        src = str(tmp_path / "stack.seq")
+        write_seq(src, frames.astype(np.int16), version=5)   # 16-bit sequences are int16 (values < 2^15 here)
+        src_hdr = bytes(1024)
+        ftype = rc.FILE_TYPE_SEQ
+    g = load_npz("g3_l1z12.npz")
+    over = dict(num_rows=ny, num_cols=nx, num_frames=10 if kind == "mrc_short" else nz, num_threads=nodes, compression_scheme=2, source_file_type=ftype,
+                calibration_file_type=rc.FILE_TYPE_MRC, source_bit_depth=depth, target_bit_depth=depth)
+    for node in range(nodes):
+        ip, cfg = _params(tmp_path, g, **over)
+        with pytest.warns(UserWarning) if kind == "seq" else _no_warning():
+            w = ReCoDeWriter(src, dark_filename=dark_path, output_directory=str(tmp_path), input_params=ip, mode="batch",
+                             node_id=node, batch_size=3)
+            w.start()
+            m = w.run()
+            w.close()
+        assert m["run_frames"] == ((5, 2) if kind == "mrc_short" else (4, 3))[node]
+    part0 = (tmp_path / "stack.rc1_part000").read_bytes()
+    assert part0[512:1536] == src_hdr
+    merge_parts(str(tmp_path), "stack.rc1", nodes)
+    want = np.where(frames > dark, frames - dark, 0).astype(np.uint16)
+    rd = ReCoDeReader(str(tmp_path / "stack.rc1"), is_intermediate=False)
+    rd.open(print_header=False)
+    assert rd.get_shape() == (nz, ny, nx) and rd.get_source_header() == src_hdr
+    for z in range(nz):
+        assert np.array_equal(np.asarray(rd.get_frame(z)[z]["data"].todense()), want[z])
+    rd.close()
+
+
+class _no_warning:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

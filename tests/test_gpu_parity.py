@@ -474,3 +474,60 @@ def test_async_error_is_not_lost_behind_later_batches(hip, orc):
         ctx.sync()   # the error has been consumed; the last batch's records are intact
         assert int(rec.cpu()[0]) == 0 and int(rec.cpu()[-1]) > 0
     ctx.close()
+
+
+def test_random_shapes_depths_schemes_fuzz(hip, orc):
+    """Seeded fuzz over tiny and odd geometries (1x1 upwards, pixel counts around multiples of 8 / 512 / 4096), every
+    packing depth 9..16, reduce-only and the three device codecs, levels 1 and 3, random densities including 0 and
+    near 1: every record is compared with the oracle (bit-exact pieces, compressed streams through the stock decoders)."""
+    rng = np.random.default_rng(20261003)
+    shapes = [(1, 1), (1, 7), (1, 8), (3, 3), (8, 1), (1, 9), (2, 255), (1, 511), (1, 512), (1, 513), (7, 585), (64, 64), (63, 65),
+              (1, 4095), (1, 4096), (1, 4097), (5, 1639), (90, 91)]
+    cases = 0
+    for ny, nx in shapes:
+        for _ in range(3):
+            d = int(rng.integers(9, 17))
+            scheme = int(rng.choice([0, 1, 2, 8]))
+            level = int(rng.choice([1, 1, 3]))
+            dens = float(rng.choice([0.0, 0.002, 0.05, 0.4, 0.97]))
+            nz = int(rng.integers(1, 4))
+            dark = rng.integers(50, 200, (ny, nx)).astype(np.uint16)
+            amp = rng.integers(1, 1 << min(d, 15), (nz, ny, nx)).astype(np.uint16)
+            frames = np.where(rng.random((nz, ny, nx)) < dens, dark + amp, (dark * rng.random((nz, ny, nx))).astype(np.uint16)).astype(np.uint16)
+            mode = 0 if scheme == 0 else 1
+            ctx = hip.ReduceContext(nx, ny, d, level, mode, scheme, 1, 0, max_batch=nz)
+            ctx.set_threshold(dark)
+            try:
+                out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=7)
+            except ValueError as e:   # record larger than the raw frame: the reference raises the same (recode_writer.py:565-566)
+                assert "Buffer size smaller" in str(e)
+                ctx.close()
+                continue
+            for z in range(nz):
+                r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+                binary, pix = orc.binarize_l1(frames[z], dark)
+                bitmap = orc.pack_binary_frame(binary).tobytes()
+                packed = orc.bit_pack(pix, d).tobytes() if level == 1 else b""
+                tag = "shape %dx%d d %d scheme %d level %d dens %g frame %d" % (ny, nx, d, scheme, level, dens, z)
+                if mode == 0:
+                    want = (struct.pack("<II", 7 + z, len(packed)) + bitmap + packed) if level == 1 else struct.pack("<I", 7 + z) + bitmap
+                    assert r == want, tag
+                    continue
+                if level == 1:
+                    fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+                    assert (fid, npk) == (7 + z, len(packed)) and len(r) == 16 + cb + cp, tag
+                    streams = [(r[16:16 + cb], bitmap), (r[16 + cb:], packed)]
+                else:
+                    fid, cb = struct.unpack_from("<II", r, 0)
+                    assert fid == 7 + z and len(r) == 8 + cb, tag
+                    streams = [(r[8:], bitmap)]
+                for stream, expect in streams:
+                    if scheme == 2:
+                        _check_lz4(orc, stream, expect)
+                    elif scheme == 1:
+                        assert _zstd_system_decode(stream) == expect, tag
+                    else:
+                        assert orc.blosc1_decode(stream) == expect, tag
+            ctx.close()
+            cases += 1
+    assert cases >= 30   # (the rest: records larger than their tiny raw frames, refused like the reference does)

@@ -82,7 +82,8 @@ struct rc_ctx {
     rc::Scratch sc, sets[2];
     int cur = 0;                          // set the NEXT batch uses
     int last = 0;                         // set of the most recent batch
-    hipStream_t pstream = nullptr;        // carries everything behind the reduce kernel
+    hipStream_t pstream = nullptr;        // carries everything behind the reduce kernel: one of the two below
+    hipStream_t pstream_all = nullptr, pstream_masked = nullptr;
     hipEvent_t ev_red[2] = {}, ev_post[2] = {};
     bool post_pending[2] = {false, false};
     bool pipelined = false;
@@ -177,7 +178,27 @@ static int ctx_alloc(rc_ctx *c)
     const uint64_t B = c->max_batch, T = c->sc.ntiles;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->pstream_all, hipStreamNonBlocking));
+    {
+        // Experiment knob, off by default.  In pipelined mode the second stage runs next to the following batch's reduce
+        // kernel; its waves (80 VGPRs, latency bound) settle on every SIMD and push out one of the three reduce waves
+        // there (168 VGPRs each).  RC_PSTREAM_CUS=n confines the second stage to the first n CU-mask bits.  Measured on
+        // bench.py, same box: LZ4 123.7 k frames/s unmasked, 126.2 k with n = 104 (96: 125.6-127.6 k, 128: 128.5 k on a
+        // faster box, 64: no gain, spread-out masks: worse) - but zstd, whose second stage also carries the FSE kernel,
+        // drops from 112 k to 103 k: the confined stage becomes the longer one.  +2 % on one codec does not pay for that.
+        const char *e = getenv("RC_PSTREAM_CUS");
+        const int ncu = e ? atoi(e) : 0;
+        c->pstream_masked = nullptr;
+        if (ncu > 0 && ncu < 256) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&c->pstream_masked, 8, mask) != hipSuccess) {
+                (void)hipGetLastError();
+                c->pstream_masked = nullptr;  // not available: pipelined mode uses the unmasked stream
+            }
+        }
+    }
+    c->pstream = c->pstream_all;
     c->stream = c->own_stream;
     HIP_TRY(hipMalloc((void **)&c->sc.thr, c->sc.N * 2));
     HIP_TRY(hipMalloc((void **)&c->d_first_err, sizeof(BatchStatus)));
@@ -276,7 +297,8 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (!c) return RC_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->pstream) (void)hipStreamSynchronize(c->pstream);
+    if (c->pstream_all) (void)hipStreamSynchronize(c->pstream_all);
+    if (c->pstream_masked) (void)hipStreamSynchronize(c->pstream_masked);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (rc::Scratch &sc : c->sets) {
         void *per_set[] = {sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
@@ -291,7 +313,8 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     hipEvent_t sync_ev[] = {c->ev_red[0], c->ev_red[1], c->ev_post[0], c->ev_post[1]};
     for (hipEvent_t e : sync_ev)
         if (e) (void)hipEventDestroy(e);
-    if (c->pstream) (void)hipStreamDestroy(c->pstream);
+    if (c->pstream_all) (void)hipStreamDestroy(c->pstream_all);
+    if (c->pstream_masked) (void)hipStreamDestroy(c->pstream_masked);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -431,7 +454,10 @@ RC_EXPORT int rc_reduce_compress_batch_async(rc_ctx *c, const uint16_t *frames_d
 RC_EXPORT int rc_ctx_set_pipelined(rc_ctx *c, int on)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->pstream));  // the second stage changes streams: drain the old one first
     c->pipelined = on != 0;
+    c->pstream = (c->pipelined && c->pstream_masked) ? c->pstream_masked : c->pstream_all;
     return RC_OK;
 }
 RC_EXPORT int rc_ctx_wait_results(rc_ctx *c, void *hip_stream)

@@ -410,12 +410,15 @@ void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32
 }
 
 // ---- per-frame scans over tiles ---------------------------------------------------------------------------
-// One 1024-thread workgroup per frame, 4 consecutive entries per thread and round:
+// One 256-thread workgroup per frame, SCAN_I consecutive entries per thread and round (4096 entries per round):
 //   tile_off = exclusive prefix of tile_cnt, frame_nnz = its total, tile_next[t] = smallest t' > t with tile_cnt[t'] > 0
 //   blk_off  = exclusive prefix of blk_size, frame_cbytes = its total              (only when a device codec ran)
-constexpr int SCAN_T = 1024, SCAN_W = SCAN_T / 64;
+// The workgroup is deliberately small: in pipelined mode this kernel is dispatched while the next batch's reduce kernel
+// owns the chip, and a 1024-thread workgroup (16 waves that must start on one CU together) waited there for hundreds of
+// microseconds (rocprofv3: 74 us with LZ4, 355 us with zstd, against 10 us when alone).
+constexpr int SCAN_T = 256, SCAN_W = SCAN_T / 64, SCAN_I = 16;
 
-__device__ __forceinline__ uint32_t scan1024_excl(uint32_t v, uint32_t *sm, uint32_t *total)
+__device__ __forceinline__ uint32_t scan_block_excl(uint32_t v, uint32_t *sm, uint32_t *total)
 {
     const int w = threadIdx.x >> 6;
     const uint32_t inc = wave_incl_scan(v);
@@ -437,15 +440,15 @@ __device__ __forceinline__ void scan_row(const uint32_t *__restrict__ row, uint3
                                          uint32_t *__restrict__ total, uint32_t *sm)
 {
     uint32_t carry = 0;
-    for (uint32_t t0 = 0; t0 < n; t0 += SCAN_T * 4) {
-        const uint32_t t = t0 + threadIdx.x * 4;
-        uint32_t v[4];
+    for (uint32_t t0 = 0; t0 < n; t0 += SCAN_T * SCAN_I) {
+        const uint32_t t = t0 + threadIdx.x * SCAN_I;
+        uint32_t v[SCAN_I], s = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = t + k < n ? row[t + k] : 0;
+        for (int k = 0; k < SCAN_I; ++k) { v[k] = t + k < n ? row[t + k] : 0; s += v[k]; }
         uint32_t tot;
-        uint32_t ex = carry + scan1024_excl(v[0] + v[1] + v[2] + v[3], sm, &tot);
+        uint32_t ex = carry + scan_block_excl(s, sm, &tot);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SCAN_I; ++k) {
             if (t + k < n) orow[t + k] = ex;
             ex += v[k];
         }
@@ -468,11 +471,18 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_cou
     uint32_t *nrow = sc.tile_next + fr;
     if (threadIdx.x == 0) s_carry = n;
     __syncthreads();
-    const uint32_t nrounds = (n + SCAN_T - 1) / SCAN_T;
+    const uint32_t per_round = SCAN_T * SCAN_I;
+    const uint32_t nrounds = (n + per_round - 1) / per_round;
     for (uint32_t c = nrounds; c-- > 0;) {
-        const uint32_t t = c * SCAN_T + threadIdx.x;
-        const uint32_t v = t < n ? row[t] : 0;
-        uint32_t m = v ? t : 0xFFFFFFFFu;  // inclusive suffix-min of "own index if non-empty" inside the wave
+        const uint32_t t = c * per_round + threadIdx.x * SCAN_I;
+        uint32_t v[SCAN_I];
+        uint32_t first = 0xFFFFFFFFu;  // smallest non-empty index of this thread's chunk
+#pragma unroll
+        for (int k = SCAN_I - 1; k >= 0; --k) {
+            v[k] = t + k < n ? row[t + k] : 0;
+            if (v[k]) first = t + k;
+        }
+        uint32_t m = first;  // inclusive suffix-min over the lanes of the wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_down(m, d);
@@ -481,13 +491,18 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_cou
         const int w = threadIdx.x >> 6;
         if (lane_id() == 0) sm[w] = m;
         __syncthreads();
-        uint32_t right = s_carry;  // min over all later rounds
+        uint32_t right = s_carry;  // min over all later rounds, then over the later waves of this round
 #pragma unroll
         for (int i = SCAN_W - 1; i >= 0; --i)
             if (i > w) right = min(right, sm[i]);
         uint32_t excl = __shfl_down(m, 1);
         if (lane_id() == 63) excl = 0xFFFFFFFFu;
-        if (t < n) nrow[t] = min(excl, right);
+        uint32_t nxt = min(excl, right);  // next non-empty index behind this thread's chunk
+#pragma unroll
+        for (int k = SCAN_I - 1; k >= 0; --k) {
+            if (t + k < n) nrow[t + k] = nxt;
+            if (v[k]) nxt = t + k;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t all = s_carry;

@@ -44,18 +44,21 @@ __global__ __launch_bounds__(WG) void k_zstd_buffer(Scratch sc)
 // (dense blocks) re-runs the chain with stores straight into the slot, in place: a sequence costs at most 29 bits and its
 // token is 32, so the write position never passes the read position.
 constexpr int FSE_ROW = 48;  // dwords of bitstream kept in LDS per lane (192 bytes; a 1 %-sparsity block needs about 15)
+// 128 threads = 25 KB of LDS per workgroup: in pipelined mode this kernel is dispatched while the next batch's reduce kernel
+// fills the CUs (3 workgroups x 39.5 KB of the 160 KB), and a 50 KB workgroup would have to wait for one of them to leave
+constexpr int FSE_T = 128;
 
-__global__ __launch_bounds__(WG) void k_zstd_fse(Scratch sc, uint32_t nslots, const ZstdTables *__restrict__ tables)
+__global__ __launch_bounds__(FSE_T) void k_zstd_fse(Scratch sc, uint32_t nslots, const ZstdTables *__restrict__ tables)
 {
     __shared__ ZstdTables T;
-    __shared__ uint32_t s_row[WG][FSE_ROW + 1];  // + 1: rows start in different banks
+    __shared__ uint32_t s_row[FSE_T][FSE_ROW + 1];  // + 1: rows start in different banks
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&T);
-        for (uint32_t i = threadIdx.x; i < sizeof(ZstdTables) / 4; i += WG) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < sizeof(ZstdTables) / 4; i += FSE_T) dst[i] = src[i];
     }
     __syncthreads();
-    const uint32_t ft = blockIdx.x * WG + threadIdx.x;
+    const uint32_t ft = blockIdx.x * FSE_T + threadIdx.x;
     if (ft >= nslots) return;
     const uint32_t word = sc.blk_size[ft];
     if (word & ZW_FINAL) { sc.blk_size[ft] = word & 0xFFFFu; return; }
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(WG) void k_zstd_fse(Scratch sc, uint32_t nslots, co
 void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s)
 {
     const uint32_t nslots = B * sc.ntiles;
-    hipLaunchKernelGGL(k_zstd_fse, dim3((nslots + WG - 1) / WG), dim3(WG), 0, s, sc, nslots,
+    hipLaunchKernelGGL(k_zstd_fse, dim3((nslots + FSE_T - 1) / FSE_T), dim3(FSE_T), 0, s, sc, nslots,
                        reinterpret_cast<const ZstdTables *>(tables_dev));
 }
 

@@ -93,6 +93,31 @@ __global__ __launch_bounds__(256) void k_read_write_nt(const u32x4 *__restrict__
         }
     }
 }
+// writes deferred to the end of the wave's 4 frames: one burst of 4 * wlines lines instead of 4 bursts of wlines
+__global__ __launch_bounds__(256) void k_read_write_deferred(const u32x4 *__restrict__ p, uint64_t frame16, uint32_t ntb, uint32_t G, uint32_t *__restrict__ wbuf,
+                                                             int wlines, uint32_t stride_dw, int contiguous)
+{
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3; const uint32_t g = j % G; const uint32_t tb = (j / G) * 8 + xcd;
+    if (tb >= ntb) return;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t keep[4];
+    for (int z = 0; z < 4; ++z) {
+        const uint32_t f = g * 4 + z;
+        const u32x4 *fr = p + (uint64_t)f * frame16 + (uint64_t)tb * 2048 + w * 512 + lane;
+        u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc += __builtin_nontemporal_load(fr + r * 64);
+        keep[z] = acc[0] + acc[1];
+    }
+    const uint64_t tile = (uint64_t)tb * 4 + w;
+    for (int z = 0; z < 4; ++z) {
+        const uint32_t f = g * 4 + z;
+        // contiguous: the 4 frames' outputs of this (tile, group) sit next to each other; else per-frame slots as before
+        const uint64_t slot = contiguous ? (tile * G + g) * 4 + z : (uint64_t)f * ntb * 4 + tile;
+        uint32_t *dst = wbuf + slot * stride_dw;
+        for (int l = 0; l < wlines; ++l) if (lane < 32) dst[l * 32 + lane] = keep[z] + l;
+    }
+}
 int main()
 {
     const uint64_t bytes = 2ull << 30, n16 = bytes / 16;
@@ -122,6 +147,10 @@ int main()
         if (wl * 32 > (int)stride) continue;
         char name[80]; snprintf(name, sizeof name, "read + %d lines, slot stride %u B, %s", wl, stride * 4, order ? "[tile][frame]" : "[frame][tile]");
         time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, stride, order, 64); }, name);
+    }
+    for (int contiguous = 0; contiguous <= 1; ++contiguous) for (int wl : {1, 3}) {
+        char name[80]; snprintf(name, sizeof name, "read 4 frames, then %d x 4 lines%s", wl, contiguous ? " contiguous" : "");
+        time([&] { hipLaunchKernelGGL(k_read_write_deferred, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, 160u, contiguous); }, name);
     }
     for (int wide = 0; wide <= 1; ++wide) for (int wl : {1, 3}) {
         char name[80]; snprintf(name, sizeof name, "read + %d lines NT stores%s, stride 640 B", wl, wide ? " (16-B)" : "");

@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--sparsity-ppm", type=int, default=10000)
     ap.add_argument("--depth", type=int, default=16)
-    ap.add_argument("--scheme", type=int, default=2, help="2 = LZ4 (headline), 0 = reduce-only pieces")
+    ap.add_argument("--scheme", type=int, default=2, help="2 = LZ4 (headline), 1 = zstd, 8 = blosc-lz4, 0 = reduce-only pieces")
+    ap.add_argument("--level", type=int, default=1, help="reduction level: 1 (headline), 2 = summary statistics, 3 = bitmap only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="plain stream order: a batch's reduce kernel waits for the previous batch's records")
     return ap.parse_args()
@@ -146,7 +147,7 @@ def main():
         hip.check(L.rc_synth_frames(local, seed, lo, n, N, a.sparsity_ppm, dark.data_ptr(), stack[lo].data_ptr()))
 
     op_mode = 1
-    ctx = hip.ReduceContext(a.nx, a.ny, a.depth, 1, op_mode, a.scheme, 1, local, max_batch=B)
+    ctx = hip.ReduceContext(a.nx, a.ny, a.depth, a.level, op_mode, a.scheme, 1, local, max_batch=B)
     ctx.set_dark(dark.data_ptr(), 0)  # eps = 0 -> thr = dark
     ctx.keep_binary_maps(False)       # no validation frames in this workload: records only (recode_writer.py:402-415)
     out_cap = B * (N // 2)  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
@@ -223,8 +224,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt_max / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {
-                "workload": "%dx%d uint16, %.2f%% sparsity, L1 + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
-                    a.ny, a.nx, a.sparsity_ppm / 1e4, {2: "LZ4 frame", 1: "zstd frame", 0: "reduce-only pieces"}.get(a.scheme, str(a.scheme)),
+                "workload": "%dx%d uint16, %.2f%% sparsity, L%d + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
+                    a.ny, a.nx, a.sparsity_ppm / 1e4, a.level,
+                    {2: "LZ4 frame", 1: "zstd frame", 8: "blosc-lz4 chunk", 0: "reduce-only pieces"}.get(a.scheme, str(a.scheme)),
                     a.depth, B, S),
                 "parallelism": "dp%d (contiguous frame blocks per rank; per step one RCCL all-gather of the metadata rows, on a side stream under the next step)" % world,
                 "record_bytes_per_frame": round(float(rec_h[-1]) / B, 1),

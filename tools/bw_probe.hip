@@ -138,7 +138,7 @@ int main()
     const uint64_t frame16 = (32ull << 20) / 16; const uint32_t ntb = 1024, G = 16;
     time([&] { hipLaunchKernelGGL(k_read_strided, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, out, 0); }, "frame-strided (groups adjacent, xcd)");
     time([&] { hipLaunchKernelGGL(k_read_strided, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, out, 1); }, "frame-strided (tiles adjacent)");
-    uint32_t *wbuf; hipMalloc(&wbuf, (uint64_t)64 * ntb * 4 * 8192 + (64ull * ntb * 4 * 4));
+    uint32_t *wbuf; hipMalloc(&wbuf, (uint64_t)64 * ntb * 4 * (8192 + 1280) + (64ull * ntb * 4 * 4) + (64ull << 20));  // slack: offset / stride sweeps
     for (int wl = 0; wl <= 4; ++wl) for (int sc = 0; sc <= 1; ++sc) {
         char name[64]; snprintf(name, sizeof name, "read + %d full lines/tile%s", wl, sc ? " + 4B scalar" : "");
         time([&] { hipLaunchKernelGGL(k_read_write, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, sc); }, name);
@@ -147,6 +147,22 @@ int main()
         if (wl * 32 > (int)stride) continue;
         char name[80]; snprintf(name, sizeof name, "read + %d lines, slot stride %u B, %s", wl, stride * 4, order ? "[tile][frame]" : "[frame][tile]");
         time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, stride, order, 64); }, name);
+    }
+    if (getenv("BW_OFFSET_SWEEP")) {
+        // does the cost of the write stream depend on where it lies relative to the read stream?  (8 KiB slot stride = the
+        // read stream's tile stride, so the relation is the same for every tile)
+        printf("p = %p  wbuf = %p\n", (void *)p, (void *)wbuf);
+        for (uint32_t off : {0u, 128u, 256u, 512u, 1024u, 2048u, 4096u, 4096u + 128u, 8192u, 16384u, 32768u, 65536u, 131072u, 262144u, 524288u,
+                             1048576u, 2097152u, 4194304u, 8388608u, 16777216u}) {
+            char name[80]; snprintf(name, sizeof name, "read + 1 line, stride 8 KiB, write base + %u", off);
+            uint32_t *wb = wbuf + off / 4;
+            time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wb, 1, 2048u, 0, 64); }, name);
+        }
+        for (uint32_t stride : {2048u, 2048u + 32u, 2048u + 64u, 2048u + 96u, 2048u + 160u, 2048u + 288u}) {
+            char name[80]; snprintf(name, sizeof name, "read + 1 line, slot stride %u B", stride * 4);
+            time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, 1, stride, 0, 64); }, name);
+        }
+        return 0;
     }
     for (int contiguous = 0; contiguous <= 1; ++contiguous) for (int wl : {1, 3}) {
         char name[80]; snprintf(name, sizeof name, "read 4 frames, then %d x 4 lines%s", wl, contiguous ? " contiguous" : "");

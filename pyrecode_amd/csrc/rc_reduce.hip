@@ -76,11 +76,13 @@ __device__ __forceinline__ u32x4 load8(const uint16_t *__restrict__ base, uint64
     }
 }
 
-// Results of one (tile, frame) that are still sitting in wave-private LDS / registers, waiting to be written out.
-// Stores are issued one frame LATE, right behind the next frame's loads: the `s_waitcnt vmcnt(0)` in front of a frame's first
-// use of its data then only meets operations that were issued a whole frame of compute earlier.  (gfx9 counts loads and stores
-// on ONE in-order counter; with the stores issued just before the wait, their full write latency was exposed on every frame:
-// measured 0.49 ms -> 0.37 ms for this kernel with the stores removed, 0.30 ms being the pure read time.)
+// Results of one (tile, frame) sitting in wave-private LDS / registers until flush_pending writes them out.  The stores are
+// issued at the END of the frame's processing, i.e. well behind the next frame's loads (which go out right after the
+// subtract): gfx9 counts loads and stores on ONE in-order counter, so the `s_waitcnt` in front of the next frame's first
+// use of its data does not have to wait for these stores, only for the loads in front of them.  (With the stores issued
+// just before that wait their full write latency was exposed on every frame: 0.49 ms -> 0.37 ms for this kernel with the
+// stores removed, 0.30 ms being the pure read time.  Holding the results back for a whole further frame cost 58 more VGPRs
+// and was slower.)
 struct Pending {
     bool valid;
     uint64_t ft;        // frame * ntiles + tile
@@ -331,10 +333,13 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 // Per frame and wavefront, with NO barrier and no cross-wave traffic (reduce_one_frame):
 //   8 x 16-byte nontemporal loads per lane, issued ONE FRAME AHEAD into the second register set
 //   -> saturating subtract (residual and mask in one op) -> 8-bit mask per lane
-//   -> [LEVEL1] DPP prefix sums of the popcounts, residuals compacted into the wave's LDS stage
-//   -> bitmap bytes transposed through wave-private LDS (8 contiguous bytes per lane)
-//   -> [CODEC 2] the 512-byte bitmap block is LZ4-encoded in LDS (rc_lz4_block.h)
-//   -> all global stores (residuals, encoded block, raw bitmap, counts) are issued ONE FRAME LATE, coalesced (flush_pending)
+//   -> [LEVEL1] the 4096 values staged in pixel order in the wave's LDS
+//   -> bitmap bytes transposed through wave-private LDS (8 contiguous bytes = the mask of 64 consecutive pixels per lane)
+//   -> [LEVEL1] one DPP prefix sum of the per-lane popcounts, each lane moves its set pixels into the compact buffer,
+//      [depth < 16] packed in place to the tile-local d-bit stream
+//   -> [CODEC 2 / 1 / 8] the 512-byte bitmap block is LZ4-encoded / zstd-tokenized / bit-shuffled + LZ4-encoded in LDS
+//      (rc_lz4_block.h, rc_zstd_wave.h)
+//   -> all global stores (residuals, encoded block, raw bitmap, counts) go out last, as whole 128-byte lines (flush_pending)
 template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,

@@ -49,6 +49,16 @@ __device__ __forceinline__ uint32_t lz4_emit_len(uint8_t *out, uint32_t o, uint3
     return o;
 }
 
+// table[k], table[k + 1] <- base + (positions of the at most two set bits of `bits`)
+__device__ __forceinline__ void table_put2(uint16_t *table, uint32_t k, uint32_t bits, int base)
+{
+    if (bits) {
+        table[k] = (uint16_t)(base + __builtin_ctz(bits));
+        const uint32_t rest = bits & (bits - 1);
+        if (rest) table[k + 1] = (uint16_t)(base + __builtin_ctz(rest));
+    }
+}
+
 // Wave-collective.  Precondition: L.raw holds the block in position order (written by this wavefront) and `own` is this
 // lane's 8 bytes raw[8*lane .. 8*lane+8), little-endian.  n: valid bytes (1..512).
 // Returns the compressed size (wave-uniform); the payload is in L.out[0..size) only when size < n.
@@ -78,8 +88,11 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
     const uint32_t tot = wave_last(inc);
     const uint32_t nm = tot & 0x3FFu;  // matches; sequences = nm + 1 (the last one has literals only)
     uint32_t kms = (inc - cnt) & 0x3FFu, kfl = ((inc - cnt) >> 10) & 0x3FFu;
-    for (; ms; ms &= ms - 1) L.ms[kms++] = (uint16_t)(base + __builtin_ctz(ms));
-    for (; fl; fl &= fl - 1) L.fl[kfl++] = (uint16_t)(base + __builtin_ctz(fl));
+    // a lane's 8 positions hold at most two match starts and two sequence starts (a match is >= 4 bytes long and is
+    // preceded by at least one literal): two predicated stores each, no loop
+    table_put2(L.ms, kms, ms, base);
+    table_put2(L.fl, kfl, fl, base);
+    __builtin_amdgcn_wave_barrier();
 
     // ---- phase 2: one sequence per lane ------------------------------------------------------------------------------
     uint32_t carry = 0, total = 0;

@@ -118,6 +118,33 @@ __global__ __launch_bounds__(256) void k_read_write_deferred(const u32x4 *__rest
         for (int l = 0; l < wlines; ++l) if (lane < 32) dst[l * 32 + lane] = keep[z] + l;
     }
 }
+// the reduce kernel's own write pattern: per (tile, frame) one line into an 8 KiB-strided slot array, two lines into a
+// 640 B-strided one, and two 4-byte stores into dense arrays - against the same bytes as three contiguous lines of ONE slot
+__global__ __launch_bounds__(256) void k_read_write_pattern(const u32x4 *__restrict__ p, uint64_t frame16, uint32_t ntb, uint32_t G, uint32_t *__restrict__ wbuf,
+                                                            int merged)
+{
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3; const uint32_t g = j % G; const uint32_t tb = (j / G) * 8 + xcd;
+    if (tb >= ntb) return;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t nslots = (uint64_t)64 * ntb * 4;
+    uint32_t *A = wbuf, *Bs = wbuf + nslots * 2048, *C = Bs + nslots * 160, *D = C + nslots;
+    for (int z = 0; z < 4; ++z) {
+        const uint32_t f = g * 4 + z;
+        const u32x4 *fr = p + (uint64_t)f * frame16 + (uint64_t)tb * 2048 + w * 512 + lane;
+        u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc += __builtin_nontemporal_load(fr + r * 64);
+        const uint64_t slot = (uint64_t)f * ntb * 4 + (uint64_t)tb * 4 + w;
+        if (merged) {
+            uint32_t *dst = A + slot * 2208;   // 8832-byte slots
+            for (int l = 0; l < 3; ++l) if (lane < 32) dst[l * 32 + lane] = acc[0] + l;
+        } else {
+            if (lane < 32) A[slot * 2048 + lane] = acc[0];
+            Bs[slot * 160 + lane] = acc[1];
+            if (lane == 0) { C[slot] = acc[2]; D[slot] = acc[3]; }
+        }
+    }
+}
 int main()
 {
     const uint64_t bytes = 2ull << 30, n16 = bytes / 16;
@@ -147,6 +174,13 @@ int main()
         if (wl * 32 > (int)stride) continue;
         char name[80]; snprintf(name, sizeof name, "read + %d lines, slot stride %u B, %s", wl, stride * 4, order ? "[tile][frame]" : "[frame][tile]");
         time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, stride, order, 64); }, name);
+    }
+    if (getenv("BW_PATTERN")) {
+        for (int rep = 0; rep < 3; ++rep) for (int merged = 0; merged <= 1; ++merged) {
+            char name[80]; snprintf(name, sizeof name, "reduce-kernel write pattern, %s", merged ? "merged into one slot (3 lines)" : "as it is (4 streams)");
+            time([&] { hipLaunchKernelGGL(k_read_write_pattern, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, merged); }, name);
+        }
+        return 0;
     }
     if (getenv("BW_OFFSET_SWEEP")) {
         // does the cost of the write stream depend on where it lies relative to the read stream?  (8 KiB slot stride = the

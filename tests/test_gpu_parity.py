@@ -531,3 +531,46 @@ def test_random_shapes_depths_schemes_fuzz(hip, orc):
             ctx.close()
             cases += 1
     assert cases >= 30   # (the rest: records larger than their tiny raw frames, refused like the reference does)
+
+
+@pytest.mark.parametrize("ny,nx,B,rounds,scheme", [(512, 512, 4, 40, 2), (2048, 2048, 8, 12, 1), (1024, 4096, 16, 10, 8)])
+def test_pipelined_soak(hip, orc, ny, nx, B, rounds, scheme):
+    """Many batches back to back in pipelined mode over the two scratch sets, eight at a time between syncs, inputs cycling
+    through different frame blocks: every batch's records must equal those of the same block computed synchronously.
+    (A hazard between batch i's second stage and batch i+2's reduce kernel on the same scratch set would show up here.)"""
+    import torch
+    nblocks = 5
+    dark, frames = synth_frames(1234, nblocks * B, ny, nx, 0.015, 16)
+    ctx = hip.ReduceContext(nx, ny, 16, 1, 1, scheme, 1, 0, max_batch=B)
+    ctx.set_threshold(orc.threshold(dark, 0))
+    ctx.keep_binary_maps(False)
+    dev = torch.device("cuda", 0)
+    fr_d = torch.from_numpy(frames.view(np.int16)).to(dev)
+    cap = B * ny * nx
+    expect = []
+    for b in range(nblocks):
+        out, rec, md = ctx.reduce_compress_batch(frames[b * B:(b + 1) * B], first_frame_id=b * B)
+        n = int(rec[-1])
+        expect.append((torch.from_numpy(out[:n].copy()).to(dev), torch.from_numpy(rec.astype(np.int64)).to(dev),
+                       torch.from_numpy(md.view(np.int32).copy()).to(dev)))
+    ctx.set_pipelined(True)
+    K = 8
+    outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(K)]
+    recs = [torch.empty(B + 1, dtype=torch.int64, device=dev) for _ in range(K)]
+    mds = [torch.empty((B, 3), dtype=torch.int32, device=dev) for _ in range(K)]
+    torch.cuda.synchronize()
+    it = 0
+    for r in range(rounds):
+        which = []
+        for k in range(K):
+            b = (it * 7 + k * 3 + r) % nblocks
+            which.append(b)
+            ctx.enqueue(fr_d[b * B].data_ptr(), B, b * B, outs[k].data_ptr(), cap, recs[k].data_ptr(), mds[k].data_ptr())
+            it += 1
+        ctx.sync()
+        for k, b in enumerate(which):
+            e_out, e_rec, e_md = expect[b]
+            assert torch.equal(recs[k], e_rec) and torch.equal(mds[k], e_md), "round %d batch %d" % (r, k)
+            assert torch.equal(outs[k][:e_out.numel()], e_out), "round %d batch %d" % (r, k)
+    ctx.set_pipelined(False)
+    ctx.close()

@@ -135,13 +135,13 @@ __global__ __launch_bounds__(256) void k_read_write_pattern(const u32x4 *__restr
 #pragma unroll
         for (int r = 0; r < 8; ++r) acc += __builtin_nontemporal_load(fr + r * 64);
         const uint64_t slot = (uint64_t)f * ntb * 4 + (uint64_t)tb * 4 + w;
-        if (merged) {
+        if (merged == 1) {
             uint32_t *dst = A + slot * 2208;   // 8832-byte slots
             for (int l = 0; l < 3; ++l) if (lane < 32) dst[l * 32 + lane] = acc[0] + l;
         } else {
             if (lane < 32) A[slot * 2048 + lane] = acc[0];
             Bs[slot * 160 + lane] = acc[1];
-            if (lane == 0) { C[slot] = acc[2]; D[slot] = acc[3]; }
+            if (lane == 0 && merged != 2) { C[slot] = acc[2]; D[slot] = acc[3]; }
         }
     }
 }
@@ -176,8 +176,8 @@ int main()
         time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, stride, order, 64); }, name);
     }
     if (getenv("BW_PATTERN")) {
-        for (int rep = 0; rep < 3; ++rep) for (int merged = 0; merged <= 1; ++merged) {
-            char name[80]; snprintf(name, sizeof name, "reduce-kernel write pattern, %s", merged ? "merged into one slot (3 lines)" : "as it is (4 streams)");
+        for (int rep = 0; rep < 3; ++rep) for (int merged = 0; merged <= 2; ++merged) {
+            char name[80]; snprintf(name, sizeof name, "reduce-kernel write pattern, %s", merged == 1 ? "merged into one slot (3 lines)" : merged == 2 ? "without the two 4-byte stores" : "as it is (4 streams)");
             time([&] { hipLaunchKernelGGL(k_read_write_pattern, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, merged); }, name);
         }
         return 0;

@@ -174,11 +174,10 @@ __device__ __forceinline__ void flush_pending(const Pending &p, uint32_t tile, u
 }
 
 // One frame of one tile: x holds the 8 loaded groups of this lane (destroyed), xn receives the prefetch of `next`.
-// TMODE: 0 threshold in registers (t), 1 threshold in wave-private LDS (tl), 2 threshold re-read from L2 (thr pointer).
-template <bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
+// t: the wave's threshold tile, in registers for all BZ frames (keeping it in LDS or re-reading it from L2 was no faster).
+template <bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
 __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], const uint16_t *__restrict__ next, bool have_next,
-                                                 const u32x4 (&t)[TMODE == 0 ? R : 1], const u32x4 *__restrict__ tl,
-                                                 const uint16_t *__restrict__ thr, uint64_t lane_px0, uint64_t N, bool full,
+                                                 const u32x4 (&t)[R], uint64_t lane_px0, uint64_t N, bool full,
                                                  uint32_t f, uint32_t tile, uint64_t ft, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
                                                  uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ blk_slots,
@@ -190,9 +189,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
     uint32_t m8[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const u32x4 tt = TMODE == 0 ? t[TMODE == 0 ? r : 0]
-                       : TMODE == 1 ? tl[r * 64 + lane]
-                                    : load8<ALIGNED, false>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
+        const u32x4 tt = t[r];
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[r][k] = pk_sub_sat_u16(x[r][k], tt[k]);
         const uint32_t one = 0x00010001u;
@@ -219,14 +216,14 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
     pend.csize = 0;
     pend.buf = st->out;
     if (LEVEL1) {
-        // the tile's values in pixel order -> LDS (level 2 keeps the raw frame value: residual + threshold, TMODE 0 only)
+        // the tile's values in pixel order -> LDS (level 2 keeps the raw frame value: residual + threshold)
         u32x4 *dst = reinterpret_cast<u32x4 *>(st->val) + lane;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             u32x4 v = x[r];
             if (RAWVAL) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = pk_add_u16(v[k], t[TMODE == 0 ? r : 0][k]);
+                for (int k = 0; k < 4; ++k) v[k] = pk_add_u16(v[k], t[r][k]);
             }
             dst[r * 64] = v;
         }
@@ -293,8 +290,8 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                             const uint32_t p23 = __builtin_amdgcn_perm(x[r][3], x[r][2], sel);
                             uint32_t d = (i & 4u) ? p23 : p01;
                             if (RAWVAL) {
-                                const uint32_t q01 = __builtin_amdgcn_perm(t[TMODE == 0 ? r : 0][1], t[TMODE == 0 ? r : 0][0], sel);
-                                const uint32_t q23 = __builtin_amdgcn_perm(t[TMODE == 0 ? r : 0][3], t[TMODE == 0 ? r : 0][2], sel);
+                                const uint32_t q01 = __builtin_amdgcn_perm(t[r][1], t[r][0], sel);
+                                const uint32_t q23 = __builtin_amdgcn_perm(t[r][3], t[r][2], sel);
                                 d += (i & 4u) ? q23 : q01;
                             }
                             st->val[o++] = (uint16_t)d;
@@ -325,7 +322,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 }
 
 // Workgroup id -> (tile block, frame group).  A tile block is WAVES consecutive tiles (one per wavefront); a frame group
-// is BZ consecutive frames.  The threshold tile is fetched once per workgroup and kept (registers or wave-private LDS)
+// is BZ consecutive frames.  The threshold tile is fetched once per workgroup and kept in registers
 // for the BZ frames.  The ngroups workgroups that share a tile block get ids that are congruent mod 8 and adjacent within
 // that residue class: the dispatcher deals workgroups round-robin over the 8 XCDs, so they meet in ONE XCD's L2 at about
 // the same time and the threshold is fetched from HBM once per batch (placement affects speed only, never results).
@@ -340,7 +337,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 //   -> [CODEC 2 / 1 / 8] the 512-byte bitmap block is LZ4-encoded / zstd-tokenized / bit-shuffled + LZ4-encoded in LDS
 //      (rc_lz4_block.h, rc_zstd_wave.h)
 //   -> all global stores (residuals, encoded block, raw bitmap, counts) go out last, as whole 128-byte lines (flush_pending)
-template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, int TMODE, bool RAWVAL>
+template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
@@ -353,7 +350,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
     if (blockIdx.x == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
     __shared__ Lz4Lds s_lz[CODEC ? WAVES : 1];                                                  // codec working set
     __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : WAVES][CODEC ? 16 : TILE_BM];  // transpose only
-    __shared__ u32x4 s_thr[TMODE == 1 ? WAVES : 1][TMODE == 1 ? R * 64 : 1];                       // threshold tile per wave
     __shared__ WaveStage s_stage[LEVEL1 ? WAVES : 1];                                           // compacted residuals
 
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -374,15 +370,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 #pragma unroll
         for (int r = 0; r < R; ++r) xa[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
     }
-    u32x4 t[TMODE == 0 ? R : 1];
-    u32x4 *tl = s_thr[TMODE == 1 ? w : 0];
-    if (TMODE != 2) {
+    u32x4 t[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const u32x4 tv = load8<ALIGNED, false>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
-            if (TMODE == 0) t[TMODE == 0 ? r : 0] = tv; else tl[r * 64 + lane] = tv;
-        }
-    }
+    for (int r = 0; r < R; ++r) t[r] = load8<ALIGNED, false>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
     const uint32_t n_blk = (uint32_t)min((uint64_t)TILE_BM, nb - (uint64_t)tile * TILE_BM);  // bitmap bytes of this tile
     Lz4Lds *lz = &s_lz[CODEC ? w : 0];
     uint8_t *bm = s_bm[CODEC ? 0 : w];
@@ -399,14 +389,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
         uint32_t f = f0 + z;
         if (f >= B) break;
         bool nxt = z + 1 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr,
+        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
                                                                              blk_size, lz, bm, st, pend);
         if (!nxt) break;
         ++f;
         nxt = z + 2 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, TMODE, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t, tl, thr,
+        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
                                                                              blk_size, lz, bm, st, pend);
@@ -415,25 +405,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
     flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st);
 }
 
-static int reduce_tmode()  // where the threshold tile lives: 0 registers (default), 1 wave-private LDS, 2 re-read from L2
-{
-    static const int v = [] { const char *e = getenv("RC_THR_MODE"); const int m = e ? atoi(e) : 0; return (m >= 0 && m <= 2) ? m : 0; }();
-    return v;
-}
-
 template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW>
 static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t depth, hipStream_t s)
 {
     const uint32_t ngroups = (B + BZ - 1) / BZ;
     const uint32_t ntb = (sc.ntiles + WAVES - 1) / WAVES;
     const uint32_t grid = ((ntb + 7) / 8) * 8 * ngroups;
-#define RC_GO(TM)                                                                                                           \
-    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP, TM, RAW>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N,         \
-                       sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size, depth, sc.status)
-    // the scalar-load instantiation and the raw-value (level 2) one exist with the threshold in registers only
-    const int tm = (AL && !RAW) ? reduce_tmode() : 0;
-    if (tm == 1) { if (AL && !RAW) RC_GO(1); } else if (tm == 2) { if (AL && !RAW) RC_GO(2); } else RC_GO(0);
-#undef RC_GO
+    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP, RAW>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N,
+                       sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size, depth, sc.status);
 }
 template <int BZ, bool AL, bool L1, bool RAW>
 static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s)

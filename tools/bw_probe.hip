@@ -145,6 +145,27 @@ __global__ __launch_bounds__(256) void k_read_write_pattern(const u32x4 *__restr
         }
     }
 }
+// outputs appended to one log per XCD (atomic cursor): what is written at about the same time lies next to each other
+__global__ __launch_bounds__(256) void k_read_write_log(const u32x4 *__restrict__ p, uint64_t frame16, uint32_t ntb, uint32_t G, uint32_t *__restrict__ wbuf,
+                                                        unsigned long long *__restrict__ cursor, uint64_t log_dw, int wlines, int nlogs)
+{
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3; const uint32_t g = j % G; const uint32_t tb = (j / G) * 8 + xcd;
+    if (tb >= ntb) return;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t lg = nlogs == 8 ? xcd : (nlogs == 1 ? 0u : (blockIdx.x % (uint32_t)nlogs));
+    for (int z = 0; z < 4; ++z) {
+        const uint32_t f = g * 4 + z;
+        const u32x4 *fr = p + (uint64_t)f * frame16 + (uint64_t)tb * 2048 + w * 512 + lane;
+        u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc += __builtin_nontemporal_load(fr + r * 64);
+        unsigned long long pos = 0;
+        if (lane == 0) pos = atomicAdd(&cursor[lg * 16], (unsigned long long)(wlines * 32));   // dwords
+        pos = __shfl(pos, 0);
+        uint32_t *dst = wbuf + (uint64_t)lg * log_dw + pos;
+        for (int l = 0; l < wlines; ++l) if (lane < 32) dst[l * 32 + lane] = acc[0] + l;
+    }
+}
 int main()
 {
     const uint64_t bytes = 2ull << 30, n16 = bytes / 16;
@@ -174,6 +195,20 @@ int main()
         if (wl * 32 > (int)stride) continue;
         char name[80]; snprintf(name, sizeof name, "read + %d lines, slot stride %u B, %s", wl, stride * 4, order ? "[tile][frame]" : "[frame][tile]");
         time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, stride, order, 64); }, name);
+    }
+    if (getenv("BW_LOG")) {
+        unsigned long long *cursor; hipMalloc(&cursor, 1024 * 16 * 8);
+        const uint64_t log_dw = (uint64_t)64 * ntb * 4 * 3 * 32;   // room for every tile-frame's 3 lines in ONE log (dwords)
+        for (int rep = 0; rep < 2; ++rep) for (int nlogs : {8, 64, 256, 1024}) for (int wl : {1, 3}) {
+            const uint64_t ldw = nlogs <= 8 ? log_dw : (log_dw / nlogs) * 2;   // per-log capacity (dwords), 2x the even share
+            char name[80]; snprintf(name, sizeof name, "read + %d lines appended to %d log(s)", wl, nlogs);
+            time([&] { hipMemsetAsync(cursor, 0, 1024 * 16 * 8, 0); hipLaunchKernelGGL(k_read_write_log, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, cursor, ldw, wl, nlogs); }, name);
+        }
+        for (int wl : {1, 3}) {
+            char name[80]; snprintf(name, sizeof name, "read + %d lines, slot stride 640 B (reference)", wl);
+            time([&] { hipLaunchKernelGGL(k_read_write2, dim3(ntb * G), dim3(256), 0, 0, p, frame16, ntb, G, wbuf, wl, 160u, 0, 64); }, name);
+        }
+        return 0;
     }
     if (getenv("BW_PATTERN")) {
         for (int rep = 0; rep < 3; ++rep) for (int merged = 0; merged <= 2; ++merged) {

@@ -69,6 +69,23 @@ int copy_out(void *dst, const void *src_dev, uint64_t bytes, hipStream_t s)
     return RC_OK;
 }
 
+// Every entry point runs on its ctx's (or the utility context's) device and puts the caller's current device back on
+// return: in a one-process-per-GPU job the thread's current device belongs to the caller (torch, RCCL), not to this library.
+struct DeviceGuard {
+    int prev = -1;
+    bool moved = false;
+    hipError_t enter(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev == dev) return hipSuccess;
+        hipError_t e = hipSetDevice(dev);
+        moved = e == hipSuccess && prev >= 0;
+        return e;
+    }
+    ~DeviceGuard() { if (moved) (void)hipSetDevice(prev); }
+};
+#define RC_ON_DEVICE(dev) DeviceGuard dev_guard_; HIP_TRY(dev_guard_.enter(dev))
+
 }  // namespace
 
 struct rc_ctx {
@@ -176,7 +193,7 @@ static int ctx_alloc(rc_ctx *c)
 {
     using namespace rc;
     const uint64_t B = c->max_batch, T = c->sc.ntiles;
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->pstream_all, hipStreamNonBlocking));
     {
@@ -295,7 +312,8 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
 RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
 {
     if (!c) return RC_OK;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dev_guard_;
+    (void)dev_guard_.enter(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->pstream_all) (void)hipStreamSynchronize(c->pstream_all);
     if (c->pstream_masked) (void)hipStreamSynchronize(c->pstream_masked);
@@ -334,7 +352,7 @@ RC_EXPORT int rc_ctx_set_stream(rc_ctx *c, void *hip_stream)
 RC_EXPORT int rc_set_threshold(rc_ctx *c, const uint16_t *thr)
 {
     if (!c || !thr) return fail(RC_ERR_BAD_ARG, "ctx / thr is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     HIP_TRY(hipMemcpyAsync(c->sc.thr, thr, c->sc.N * 2, is_device_ptr(thr) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -345,7 +363,7 @@ RC_EXPORT int rc_set_threshold(rc_ctx *c, const uint16_t *thr)
 RC_EXPORT int rc_set_dark(rc_ctx *c, const uint16_t *dark, int64_t epsilon)
 {
     if (!c || !dark) return fail(RC_ERR_BAD_ARG, "ctx / dark is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     const uint16_t *src = dark;
     if (!is_device_ptr(dark)) {
         int r = ensure(c->d_dark, c->d_dark_cap, c->sc.N * 2);
@@ -417,7 +435,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     HIP_TRY(hipStreamWaitEvent(ps, red, 0));
     if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
         launch_scans(sc, n, true, false, ps);
-        launch_l2(sc, c->l2, n, c->nx, c->l2_sum, ps);
+        launch_l2(sc, c->l2, n, c->nx, c->l2_sum ? (1u << c->depth) - 1u : 0u, ps);
     }
     if (c->emit == RC_SCHEME_ZSTD) launch_zstd_fse(sc, n, c->d_ztab, ps);
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], ps));
@@ -447,14 +465,14 @@ RC_EXPORT int rc_reduce_compress_batch_async(rc_ctx *c, const uint16_t *frames_d
 {
     int r = check_batch_args(c, frames_dev, n, out_dev, rec_offsets_dev, md_dev);
     if (r != RC_OK) return r;
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     return enqueue_batch(c, frames_dev, n, first_frame_id, out_dev, out_cap, rec_offsets_dev, md_dev, false);
 }
 
 RC_EXPORT int rc_ctx_set_pipelined(rc_ctx *c, int on)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     HIP_TRY(hipStreamSynchronize(c->pstream));  // the second stage changes streams: drain the old one first
     c->pipelined = on != 0;
     c->pstream = (c->pipelined && c->pstream_masked) ? c->pstream_masked : c->pstream_all;
@@ -463,7 +481,7 @@ RC_EXPORT int rc_ctx_set_pipelined(rc_ctx *c, int on)
 RC_EXPORT int rc_ctx_wait_results(rc_ctx *c, void *hip_stream)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     if (c->post_pending[c->last])
         HIP_TRY(hipStreamWaitEvent(hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream, c->ev_post[c->last], 0));
     return RC_OK;
@@ -472,7 +490,7 @@ RC_EXPORT int rc_ctx_wait_results(rc_ctx *c, void *hip_stream)
 RC_EXPORT int rc_ctx_sync(rc_ctx *c)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     HIP_TRY(hipMemcpyAsync(&c->h_status[0], c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->pstream));
     HIP_TRY(hipMemcpyAsync(&c->h_status[1], c->d_first_err, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->pstream));
     HIP_TRY(hipMemsetAsync(c->d_first_err, 0, sizeof(rc::BatchStatus), c->pstream));
@@ -508,7 +526,7 @@ RC_EXPORT int rc_reduce_compress_batch(rc_ctx *c, const uint16_t *frames, uint32
 {
     int r = check_batch_args(c, frames, n, out, rec_offsets, md);
     if (r != RC_OK) return r;
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     const uint64_t frame_bytes = c->sc.N * 2;
     const uint16_t *fdev = frames;
     if (!is_device_ptr(frames)) {
@@ -546,7 +564,7 @@ RC_EXPORT int rc_get_binary_map(rc_ctx *c, uint32_t i, uint8_t *bitmap_out)
     if (!c || !bitmap_out) return fail(RC_ERR_BAD_ARG, "NULL argument");
     if (i >= c->last_n) return fail(RC_ERR_BAD_ARG, "frame index outside the most recent batch");
     if (!c->keep_bitmap && c->emit != 0 && c->level != 2) return fail(RC_ERR_BAD_ARG, "binary maps are not kept (rc_ctx_keep_binary_maps(ctx, 0))");
-    HIP_TRY(hipSetDevice(c->device));
+    RC_ON_DEVICE(c->device);
     int r = copy_out(bitmap_out, c->sc.bitmap + (uint64_t)i * c->sc.nb_stride, c->sc.nb, c->stream);
     if (r != RC_OK) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -590,7 +608,9 @@ RC_EXPORT int rc_get_stage_ms(rc_ctx *c, float ms[5])
     return RC_OK;
 }
 
-// ---- utility context for the stateless seams (2 and 3) ----------------------------------------------------------
+// ---- utility contexts for the stateless seams (2 and 3) ----------------------------------------------------------
+// One per GPU, created on first use.  A call runs on RC_DEVICE (env) when that is set, otherwise on the CALLER'S CURRENT
+// device - in a one-process-per-GPU job that is the rank's own GPU - and leaves the current device as it found it.
 namespace {
 struct Util {
     std::mutex mu;
@@ -603,28 +623,37 @@ struct Util {
     uint64_t *h_scalar = nullptr;               // pinned
     void *ztab = nullptr;                       // zstd FSE tables
 };
-Util g_util;
+constexpr int RC_MAX_DEV = 64;
+Util g_utils[RC_MAX_DEV];
+thread_local Util *t_util = nullptr;
+#define g_util (*t_util)
 
-int util_init()
-{
-    if (g_util.device >= 0) {
-        HIP_TRY(hipSetDevice(g_util.device));
+struct UtilScope {
+    DeviceGuard guard;
+    std::unique_lock<std::mutex> lock;
+    int enter()
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+            (void)hipGetLastError();
+            return fail(RC_ERR_DEVICE, "no HIP device visible (this library has no CPU path)");
+        }
+        int dev = 0;
+        const char *env = getenv("RC_DEVICE");
+        if (env) dev = atoi(env);
+        else if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        if (dev < 0 || dev >= ndev || dev >= RC_MAX_DEV) return fail(RC_ERR_BAD_ARG, "RC_DEVICE out of range");
+        t_util = &g_utils[dev];
+        lock = std::unique_lock<std::mutex>(t_util->mu);
+        HIP_TRY(guard.enter(dev));
+        if (t_util->device < 0) {
+            HIP_TRY(hipStreamCreateWithFlags(&t_util->stream, hipStreamNonBlocking));
+            HIP_TRY(hipHostMalloc((void **)&t_util->h_scalar, 64, hipHostMallocDefault));
+            t_util->device = dev;
+        }
         return RC_OK;
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-        (void)hipGetLastError();
-        return fail(RC_ERR_DEVICE, "no HIP device visible (this library has no CPU path)");
-    }
-    const char *env = getenv("RC_DEVICE");
-    int dev = env ? atoi(env) : 0;
-    if (dev < 0 || dev >= ndev) return fail(RC_ERR_BAD_ARG, "RC_DEVICE out of range");
-    HIP_TRY(hipSetDevice(dev));
-    HIP_TRY(hipStreamCreateWithFlags(&g_util.stream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc((void **)&g_util.h_scalar, 64, hipHostMallocDefault));
-    g_util.device = dev;
-    return RC_OK;
-}
+};
 
 // device-visible view of caller memory: the pointer itself, or a staged copy in `buf`
 template <class T>
@@ -653,8 +682,8 @@ RC_EXPORT int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_
     if (!bitmap || nx == 0 || ny == 0 || (!out && out_cap_triplets)) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
     if (reduction_level == 1 && (bit_depth == 0 || bit_depth > 64)) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..64");
     if (reduction_level == 1 && !pixvals && pixvals_bytes) return fail(RC_ERR_BAD_ARG, "pixvals is NULL");
-    std::lock_guard<std::mutex> lock(g_util.mu);
-    int r = util_init();
+    UtilScope util_scope;
+    int r = util_scope.enter();
     if (r != RC_OK) return r;
     Util &u = g_util;
     const uint64_t N = (uint64_t)nx * ny, nb = (N + 7) / 8, nb8 = (nb + 7) / 8;
@@ -671,7 +700,7 @@ RC_EXPORT int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_
     uint32_t *blk_cnt = reinterpret_cast<uint32_t *>(u.w), *blk_off = blk_cnt + nblk;
     uint64_t *nnz_dev = reinterpret_cast<uint64_t *>(blk_cnt + 2 * (uint64_t)nblk);
     // pass 1: count, so the output can be bounds-checked (and sized) before anything is written
-    rc::launch_expand_count(d_bm, nb8, blk_cnt, blk_off, nnz_dev, u.stream);
+    rc::launch_expand_count(d_bm, nb8, N, blk_cnt, blk_off, nnz_dev, u.stream);
     HIP_TRY(hipMemcpyAsync(u.h_scalar, nnz_dev, 8, hipMemcpyDeviceToHost, u.stream));
     HIP_TRY(hipStreamSynchronize(u.stream));
     const uint64_t nnz = *u.h_scalar;
@@ -700,8 +729,8 @@ RC_EXPORT int rc_bit_pack(const uint16_t *pixvals, uint64_t n, uint32_t bit_dept
     if (bit_depth == 0 || bit_depth > 32) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..32");
     if (out_n != (n * bit_depth + 7) / 8) return fail(RC_ERR_BAD_ARG, "out_n must be ceil(n*bit_depth/8)");
     if (out_n == 0) return RC_OK;
-    std::lock_guard<std::mutex> lock(g_util.mu);
-    int r = util_init();
+    UtilScope util_scope;
+    int r = util_scope.enter();
     if (r != RC_OK) return r;
     Util &u = g_util;
     const uint16_t *d_in = nullptr;
@@ -727,8 +756,8 @@ RC_EXPORT int rc_bit_unpack(const uint8_t *packed, uint64_t packed_bytes, uint64
     if (bit_depth == 0 || bit_depth > 64) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..64");
     if ((n * bit_depth + 7) / 8 > packed_bytes) return fail(RC_ERR_CORRUPT, "packed shorter than n * bit_depth bits");
     if (n == 0) return RC_OK;
-    std::lock_guard<std::mutex> lock(g_util.mu);
-    int r = util_init();
+    UtilScope util_scope;
+    int r = util_scope.enter();
     if (r != RC_OK) return r;
     Util &u = g_util;
     const uint8_t *d_in = nullptr;
@@ -990,15 +1019,15 @@ RC_EXPORT int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, u
     (void)level;  // the device encoders have a single effort level
     if (!dst || !out_n || (!src && n)) return fail(RC_ERR_BAD_ARG, "NULL argument");
     if (scheme == RC_SCHEME_BLOSC_LZ4) {
-        std::lock_guard<std::mutex> lock(g_util.mu);
-        int r = util_init();
+        UtilScope util_scope;
+        int r = util_scope.enter();
         if (r != RC_OK) return r;
         return blosc_compress(src, n, dst, dst_cap, out_n);
     }
     if (scheme != RC_SCHEME_LZ4 && scheme != RC_SCHEME_ZSTD)
         return fail(RC_ERR_UNSUPPORTED, "rc_compress: compression scheme not implemented on device");
-    std::lock_guard<std::mutex> lock(g_util.mu);
-    int r = util_init();
+    UtilScope util_scope;
+    int r = util_scope.enter();
     if (r != RC_OK) return r;
     return scheme == RC_SCHEME_LZ4 ? lz4_compress(src, n, dst, dst_cap, out_n) : zstd_compress(src, n, dst, dst_cap, out_n);
 }
@@ -1100,8 +1129,8 @@ RC_EXPORT int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uin
     if (!src || !out_n || (!dst && dst_cap)) return fail(RC_ERR_BAD_ARG, "NULL argument");
     if (scheme != RC_SCHEME_LZ4 && scheme != RC_SCHEME_BLOSC_LZ4)  // zstd decoding stays with the stock library on the host, like the reference (recode_compressors.py:46)
         return fail(RC_ERR_UNSUPPORTED, "rc_decompress: compression scheme not implemented on device");
-    std::lock_guard<std::mutex> lock(g_util.mu);
-    int r = util_init();
+    UtilScope util_scope;
+    int r = util_scope.enter();
     if (r != RC_OK) return r;
     return scheme == RC_SCHEME_LZ4 ? lz4_decompress(src, n, dst, dst_cap, out_n) : blosc_decompress(src, n, dst, dst_cap, out_n);
 }
@@ -1118,7 +1147,7 @@ RC_EXPORT uint64_t rc_compress_bound(uint32_t scheme, uint64_t n)
 RC_EXPORT int rc_synth_dark(int device_id, uint32_t seed, uint64_t n_pixels, uint16_t *dark_dev)
 {
     if (!dark_dev) return fail(RC_ERR_BAD_ARG, "NULL argument");
-    HIP_TRY(hipSetDevice(device_id));
+    RC_ON_DEVICE(device_id);
     rc::launch_synth_dark(seed, n_pixels, dark_dev, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -1128,7 +1157,7 @@ RC_EXPORT int rc_synth_frames(int device_id, uint32_t seed, uint32_t first_frame
                               uint32_t sparsity_ppm, const uint16_t *dark_dev, uint16_t *frames_dev)
 {
     if (!dark_dev || !frames_dev || n_frames == 0) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
-    HIP_TRY(hipSetDevice(device_id));
+    RC_ON_DEVICE(device_id);
     rc::launch_synth_frames(seed, first_frame, n_frames, n_pixels, sparsity_ppm, dark_dev, frames_dev, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

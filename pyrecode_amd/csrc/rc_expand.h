@@ -3,8 +3,8 @@
 #include "rc_device.h"
 
 namespace rc {
-void launch_expand_count(const uint8_t *bitmap_pad8, uint64_t nb8, uint32_t *blk_cnt, uint32_t *blk_off, uint64_t *nnz_dev,
-                         hipStream_t s);
+void launch_expand_count(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, uint32_t *blk_cnt, uint32_t *blk_off,
+                         uint64_t *nnz_dev, hipStream_t s);
 void launch_expand_emit(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, uint32_t nx, const uint32_t *blk_off,
                         const uint8_t *pix, uint64_t pix_bytes, uint32_t d, uint32_t level, uint64_t cap, uint64_t *out,
                         hipStream_t s);

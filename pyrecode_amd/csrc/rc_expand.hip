@@ -10,15 +10,24 @@ namespace rc {
 
 
 // bitmap is padded with zero bytes to a multiple of 8 by the host wrapper, so 8-byte loads are always in bounds.
-__global__ __launch_bounds__(WG) void k_expand_count(const uint8_t *__restrict__ bitmap, uint64_t nb8, uint32_t *__restrict__ blk_cnt)
+// 64 bitmap bits of word i with the bits of pixels at or past N cleared: a well-formed bitmap has them zero, a foreign or
+// damaged file may not, and the count pass and the emit pass must agree on what they see
+__device__ __forceinline__ uint64_t expand_word(const uint8_t *__restrict__ bitmap, uint64_t nb8, uint64_t N, uint64_t i)
+{
+    if (i >= nb8) return 0;
+    const u32x2 v = reinterpret_cast<const u32x2 *>(bitmap)[i];
+    uint64_t bits = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    const uint64_t k0 = i * 64;
+    if (k0 + 64 > N) bits = k0 >= N ? 0 : bits & ((1ull << (N - k0)) - 1);
+    return bits;
+}
+
+__global__ __launch_bounds__(WG) void k_expand_count(const uint8_t *__restrict__ bitmap, uint64_t nb8, uint64_t N,
+                                                       uint32_t *__restrict__ blk_cnt)
 {
     __shared__ uint32_t sm[WAVES + 1];
     const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;  // 8-byte word index
-    uint32_t c = 0;
-    if (i < nb8) {
-        const u32x2 v = reinterpret_cast<const u32x2 *>(bitmap)[i];
-        c = (uint32_t)(__builtin_popcount(v[0]) + __builtin_popcount(v[1]));
-    }
+    const uint32_t c = (uint32_t)__builtin_popcountll(expand_word(bitmap, nb8, N, i));
     uint32_t tot;
     (void)block_excl_scan(c, sm, &tot);
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
@@ -64,14 +73,8 @@ __global__ __launch_bounds__(WG) void k_expand_emit(const uint8_t *__restrict__ 
 {
     __shared__ uint32_t sm[WAVES + 1];
     const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    uint64_t bits = 0;
-    if (i < nb8) {
-        const u32x2 v = reinterpret_cast<const u32x2 *>(bitmap)[i];
-        bits = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
-    }
-    // pixels at or past N never count (a well-formed bitmap has them zero; be safe on foreign files)
+    uint64_t bits = expand_word(bitmap, nb8, N, i);
     const uint64_t k0 = i * 64;
-    if (k0 + 64 > N) bits = k0 >= N ? 0 : bits & ((1ull << (N - k0)) - 1);
     uint32_t tot;
     uint64_t rank = blk_off[blockIdx.x] + block_excl_scan((uint32_t)__builtin_popcountll(bits), sm, &tot);
     for (; bits; bits &= bits - 1, ++rank) {
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(WG) void k_expand_emit(const uint8_t *__restrict__ 
     }
 }
 
-void launch_expand_count(const uint8_t *bitmap_pad8, uint64_t nb8, uint32_t *blk_cnt, uint32_t *blk_off, uint64_t *nnz_dev,
-                         hipStream_t s)
+void launch_expand_count(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, uint32_t *blk_cnt, uint32_t *blk_off,
+                         uint64_t *nnz_dev, hipStream_t s)
 {
     const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
-    hipLaunchKernelGGL(k_expand_count, dim3(nblk), dim3(WG), 0, s, bitmap_pad8, nb8, blk_cnt);
+    hipLaunchKernelGGL(k_expand_count, dim3(nblk), dim3(WG), 0, s, bitmap_pad8, nb8, N, blk_cnt);
     hipLaunchKernelGGL(k_expand_scan, dim3(1), dim3(WG), 0, s, blk_cnt, blk_off, nblk, nnz_dev);
 }
 void launch_expand_emit(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, uint32_t nx, const uint32_t *blk_off,

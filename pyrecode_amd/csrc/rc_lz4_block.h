@@ -193,8 +193,12 @@ __device__ __forceinline__ uint64_t bitshuffle_block(uint64_t elem, uint32_t n, 
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// Wave-collective: write the block to its slot = [u32 LZ4F block word][payload]; returns slot bytes used.
-__device__ __forceinline__ uint32_t lz4_store_block(uint8_t *slot, uint64_t own, uint32_t n, uint32_t csize, const Lz4Lds &L)
+// Wave-collective: write the block to its slot = [u32 LZ4F block word][payload]; returns slot bytes used.  *nst (optional)
+// is increased by the number of vector store instructions issued, or by FEWER when that is not certain: the reduce kernel
+// waits for its prefetched loads with `s_waitcnt vmcnt(nst)` (rc_reduce.hip), where an over-estimate would be an error and an
+// under-estimate only waits a little longer.
+__device__ __forceinline__ uint32_t lz4_store_block(uint8_t *slot, uint64_t own, uint32_t n, uint32_t csize, const Lz4Lds &L,
+                                                    uint32_t *nst = nullptr)
 {
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(slot);
     const int lane = lane_id();
@@ -204,13 +208,19 @@ __device__ __forceinline__ uint32_t lz4_store_block(uint8_t *slot, uint64_t own,
             slot32[1 + 2 * lane] = (uint32_t)own;
             slot32[2 + 2 * lane] = (uint32_t)(own >> 32);
         }
+        if (nst) *nst += 2;  // the size word + at least one store of the payload (n >= 1: lane 0 takes part)
         return 4 + n;
     }
     // [size word][payload] written as whole 128-byte lines (slots are 128-byte aligned, BLK_SLOT is a multiple of 128): the
     // bytes behind the payload are unused slot space, and partial-line writes cost a read-modify-write at the memory side
     const uint32_t *p = reinterpret_cast<const uint32_t *>(L.out);
-    const uint32_t ndw = ((1u + (csize + 3) / 4) + 31u) & ~31u;
+    const uint32_t ndw = ((1u + (csize + 3) / 4) + 31u) & ~31u;   // >= 32: every round below stores with lanes active
+#if defined(RC_ABLATE) && (RC_ABLATE & 2)
+    for (uint32_t i = lane; i < ndw; i += 64) if ((i == 0 ? csize : p[i - 1]) == 0x9E3779B9u) slot32[i] = 1;
+#else
     for (uint32_t i = lane; i < ndw; i += 64) slot32[i] = i == 0 ? csize : p[i - 1];
+    if (nst) *nst += (ndw + 63u) >> 6;
+#endif
     return 4 + csize;
 }
 

@@ -15,6 +15,14 @@
 
 namespace rc {
 
+// Profiling builds only (tools/build_ablate.sh): -DRC_ABLATE=<bits> drops one kind of global store of the reduce kernel while
+// keeping every computation alive (a value is "stored" only if it equals a magic number).
+//   1: residual lines   2: encoded block lines   4: the 4-byte count / size stores
+#ifndef RC_ABLATE
+#define RC_ABLATE 0
+#endif
+__device__ uint32_t g_ablate_sink;
+#define RC_ST(bit, lhs, v) do { if (RC_ABLATE & (bit)) { if ((uint32_t)(v) == 0x9E3779B9u) g_ablate_sink = 1; } else { lhs = (v); } } while (0)
 
 __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b)
 {
@@ -77,12 +85,14 @@ __device__ __forceinline__ u32x4 load8(const uint16_t *__restrict__ base, uint64
 }
 
 // Results of one (tile, frame) sitting in wave-private LDS / registers until flush_pending writes them out.  The stores are
-// issued at the END of the frame's processing, i.e. well behind the next frame's loads (which go out right after the
-// subtract): gfx9 counts loads and stores on ONE in-order counter, so the `s_waitcnt` in front of the next frame's first
-// use of its data does not have to wait for these stores, only for the loads in front of them.  (With the stores issued
-// just before that wait their full write latency was exposed on every frame: 0.49 ms -> 0.37 ms for this kernel with the
-// stores removed, 0.30 ms being the pure read time.  Holding the results back for a whole further frame cost 58 more VGPRs
-// and was slower.)
+// issued at the END of the frame's processing, i.e. behind the next frame's loads (which go out right after the subtract).
+// gfx9 counts loads and stores on ONE in-order counter (vmcnt), so the wait in front of the next frame's first use of its data
+// needs to cover the loads only: `s_waitcnt vmcnt(k)` with k = the number of store instructions issued behind them.  The
+// compiler cannot know k (the stores sit in loops) and waits with vmcnt(0), i.e. for the stores as well - under a saturated
+// read stream a store's acknowledgement takes as long as a load, and that whole latency was exposed once per frame
+// (0.445 ms; 0.324 ms with every store dropped, everything else kept: tools/prof_ablate.sh, profiles/r02_reduce_stores.md).
+// So the steady-state loads are issued by inline assembly (invisible to the compiler's wait insertion), flush_pending counts
+// the store instructions it issues, and vm_wait_loads waits with exactly that k.
 struct Pending {
     bool valid;
     uint64_t ft;        // frame * ntiles + tile
@@ -96,6 +106,42 @@ struct Pending {
     uint32_t depth;     // bits per staged value (16 = plain uint16)
     uint16_t *buf;      // where the compacted (and packed) values sit in the wave's LDS stage
 };
+
+// ---- explicit vmcnt management (see above) -----------------------------------------------------------------------------
+// The eight 16-byte loads of one tile of one frame: base + lane*16 + r*1024.  Issued by inline assembly; the results may be
+// read only behind vm_wait_loads.
+__device__ __forceinline__ void vm_issue_loads(u32x4 (&x)[R], const uint16_t *lane_ptr)
+{
+    const uint8_t *p0 = reinterpret_cast<const uint8_t *>(lane_ptr), *p1 = p0 + 4096;
+    asm volatile("global_load_dwordx4 %0, %4, off nt\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:1024 nt\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048 nt\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:3072 nt"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %4, off nt\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:1024 nt\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048 nt\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:3072 nt"
+                 : "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]) : "v"(p1) : "memory");
+}
+// Wait until at most `later` vector-memory instructions are outstanding, `later` (wave-uniform) being the number issued
+// BEHIND the loads of x; an over-estimate would let the loads through unfinished, so anything unusual waits for everything.
+// The empty statement at the end names the registers as operands: no use of them can be scheduled in front of the wait.
+__device__ __forceinline__ void vm_wait_loads(uint32_t later, u32x4 (&x)[R])
+{
+    switch (later) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) :: "memory");
+}
 
 // Wave-private LDS stage of the residual path.  `val` receives the tile's 4096 values in pixel order (8 x ds_write_b128 per
 // lane); sparse tiles are compacted from there into `out`, tiles with more than STAGE_CAP set pixels are compacted straight
@@ -136,55 +182,68 @@ __device__ __forceinline__ void pack_stage(uint16_t *pix, uint32_t cnt, uint32_t
     }
 }
 
+// Returns the number of vector store instructions issued (never more than were: see lz4_store_block).
 template <bool LEVEL1, int CODEC, bool KEEP_BITMAP>
-__device__ __forceinline__ void flush_pending(const Pending &p, uint32_t tile, uint32_t n_blk, uint8_t *__restrict__ bitmap,
-                                              uint64_t nb_stride, uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
-                                              uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, const Lz4Lds *lz,
-                                              const WaveStage *st)
+__device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t tile, uint32_t n_blk, uint8_t *__restrict__ bitmap,
+                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
+                                                  uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, const Lz4Lds *lz,
+                                                  const WaveStage *st)
 {
-    if (!p.valid) return;
+    if (!p.valid) return 0;
     const int lane = lane_id();
+    uint32_t nst = 0;
     if (LEVEL1) {
         uint32_t *dst = reinterpret_cast<uint32_t *>(pix_slots + p.ft * TILE_PX);   // slots are 8 KiB aligned
         const uint32_t *src = reinterpret_cast<const uint32_t *>(p.buf);
         // whole 128-byte lines only (the tail of the last line is unused slot space): partial-line writes cost a
         // read-modify-write at the memory side
         const uint32_t ndw = (((p.cnt * p.depth + 31) >> 5) + 31u) & ~31u;
-        for (uint32_t i = lane; i < ndw; i += 64) dst[i] = src[i];
-        if (lane == 0) tile_cnt[p.ft] = p.cnt;
+        for (uint32_t i = lane; i < ndw; i += 64) RC_ST(1, dst[i], src[i]);
+        if (lane == 0) RC_ST(4, tile_cnt[p.ft], p.cnt);
+        if (!(RC_ABLATE & 1)) nst += (ndw + 63u) >> 6;
+        if (!(RC_ABLATE & 4)) nst += 1;
     }
-    if (KEEP_BITMAP) *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)p.f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = p.own;
+    if (KEEP_BITMAP) {
+        *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)p.f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = p.own;
+        nst += 1;
+    }
     if (CODEC == 2) {
         const uint64_t bytes = (uint64_t)p.own[0] | ((uint64_t)p.own[1] << 32);
-        const uint32_t used = lz4_store_block(blk_slots + p.ft * BLK_SLOT, bytes, n_blk, p.csize, *lz);
-        if (lane == 0) blk_size[p.ft] = used;
+        const uint32_t used = lz4_store_block(blk_slots + p.ft * BLK_SLOT, bytes, n_blk, p.csize, *lz, &nst);
+        if (lane == 0) RC_ST(4, blk_size[p.ft], used);
+        if (!(RC_ABLATE & 4)) nst += 1;
     }
     if (CODEC == 1) {
-        zstd_store_block(blk_slots + p.ft * BLK_SLOT, n_blk, p.last, p.csize, p.staged, *lz);
+        zstd_store_block(blk_slots + p.ft * BLK_SLOT, n_blk, p.last, p.csize, p.staged, *lz, &nst);
         if (lane == 0) blk_size[p.ft] = p.csize;
+        nst += 1;
     }
     if (CODEC == 8) {
         uint8_t *slot = blk_slots + p.ft * BLK_SLOT;
-        const uint32_t used = lz4_store_block(slot, p.cown, n_blk, p.csize, *lz);
+        const uint32_t used = lz4_store_block(slot, p.cown, n_blk, p.csize, *lz, &nst);
         if (lane == 0) {
             if (p.csize >= n_blk) reinterpret_cast<uint32_t *>(slot)[0] = n_blk;  // blosc marks a stored block by csize == size
             blk_size[p.ft] = used;
         }
+        nst += 1;   // (the rewritten size word of a stored block is not counted: fewer is safe)
     }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)nst);
 }
 
 // One frame of one tile: x holds the 8 loaded groups of this lane (destroyed), xn receives the prefetch of `next`.
 // t: the wave's threshold tile, in registers for all BZ frames (keeping it in LDS or re-reading it from L2 was no faster).
-template <bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
+template <bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
 __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], const uint16_t *__restrict__ next, bool have_next,
                                                  const u32x4 (&t)[R], uint64_t lane_px0, uint64_t N, bool full,
                                                  uint32_t f, uint32_t tile, uint64_t ft, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
                                                  uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ blk_slots,
                                                  uint32_t *__restrict__ blk_size, Lz4Lds *s_lz, uint8_t *s_bm, WaveStage *st,
-                                                 Pending &pend)
+                                                 Pending &pend, uint32_t &stores_behind)
 {
     const int lane = lane_id();
+    // x was fetched by vm_issue_loads during the previous frame: wait for those loads, not for the stores issued since
+    if (ASMLOAD) vm_wait_loads(stores_behind, x);
     // residuals (saturating subtract, in place) and the 8-bit mask of this lane's 8 pixels, per group
     uint32_t m8[R];
 #pragma unroll
@@ -200,7 +259,9 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
     // this frame's data has arrived (the subtract above consumed it): start the NEXT frame's loads now, into the other
     // register set, so that they fly during the whole compaction + encoding of this frame ...
     if (have_next) {
-        if (ALIGNED && full) {  // the whole tile lies inside the frame (all tiles but possibly a frame's last): no predication
+        if (ASMLOAD) {  // the whole tile lies inside the frame (all tiles but possibly a frame's last): no predication
+            vm_issue_loads(xn, next + lane_px0);
+        } else if (ALIGNED && full) {
             const u32x4 *p = reinterpret_cast<const u32x4 *>(next + lane_px0);
 #pragma unroll
             for (int r = 0; r < R; ++r) xn[r] = __builtin_nontemporal_load(p + r * (GROUP_PX / 8));
@@ -317,7 +378,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
         pend.cown = bitshuffle_block(bytes, n_blk, *s_lz);
         pend.csize = lz4_encode_block(pend.cown, n_blk, *s_lz);
     }
-    flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st);
+    stores_behind = flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st);
     pend.valid = false;
 }
 
@@ -337,9 +398,14 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 //   -> [CODEC 2 / 1 / 8] the 512-byte bitmap block is LZ4-encoded / zstd-tokenized / bit-shuffled + LZ4-encoded in LDS
 //      (rc_lz4_block.h, rc_zstd_wave.h)
 //   -> all global stores (residuals, encoded block, raw bitmap, counts) go out last, as whole 128-byte lines (flush_pending)
-template <int BZ, bool ALIGNED, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
+//
+// ASMLOAD instantiation (aligned frames, every tile of the launch lies wholly inside the frame): the frames are read through
+// vm_issue_loads / vm_wait_loads, see Pending.  The other instantiation (the last, partial tile of a frame; unaligned frames)
+// leaves loads and waits to the compiler.  tile0: first tile of this launch.
+template <int BZ, bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
+                                                       uint32_t tile0, uint32_t tile_end,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
                                                        uint8_t *__restrict__ bitmap, uint64_t nb_stride,
                                                        uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
@@ -357,18 +423,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
     const uint32_t tblock = (j / ngroups) * 8u + xcd;
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t tile = tblock * WAVES + w;
-    if (tile >= ntiles) return;  // whole wavefront leaves; nothing below synchronises across wavefronts
+    const uint32_t tile = tile0 + tblock * WAVES + w;
+    if (tile >= tile_end) return;  // whole wavefront leaves; nothing below synchronises across wavefronts
     const uint64_t lane_px0 = (uint64_t)tile * TILE_PX + (uint64_t)lane * 8;
     const uint32_t f0 = grp * BZ;
     if (f0 >= B) return;
-    const bool full = (uint64_t)(tile + 1) * TILE_PX <= N;  // wave-uniform
+    const bool full = (uint64_t)(tile + 1) * TILE_PX <= N;  // wave-uniform (always true in the ASMLOAD instantiation)
 
     u32x4 xa[R], xb[R];
     {
         const uint16_t *fr = frames + (uint64_t)f0 * N;
+        if (ASMLOAD) vm_issue_loads(xa, fr + lane_px0);
+        else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) xa[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
+            for (int r = 0; r < R; ++r) xa[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
+        }
     }
     u32x4 t[R];
 #pragma unroll
@@ -384,22 +453,25 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
     pend.depth = (LEVEL1 && !RAWVAL) ? depth : 16u;
     pend.buf = nullptr;
 
+    // (first frame: the threshold loads were issued behind the frame's; their count is not known to be exact once the
+    // compiler has had its way with them, so the first wait is for everything)
+    uint32_t stores_behind = 0;
 #pragma unroll 1
     for (int z = 0; z < BZ; z += 2) {
         uint32_t f = f0 + z;
         if (f >= B) break;
         bool nxt = z + 1 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t,
+        reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
-                                                                             blk_size, lz, bm, st, pend);
+                                                                             blk_size, lz, bm, st, pend, stores_behind);
         if (!nxt) break;
         ++f;
         nxt = z + 2 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t,
+        reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
-                                                                             blk_size, lz, bm, st, pend);
+                                                                             blk_size, lz, bm, st, pend, stores_behind);
         if (!nxt) break;
     }
     flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st);
@@ -409,10 +481,18 @@ template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW>
 static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t depth, hipStream_t s)
 {
     const uint32_t ngroups = (B + BZ - 1) / BZ;
-    const uint32_t ntb = (sc.ntiles + WAVES - 1) / WAVES;
-    const uint32_t grid = ((ntb + 7) / 8) * 8 * ngroups;
-    hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, L1, CODEC, KEEP, RAW>), dim3(grid), dim3(WG), 0, s, frames, sc.thr, sc.N,
-                       sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots, sc.blk_size, depth, sc.status);
+    auto grid_for = [&](uint32_t nt) { return (((nt + WAVES - 1) / WAVES + 7) / 8) * 8 * ngroups; };
+    // aligned frames: the tiles that lie wholly inside the frame go through the explicit-wait instantiation; a partial last
+    // tile (N not a multiple of TILE_PX) gets a second, tiny launch of the plain one
+    const uint32_t nfull = AL ? (uint32_t)(sc.N / TILE_PX) : 0u;
+    if (nfull)
+        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, AL, L1, CODEC, KEEP, RAW>), dim3(grid_for(nfull)), dim3(WG), 0, s, frames, sc.thr, sc.N,
+                           sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
+                           sc.blk_size, depth, sc.status);
+    if (nfull < sc.ntiles)
+        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(WG), 0, s, frames,
+                           sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
+                           sc.blk_slots, sc.blk_size, depth, sc.status);
 }
 template <int BZ, bool AL, bool L1, bool RAW>
 static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s)

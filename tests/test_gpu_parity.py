@@ -362,14 +362,15 @@ def test_synth_generator_host_device_identical(hip):
 
 
 # ---- reduction level 2: specification by intent, checked against scipy.ndimage.label + numpy -----------------
-def _l2_expected(frame, thr, stat):
+def _l2_expected(frame, thr, stat, d=16):
     import scipy.ndimage as nd
     binary = frame > thr
     labels, n = nd.label(binary, structure=np.ones((3, 3), int))        # recode_writer.py:443 (8-connectivity, raster label order)
     idx = np.arange(1, n + 1)
     f = frame.astype(np.int64)
     vals = nd.maximum(f, labels, idx) if stat in (0, 1) else nd.sum(f, labels, idx)
-    return binary, (np.asarray(vals, np.int64) & 0xFFFF).astype(np.uint16) if n else np.zeros(0, np.uint16)
+    # the statistic is stored in d bits like every pixel value: a sum that does not fit is clamped at 2^d - 1 (rc_l2.hip)
+    return binary, np.minimum(np.asarray(vals, np.int64), (1 << d) - 1).astype(np.uint16) if n else np.zeros(0, np.uint16)
 
 
 @pytest.mark.parametrize("ny,nx,s,d,stat,scheme,mode", [
@@ -388,7 +389,7 @@ def test_l2_summary_statistics(hip, orc, ny, nx, s, d, stat, scheme, mode):
     out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
     for z in range(frames.shape[0]):
         r = out[int(rec[z]):int(rec[z + 1])].tobytes()
-        binary, vals = _l2_expected(frames[z], thr, stat)
+        binary, vals = _l2_expected(frames[z], thr, stat, d)
         bitmap = orc.pack_binary_frame(binary).tobytes()
         packed = orc.bit_pack(vals, d).tobytes()
         if mode == 0:

@@ -1,7 +1,11 @@
 #!/bin/bash
-# A/B on one box: ab_build/librecode_hip_A.so (a build of an earlier commit) against the in-tree library, interleaved.
-# usage: tools/ab.sh <quick_perf args...>
-for i in $(seq 1 ${AB_N:-3}); do
-  echo "A:"; RC_AB_LIB=ab_build/librecode_hip_A.so timeout -k 10 120 python tools/quick_perf.py "$@" || exit 1
-  echo "B:"; timeout -k 10 120 python tools/quick_perf.py "$@" || exit 1
+# Same-box A/B of library builds with tools/quick_perf.py: tools/ab.sh "<quick_perf args>" libA.so libB.so ...  ("main" = the product build)
+# three interleaved rounds; prints one line per (round, build).
+ARGS=$1; shift
+for round in 1 2 3; do
+  for v in "$@"; do
+    if [ $v = main ]; then unset RC_AB_LIB; else export RC_AB_LIB=$(pwd)/$v; fi
+    echo -n "$(basename $v): "
+    python3 tools/quick_perf.py $ARGS 2>&1 | grep shape | sed 's/.*median ms/median ms/'
+  done
 done

@@ -29,11 +29,34 @@ namespace rc {
 constexpr int ZSTD_BLK = 512;
 constexpr int ZSTD_SLOT_MAX = ZSTD_BLK + 3;  // raw block: 3-byte header + payload
 
-// FSE compression tables of the predefined literal-length and match-length distributions (accuracy log 6).
+// FSE compression tables of a literal-length and a match-length distribution: the format's predefined ones (accuracy log 6,
+// zstd_build_tables) or a ctx's fitted ones (accuracy log up to 9, rc_zstd_model.h).
 struct ZstdTables {
-    uint16_t ll_state[64], ml_state[64];
+    uint16_t ll_state[512], ml_state[512];
     uint32_t ll_dnb[36], ml_dnb[53];   // deltaNbBits
     int32_t ll_dfs[36], ml_dfs[53];    // deltaFindState
+    uint32_t ll_log, ml_log;           // accuracy logs
+};
+
+// ---- the "modelled" encoder's tables (fitted on the host, rc_zstd_model.h; used by the kernels) -----------------------------
+constexpr int ZM_HUF_MAXBITS = 11;   // Huffman: the format's maximum code length
+constexpr int ZM_LL_SYMS = 36, ZM_ML_SYMS = 53;
+constexpr int ZM_DESC_MAX = 192;     // bytes reserved for one description
+// a flat POD copied to the device as it stands
+struct ZstdModel {
+    // Huffman code of every byte value: code value | length << 12 (length 1..11), for the bitmap literals and for the bytes of
+    // the packed residual stream
+    uint16_t lit_code[256];
+    uint16_t pix_code[256];
+    ZstdTables seq;                       // FSE compression tables of the literal-length / match-length codes
+    uint8_t lit_desc[ZM_DESC_MAX];        // Huffman tree description of lit_code (as it stands in a Compressed_Literals_Block)
+    uint8_t pix_desc[ZM_DESC_MAX];
+    uint8_t seq_desc[ZM_DESC_MAX];        // [LL FSE table description][0x00 = the offset code of RLE mode][ML description]
+    uint32_t lit_desc_len, pix_desc_len, seq_desc_len;
+    uint32_t valid;                       // bit 0: lit, bit 1: pix, bit 2: seq usable
+};
+struct ZstdSample {   // histograms gathered by k_zstd_sample over a sample of frames
+    uint32_t lit[256], pix[256], ll[64], ml[64];
 };
 
 // (host side) FSE_buildCTable of the reference implementation, restated: spread symbols with step (size/2 + size/8 + 3), low-probability
@@ -93,6 +116,8 @@ inline void zstd_build_tables(ZstdTables &t)
                                    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
     zstd_build_ctable(ll, 36, 6, t.ll_state, t.ll_dnb, t.ll_dfs);
     zstd_build_ctable(ml, 53, 6, t.ml_state, t.ml_dnb, t.ml_dfs);
+    t.ll_log = 6;
+    t.ml_log = 6;
 }
 
 // literal-length / match-length value -> (code, number of extra bits); the extra bits are value - baseline(code)
@@ -237,8 +262,8 @@ RC_HD uint32_t zstd_encode_block(const uint8_t *src, uint32_t n, uint8_t *dst, Z
             zb_add(b, mle, mlb);
             zb_flush(b);
         }
-        zb_add(b, st_ml, 6);  // FSE_flushCState: match length, (offset: 0 bits), literal length
-        zb_add(b, st_ll, 6);
+        zb_add(b, st_ml, T.ml_log);  // FSE_flushCState: match length, (offset: 0 bits), literal length
+        zb_add(b, st_ll, T.ll_log);
         zb_add(b, 1, 1);      // end mark
         zb_flush(b);
         if (b.n) { *b.p++ = (uint8_t)b.acc; }
@@ -280,8 +305,214 @@ RC_HD void fse_first(FseState &f, uint32_t llc, uint32_t mlc, const ZstdTables &
     f.st_ll = T.ll_state[(int32_t)(v >> b) + T.ll_dfs[llc]];
 }
 
+// ---- modelled blocks: Huffman-coded literals + fitted FSE tables, defined once per frame ----------------------------------
+// Every block is encoded as if the frame's tables were already known to the decoder (Treeless_Literals_Block, Repeat_Mode for
+// all three sequence tables); the FIRST block of a frame that uses the Huffman tree / the sequence tables then gets their
+// descriptions inserted (zm_insert_defs, done per frame behind the block encoders).  These serial forms are the
+// specification of what the wave-collective encoders produce (rc_zstd_wave.h, rc_pix_huff.hip) and what the CPU format
+// check feeds to stock libzstd.
+
+// Single-stream Huffman bitstream of lits[0..nlit): the LAST literal occupies the lowest bits, the first literal the
+// highest, then the end mark.  Returns the stream's byte count (dst needs nlit * 11 / 8 + 2 bytes).
+RC_HD uint32_t zm_huf_stream(const uint8_t *lits, uint32_t nlit, const uint16_t *code, uint8_t *dst)
+{
+    uint64_t acc = 0;
+    uint32_t nb = 0, o = 0;
+    for (uint32_t i = nlit; i-- > 0;) {
+        const uint32_t c = code[lits[i]];
+        acc |= (uint64_t)(c & 0xFFFu) << nb;
+        nb += c >> 12;
+        while (nb >= 8) { dst[o++] = (uint8_t)acc; acc >>= 8; nb -= 8; }
+    }
+    acc |= (uint64_t)1 << nb;
+    ++nb;
+    while (nb > 0) { dst[o++] = (uint8_t)acc; acc >>= 8; nb = nb > 8 ? nb - 8 : 0; }
+    return o;
+}
+// 3-byte literals section header, size format 0 (single stream, 10-bit sizes): type 2 = with tree, 3 = treeless
+RC_HD void zm_lit_header(uint8_t *p, uint32_t type, uint32_t regen, uint32_t comp)
+{
+    const uint32_t h = type | (regen << 4) | (comp << 14);
+    p[0] = (uint8_t)h; p[1] = (uint8_t)(h >> 8); p[2] = (uint8_t)(h >> 16);
+}
+RC_HD uint32_t zm_raw_lit_header(uint8_t *p, uint32_t nlit)
+{
+    if (nlit < 32) { p[0] = (uint8_t)(nlit << 3); return 1; }
+    p[0] = (uint8_t)((nlit << 4) | (1u << 2)); p[1] = (uint8_t)(nlit >> 4);   // 12-bit size (nlit <= 4095)
+    return 2;
+}
+// a compressed block may take part only if it still fits its slot once BOTH descriptions have been inserted into it
+RC_HD uint32_t zm_block_budget(const ZstdModel &M, uint32_t slot_bytes)
+{
+    return slot_bytes - 8u - ((M.valid & 1u) ? M.lit_desc_len : 0u) - ((M.valid & 4u) ? M.seq_desc_len : 0u);
+}
+
+// One block, serial (host only): the same parse as zstd_encode_block (zero runs >= 4 -> [literal 00][match: repeat offset 1]).
+// dst capacity: ZSTD_SLOT_MAX + 8.  lits / hbuf: caller scratch of n and n * 11 / 8 + 2 bytes.
+inline uint32_t zstd_encode_block_model(const uint8_t *src, uint32_t n, uint8_t *dst, ZstdSeq *seq, uint8_t *lits, uint8_t *hbuf,
+                                       const ZstdModel &M, bool last, uint32_t slot_bytes = 640)
+{
+    const uint32_t lastbit = last ? 1u : 0u;
+    uint32_t nseq = 0, nlit = 0, any = 0;
+    {
+        uint32_t i = 0, lit_start = 0;
+        while (i < n) {
+            if (src[i] != 0) { any = 1; ++i; continue; }
+            uint32_t j = i + 1;
+            while (j < n && src[j] == 0) ++j;
+            if (j - i >= 4) {
+                for (uint32_t k = lit_start; k <= i; ++k) lits[nlit++] = src[k];
+                seq[nseq].ll = (uint16_t)(i + 1 - lit_start);
+                seq[nseq].ml = (uint16_t)(j - i - 1);
+                ++nseq;
+                lit_start = j;
+            }
+            i = j;
+        }
+        for (uint32_t k = lit_start; k < n; ++k) lits[nlit++] = src[k];
+    }
+    if (!any) {
+        const uint32_t h = lastbit | (1u << 1) | (n << 3);
+        dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); dst[3] = 0;
+        return 4;
+    }
+    uint8_t *p = dst + 3;
+    uint32_t hb = 0;
+    if (M.valid & 1u) hb = zm_huf_stream(lits, nlit, M.lit_code, hbuf);
+    if ((M.valid & 1u) && 3 + hb < zm_raw_lit_header(p, nlit) + nlit) {   // Huffman pays
+        zm_lit_header(p, 3, nlit, hb);
+        p += 3;
+        for (uint32_t i = 0; i < hb; ++i) *p++ = hbuf[i];
+    } else {
+        p += zm_raw_lit_header(p, nlit);
+        for (uint32_t i = 0; i < nlit; ++i) *p++ = lits[i];
+    }
+    if (nseq < 128) *p++ = (uint8_t)nseq;
+    else { *p++ = (uint8_t)(128 + (nseq >> 8)); *p++ = (uint8_t)nseq; }
+    if (nseq) {
+        const bool fitted = (M.valid & 4u) != 0;
+        ZstdTables pre;
+        if (!fitted) zstd_build_tables(pre);
+        const ZstdTables &T = fitted ? M.seq : pre;
+        if (fitted) *p++ = 0xFC;                       // Repeat_Mode x 3
+        else { *p++ = (uint8_t)(1u << 4); *p++ = 0; }  // predefined, RLE offsets (code 0), predefined
+        ZstdBits b{0, 0, p};
+        uint32_t llc, llb, lle, mlc, mlb, mle;
+        zstd_ll_code(seq[nseq - 1].ll, llc, llb, lle);
+        zstd_ml_code(seq[nseq - 1].ml, mlc, mlb, mle);
+        FseState f;
+        fse_first(f, llc, mlc, T);
+        zb_add(b, lle, llb);
+        zb_add(b, mle, mlb);
+        zb_flush(b);
+        for (uint32_t s = nseq - 1; s-- > 0;) {
+            zstd_ll_code(seq[s].ll, llc, llb, lle);
+            zstd_ml_code(seq[s].ml, mlc, mlb, mle);
+            uint32_t nb = (f.st_ml + T.ml_dnb[mlc]) >> 16;
+            zb_add(b, f.st_ml, nb);
+            f.st_ml = T.ml_state[(int32_t)(f.st_ml >> nb) + T.ml_dfs[mlc]];
+            nb = (f.st_ll + T.ll_dnb[llc]) >> 16;
+            zb_add(b, f.st_ll, nb);
+            f.st_ll = T.ll_state[(int32_t)(f.st_ll >> nb) + T.ll_dfs[llc]];
+            zb_flush(b);
+            zb_add(b, lle, llb);
+            zb_add(b, mle, mlb);
+            zb_flush(b);
+        }
+        zb_add(b, f.st_ml, T.ml_log);
+        zb_add(b, f.st_ll, T.ll_log);
+        zb_add(b, 1, 1);
+        zb_flush(b);
+        if (b.n) *b.p++ = (uint8_t)b.acc;
+        p = b.p;
+    }
+    const uint32_t content = (uint32_t)(p - (dst + 3));
+    if (content >= n || 3 + content > zm_block_budget(M, slot_bytes)) {   // would not shrink (or no room for the descriptions): Raw block
+        const uint32_t h = lastbit | (n << 3);
+        dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16);
+        for (uint32_t i = 0; i < n; ++i) dst[3 + i] = src[i];
+        return 3 + n;
+    }
+    const uint32_t h = lastbit | (2u << 1) | (content << 3);
+    dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16);
+    return 3 + content;
+}
+
+// What a finished block needs from the frame's definitions: bit 0 = it is a compressed block with treeless literals,
+// bit 1 = it is a compressed block whose sequences use Repeat_Mode.  *seq_pos = offset just behind its modes byte.
+RC_HD uint32_t zm_block_needs(const uint8_t *blk, uint32_t *seq_pos)
+{
+    *seq_pos = 0;
+    if (((blk[0] >> 1) & 3u) != 2u) return 0;
+    const uint32_t lt = blk[3] & 3u;
+    uint32_t needs = 0, lsz;   // lsz: literals section bytes (header + content)
+    if (lt == 3u || lt == 2u) {
+        const uint32_t h = (uint32_t)blk[3] | ((uint32_t)blk[4] << 8) | ((uint32_t)blk[5] << 16);
+        lsz = 3 + (h >> 14);
+        if (lt == 3u) needs |= 1u;
+    } else {
+        const uint32_t sf = (blk[3] >> 2) & 3u;
+        lsz = (sf == 1u) ? 2 + (((uint32_t)blk[3] >> 4) | ((uint32_t)blk[4] << 4)) : 1 + (blk[3] >> 3);
+    }
+    const uint32_t q = 3 + lsz;
+    const uint32_t nb = blk[q] < 128 ? 1u : 2u;
+    if (blk[q] != 0 && blk[q + nb] == 0xFC) { needs |= 2u; *seq_pos = q + nb + 1; }
+    return needs;
+}
+// Byte i of the block with the descriptions selected by `add` inserted (tree behind the literals header at offset 6, sequence
+// tables behind the modes byte at seq_pos) and the three affected header fields patched.  Pure function of i: the device
+// applies it with one thread per byte, the host check in a loop.  tl / sl: lengths to insert (0 = not this block); the new
+// block is tl + sl bytes longer.
+RC_HD uint8_t zm_defs_byte(const uint8_t *blk, uint32_t seq_pos, const uint8_t *tree, uint32_t tl, const uint8_t *sdesc, uint32_t sl,
+                           uint32_t i)
+{
+    if (i < 3) {   // Block_Header: Block_Size grows
+        const uint32_t h = ((uint32_t)blk[0] | ((uint32_t)blk[1] << 8) | ((uint32_t)blk[2] << 16)) + ((tl + sl) << 3);
+        return (uint8_t)(h >> (8 * i));
+    }
+    if (i < 6 && tl) {   // literals header: treeless -> with tree, compressed size grows
+        uint32_t h = (uint32_t)blk[3] | ((uint32_t)blk[4] << 8) | ((uint32_t)blk[5] << 16);
+        h = (h & ~3u) | 2u;
+        h += tl << 14;
+        return (uint8_t)(h >> (8 * (i - 3)));
+    }
+    if (tl && i >= 6 && i < 6 + tl) return tree[i - 6];
+    uint32_t j = i - tl;                 // position in the original block (behind the tree insertion)
+    if (sl) {
+        if (j == seq_pos - 1) return 0x98;   // modes: FSE_Compressed, RLE, FSE_Compressed
+        if (j >= seq_pos) {
+            if (j < seq_pos + sl) return sdesc[j - seq_pos];
+            j -= sl;
+        }
+    }
+    return blk[j];
+}
+
+// One chunk of the packed residual stream as a block of Huffman-coded literals without sequences, or a Raw block.
+// dst capacity n + 16; hbuf scratch n * 11 / 8 + 2.
+RC_HD uint32_t zm_encode_pix_chunk(const uint8_t *src, uint32_t n, uint8_t *dst, uint8_t *hbuf, const ZstdModel &M, bool last)
+{
+    const uint32_t lastbit = last ? 1u : 0u;
+    uint32_t hb = 0;
+    if ((M.valid & 2u) && n) hb = zm_huf_stream(src, n, M.pix_code, hbuf);
+    const uint32_t budget = n > M.pix_desc_len + 8u ? n - M.pix_desc_len - 8u : 0u;   // must still beat Raw with the tree inserted
+    if (!(M.valid & 2u) || n == 0 || 3 + hb + 1 >= budget) {
+        const uint32_t h = lastbit | (n << 3);
+        dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16);
+        for (uint32_t i = 0; i < n; ++i) dst[3 + i] = src[i];
+        return 3 + n;
+    }
+    const uint32_t content = 3 + hb + 1;
+    const uint32_t h = lastbit | (2u << 1) | (content << 3);
+    dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16);
+    zm_lit_header(dst + 3, 3, n, hb);
+    for (uint32_t i = 0; i < hb; ++i) dst[6 + i] = hbuf[i];
+    dst[6 + hb] = 0;   // Number_of_Sequences
+    return 3 + content;
+}
+
 // Runs the chain over the tokens; emit(dword) receives the finished dwords in order.  acc/nb enter holding the (P & 3)
-// fixed-part bytes that share the first dword.  Returns the bit count left in acc (at most 44).  Tokens are read two
+// fixed-part bytes that share the first dword.  Returns the bit count left in acc (at most 50).  Tokens are read two
 // 16-byte chunks ahead of their use, and a sequence adds at most 29 bits for its 32-bit token, so emit() may store IN PLACE
 // from dword P >> 2 of the same slot: the write position never passes the read position.
 template <class Emit>
@@ -319,9 +550,10 @@ RC_HD uint32_t fse_chain(const ZW4 *tok4, uint32_t nseq, uint64_t &acc, uint32_t
         cur = nxt;
         nxt = ahead;
     }
-    // FSE_flushCState: match length, (offset: 0 bits), literal length; then the end mark
-    acc |= (uint64_t)(f.st_ml & 63u) << nb; nb += 6;
-    acc |= (uint64_t)(f.st_ll & 63u) << nb; nb += 6;
+    // FSE_flushCState: match length, (offset: 0 bits), literal length; then the end mark.  (Up to 31 bits are pending
+    // here and the two states add up to 18: the caller's accumulator is 64 bits wide.)
+    acc |= (uint64_t)(f.st_ml & ((1u << T.ml_log) - 1u)) << nb; nb += T.ml_log;
+    acc |= (uint64_t)(f.st_ll & ((1u << T.ll_log) - 1u)) << nb; nb += T.ll_log;
     acc |= (uint64_t)1 << nb; nb += 1;
     return nb;
 }

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../pyrecode_amd/csrc/rc_zstd_block.h"
+#include "../../pyrecode_amd/csrc/rc_zstd_model.h"
 
 // scalar stand-in for zstd_tokenize_block + k_zstd_fse on one block; slot: 640 bytes, 16-byte aligned
 static uint32_t token_form_block(const uint8_t *src, uint32_t n, uint8_t *slot, const rc::ZstdTables &T, bool last)
@@ -110,6 +111,88 @@ extern "C" int64_t zstd_check_encode_frame(const uint8_t *src, uint64_t n, uint8
         if ((uint64_t)(p - dst) + used > cap) return -1;
         memcpy(p, tmp, used);
         p += used;
+    }
+    return p - dst;
+}
+
+// ---- modelled encoder (rc_zstd_model.h + the serial block forms of rc_zstd_block.h) --------------------------------------
+// scalar stand-in for k_zstd_sample: histograms of what the plain parse of `bitmap` (512-byte blocks) and the bytes of `pix` hold
+extern "C" uint32_t zm_check_build(const uint8_t *bitmap, uint64_t nb, const uint8_t *pix, uint64_t np, rc::ZstdModel *out)
+{
+    rc::ZstdSample h;
+    memset(&h, 0, sizeof h);
+    for (uint64_t o = 0; o < nb; o += rc::ZSTD_BLK) {
+        const uint32_t n = (uint32_t)((nb - o) < rc::ZSTD_BLK ? (nb - o) : rc::ZSTD_BLK);
+        const uint8_t *src = bitmap + o;
+        uint32_t i = 0, lit_start = 0;
+        while (i < n) {
+            if (src[i] != 0) { ++i; continue; }
+            uint32_t j = i + 1;
+            while (j < n && src[j] == 0) ++j;
+            if (j - i >= 4) {
+                for (uint32_t k = lit_start; k <= i; ++k) h.lit[src[k]]++;
+                uint32_t c, b, e;
+                rc::zstd_ll_code(i + 1 - lit_start, c, b, e); h.ll[c]++;
+                rc::zstd_ml_code(j - i - 1, c, b, e); h.ml[c]++;
+                lit_start = j;
+            }
+            i = j;
+        }
+        for (uint32_t k = lit_start; k < n; ++k) h.lit[src[k]]++;
+    }
+    for (uint64_t i = 0; i < np; ++i) h.pix[pix[i]]++;
+    rc::zm_build_model(h, *out);
+    return out->valid;
+}
+extern "C" uint64_t zm_model_bytes() { return sizeof(rc::ZstdModel); }
+
+static const uint8_t kFrameHdr[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x00};  // 1 KiB window
+
+extern "C" int64_t zm_check_encode_bitmap_frame(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, const rc::ZstdModel *M)
+{
+    uint8_t *p = dst;
+    if (cap < 9) return -1;
+    memcpy(p, kFrameHdr, 6);
+    p += 6;
+    if (n == 0) { p[0] = 1; p[1] = 0; p[2] = 0; return 9; }
+    std::vector<rc::ZstdSeq> seq(rc::ZSTD_BLK / 4 + 2);
+    uint8_t lits[rc::ZSTD_BLK + 8], hbuf[rc::ZSTD_BLK * 11 / 8 + 16], blk[640 + 16];
+    uint32_t have = 0;   // definitions the frame already carries
+    for (uint64_t o = 0; o < n; o += rc::ZSTD_BLK) {
+        const uint32_t len = (uint32_t)((n - o) < rc::ZSTD_BLK ? (n - o) : rc::ZSTD_BLK);
+        uint32_t used = rc::zstd_encode_block_model(src + o, len, blk, seq.data(), lits, hbuf, *M, o + len >= n);
+        uint32_t seq_pos;
+        const uint32_t add = rc::zm_block_needs(blk, &seq_pos) & ~have;
+        have |= add;
+        const uint32_t tl = (add & 1u) ? M->lit_desc_len : 0u, sl = (add & 2u) ? M->seq_desc_len : 0u;
+        if (used + tl + sl > 640) return -2;   // the budget rule must have prevented this
+        if ((uint64_t)(p - dst) + used + tl + sl > cap) return -1;
+        for (uint32_t i = 0; i < used + tl + sl; ++i) p[i] = rc::zm_defs_byte(blk, seq_pos, M->lit_desc, tl, M->seq_desc, sl, i);
+        p += used + tl + sl;
+    }
+    return p - dst;
+}
+
+extern "C" int64_t zm_check_encode_pix_frame(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap, const rc::ZstdModel *M,
+                                             uint32_t chunk)
+{
+    uint8_t *p = dst;
+    if (cap < 9 || chunk == 0 || chunk > 1023) return -1;
+    memcpy(p, kFrameHdr, 6);
+    p += 6;
+    if (n == 0) { p[0] = 1; p[1] = 0; p[2] = 0; return 9; }
+    std::vector<uint8_t> hbuf(chunk * 11 / 8 + 16), blk(chunk + 32);
+    bool have = false;
+    for (uint64_t o = 0; o < n; o += chunk) {
+        const uint32_t len = (uint32_t)((n - o) < chunk ? (n - o) : chunk);
+        const uint32_t used = rc::zm_encode_pix_chunk(src + o, len, blk.data(), hbuf.data(), *M, o + len >= n);
+        uint32_t seq_pos;
+        const bool add = (rc::zm_block_needs(blk.data(), &seq_pos) & 1u) && !have;
+        have |= add;
+        const uint32_t tl = add ? M->pix_desc_len : 0u;
+        if ((uint64_t)(p - dst) + used + tl > cap) return -1;
+        for (uint32_t i = 0; i < used + tl; ++i) p[i] = rc::zm_defs_byte(blk.data(), 0, M->pix_desc, tl, nullptr, 0, i);
+        p += used + tl;
     }
     return p - dst;
 }

@@ -14,6 +14,7 @@
 #include "../../include/recode_hip.h"
 #include "rc_expand.h"
 #include "rc_launch.h"
+#include "rc_zstd_block.h"
 
 #define RC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -114,6 +115,10 @@ struct rc_ctx {
     uint64_t *d_rec_off = nullptr;
     uint32_t *d_md = nullptr;
     void *d_ztab = nullptr;               // zstd FSE tables (emit == 1)
+    // modelled zstd (compression_level >= 1): tables fitted to a sample of the ctx's first batch (rc_zstd_model.h)
+    bool modelled = false, model_ready = false;
+    rc::ZstdModel *d_model = nullptr, *h_model = nullptr;
+    rc::ZstdSample *d_sample = nullptr, *h_sample = nullptr;
     rc::L2Work l2;                        // level 2 workspace
     uint32_t l2_sum = 0;                  // L2_statistics: 0/1 max, 2 sum
     rc::BatchStatus *h_status = nullptr;  // pinned: [0] most recent batch, [1] first failed batch since the last sync
@@ -244,6 +249,15 @@ static int ctx_alloc(rc_ctx *c)
         zstd_tables_host(tab.data());
         HIP_TRY(hipMalloc(&c->d_ztab, tab.size()));
         HIP_TRY(hipMemcpy(c->d_ztab, tab.data(), tab.size(), hipMemcpyHostToDevice));
+        // compression_level 0 = the fast encoder (raw literals, predefined tables, stored residuals); any other level = the
+        // modelled one.  (The reference hands the level to libzstd, recode_writer.py:175-178; the device encoders have these two.)
+        c->modelled = c->clevel != 0;
+        if (c->modelled) {
+            HIP_TRY(hipMalloc((void **)&c->d_model, sizeof(ZstdModel)));
+            HIP_TRY(hipMalloc((void **)&c->d_sample, sizeof(ZstdSample)));
+            HIP_TRY(hipHostMalloc((void **)&c->h_model, sizeof(ZstdModel), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void **)&c->h_sample, sizeof(ZstdSample), hipHostMallocDefault));
+        }
     }
     HIP_TRY(hipMalloc((void **)&c->d_rec_off, (B + 1) * 8));
     HIP_TRY(hipMalloc((void **)&c->d_md, B * 3 * 4));
@@ -324,8 +338,10 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
         for (void *b : per_set)
             if (b) (void)hipFree(b);
     }
+    if (c->h_model) (void)hipHostFree(c->h_model);
+    if (c->h_sample) (void)hipHostFree(c->h_sample);
     void *bufs[] = {c->sc.thr, c->d_first_err, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
-                    c->d_md, c->d_ztab, c->l2.pos, c->l2.val, c->l2.parent, c->l2.stat, c->l2.word_rank, c->l2.frame_base};
+                    c->d_md, c->d_ztab, c->d_model, c->d_sample, c->l2.pos, c->l2.val, c->l2.parent, c->l2.stat, c->l2.word_rank, c->l2.frame_base};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     hipEvent_t sync_ev[] = {c->ev_red[0], c->ev_red[1], c->ev_post[0], c->ev_post[1]};
@@ -388,11 +404,48 @@ RC_EXPORT uint32_t rc_md_fields(const rc_ctx *c)
     return comp ? 1 : 0;
 }
 
+// Modelled zstd: fit the ctx's tables to (up to two frames of) its first batch.  The sample is tokenized by the plain encoder
+// into the scratch set the batch is about to use, k_zstd_sample turns the slots into histograms, the host builds the model
+// (rc_zstd_model.h).  Synchronous, once per ctx; every later frame carries this model's descriptions.
+static int fit_model(rc_ctx *c, const uint16_t *frames_dev, uint32_t n)
+{
+    using namespace rc;
+    hipStream_t s = c->stream;
+    const Scratch &sc = c->sets[c->cur];
+    const uint32_t ns = n < 2 ? n : 2;
+    for (int k = 0; k < 2; ++k)
+        if (c->post_pending[k]) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
+    HIP_TRY(hipMemsetAsync(c->d_sample, 0, sizeof(ZstdSample), s));
+    launch_reduce(sc, frames_dev, ns, c->level == 3 ? 3u : 1u, 1u, false, c->depth, s);
+    launch_zstd_sample(sc, ns, c->level == 1, c->depth, c->d_sample, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_sample, c->d_sample, sizeof(ZstdSample), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    zstd_model_from_sample(c->h_sample, c->h_model);
+    if (c->level != 1) c->h_model->valid &= ~2u;   // level 2 statistics / level 3: no residual-stream code
+    HIP_TRY(hipMemcpyAsync(c->d_model, c->h_model, sizeof(ZstdModel), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const ZstdModel &M = *c->h_model;
+    for (Scratch *set : {&c->sets[0], &c->sets[1], &c->sc}) {
+        set->zm_model = c->d_model;
+        set->zm_lit_code = c->d_model->lit_code;
+        set->zm_valid = M.valid;
+        set->zm_budget = zm_block_budget(M, BLK_SLOT);
+        set->zm_seq_bits = (M.valid & 4u) ? M.seq.ll_log + M.seq.ml_log : 12u;
+    }
+    c->model_ready = true;
+    return RC_OK;
+}
+
 static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint32_t first_frame_id, uint8_t *out_dev,
                          uint64_t out_cap, uint64_t *rec_off_dev, uint32_t *md_dev, bool timed)
 {
     using namespace rc;
     hipStream_t s = c->stream;
+    if (c->modelled && !c->model_ready) {
+        int r = fit_model(c, frames_dev, n);
+        if (r != RC_OK) return r;
+    }
     RecordParams rp;
     rp.level = c->level == 3 ? 3u : 1u;  // level 2 records are framed exactly like level 1 (statistics in place of residuals)
     rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
@@ -425,7 +478,8 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     // every device codec's block encoder runs inside the reduce kernel (LZ4; blosc = bit-shuffle + LZ4; zstd: the
     // byte-parallel half - literals, sequence tokens - with the serial FSE half lane-per-block behind it)
-    launch_reduce(sc, frames_dev, n, c->level, c->emit, c->keep_bitmap || c->emit == 0, c->depth, s);
+    const bool fitted_seq = c->modelled && (c->h_model->valid & 4u);
+    launch_reduce(sc, frames_dev, n, c->level, c->modelled ? 3u : c->emit, c->keep_bitmap || c->emit == 0, c->depth, s);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);
@@ -437,7 +491,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
         launch_scans(sc, n, true, false, ps);
         launch_l2(sc, c->l2, n, c->nx, c->l2_sum ? (1u << c->depth) - 1u : 0u, ps);
     }
-    if (c->emit == RC_SCHEME_ZSTD) launch_zstd_fse(sc, n, c->d_ztab, ps);
+    if (c->emit == RC_SCHEME_ZSTD) launch_zstd_fse(sc, n, fitted_seq ? (const void *)&c->d_model->seq : c->d_ztab, fitted_seq, ps);
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], ps));
     launch_scans(sc, n, c->level == 1, c->emit != 0, ps);  // (level 2: k_l2_emit has already described its value list)
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], ps));

@@ -28,6 +28,10 @@ struct Scratch {
     BatchStatus *status = nullptr;     // [1] of this batch
     BatchStatus *first_err = nullptr;  // [1] shared by both scratch sets: first failed batch since the last rc_ctx_sync
                                        //     (code, frame, total = number of the batch among those enqueued since then)
+    // modelled zstd (codec 3, rc_zstd_model.h): the ctx's model on the device and what the block encoders need of it
+    const void *zm_model = nullptr;    // ZstdModel
+    const void *zm_lit_code = nullptr; // &model->lit_code
+    uint32_t zm_valid = 0, zm_budget = 0, zm_seq_bits = 12;
 };
 
 // workspace of reduction level 2 (connected-component statistics), indexed by the batch-global compact pixel index
@@ -52,6 +56,7 @@ struct RecordParams {
 
 // rc_reduce.hip
 void launch_threshold(const uint16_t *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s);
+// codec: 0 none, 2 LZ4, 1 zstd (plain), 3 zstd (modelled), 8 blosc-lz4.
 // level: 1 residuals, 2 raw values of the set pixels (input of launch_l2), 3 bitmap only.  depth < 16 (level 1 only):
 // every tile's residuals are left in its slot already bit-packed (tile-local LSB-first stream of depth-bit fields)
 void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
@@ -77,7 +82,13 @@ void launch_blosc_unshuffle(const uint8_t *in, uint8_t *out, uint64_t nbytes, ui
                             uint32_t shuffle, hipStream_t s);
 // rc_zstd.hip
 void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s);
-void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s);  // 2nd half of the fused path
+void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, bool fitted, hipStream_t s);  // 2nd half of the fused path
+// modelled encoder (rc_zstd_model.h): histograms of a sample of plain-tokenized frames -> model (host) -> kernels
+void launch_zstd_sample(const Scratch &sc, uint32_t B, bool with_pix, uint32_t depth, void *sample_dev, hipStream_t s);
+size_t zstd_model_bytes();
+size_t zstd_sample_bytes();
+void zstd_model_from_sample(const void *sample_host, void *model_host);
+struct ZstdModel;
 void launch_zstd_gather(const Scratch &sc, uint8_t *out, hipStream_t s);
 size_t zstd_tables_bytes();
 void zstd_tables_host(void *dst);  // rc_reduce.hip: FLG | BD << 8 | HC << 16

@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
         if (lane == 0) RC_ST(4, blk_size[p.ft], used);
         if (!(RC_ABLATE & 4)) nst += 1;
     }
-    if (CODEC == 1) {
+    if (CODEC == 1 || CODEC == 3) {
         zstd_store_block(blk_slots + p.ft * BLK_SLOT, n_blk, p.last, p.csize, p.staged, *lz, &nst);
         if (lane == 0) blk_size[p.ft] = p.csize;
         nst += 1;
@@ -239,7 +239,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
                                                  uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ blk_slots,
                                                  uint32_t *__restrict__ blk_size, Lz4Lds *s_lz, uint8_t *s_bm, WaveStage *st,
-                                                 Pending &pend, uint32_t &stores_behind)
+                                                 Pending &pend, uint32_t &stores_behind, const ZmParams &zp)
 {
     const int lane = lane_id();
     // x was fetched by vm_issue_loads during the previous frame: wait for those loads, not for the stores issued since
@@ -373,6 +373,10 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
         const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
         pend.csize = zstd_tokenize_block(bytes, n_blk, pend.last, *s_lz, pend.staged);
     }
+    if (CODEC == 3) {  // zstd, modelled: Huffman-coded literals + tokens for the ctx's fitted tables (rc_zstd_wave.h)
+        const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
+        pend.csize = zstd_tokenize_block_m(bytes, n_blk, pend.last, *s_lz, pend.staged, zp);
+    }
     if (CODEC == 8) {  // blosc1 block: bit-shuffle (typesize 8), then the LZ4 block encoder
         const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
         pend.cown = bitshuffle_block(bytes, n_blk, *s_lz);
@@ -410,10 +414,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
                                                        uint8_t *__restrict__ bitmap, uint64_t nb_stride,
                                                        uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
                                                        uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, uint32_t depth,
-                                                       BatchStatus *__restrict__ status)
+                                                       BatchStatus *__restrict__ status, ZmParams zm)
 {
     // first kernel of a batch: clears the batch's status word (written later by k_layout / the level-2 kernels)
     if (blockIdx.x == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
+    __shared__ uint16_t s_code[CODEC == 3 ? 256 : 2];                                           // modelled zstd: Huffman code table
+    if (CODEC == 3) {   // (the only barrier of the kernel, in front of every early exit)
+        if (threadIdx.x < 128) reinterpret_cast<uint32_t *>(s_code)[threadIdx.x] = reinterpret_cast<const uint32_t *>(zm.lit_code)[threadIdx.x];
+        __syncthreads();
+        zm.lit_code = s_code;
+    }
     __shared__ Lz4Lds s_lz[CODEC ? WAVES : 1];                                                  // codec working set
     __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : WAVES][CODEC ? 16 : TILE_BM];  // transpose only
     __shared__ WaveStage s_stage[LEVEL1 ? WAVES : 1];                                           // compacted residuals
@@ -464,14 +474,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
         reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
-                                                                             blk_size, lz, bm, st, pend, stores_behind);
+                                                                             blk_size, lz, bm, st, pend, stores_behind, zm);
         if (!nxt) break;
         ++f;
         nxt = z + 2 < BZ && f + 1 < B;
         reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
-                                                                             blk_size, lz, bm, st, pend, stores_behind);
+                                                                             blk_size, lz, bm, st, pend, stores_behind, zm);
         if (!nxt) break;
     }
     flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st);
@@ -485,14 +495,15 @@ static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t 
     // aligned frames: the tiles that lie wholly inside the frame go through the explicit-wait instantiation; a partial last
     // tile (N not a multiple of TILE_PX) gets a second, tiny launch of the plain one
     const uint32_t nfull = AL ? (uint32_t)(sc.N / TILE_PX) : 0u;
+    const ZmParams zm{reinterpret_cast<const uint16_t *>(sc.zm_lit_code), sc.zm_valid, sc.zm_budget, sc.zm_seq_bits};
     if (nfull)
         hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, AL, L1, CODEC, KEEP, RAW>), dim3(grid_for(nfull)), dim3(WG), 0, s, frames, sc.thr, sc.N,
                            sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
-                           sc.blk_size, depth, sc.status);
+                           sc.blk_size, depth, sc.status, zm);
     if (nfull < sc.ntiles)
         hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(WG), 0, s, frames,
                            sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
-                           sc.blk_slots, sc.blk_size, depth, sc.status);
+                           sc.blk_slots, sc.blk_size, depth, sc.status, zm);
 }
 template <int BZ, bool AL, bool L1, bool RAW>
 static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s)
@@ -506,6 +517,7 @@ static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t 
     } while (0)
     if (codec == 2) RC_CODEC(2);
     else if (codec == 1) RC_CODEC(1);
+    else if (codec == 3) RC_CODEC(3);
     else if (codec == 8) RC_CODEC(8);
     else launch_reduce_t<BZ, AL, L1, 0, true, RAW>(sc, frames, B, depth, s);
 #undef RC_CODEC
@@ -554,15 +566,26 @@ __device__ __forceinline__ uint32_t scan_block_excl(uint32_t v, uint32_t *sm, ui
     return base + inc - v;
 }
 
-__device__ __forceinline__ void scan_row(const uint32_t *__restrict__ row, uint32_t *__restrict__ orow, uint32_t n,
-                                         uint32_t *__restrict__ total, uint32_t *sm)
+// adj (optional): {tile a, bytes added to a, tile b, bytes added to b}: the row's size words are read without their flag bits,
+// the two additions applied, and the clean sizes written back
+__device__ __forceinline__ void scan_row(uint32_t *__restrict__ row, uint32_t *__restrict__ orow, uint32_t n,
+                                         uint32_t *__restrict__ total, uint32_t *sm, const uint32_t *adj = nullptr)
 {
     uint32_t carry = 0;
     for (uint32_t t0 = 0; t0 < n; t0 += SCAN_T * SCAN_I) {
         const uint32_t t = t0 + threadIdx.x * SCAN_I;
         uint32_t v[SCAN_I], s = 0;
 #pragma unroll
-        for (int k = 0; k < SCAN_I; ++k) { v[k] = t + k < n ? row[t + k] : 0; s += v[k]; }
+        for (int k = 0; k < SCAN_I; ++k) {
+            v[k] = t + k < n ? row[t + k] : 0;
+            if (adj) {
+                v[k] &= 0xFFFFu;
+                if (t + k == adj[0]) v[k] += adj[1];
+                if (t + k == adj[2]) v[k] += adj[3];
+                if (t + k < n) row[t + k] = v[k];
+            }
+            s += v[k];
+        }
         uint32_t tot;
         uint32_t ex = carry + scan_block_excl(s, sm, &tot);
 #pragma unroll
@@ -575,15 +598,65 @@ __device__ __forceinline__ void scan_row(const uint32_t *__restrict__ row, uint3
     if (threadIdx.x == 0) *total = carry;
 }
 
+// Modelled zstd: every block of the frame was encoded as if the decoder already had the frame's Huffman tree and sequence
+// tables (rc_zstd_wave.h).  The first block that uses the tree (ZW_TREE) and the first whose sequences use the tables
+// (ZW_SEQ) - usually the same one, tile 0 - get the descriptions inserted here: the workgroup copies the block into LDS and
+// rewrites its slot byte by byte through zm_defs_byte (the block encoders left room: zm_block_budget).  adj receives what
+// scan_row has to add to the two blocks' sizes.
+__device__ __forceinline__ void zstd_place_defs(const Scratch &sc, uint32_t f, uint32_t *adj)
+{
+    __shared__ uint32_t s_first[2];
+    __shared__ uint32_t s_pos;
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[BLK_SLOT + 16];
+    const ZstdModel *M = reinterpret_cast<const ZstdModel *>(sc.zm_model);
+    const uint32_t n = sc.ntiles;
+    const uint32_t *row = sc.blk_size + (uint64_t)f * n;
+    if (threadIdx.x < 2) s_first[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t mt = 0xFFFFFFFFu, mq = 0xFFFFFFFFu;
+    for (uint32_t t = threadIdx.x; t < n; t += SCAN_T) {
+        const uint32_t w = row[t];
+        if ((w & ZW_TREE) && t < mt) mt = t;
+        if ((w & ZW_SEQ) && t < mq) mq = t;
+    }
+    if (mt != 0xFFFFFFFFu) atomicMin(&s_first[0], mt);
+    if (mq != 0xFFFFFFFFu) atomicMin(&s_first[1], mq);
+    __syncthreads();
+    const uint32_t t_tree = s_first[0], t_seq = s_first[1];
+    const uint32_t tl = t_tree != 0xFFFFFFFFu ? M->lit_desc_len : 0u, sl = t_seq != 0xFFFFFFFFu ? M->seq_desc_len : 0u;
+    if (threadIdx.x == 0) { adj[0] = t_tree; adj[1] = tl; adj[2] = t_seq; adj[3] = sl; }
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t t = pass == 0 ? t_tree : t_seq;
+        if (t == 0xFFFFFFFFu || (pass == 1 && t == t_tree)) continue;   // (wave-uniform: shared values)
+        const uint32_t a_tl = pass == 0 ? tl : 0u, a_sl = (pass == 1 || t_seq == t_tree) ? sl : 0u;
+        uint8_t *slot = sc.blk_slots + ((uint64_t)f * n + t) * BLK_SLOT;
+        const uint32_t size = row[t] & 0xFFFFu;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (size + 3) / 4; i += SCAN_T)
+            reinterpret_cast<uint32_t *>(s_img)[i] = reinterpret_cast<const uint32_t *>(slot)[i];
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t q; (void)zm_block_needs(s_img, &q); s_pos = q; }
+        __syncthreads();
+        const uint32_t pos = s_pos;
+        for (uint32_t i = threadIdx.x; i < size + a_tl + a_sl; i += SCAN_T)
+            slot[i] = zm_defs_byte(s_img, pos, M->lit_desc, a_tl, M->seq_desc, a_sl, i);
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_counts, int with_blocks)
 {
     __shared__ uint32_t sm[SCAN_W];
     __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_adj[4];
     const uint32_t f = blockIdx.x, n = sc.ntiles;
     const uint64_t fr = (uint64_t)f * n;
-    if (with_blocks) scan_row(sc.blk_size + fr, sc.blk_off + fr, n, sc.frame_cbytes + f, sm);
+    if (with_blocks) {
+        if (sc.zm_model) zstd_place_defs(sc, f, s_adj);
+        scan_row(sc.blk_size + fr, sc.blk_off + fr, n, sc.frame_cbytes + f, sm, sc.zm_model ? s_adj : nullptr);
+    }
     if (!with_counts) return;
-    const uint32_t *row = sc.tile_cnt + fr;
+    uint32_t *row = sc.tile_cnt + fr;
     scan_row(row, sc.tile_off + fr, n, sc.frame_nnz + f, sm);
     // suffix pass, rounds from the end: next non-empty tile
     uint32_t *nrow = sc.tile_next + fr;

@@ -9,6 +9,7 @@
 
 #include "rc_launch.h"
 #include "rc_zstd_block.h"
+#include "rc_zstd_model.h"
 #include "rc_zstd_wave.h"
 
 namespace rc {
@@ -48,7 +49,9 @@ constexpr int FSE_ROW = 48;  // dwords of bitstream kept in LDS per lane (192 by
 // fills the CUs (3 workgroups x 39.5 KB of the 160 KB), and a 50 KB workgroup would have to wait for one of them to leave
 constexpr int FSE_T = 128;
 
-__global__ __launch_bounds__(FSE_T) void k_zstd_fse(Scratch sc, uint32_t nslots, const ZstdTables *__restrict__ tables)
+// fitted != 0: the tables are a ctx's fitted ones and the blocks' sequences are in Repeat_Mode (ZW_SEQ is reported in the
+// size word, next to the tokenizer's ZW_TREE, for k_scan_frames to place the frame's definitions).
+__global__ __launch_bounds__(FSE_T) void k_zstd_fse(Scratch sc, uint32_t nslots, const ZstdTables *__restrict__ tables, uint32_t fitted)
 {
     __shared__ ZstdTables T;
     __shared__ uint32_t s_row[FSE_T][FSE_ROW + 1];  // + 1: rows start in different banks
@@ -61,8 +64,8 @@ __global__ __launch_bounds__(FSE_T) void k_zstd_fse(Scratch sc, uint32_t nslots,
     const uint32_t ft = blockIdx.x * FSE_T + threadIdx.x;
     if (ft >= nslots) return;
     const uint32_t word = sc.blk_size[ft];
-    if (word & ZW_FINAL) { sc.blk_size[ft] = word & 0xFFFFu; return; }
-    const uint32_t P = word & 0xFFFFu, nseq = word >> 16;
+    if (word & ZW_FINAL) { sc.blk_size[ft] = word & (0xFFFFu | ZW_TREE); return; }
+    const uint32_t P = word & 0xFFFFu, nseq = (word >> 16) & 0xFFu;
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(sc.blk_slots + (uint64_t)ft * BLK_SLOT);
     const ZW4 *tok4 = reinterpret_cast<const ZW4 *>(slot32 + (zstd_token_offset(P) >> 2));
     const uint32_t w0 = P >> 2, nb0 = 8 * (P & 3u);
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(FSE_T) void k_zstd_fse(Scratch sc, uint32_t nslots,
     uint32_t o = 0;
     uint64_t acc = acc0;
     uint32_t nb = fse_chain(tok4, nseq, acc, nb0, T, [&](uint32_t v) { if (o < (uint32_t)FSE_ROW) row[o] = v; ++o; });
-    // at most 44 bits are left: one or two more dwords
+    // at most 50 bits are left: one or two more dwords
     uint32_t ndw = o + ((nb + 31) >> 5);
     const uint32_t end = 4 * (w0 + o) + ((nb + 7) >> 3);  // first byte behind the bitstream
     if (ndw <= (uint32_t)FSE_ROW) {
@@ -86,19 +89,61 @@ __global__ __launch_bounds__(FSE_T) void k_zstd_fse(Scratch sc, uint32_t nslots,
     const uint32_t content = end - 3;
     const uint32_t lastbit = (ft % sc.ntiles) + 1 == sc.ntiles ? 1u : 0u;
     slot32[0] |= lastbit | (2u << 1) | (content << 3);  // bytes 0..2 were left zero; byte 3 is the literals header
-    sc.blk_size[ft] = end;
+    sc.blk_size[ft] = end | (word & ZW_TREE) | (fitted ? ZW_SEQ : 0u);
 }
-void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s)
+void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, bool fitted, hipStream_t s)
 {
     const uint32_t nslots = B * sc.ntiles;
     hipLaunchKernelGGL(k_zstd_fse, dim3((nslots + FSE_T - 1) / FSE_T), dim3(FSE_T), 0, s, sc, nslots,
-                       reinterpret_cast<const ZstdTables *>(tables_dev));
+                       reinterpret_cast<const ZstdTables *>(tables_dev), fitted ? 1u : 0u);
 }
 
 void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s)
 {
     hipLaunchKernelGGL(k_zstd_buffer, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc);
-    launch_zstd_fse(sc, B, tables_dev, s);
+    launch_zstd_fse(sc, B, tables_dev, false, s);
+}
+
+// ---- sample for the modelled encoder ----------------------------------------------------------------------------------------
+// Runs over the slots the PLAIN tokenizer left (before k_zstd_fse): literal bytes, literal-length / match-length codes of the
+// tokens, and the bytes of the tiles' packed residual streams, into the histograms rc_zstd_model.h fits its tables to.
+__global__ __launch_bounds__(WG) void k_zstd_sample(Scratch sc, uint32_t B, uint32_t with_pix, uint32_t depth, ZstdSample *__restrict__ h)
+{
+    const uint32_t t = blockIdx.x * WAVES + (threadIdx.x >> 6), f = blockIdx.y;
+    if (t >= sc.ntiles || f >= B) return;
+    const int lane = lane_id();
+    const uint64_t ft = (uint64_t)f * sc.ntiles + t;
+    const uint32_t word = sc.blk_size[ft];
+    if (!(word & ZW_FINAL)) {
+        const uint8_t *slot = sc.blk_slots + ft * BLK_SLOT;
+        const uint32_t P = word & 0xFFFFu, nseq = word >> 16;
+        const uint32_t b3 = slot[3];
+        const uint32_t lh = (b3 & 4u) ? 2u : 1u;
+        const uint32_t nlit = lh == 1 ? (b3 >> 3) : ((b3 >> 4) | ((uint32_t)slot[4] << 4));
+        for (uint32_t i = lane; i < nlit; i += 64) atomicAdd(&h->lit[slot[3 + lh + i]], 1u);
+        const uint32_t *tok = reinterpret_cast<const uint32_t *>(slot + zstd_token_offset(P));
+        for (uint32_t i = lane; i < nseq; i += 64) {
+            const uint32_t k = tok[i];
+            atomicAdd(&h->ll[k & 63u], 1u);
+            atomicAdd(&h->ml[(k >> 6) & 63u], 1u);
+        }
+    }
+    if (with_pix) {
+        const uint32_t nbytes = (sc.tile_cnt[ft] * depth + 7) >> 3;
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * TILE_PX);
+        for (uint32_t i = lane; i < nbytes; i += 64) atomicAdd(&h->pix[p[i]], 1u);
+    }
+}
+void launch_zstd_sample(const Scratch &sc, uint32_t B, bool with_pix, uint32_t depth, void *sample_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_zstd_sample, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc, B, with_pix ? 1u : 0u, depth,
+                       reinterpret_cast<ZstdSample *>(sample_dev));
+}
+size_t zstd_model_bytes() { return sizeof(ZstdModel); }
+size_t zstd_sample_bytes() { return sizeof(ZstdSample); }
+void zstd_model_from_sample(const void *sample_host, void *model_host)
+{
+    zm_build_model(*reinterpret_cast<const ZstdSample *>(sample_host), *reinterpret_cast<ZstdModel *>(model_host));
 }
 
 size_t zstd_tables_bytes() { return sizeof(ZstdTables); }

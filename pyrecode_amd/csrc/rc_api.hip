@@ -188,6 +188,16 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
         HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
         HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
     }
+    if (c->emit == RC_SCHEME_ZSTD && c->clevel != 0 && c->level == 1) {   // modelled zstd: Huffman stage of the residual stream
+        sc.pixraw_stride = ((sc.N * 2 + 15) & ~15ull) + 32;
+        sc.nchunk_max = (uint32_t)((sc.N * 2 + PIX_CHUNK - 1) / PIX_CHUNK) + 1;
+        HIP_TRY(hipMalloc((void **)&sc.pixraw, B * sc.pixraw_stride + 64));
+        HIP_TRY(hipMalloc((void **)&sc.pix_chunks, B * (uint64_t)sc.nchunk_max * PIX_SLOT + 64));
+        HIP_TRY(hipMalloc((void **)&sc.chunk_size, B * (uint64_t)sc.nchunk_max * 4));
+        HIP_TRY(hipMalloc((void **)&sc.chunk_off, B * (uint64_t)sc.nchunk_max * 4));
+        HIP_TRY(hipMalloc((void **)&sc.frame_pbytes, B * 4));
+        HIP_TRY(hipMemset(sc.frame_pbytes, 0, B * 4));
+    }
     HIP_TRY(hipMemset(sc.frame_nnz, 0, B * 4));
     HIP_TRY(hipMemset(sc.frame_cbytes, 0, B * 4));
     HIP_TRY(hipMemset(sc.status, 0, sizeof(BatchStatus)));
@@ -334,7 +344,8 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (rc::Scratch &sc : c->sets) {
         void *per_set[] = {sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
-                           sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.status};
+                           sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.status, sc.pixraw, sc.pix_chunks, sc.chunk_size,
+                           sc.chunk_off, sc.frame_pbytes};
         for (void *b : per_set)
             if (b) (void)hipFree(b);
     }
@@ -423,6 +434,11 @@ static int fit_model(rc_ctx *c, const uint16_t *frames_dev, uint32_t n)
     HIP_TRY(hipStreamSynchronize(s));
     zstd_model_from_sample(c->h_sample, c->h_model);
     if (c->level != 1) c->h_model->valid &= ~2u;   // level 2 statistics / level 3: no residual-stream code
+    {   // a residual stream the byte-wise code cannot shrink (bit-packed depths) is stored instead, in 128 KiB Raw blocks
+        uint64_t bits = 0, total = 0;
+        for (int v = 0; v < 256; ++v) { bits += (uint64_t)c->h_sample->pix[v] * (c->h_model->pix_code[v] >> 12); total += c->h_sample->pix[v]; }
+        if (total == 0 || bits > total * 8 * 97 / 100) c->h_model->valid &= ~2u;
+    }
     HIP_TRY(hipMemcpyAsync(c->d_model, c->h_model, sizeof(ZstdModel), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     const ZstdModel &M = *c->h_model;
@@ -495,8 +511,19 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], ps));
     launch_scans(sc, n, c->level == 1, c->emit != 0, ps);  // (level 2: k_l2_emit has already described its value list)
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], ps));
+    // modelled zstd, level 1: the residual stream is laid out flat, Huffman-coded in chunks, and placed behind the bitmap stream
+    // (rc_pix_huff.hip); its encoded size is part of the record layout
+    const bool pix_huff = c->modelled && c->level == 1 && (c->h_model->valid & 2u) && sc.pixraw;
+    if (pix_huff) {
+        rp.pix_mode = 1;
+        launch_assemble(sc, rp, n, out_dev, rec_off_dev, c->batch_seq, ps);
+        launch_pix_huff(sc, n, c->depth, ps);
+        launch_pix_scan(sc, n, c->depth, ps);
+        rp.pix_mode = 2;
+    }
     launch_layout(sc, rp, n, out_cap, rec_off_dev, md_dev, ps);
     launch_assemble(sc, rp, n, out_dev, rec_off_dev, c->batch_seq++, ps);
+    if (pix_huff) launch_pix_gather(sc, n, c->depth, 16, out_dev, rec_off_dev, ps);
     if (ev) HIP_TRY(hipEventRecord(ev[4], ps));
     HIP_TRY(hipEventRecord(c->ev_post[k], ps));
     c->post_pending[k] = true;

@@ -28,6 +28,14 @@ struct Scratch {
     BatchStatus *status = nullptr;     // [1] of this batch
     BatchStatus *first_err = nullptr;  // [1] shared by both scratch sets: first failed batch since the last rc_ctx_sync
                                        //     (code, frame, total = number of the batch among those enqueued since then)
+    // modelled zstd, residual stream (rc_pix_huff.hip): the frame's packed stream flat, its PIX_CHUNK-byte chunks encoded
+    uint8_t *pixraw = nullptr;         // [B][pixraw_stride]
+    uint64_t pixraw_stride = 0;
+    uint8_t *pix_chunks = nullptr;     // [B][nchunk_max][PIX_SLOT]
+    uint32_t *chunk_size = nullptr;    // [B][nchunk_max]   encoded bytes (ZW_TREE flag: the chunk's literals are treeless)
+    uint32_t *chunk_off = nullptr;     // [B][nchunk_max]   exclusive prefix inside the frame
+    uint32_t *frame_pbytes = nullptr;  // [B]               sum of chunk_size
+    uint32_t nchunk_max = 0;
     // modelled zstd (codec 3, rc_zstd_model.h): the ctx's model on the device and what the block encoders need of it
     const void *zm_model = nullptr;    // ZstdModel
     const void *zm_lit_code = nullptr; // &model->lit_code
@@ -52,6 +60,9 @@ struct RecordParams {
     uint32_t packed_slots; // 1: pix_slots hold tile-local packed streams (level 1); 0: uint16 values (level 2 statistics)
     uint32_t first_frame_id;
     uint64_t frame_bytes;  // raw frame size = N * 2 (record upper bound, recode_writer.py:565-566)
+    uint32_t pix_mode = 0; // k_assemble / k_layout: 0 = the residual stream goes into the record as it is (stored chunks);
+                           // 1 = ONLY the residual stream, flat, into Scratch::pixraw (input of the Huffman stage);
+                           // 2 = everything but the residual stream, whose encoded size is Scratch::frame_pbytes
 };
 
 // rc_reduce.hip
@@ -68,6 +79,12 @@ void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64
                    uint32_t *md, hipStream_t s);
 void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off,
                      uint32_t batch_seq, hipStream_t s);
+// rc_pix_huff.hip: the packed residual stream of every frame (Scratch::pixraw) -> Huffman-coded zstd blocks -> the records
+constexpr uint32_t PIX_CHUNK = 1008, PIX_SLOT = 1024;
+void launch_pix_huff(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t s);
+void launch_pix_scan(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t s);   // (rc_reduce.hip)
+void launch_pix_gather(const Scratch &sc, uint32_t B, uint32_t depth, uint32_t level1_hdr, uint8_t *out, const uint64_t *rec_off,
+                       hipStream_t s);
 // rc_lz4.hip
 struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
 void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s);  // sc.bitmap = the buffer, sc.nb = its length

@@ -598,19 +598,18 @@ __device__ __forceinline__ void scan_row(uint32_t *__restrict__ row, uint32_t *_
     if (threadIdx.x == 0) *total = carry;
 }
 
-// Modelled zstd: every block of the frame was encoded as if the decoder already had the frame's Huffman tree and sequence
-// tables (rc_zstd_wave.h).  The first block that uses the tree (ZW_TREE) and the first whose sequences use the tables
-// (ZW_SEQ) - usually the same one, tile 0 - get the descriptions inserted here: the workgroup copies the block into LDS and
-// rewrites its slot byte by byte through zm_defs_byte (the block encoders left room: zm_block_budget).  adj receives what
-// scan_row has to add to the two blocks' sizes.
-__device__ __forceinline__ void zstd_place_defs(const Scratch &sc, uint32_t f, uint32_t *adj)
+// Modelled zstd: every block of a frame was encoded as if the decoder already had the frame's Huffman tree and sequence
+// tables (rc_zstd_wave.h, rc_pix_huff.hip).  The first block that uses the tree (ZW_TREE in its size word) and the first whose
+// sequences use the tables (ZW_SEQ) - usually the same one, the frame's first - get the descriptions inserted here: the
+// workgroup copies the block into LDS and rewrites its slot byte by byte through zm_defs_byte (the block encoders left
+// room).  row: the frame's size words; adj receives what scan_row has to add to the two blocks' sizes.
+__device__ __forceinline__ void zstd_place_defs(const uint32_t *__restrict__ row, uint32_t n, uint8_t *__restrict__ slots, uint32_t stride,
+                                                const uint8_t *__restrict__ tree, uint32_t tree_len, const uint8_t *__restrict__ sdesc,
+                                                uint32_t sdesc_len, uint32_t *adj)
 {
     __shared__ uint32_t s_first[2];
     __shared__ uint32_t s_pos;
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[BLK_SLOT + 16];
-    const ZstdModel *M = reinterpret_cast<const ZstdModel *>(sc.zm_model);
-    const uint32_t n = sc.ntiles;
-    const uint32_t *row = sc.blk_size + (uint64_t)f * n;
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[PIX_SLOT + 16];
     if (threadIdx.x < 2) s_first[threadIdx.x] = 0xFFFFFFFFu;
     __syncthreads();
     uint32_t mt = 0xFFFFFFFFu, mq = 0xFFFFFFFFu;
@@ -623,13 +622,13 @@ __device__ __forceinline__ void zstd_place_defs(const Scratch &sc, uint32_t f, u
     if (mq != 0xFFFFFFFFu) atomicMin(&s_first[1], mq);
     __syncthreads();
     const uint32_t t_tree = s_first[0], t_seq = s_first[1];
-    const uint32_t tl = t_tree != 0xFFFFFFFFu ? M->lit_desc_len : 0u, sl = t_seq != 0xFFFFFFFFu ? M->seq_desc_len : 0u;
+    const uint32_t tl = t_tree != 0xFFFFFFFFu ? tree_len : 0u, sl = t_seq != 0xFFFFFFFFu ? sdesc_len : 0u;
     if (threadIdx.x == 0) { adj[0] = t_tree; adj[1] = tl; adj[2] = t_seq; adj[3] = sl; }
     for (int pass = 0; pass < 2; ++pass) {
         const uint32_t t = pass == 0 ? t_tree : t_seq;
-        if (t == 0xFFFFFFFFu || (pass == 1 && t == t_tree)) continue;   // (wave-uniform: shared values)
+        if (t == 0xFFFFFFFFu || (pass == 1 && t == t_tree)) continue;   // (uniform: shared values)
         const uint32_t a_tl = pass == 0 ? tl : 0u, a_sl = (pass == 1 || t_seq == t_tree) ? sl : 0u;
-        uint8_t *slot = sc.blk_slots + ((uint64_t)f * n + t) * BLK_SLOT;
+        uint8_t *slot = slots + (uint64_t)t * stride;
         const uint32_t size = row[t] & 0xFFFFu;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < (size + 3) / 4; i += SCAN_T)
@@ -639,9 +638,30 @@ __device__ __forceinline__ void zstd_place_defs(const Scratch &sc, uint32_t f, u
         __syncthreads();
         const uint32_t pos = s_pos;
         for (uint32_t i = threadIdx.x; i < size + a_tl + a_sl; i += SCAN_T)
-            slot[i] = zm_defs_byte(s_img, pos, M->lit_desc, a_tl, M->seq_desc, a_sl, i);
+            slot[i] = zm_defs_byte(s_img, pos, tree, a_tl, sdesc, a_sl, i);
     }
     __syncthreads();
+}
+
+__host__ __device__ inline uint32_t packed_bytes(uint32_t nnz, uint32_t depth);
+
+// Residual stream of the modelled zstd encoder (rc_pix_huff.hip): per frame, sizes of the encoded chunks -> offsets, total;
+// the tree goes into the first Huffman-coded chunk.
+__global__ __launch_bounds__(SCAN_T) void k_pix_scan(Scratch sc, uint32_t depth)
+{
+    __shared__ uint32_t sm[SCAN_W];
+    __shared__ uint32_t s_adj[4];
+    const uint32_t f = blockIdx.x;
+    const ZstdModel *M = reinterpret_cast<const ZstdModel *>(sc.zm_model);
+    const uint32_t npk = packed_bytes(sc.frame_nnz[f], depth);
+    const uint32_t nch = npk ? (npk + PIX_CHUNK - 1) / PIX_CHUNK : 1u;
+    uint32_t *row = sc.chunk_size + (uint64_t)f * sc.nchunk_max;
+    zstd_place_defs(row, nch, sc.pix_chunks + (uint64_t)f * sc.nchunk_max * PIX_SLOT, PIX_SLOT, M->pix_desc, M->pix_desc_len, nullptr, 0, s_adj);
+    scan_row(row, sc.chunk_off + (uint64_t)f * sc.nchunk_max, nch, sc.frame_pbytes + f, sm, s_adj);
+}
+void launch_pix_scan(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pix_scan, dim3(B), dim3(SCAN_T), 0, s, sc, depth);
 }
 
 __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_counts, int with_blocks)
@@ -652,7 +672,11 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_cou
     const uint32_t f = blockIdx.x, n = sc.ntiles;
     const uint64_t fr = (uint64_t)f * n;
     if (with_blocks) {
-        if (sc.zm_model) zstd_place_defs(sc, f, s_adj);
+        if (sc.zm_model) {
+            const ZstdModel *M = reinterpret_cast<const ZstdModel *>(sc.zm_model);
+            zstd_place_defs(sc.blk_size + fr, n, sc.blk_slots + fr * BLK_SLOT, BLK_SLOT, M->lit_desc, M->lit_desc_len, M->seq_desc,
+                            M->seq_desc_len, s_adj);
+        }
         scan_row(sc.blk_size + fr, sc.blk_off + fr, n, sc.frame_cbytes + f, sm, sc.zm_model ? s_adj : nullptr);
     }
     if (!with_counts) return;
@@ -745,7 +769,8 @@ __host__ __device__ inline uint32_t stored_size(const FrameFmt &ff, uint32_t n)
 }
 
 __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ frame_nnz,
-                                                 const uint32_t *__restrict__ frame_cbytes, RecordParams rp, uint64_t nb,
+                                                 const uint32_t *__restrict__ frame_cbytes, const uint32_t *__restrict__ frame_pbytes,
+                                                 RecordParams rp, uint64_t nb,
                                                  uint32_t ntiles, uint32_t B, uint64_t out_cap, uint64_t *__restrict__ rec_off,
                                                  uint32_t *__restrict__ md, BatchStatus *__restrict__ st)
 {
@@ -769,7 +794,7 @@ __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ fram
             const FrameFmt ff = frame_fmt(rp.emit);
             const uint32_t cb = bitmap_hdr(ff, rp.emit, ntiles) + frame_cbytes[f] + ff.end;
             if (rp.level == 1) {
-                const uint32_t cp = stored_size(ff, npk);
+                const uint32_t cp = rp.pix_mode == 2 ? ff.hdr + frame_pbytes[f] : stored_size(ff, npk);
                 sz = 16 + (uint64_t)cb + cp; m0 = cb; m1 = cp; m2 = npk;
             } else { sz = 8 + (uint64_t)cb; m0 = cb; }
         }
@@ -801,7 +826,7 @@ __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ fram
 void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
                    uint32_t *md, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(WG), 0, s, sc.frame_nnz, sc.frame_cbytes, rp, sc.nb, sc.ntiles, B, out_cap,
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(WG), 0, s, sc.frame_nnz, sc.frame_cbytes, sc.frame_pbytes, rp, sc.nb, sc.ntiles, B, out_cap,
                        rec_off, md, sc.status);
 }
 
@@ -915,7 +940,10 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     const uint32_t t0 = (blockIdx.x * WAVES + w) * ASM_TPW;
     const int lane = lane_id();
     if (t0 >= sc.ntiles) return;
-    uint8_t *rec = out + rec_off[f];
+    // pix_mode 1: ONLY the packed residual stream, flat (no container), into the frame's row of sc.pixraw - record offsets do
+    // not exist yet; pix_mode 2: everything but the residual stream (k_pix_gather places its encoded chunks)
+    const bool flat = rp.pix_mode == 1, skip_pix = rp.pix_mode == 2;
+    uint8_t *rec = flat ? sc.pixraw + (uint64_t)f * sc.pixraw_stride : out + rec_off[f];
     const uint64_t frow = (uint64_t)f * sc.ntiles;
     const uint32_t nnz = rp.level == 1 ? sc.frame_nnz[f] : 0;
     const uint32_t npk = rp.level == 1 ? packed_bytes(nnz, rp.depth) : 0;
@@ -924,7 +952,10 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     uint32_t cb = 0;
     const FrameFmt ff = frame_fmt(rp.emit);
     const uint32_t bhdr = bitmap_hdr(ff, rp.emit, sc.ntiles);
-    if (rp.emit == 0) {
+    if (flat) {
+        bitmap_pos = 0;
+        pix_pos = 0;
+    } else if (rp.emit == 0) {
         bitmap_pos = rp.level == 1 ? 8 : 4;
         pix_pos = bitmap_pos + sc.nb;
     } else {
@@ -934,7 +965,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     }
 
     // fixed fields
-    if (t0 == 0 && lane == 0) {
+    if (t0 == 0 && lane == 0 && !flat) {
         store_u32_le(rec, rp.first_frame_id + f);
         if (rp.emit == 0) {
             if (rp.level == 1) store_u32_le(rec + 4, npk);
@@ -955,7 +986,10 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                 bf[6] = (uint8_t)((lz4f_hdr_bitmap >> 16) & 0xFF);
                 store_u32_le(bf + cb - ff.end, 0);
             }
-            if (rp.level == 1) {
+            if (rp.level == 1 && skip_pix) {
+                store_u32_le(rec + 8, ff.hdr + sc.frame_pbytes[f]);
+                store_u32_le(rec + 12, npk);
+            } else if (rp.level == 1) {
                 const uint32_t cp = stored_size(ff, npk);
                 store_u32_le(rec + 8, cp);
                 store_u32_le(rec + 12, npk);
@@ -999,7 +1033,8 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     const uint32_t sub = (uint32_t)lane >> 4, sl = (uint32_t)lane & 15u;
     const uint32_t d = rp.depth;
     // residual slots holding a tile-local packed stream of d-bit fields (level 1; uint16 values are the d = 16 case)
-    const bool pixp = rp.level == 1 && (rp.packed_slots || d == 16);
+    const bool pixp = rp.level == 1 && (rp.packed_slots || d == 16) && !skip_pix;
+    const bool plain_pos = rp.emit == 0 || flat;   // residual byte b sits at offset b (no stored-chunk headers in between)
     uint8_t *pdst = rec + pix_pos;
     constexpr int BIT = 4, PIT = 2;  // unrolled 16-dword steps per segment: 256 B of block, 128 B of residuals; longer: loop
     uint8_t *bdst[ASM_PASSES], *pdstp[ASM_PASSES];
@@ -1017,7 +1052,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
         const bool have = k < ntl;
         bn[ps] = 0; pn[ps] = 0; ps0[ps] = 0; fin_avail[ps] = 0; fin_q[ps] = 0; fin_next[ps] = sc.ntiles; fin_b[ps] = 0;
         bdst[ps] = rec; pdstp[ps] = rec; bsrc[ps] = sc.blk_slots; psrc[ps] = sc.blk_slots;
-        if (have) {
+        if (have && !flat) {
             if (rp.emit == 0) {
                 const uint64_t b0 = (uint64_t)tl * TILE_BM;
                 bn[ps] = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
@@ -1030,6 +1065,8 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                 bsrc[ps] = sc.blk_slots + (frow + tl) * BLK_SLOT;
                 if (rp.emit == 8 && sl == 0) store_u32_le(rec + bitmap_pos + 16 + 4 * (uint64_t)tl, boff);  // blosc bstarts[tl]
             }
+        }
+        if (have) {
             if (pixp) {
                 const uint32_t c = sc.tile_cnt[frow + tl];
                 if (c) {
@@ -1048,7 +1085,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                         fin_next[ps] = sc.tile_next[frow + tl];
                     }
                     pn[ps] = n;
-                    if (n && rp.emit != 0 && (b_lo >> ff.chunk_shift) != ((b_lo + n - 1) >> ff.chunk_shift)) {
+                    if (n && !plain_pos && (b_lo >> ff.chunk_shift) != ((b_lo + n - 1) >> ff.chunk_shift)) {
                         // straddles a stored-chunk header of the pixel frame (once per 4 MiB): byte by byte
                         const uint32_t *s32 = reinterpret_cast<const uint32_t *>(psrc[ps]);
                         for (uint32_t i = sl; i < n; i += 16) {
@@ -1057,7 +1094,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                         }
                         pn[ps] = 0;
                     }
-                    pdstp[ps] = pdst + (rp.emit == 0 ? b_lo : stored_pos(ff, b_lo));
+                    pdstp[ps] = pdst + (plain_pos ? b_lo : stored_pos(ff, b_lo));
                 }
             }
         }
@@ -1135,10 +1172,10 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                     first = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + tt) * TILE_PX);
                 }
             }
-            pdst[rp.emit == 0 ? fin_b[ps] : stored_pos(ff, fin_b[ps])] = (uint8_t)byte;
+            pdst[plain_pos ? fin_b[ps] : stored_pos(ff, fin_b[ps])] = (uint8_t)byte;
         }
     }
-    if (rp.level != 1 || pixp) return;
+    if (rp.level != 1 || pixp || skip_pix) return;
 
     // ---- uint16 value lists that still need packing (level 2 statistics with d < 16): bit-packed on the way, byte-wise -------
     const uint32_t tl_ = t0 + (uint32_t)lane;
@@ -1167,7 +1204,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
                 acc |= (pix_fetch(ps, v) & dmask) << filled;
                 filled += d;
             }
-            pdst[rp.emit == 0 ? b : stored_pos(ff, b)] = (uint8_t)acc;
+            pdst[plain_pos ? b : stored_pos(ff, b)] = (uint8_t)acc;
         }
     }
 }

@@ -121,12 +121,13 @@ def test_lz4_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
     ctx.close()
 
 
+@pytest.mark.parametrize("clevel", [0, 1])   # 0: the fast encoder (raw literals, predefined tables), >= 1: the modelled one
 @pytest.mark.parametrize("ny,nx,s,d,eps", SHAPES)
-def test_zstd_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
+def test_zstd_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps, clevel):
     """scheme 1: each stream must be a zstd frame that the STOCK libzstd expands to the bit-exact payload."""
     dark, frames = synth_frames(31 + nx, 4, ny, nx, s, d)
     thr = orc.threshold(dark, eps)
-    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 1, 1, 0, max_batch=4)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 1, clevel, 0, max_batch=4)
     ctx.set_threshold(thr)
     out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=3)
     for z in range(frames.shape[0]):
@@ -173,15 +174,15 @@ def _pattern_frames(ny, nx):
     return np.stack(frames).reshape(-1, ny, nx)
 
 
-@pytest.mark.parametrize("scheme", [1, 2])
+@pytest.mark.parametrize("scheme,clevel", [(1, 0), (1, 1), (2, 1)])
 @pytest.mark.parametrize("ny,nx", [(128, 256), (130, 250)])
-def test_codec_block_types(hip, orc, scheme, ny, nx):
+def test_codec_block_types(hip, orc, scheme, clevel, ny, nx):
     """Every block type of the fused encoders (zstd: RLE / Raw / Compressed incl. the in-place path for long bitstreams and
     the slot-capacity fallback; LZ4: compressed / stored) decodes with the stock library to the bit-exact bitmap."""
     frames = _pattern_frames(ny, nx)
     thr = np.full((ny, nx), 100, np.uint16)
     B = frames.shape[0]
-    ctx = hip.ReduceContext(nx, ny, 16, 1, 1, scheme, 1, 0, max_batch=B)
+    ctx = hip.ReduceContext(nx, ny, 16, 1, 1, scheme, clevel, 0, max_batch=B)
     ctx.set_threshold(thr)
     out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
     for z in range(B):
@@ -359,6 +360,63 @@ def test_synth_generator_host_device_identical(hip):
     assert np.array_equal(fr_d.cpu().numpy().view(np.uint16), synth.frames(42, 5, 3, N, 10000, dark_h))
     frac = (fr_d.cpu().numpy().view(np.uint16) > dark_h).mean()
     assert 0.008 < frac < 0.012
+
+
+# ---- zstd, modelled encoder (compression_level >= 1): tables fitted to the ctx's first batch ------------------------------
+def _check_zstd_record(orc, r, frame, thr, d, fid):
+    f, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+    assert f == fid and len(r) == 16 + cb + cp
+    binary, pix = orc.binarize_l1(frame, thr)
+    assert _zstd_system_decode(r[16:16 + cb]) == orc.pack_binary_frame(binary).tobytes()
+    packed = orc.bit_pack(pix, d).tobytes()
+    assert npk == len(packed) and _zstd_system_decode(r[16 + cb:]) == packed
+    return cb, cp, npk
+
+
+def test_zstd_modelled_ratio_on_bench_like_data(hip, orc):
+    """1 % sparse frames, residuals uniform in [1, 2047]: the modelled encoder must reach what stock libzstd
+    level 1 reaches on the same data - bitmap <= 0.16 of raw (libzstd: 0.143), residual stream <= 0.82 (libzstd: 0.80, the
+    byte-wise Huffman bound of that distribution) - and stock libzstd must expand every stream bit-exactly."""
+    ny = nx = 1024
+    dark, frames = synth_frames(5, 6, ny, nx, 0.01, 16)
+    thr = orc.threshold(dark, 0)
+    ctx = hip.ReduceContext(nx, ny, 16, 1, 1, 1, 1, 0, max_batch=3)
+    ctx.set_threshold(thr)
+    nb = ny * nx // 8
+    for lo in (0, 3):   # second batch: the model of the first one is reused
+        out, rec, md = ctx.reduce_compress_batch(frames[lo:lo + 3], first_frame_id=lo)
+        for z in range(3):
+            cb, cp, npk = _check_zstd_record(orc, out[int(rec[z]):int(rec[z + 1])].tobytes(), frames[lo + z], thr, 16, lo + z)
+            assert cb / nb <= 0.16, cb / nb
+            assert cp / npk <= 0.82, cp / npk
+    ctx.close()
+
+
+@pytest.mark.parametrize("d", [16, 12])
+def test_zstd_modelled_frames_unlike_the_sample(hip, orc, d):
+    """The model is fitted to the first batch only; later frames may look nothing like it (dense, empty, patterned,
+    definitions needed only by a late block) and must still come out as valid frames of the exact content."""
+    ny, nx = 96, 512
+    dark, sparse = synth_frames(77, 2, ny, nx, 0.01, d)
+    thr = orc.threshold(dark, 2)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 1, 3, 0, max_batch=4)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(sparse, first_frame_id=0)
+    for z in range(2):
+        _check_zstd_record(orc, out[int(rec[z]):int(rec[z + 1])].tobytes(), sparse[z], thr, d, z)
+    rng = np.random.default_rng(1)
+    hi = (1 << d) - 1
+    _, dense = synth_frames(78, 1, ny, nx, 0.4, d)
+    empty = np.zeros((1, ny, nx), np.uint16)
+    late = (dark // 2)[None].copy()                      # only the last rows carry events: the first blocks are all RLE
+    late[0, -3:, ::7] = np.minimum(dark[-3:, ::7].astype(np.int64) + rng.integers(3, 2000, dark[-3:, ::7].shape), hi)
+    full = np.zeros((1, ny, nx), np.uint16)              # solid block of set pixels (a record may not exceed the raw frame:
+    full[0, : ny * 6 // 10] = hi                         # reference recode_writer.py:565-566, so not the whole frame)
+    batch = np.concatenate([dense, empty, late, full])
+    out, rec, md = ctx.reduce_compress_batch(batch, first_frame_id=10)
+    for z in range(4):
+        _check_zstd_record(orc, out[int(rec[z]):int(rec[z + 1])].tobytes(), batch[z], thr, d, 10 + z)
+    ctx.close()
 
 
 # ---- reduction level 2 (SURVEY N1): specification by intent, checked against scipy.ndimage.label + numpy -----------------

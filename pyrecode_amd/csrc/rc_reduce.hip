@@ -93,6 +93,9 @@ __device__ __forceinline__ u32x4 load8(const uint16_t *__restrict__ base, uint64
 // (0.445 ms; 0.324 ms with every store dropped, everything else kept: tools/prof_ablate.sh, profiles/r02_reduce_stores.md).
 // So the steady-state loads are issued by inline assembly (invisible to the compiler's wait insertion), flush_pending counts
 // the store instructions it issues, and vm_wait_loads waits with exactly that k.
+// Where the stores are issued matters as well (same box, LZ4, 64 frames): at the end of the frame's processing 0.428 ms;
+// at the top of the next frame, in front of its loads 0.478 ms; right behind those loads 0.482 ms - next to a burst of loads
+// they cost more than spread out in time.
 struct Pending {
     bool valid;
     uint64_t ft;        // frame * ntiles + tile

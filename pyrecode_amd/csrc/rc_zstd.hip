@@ -5,6 +5,7 @@
 //
 // Replaces `ZstdCompressor(level, write_content_size=False).compress(bitmap)` (pyrecode/recode_writer.py:175-178,
 // recode_compressors.py:88).  Decoding stays with the stock library on the host (recode_compressors.py:46).
+#include <algorithm>
 #include <cstring>
 
 #include "rc_launch.h"
@@ -109,34 +110,47 @@ void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables
 // tokens, and the bytes of the tiles' packed residual streams, into the histograms rc_zstd_model.h fits its tables to.
 __global__ __launch_bounds__(WG) void k_zstd_sample(Scratch sc, uint32_t B, uint32_t with_pix, uint32_t depth, ZstdSample *__restrict__ h)
 {
-    const uint32_t t = blockIdx.x * WAVES + (threadIdx.x >> 6), f = blockIdx.y;
-    if (t >= sc.ntiles || f >= B) return;
+    // histograms per workgroup in LDS, added to the global ones once at the end (a few hundred counters shared by every tile
+    // of the sample: global atomics alone took 94 ms on an 11520x8184 frame)
+    __shared__ ZstdSample s_h;
+    constexpr uint32_t NW = sizeof(ZstdSample) / 4;
+    for (uint32_t i = threadIdx.x; i < NW; i += WG) reinterpret_cast<uint32_t *>(&s_h)[i] = 0;
+    __syncthreads();
+    const uint32_t f = blockIdx.y;
     const int lane = lane_id();
-    const uint64_t ft = (uint64_t)f * sc.ntiles + t;
-    const uint32_t word = sc.blk_size[ft];
-    if (!(word & ZW_FINAL)) {
-        const uint8_t *slot = sc.blk_slots + ft * BLK_SLOT;
-        const uint32_t P = word & 0xFFFFu, nseq = word >> 16;
-        const uint32_t b3 = slot[3];
-        const uint32_t lh = (b3 & 4u) ? 2u : 1u;
-        const uint32_t nlit = lh == 1 ? (b3 >> 3) : ((b3 >> 4) | ((uint32_t)slot[4] << 4));
-        for (uint32_t i = lane; i < nlit; i += 64) atomicAdd(&h->lit[slot[3 + lh + i]], 1u);
-        const uint32_t *tok = reinterpret_cast<const uint32_t *>(slot + zstd_token_offset(P));
-        for (uint32_t i = lane; i < nseq; i += 64) {
-            const uint32_t k = tok[i];
-            atomicAdd(&h->ll[k & 63u], 1u);
-            atomicAdd(&h->ml[(k >> 6) & 63u], 1u);
+    for (uint32_t t = blockIdx.x * WAVES + (threadIdx.x >> 6); t < sc.ntiles && f < B; t += gridDim.x * WAVES) {
+        const uint64_t ft = (uint64_t)f * sc.ntiles + t;
+        const uint32_t word = sc.blk_size[ft];
+        if (!(word & ZW_FINAL)) {
+            const uint8_t *slot = sc.blk_slots + ft * BLK_SLOT;
+            const uint32_t P = word & 0xFFFFu, nseq = word >> 16;
+            const uint32_t b3 = slot[3];
+            const uint32_t lh = (b3 & 4u) ? 2u : 1u;
+            const uint32_t nlit = lh == 1 ? (b3 >> 3) : ((b3 >> 4) | ((uint32_t)slot[4] << 4));
+            for (uint32_t i = lane; i < nlit; i += 64) atomicAdd(&s_h.lit[slot[3 + lh + i]], 1u);
+            const uint32_t *tok = reinterpret_cast<const uint32_t *>(slot + zstd_token_offset(P));
+            for (uint32_t i = lane; i < nseq; i += 64) {
+                const uint32_t k = tok[i];
+                atomicAdd(&s_h.ll[k & 63u], 1u);
+                atomicAdd(&s_h.ml[(k >> 6) & 63u], 1u);
+            }
+        }
+        if (with_pix) {
+            const uint32_t nbytes = (sc.tile_cnt[ft] * depth + 7) >> 3;
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * TILE_PX);
+            for (uint32_t i = lane; i < nbytes; i += 64) atomicAdd(&s_h.pix[p[i]], 1u);
         }
     }
-    if (with_pix) {
-        const uint32_t nbytes = (sc.tile_cnt[ft] * depth + 7) >> 3;
-        const uint8_t *p = reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * TILE_PX);
-        for (uint32_t i = lane; i < nbytes; i += 64) atomicAdd(&h->pix[p[i]], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < NW; i += WG) {
+        const uint32_t v = reinterpret_cast<uint32_t *>(&s_h)[i];
+        if (v) atomicAdd(reinterpret_cast<uint32_t *>(h) + i, v);
     }
 }
 void launch_zstd_sample(const Scratch &sc, uint32_t B, bool with_pix, uint32_t depth, void *sample_dev, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_zstd_sample, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc, B, with_pix ? 1u : 0u, depth,
+    const uint32_t gx = std::min<uint32_t>((sc.ntiles + WAVES - 1) / WAVES, 512u);   // workgroups loop over the tiles of their frame
+    hipLaunchKernelGGL(k_zstd_sample, dim3(gx, B), dim3(WG), 0, s, sc, B, with_pix ? 1u : 0u, depth,
                        reinterpret_cast<ZstdSample *>(sample_dev));
 }
 size_t zstd_model_bytes() { return sizeof(ZstdModel); }

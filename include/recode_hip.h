@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 1
+#define RC_ABI_VERSION 2
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -133,6 +133,32 @@ int rc_ctx_sync(rc_ctx *ctx);
  * No counterpart in the reference (one frame at a time on one core, recode_writer.py:383-399). */
 int rc_ctx_set_pipelined(rc_ctx *ctx, int on);
 int rc_ctx_wait_results(rc_ctx *ctx, void *hip_stream);
+
+/* ---- seam 1, host streaming form: the ingest / egress side of the writer's frame loop --------------------------------
+ * Replaces the body of ReCoDeWriter.run's loop and its buffered file append (pyrecode/recode_writer.py:383-399, 605-607)
+ * for callers whose frames live in host memory: RC_PIPE_SLOTS batches are in flight at once, so that the host-to-device
+ * copy of batch i+1, the kernels of batch i, the device-to-host copy of batch i-1's records and the caller's file append
+ * of batch i-2 overlap.  A slot owns device input / output buffers and pinned metadata; the caller owns the host buffers.
+ * Call order per slot: submit -> [input_done] -> result -> fetch -> fetch_wait -> submit ...
+ *
+ *   rc_host_alloc / rc_host_free          page-locked host memory (for frames read from a file and for fetched records)
+ *   rc_host_register / rc_host_unregister pin caller memory in place (a stack that is already in RAM)
+ *   rc_pipe_submit      enqueue copy-in + all kernels of one batch; returns at once.  frames_host must stay untouched until
+ *                       rc_pipe_input_done (pinned / registered memory) - pageable memory also works, the copy is then
+ *                       synchronous inside the HIP runtime
+ *   rc_pipe_result      wait for the batch; rec_offsets[n+1], md[n][3], *total = bytes of the n records.  Returns the batch's
+ *                       status (RC_ERR_RECORD_TOO_LARGE, ...)
+ *   rc_pipe_fetch       start copying the records (bytes <= *total) into dst_host; rc_pipe_fetch_wait waits for it */
+#define RC_PIPE_SLOTS 3
+void *rc_host_alloc(uint64_t bytes);
+int rc_host_free(void *p);
+int rc_host_register(void *p, uint64_t bytes);
+int rc_host_unregister(void *p);
+int rc_pipe_submit(rc_ctx *ctx, uint32_t slot, const uint16_t *frames_host, uint32_t n, uint32_t first_frame_id);
+int rc_pipe_input_done(rc_ctx *ctx, uint32_t slot);
+int rc_pipe_result(rc_ctx *ctx, uint32_t slot, uint64_t *rec_offsets, uint32_t *md, uint64_t *total);
+int rc_pipe_fetch(rc_ctx *ctx, uint32_t slot, uint8_t *dst_host, uint64_t bytes);
+int rc_pipe_fetch_wait(rc_ctx *ctx, uint32_t slot);
 
 /* Packed binary map (ceil(nx*ny/8) bytes, LSB-first) of frame i of the most recent batch: what the third element
  * of _reduce_compress's return value carries for validation frames (recode_writer.py:386,402-415,557). */

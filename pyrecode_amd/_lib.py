@@ -47,6 +47,15 @@ SIGNATURES = {
     "rc_get_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rc_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rc_ctx_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "rc_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "rc_host_free": (C.c_int, [C.c_void_p]),
+    "rc_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rc_host_unregister": (C.c_int, [C.c_void_p]),
+    "rc_pipe_submit": (C.c_int, [C.c_void_p, C.c_uint32, _u16p, C.c_uint32, C.c_uint32]),
+    "rc_pipe_input_done": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rc_pipe_result": (C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u32p, C.POINTER(C.c_uint64)]),
+    "rc_pipe_fetch": (C.c_int, [C.c_void_p, C.c_uint32, _u8p, C.c_uint64]),
+    "rc_pipe_fetch_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rc_compress": (C.c_int, [C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rc_decompress": (C.c_int, [C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rc_compress_bound": (C.c_uint64, [C.c_uint32, C.c_uint64]),
@@ -82,7 +91,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here == header / library mismatch
             fn.restype, fn.argtypes = res, args
-        if L.rc_abi_version() != 1:
+        if L.rc_abi_version() != 2:
             raise RecodeHipError("librecode_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -119,6 +128,29 @@ def ptr(a):
     if a is None:
         return None
     return int(a)
+
+
+PIPE_SLOTS = 3
+
+
+class PinnedBuffer:
+    """Page-locked host memory (rc_host_alloc) seen as a numpy uint8 array: the staging the streaming form copies from / to
+    without the HIP runtime's intermediate copy."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self._p = lib().rc_host_alloc(self.nbytes)
+        if not self._p:
+            raise RecodeHipError("rc_host_alloc(%d): %s" % (self.nbytes, last_error()))
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self._p))[:self.nbytes]
+
+    def close(self):
+        p, self._p = getattr(self, "_p", None), None
+        if p and _lib is not None:
+            self.array = None
+            _lib.rc_host_free(p)
+
+    __del__ = close
 
 
 class ReduceContext:
@@ -188,6 +220,27 @@ class ReduceContext:
     def wait_results(self, stream_handle=None):
         """Order `stream_handle` (None: the ctx's stream) behind the most recent batch's records."""
         check(lib().rc_ctx_wait_results(self._h, C.c_void_p(stream_handle) if stream_handle else None), "rc_ctx_wait_results")
+
+    # ---- host streaming form (include/recode_hip.h, rc_pipe_*) ---------------------------------------------------------
+    def pipe_submit(self, slot, frames_host, n, first_frame_id):
+        check(lib().rc_pipe_submit(self._h, slot, ptr(frames_host), n, first_frame_id), "rc_pipe_submit")
+
+    def pipe_input_done(self, slot):
+        check(lib().rc_pipe_input_done(self._h, slot), "rc_pipe_input_done")
+
+    def pipe_result(self, slot, n):
+        """Wait for the slot's batch: (rec_offsets u64[n+1], md u32[n,3], total record bytes)."""
+        rec = np.zeros(n + 1, np.uint64)
+        md = np.zeros((n, 3), np.uint32)
+        total = C.c_uint64(0)
+        check(lib().rc_pipe_result(self._h, slot, ptr(rec), ptr(md), C.byref(total)), "rc_pipe_result")
+        return rec, md, total.value
+
+    def pipe_fetch(self, slot, dst_host, nbytes):
+        check(lib().rc_pipe_fetch(self._h, slot, ptr(dst_host), nbytes), "rc_pipe_fetch")
+
+    def pipe_fetch_wait(self, slot):
+        check(lib().rc_pipe_fetch_wait(self._h, slot), "rc_pipe_fetch_wait")
 
     def binary_map(self, i):
         out = np.empty(self.bitmap_bytes, np.uint8)

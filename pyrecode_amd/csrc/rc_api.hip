@@ -129,6 +129,19 @@ struct rc_ctx {
     // optional per-enqueue stage events for the asynchronous path (rc_ctx_set_profiling)
     bool profiling = false;
     bool profile_all = getenv("RC_PROFILE_ALL_STAGES") != nullptr;
+    // host streaming form (rc_pipe_*): per slot device buffers, pinned metadata, events
+    struct PipeSlot {
+        uint16_t *d_in = nullptr;
+        uint8_t *d_out = nullptr;
+        uint64_t *d_rec = nullptr, *h_rec = nullptr;
+        uint32_t *d_md = nullptr, *h_md = nullptr;
+        rc::BatchStatus *h_stat = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_fetch = nullptr;
+        uint32_t n = 0;
+        bool zero_copy = false;
+        int state = 0;   // 0 free, 1 submitted, 2 result taken, 3 fetching
+    } pipe[RC_PIPE_SLOTS];
+    hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
     std::vector<hipEvent_t> prof_ev;   // 5 events per enqueued batch, in enqueue order
     size_t prof_used = 0;              // events consumed since the last rc_ctx_sync
     double prof_sum_ms[5] = {};
@@ -349,6 +362,16 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
         for (void *b : per_set)
             if (b) (void)hipFree(b);
     }
+    for (auto &p : c->pipe) {
+        void *dev[] = {p.d_in, p.d_out, p.d_rec, p.d_md};
+        for (void *b : dev) if (b) (void)hipFree(b);
+        void *host[] = {p.h_rec, p.h_md, p.h_stat};
+        for (void *b : host) if (b) (void)hipHostFree(b);
+        hipEvent_t evs[] = {p.ev_h2d, p.ev_done, p.ev_fetch};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_sample) (void)hipHostFree(c->h_sample);
     void *bufs[] = {c->sc.thr, c->d_first_err, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
@@ -637,6 +660,151 @@ RC_EXPORT int rc_reduce_compress_batch(rc_ctx *c, const uint16_t *frames, uint32
     if (r2 == RC_OK && out_host) r2 = copy_out(out, c->d_out, c->h_status->total, c->stream);
     if (r2 != RC_OK) return r2;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return RC_OK;
+}
+
+// ---- seam 1, host streaming form ----------------------------------------------------------------------------------------
+RC_EXPORT void *rc_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(RC_ERR_DEVICE, "hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+RC_EXPORT int rc_host_free(void *p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return RC_OK;
+}
+RC_EXPORT int rc_host_register(void *p, uint64_t bytes)
+{
+    if (!p || !bytes) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return RC_OK;
+}
+RC_EXPORT int rc_host_unregister(void *p)
+{
+    if (p) HIP_TRY(hipHostUnregister(p));
+    return RC_OK;
+}
+
+static int pipe_slot_init(rc_ctx *c, rc_ctx::PipeSlot &p)
+{
+    const uint64_t B = c->max_batch;
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->d2h_stream) HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void **)&p.d_in, B * c->sc.N * 2 + 64));
+    HIP_TRY(hipMalloc((void **)&p.d_out, rc_out_capacity(c, (uint32_t)B) + 64));
+    HIP_TRY(hipMalloc((void **)&p.d_rec, (B + 1) * 8));
+    HIP_TRY(hipMalloc((void **)&p.d_md, B * 12));
+    HIP_TRY(hipHostMalloc((void **)&p.h_rec, (B + 1) * 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&p.h_md, B * 12, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&p.h_stat, sizeof(rc::BatchStatus), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_h2d, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_fetch, hipEventDisableTiming));
+    return RC_OK;
+}
+
+RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const uint16_t *frames_host, uint32_t n, uint32_t first_frame_id)
+{
+    if (!c || !frames_host || slot >= RC_PIPE_SLOTS) return fail(RC_ERR_BAD_ARG, "NULL argument / slot out of range");
+    if (n == 0 || n > c->max_batch) return fail(RC_ERR_BAD_ARG, "n must be in 1..max_batch");
+    if (!c->thr_set) return fail(RC_ERR_BAD_ARG, "threshold not set (rc_set_threshold / rc_set_dark)");
+    RC_ON_DEVICE(c->device);
+    rc_ctx::PipeSlot &p = c->pipe[slot];
+    if (p.state != 0) return fail(RC_ERR_BAD_ARG, "slot is still in use (result / fetch_wait not called)");
+    if (!p.d_in) {
+        int r = pipe_slot_init(c, p);
+        if (r != RC_OK) return r;
+    }
+    if (!c->pipelined) {   // the streaming form always lets consecutive batches overlap
+        HIP_TRY(hipStreamSynchronize(c->pstream));
+        c->pipelined = true;
+        c->pstream = c->pstream_masked ? c->pstream_masked : c->pstream_all;
+    }
+    // Page-locked (or registered) frames are read by the reduce kernel IN PLACE, over the link: every frame byte is needed
+    // exactly once, by wide nontemporal loads, so a copy into device memory first would only add a pass (and the copy
+    // engines moved 26-31 GB/s here where the kernel's own reads move what the link gives).  RC_PIPE_COPY=1 forces the copy.
+    const uint16_t *fdev = nullptr;
+    static const bool force_copy = getenv("RC_PIPE_COPY") != nullptr;
+    if (!force_copy) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, frames_host) == hipSuccess) {
+            if (a.type == hipMemoryTypeHost && a.devicePointer) fdev = reinterpret_cast<const uint16_t *>(a.devicePointer);
+        } else (void)hipGetLastError();
+    }
+    p.zero_copy = fdev != nullptr;
+    if (!fdev) {
+        HIP_TRY(hipMemcpyAsync(p.d_in, frames_host, (uint64_t)n * c->sc.N * 2, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(p.ev_h2d, c->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, p.ev_h2d, 0));
+        fdev = p.d_in;
+    }
+    int r = enqueue_batch(c, fdev, n, first_frame_id, p.d_out, rc_out_capacity(c, c->max_batch), p.d_rec, p.d_md, false);
+    if (r != RC_OK) return r;
+    if (p.zero_copy) HIP_TRY(hipEventRecord(p.ev_h2d, c->stream));   // "input consumed" = the reduce kernel has run
+    hipStream_t ps = c->pstream;   // carries the batch's assembly: the metadata follows it
+    HIP_TRY(hipMemcpyAsync(p.h_rec, p.d_rec, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipMemcpyAsync(p.h_md, p.d_md, (uint64_t)n * 12, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipMemcpyAsync(p.h_stat, c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipEventRecord(p.ev_done, ps));
+    p.n = n;
+    p.state = 1;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_pipe_input_done(rc_ctx *c, uint32_t slot)
+{
+    if (!c || slot >= RC_PIPE_SLOTS) return fail(RC_ERR_BAD_ARG, "NULL argument / slot out of range");
+    if (c->pipe[slot].state == 0) return RC_OK;
+    HIP_TRY(hipEventSynchronize(c->pipe[slot].ev_h2d));
+    return RC_OK;
+}
+
+RC_EXPORT int rc_pipe_result(rc_ctx *c, uint32_t slot, uint64_t *rec_offsets, uint32_t *md, uint64_t *total)
+{
+    if (!c || slot >= RC_PIPE_SLOTS || !rec_offsets || !md || !total) return fail(RC_ERR_BAD_ARG, "NULL argument / slot out of range");
+    rc_ctx::PipeSlot &p = c->pipe[slot];
+    if (p.state != 1) return fail(RC_ERR_BAD_ARG, "nothing submitted on this slot");
+    HIP_TRY(hipEventSynchronize(p.ev_done));
+    p.state = 2;
+    if (p.h_stat->code != 0) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "%s (frame %u of the batch)", rc_strerror(p.h_stat->code), p.h_stat->frame);
+        p.state = 0;
+        return fail(p.h_stat->code, msg);
+    }
+    memcpy(rec_offsets, p.h_rec, (uint64_t)(p.n + 1) * 8);
+    memcpy(md, p.h_md, (uint64_t)p.n * 12);
+    *total = p.h_stat->total;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_pipe_fetch(rc_ctx *c, uint32_t slot, uint8_t *dst_host, uint64_t bytes)
+{
+    if (!c || slot >= RC_PIPE_SLOTS || (!dst_host && bytes)) return fail(RC_ERR_BAD_ARG, "NULL argument / slot out of range");
+    rc_ctx::PipeSlot &p = c->pipe[slot];
+    if (p.state != 2) return fail(RC_ERR_BAD_ARG, "rc_pipe_result has not been called for this slot");
+    if (bytes > p.h_stat->total) return fail(RC_ERR_BAD_ARG, "more bytes than the batch's records hold");
+    RC_ON_DEVICE(c->device);
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst_host, p.d_out, bytes, hipMemcpyDeviceToHost, c->d2h_stream));
+    HIP_TRY(hipEventRecord(p.ev_fetch, c->d2h_stream));
+    p.state = 3;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_pipe_fetch_wait(rc_ctx *c, uint32_t slot)
+{
+    if (!c || slot >= RC_PIPE_SLOTS) return fail(RC_ERR_BAD_ARG, "NULL argument / slot out of range");
+    rc_ctx::PipeSlot &p = c->pipe[slot];
+    if (p.state == 2) { p.state = 0; return RC_OK; }   // nothing fetched: the slot is simply released
+    if (p.state != 3) return fail(RC_ERR_BAD_ARG, "rc_pipe_fetch has not been called for this slot");
+    HIP_TRY(hipEventSynchronize(p.ev_fetch));
+    p.state = 0;
     return RC_OK;
 }
 

@@ -111,6 +111,9 @@ class ReCoDeWriter:
         self._vc_n_pixels = None
         self._vc_dose_rate = 0.0
         self._compressor_context = None
+        self._pin_in = self._pin_out = None
+        self._pin_mode = os.environ.get('RC_WRITER_PIN', 'auto')   # auto | register | stage
+        self._copy_threads = int(os.environ.get('RC_WRITER_COPY_THREADS', '6'))
         if ip.compression_scheme == 1 and not _lib.lib().rc_scheme_on_device(1):
             import zstandard as zstd
             self._compressor_context = zstd.ZstdCompressor(level=ip.compression_level, write_content_size=False)
@@ -164,6 +167,8 @@ class ReCoDeWriter:
         self._vc_roi['x_start'] = math.floor((nx - self._vc_roi['nx']) / 2.0)
         self._vc_roi['y_start'] = math.floor((ny - self._vc_roi['ny']) / 2.0)
         self._vc_n_pixels = self._vc_roi['nx'] * self._vc_roi['ny']
+        if init.validation_frame_gap <= 0:
+            self._alloc_staging()
 
     def _do_sanity_checks(self, is_first_chunk, data=None):
         ip = self._input_params
@@ -238,26 +243,135 @@ class ReCoDeWriter:
 
         run_start = datetime.now()
         gap = init.validation_frame_gap
-        for lo in range(0, available_frames, self._batch_size):
-            batch = np.ascontiguousarray(data[lo:lo + self._batch_size])
-            first_id = self._chunk_offset + frame_offset + lo
-            records, metrics = self._reduce_compress_batch(batch, first_id)
-            for rec in records:
-                if self._buffer_sz - len(self._rct_buffer) < len(rec):
-                    self._offload_buffer()
-                self._rct_buffer += rec
-            if gap > 0:
+        if gap > 0:
+            # validation frames need every batch's binary maps on the host: the synchronous path
+            for lo in range(0, available_frames, self._batch_size):
+                batch = np.ascontiguousarray(data[lo:lo + self._batch_size])
+                first_id = self._chunk_offset + frame_offset + lo
+                records, metrics = self._reduce_compress_batch(batch, first_id)
+                for rec in records:
+                    if self._buffer_sz - len(self._rct_buffer) < len(rec):
+                        self._offload_buffer()
+                    self._rct_buffer += rec
                 for i in range(batch.shape[0]):
                     if (first_id + i) % gap == 0:
                         self._validation_file.write(batch[i].tobytes())
                         run_metrics.setdefault('run_dose_rates', []).append(self._count_validation_frame(i))
-            for key, value in metrics.items():
-                run_metrics[key] = run_metrics[key] + value if key in run_metrics else value
+                for key, value in metrics.items():
+                    run_metrics[key] = run_metrics[key] + value if key in run_metrics else value
+        else:
+            for key, value in self._run_streamed(data, available_frames, self._chunk_offset + frame_offset).items():
+                run_metrics[key] = value
         self._chunk_offset += n_frames_in_chunk
         self._num_frames_in_part += available_frames
         run_metrics['run_time'] = datetime.now() - run_start
         run_metrics['run_frames'] = available_frames
         return run_metrics
+
+    def _alloc_staging(self):
+        """Page-locked staging of the streaming form: three input buffers, PIPE_SLOTS output buffers (grown on demand)."""
+        if self._pin_in is None:
+            B = self._batch_size
+            self._pin_in = [_lib.PinnedBuffer(B * self._frame_sz) for _ in range(3)]
+            self._pin_out = [_lib.PinnedBuffer(max(B * self._frame_sz // 8, 1 << 20)) for _ in range(_lib.PIPE_SLOTS)]
+
+    def _run_streamed(self, data, n_frames, first_id):
+        """The frame loop of the reference (recode_writer.py:383-399) as a stream over batches (rc_pipe_*).  Four things run at
+        once: a stager thread fills page-locked staging buffers from the source (a few copy threads; the file pages / the
+        caller's array are read exactly once), the GPU reads batch i straight out of its staging buffer and builds its
+        records, batch i-1's records travel back into a page-locked buffer, and a writer thread appends batch i-2's records
+        to the part file from that buffer - no per-record Python objects (host-compressed schemes excepted: the reference's
+        own library call needs the pieces)."""
+        from concurrent.futures import ThreadPoolExecutor
+        ctx, B = self._ctx, self._batch_size
+        frame_bytes = self._frame_sz
+        zero = timedelta(0)
+        metrics = {k: zero for k in _STAGE_KEYS}
+        if n_frames == 0:
+            return metrics
+        t_run = datetime.now()
+        nbatch = -(-n_frames // B)
+        slots = _lib.PIPE_SLOTS
+        n_in = 3
+        self._alloc_staging()
+        # RC_WRITER_PIN=register: a stack that is already in RAM is pinned in place instead and read from where it lies
+        # (saves the staging copy, costs one page-locking pass over the whole stack up front)
+        registered = None
+        if self._pin_mode == 'register' and isinstance(data, np.ndarray) and not isinstance(data, np.memmap) \
+                and data.flags['C_CONTIGUOUS'] and data.dtype == np.uint16:
+            try:
+                _lib.check(_lib.lib().rc_host_register(data.ctypes.data, data.nbytes), 'rc_host_register')
+                registered = data.ctypes.data
+            except Exception:
+                registered = None
+        copy_pool = ThreadPoolExecutor(max_workers=self._copy_threads)
+        stager = ThreadPoolExecutor(max_workers=1)
+        writer = ThreadPoolExecutor(max_workers=1)
+        info = [None] * nbatch        # per batch: [n, rec offsets, md, total]
+        staged = [None] * nbatch      # futures of the stager
+        written = [None] * nbatch     # futures of the writer
+        ny, nx = self._header['ny'], self._header['nx']
+
+        def stage(i):   # (stager thread) batch i -> staging buffer i % n_in, once the batch that last used it has been read
+            lo = i * B
+            n = min(B, n_frames - lo)
+            if registered is not None:
+                return data[lo:lo + n]
+            if i >= n_in:
+                ctx.pipe_input_done((i - n_in) % slots)
+            view = self._pin_in[i % n_in].array[:n * frame_bytes].view(np.uint16).reshape(n, ny, nx)
+            parts = max(1, min(self._copy_threads * 2, n))
+            step = -(-n // parts)
+            list(copy_pool.map(lambda a: np.copyto(view[a:a + step], data[lo + a:lo + min(a + step, n)], casting='unsafe'),
+                               range(0, n, step)))
+            return view
+
+        def append(i):  # (writer thread) batch i's records: page-locked buffer -> part file
+            ctx.pipe_fetch_wait(i % slots)
+            n, rec, md, total = info[i]
+            buf = self._pin_out[i % slots].array
+            if self._host_compress:
+                for z in range(n):
+                    self._intermediate_file.write(self._host_compress_record(buf[int(rec[z]):int(rec[z + 1])].tobytes(), metrics))
+            else:
+                self._intermediate_file.write(memoryview(buf)[:total])
+            info[i] = None
+
+        try:
+            for i in range(min(n_in - 1, nbatch)):
+                staged[i] = stager.submit(stage, i)
+            for i in range(nbatch + 1):
+                if i < nbatch:
+                    if i >= slots:
+                        written[i - slots].result()      # the slot's previous batch has left its output buffer
+                    frames = staged[i].result()
+                    n = frames.shape[0]
+                    ctx.pipe_submit(i % slots, frames, n, first_id + i * B)
+                    info[i] = [n, None, None, 0]
+                    if i + n_in - 1 < nbatch:
+                        staged[i + n_in - 1] = stager.submit(stage, i + n_in - 1)
+                if 0 <= i - 1 < nbatch:   # batch i-1 has been computed: sizes known, start copying its records out
+                    j = i - 1
+                    rec, md, total = ctx.pipe_result(j % slots, info[j][0])
+                    info[j][1:] = [rec, md, total]
+                    buf = self._pin_out[j % slots]
+                    if total > buf.nbytes:
+                        buf.close()
+                        buf = self._pin_out[j % slots] = _lib.PinnedBuffer(int(total * 1.25))
+                    ctx.pipe_fetch(j % slots, buf.array, total)
+                    written[j] = writer.submit(append, j)
+            for f in written:
+                if f is not None:
+                    f.result()
+        finally:
+            for pool in (stager, writer, copy_pool):
+                pool.shutdown(wait=True)
+            if registered is not None:
+                _lib.check(_lib.lib().rc_host_unregister(registered), 'rc_host_unregister')
+        self._intermediate_file.flush()
+        metrics['frame_time'] = datetime.now() - t_run
+        metrics['frame_thresholding_and_counting_time'] = metrics['frame_time']   # one fused, overlapped stream: not separable
+        return metrics
 
     def _count_validation_frame(self, i):
         """Dose-rate estimate on the central ROI of frame i's binary map (reference :402-415)."""
@@ -335,6 +449,9 @@ class ReCoDeWriter:
         self._intermediate_file.close()
         if self._init_params.validation_frame_gap > 0:
             self._validation_file.close()
+        for buf in (self._pin_in or []) + (self._pin_out or []):
+            buf.close()
+        self._pin_in = self._pin_out = None
         if self._ctx is not None:
             self._ctx.close()
             self._ctx = None

@@ -7,9 +7,9 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --steps 20 --warmup 3 --min-seconds 0.1 --no-cpu-baseline "$@" > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py --steps 5 --warmup 1 --min-seconds 0 --no-cpu-baseline "$@" > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $REPO/bench.py --steps 5 --warmup 1 --min-seconds 0 --no-cpu-baseline "$@" > /dev/null 2> $OUT/write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --steps 20 --warmup 3 --min-seconds 0.1 --no-cpu-baseline --no-ingest "$@" > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py --steps 5 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-ingest "$@" > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $REPO/bench.py --steps 5 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-ingest "$@" > /dev/null 2> $OUT/write.err
 cd $REPO
 python3 tools/summarize_rocprof.py $OUT > $OUT/summary.md
 # keep only the small files (gpurun_out merge limit)

@@ -71,26 +71,82 @@ def read_part_records(path):
     return hdr, out
 
 
-def merge_direct(folder_path, base_filename, rank=None, world=None, records=None):
-    """Collective.  Every rank passes (or re-reads from `<base>_part<rank>`) its own records and writes its share of
-    `<base>`; rank 0 also writes the header (copy of part 000's, nz patched) and the metadata table.
-    Layout: reference recode_reader.py:518-592 / SURVEY appendix A."""
+def _copy_range(src_fd, dst_fd, src_off, dst_off, count, bufsize=32 << 20):
+    """count bytes from src_fd@src_off to dst_fd@dst_off with bounded memory (copy_file_range where the kernel has it)."""
+    while count > 0:
+        n = 0
+        if hasattr(os, 'copy_file_range'):
+            try:
+                n = os.copy_file_range(src_fd, dst_fd, min(count, 1 << 30), src_off, dst_off)
+            except OSError:
+                n = 0
+        if n <= 0:
+            buf = os.pread(src_fd, min(count, bufsize), src_off)
+            if not buf:
+                raise IOError('part file shorter than its frame index says')
+            n = os.pwrite(dst_fd, buf, dst_off)
+        src_off += n
+        dst_off += n
+        count -= n
+
+
+def part_index(path):
+    """(header, rows int64[n, 2 + n_md] = [frame_id, data bytes, metadata...], data offsets int64[n]) of one part file, read
+    WITHOUT its frame data (headers only): what merge_direct needs when the writer did not hand its own index over."""
+    rd = ReCoDeReader(path, is_intermediate=True)
+    rd.open(print_header=False)
+    rows, pos = [], []
+    while True:
+        f = rd.get_next_frame_raw(read_data=False)
+        if f is None:
+            break
+        (fid, body), = f.items()
+        md = [int(v) for v in body['metadata'].values()]
+        end = int(body['data'])          # file position behind the frame's data
+        h = rd.get_header().as_dict()
+        size = rd._structures.get_frame_data_size(h['reduction_level'], h['rc_operation_mode'], body['metadata'])
+        rows.append([int(fid), size] + md)
+        pos.append(end - size)
+    hdr = rd.get_header()
+    rd.close()
+    n_md = len(rows[0]) - 2 if rows else 0
+    return hdr, np.array(rows, dtype=np.int64).reshape(len(rows), 2 + n_md), np.array(pos, dtype=np.int64)
+
+
+def merge_direct(folder_path, base_filename, rank=None, world=None, records=None, index=None):
+    """Collective.  Every rank contributes its own frames to `<base>`; rank 0 also writes the header (copy of part 000's, nz
+    patched) and the metadata table.  A rank describes its frames by, in order of preference: `index` = (rows, offsets)
+    from ReCoDeWriter.frame_index() (nothing is read back), the headers of its part file (part_index: frame data skipped),
+    or `records` = [(frame_id, [metadata], data bytes)] held in memory.  Frame data is copied part file -> merged file
+    with bounded memory.  Layout: reference recode_reader.py:518-592 / SURVEY appendix A."""
     dist = _dist()
     if rank is None:
         rank = dist.get_rank() if dist else 0
     if world is None:
         world = dist.get_world_size() if dist else 1
     part = os.path.join(folder_path, '%s_part%03d' % (base_filename, rank))
-    hdr, recs = read_part_records(part)
+    pos = None
     if records is not None:
-        recs = records
-    n_md = len(recs[0][1]) if recs else 0
-    rows = np.array([[fid, len(data)] + md for fid, md, data in recs], dtype=np.int64).reshape(len(recs), 2 + n_md)
+        rd = ReCoDeReader(part, is_intermediate=True)
+        rd.open(print_header=False)
+        hdr = rd.get_header()
+        rd.close()
+        n_md = len(records[0][1]) if records else 0
+        rows = np.array([[fid, len(data)] + md for fid, md, data in records], dtype=np.int64).reshape(len(records), 2 + n_md)
+    elif index is not None:
+        rd = ReCoDeReader(part, is_intermediate=True)
+        rd.open(print_header=False)
+        hdr = rd.get_header()
+        rd.close()
+        rows, pos = index
+    else:
+        hdr, rows, pos = part_index(part)
     if rows.shape[0] == 0:  # width must agree across ranks: derive it from the header's (level, mode)
         from .structures import ReCoDeStructures
         h = hdr.as_dict()
         n_md = len(ReCoDeStructures(h).standard_frame_metadata_structure_for(h['reduction_level'], h['rc_operation_mode']))
         rows = np.zeros((0, 2 + n_md), dtype=np.int64)
+    n_md = rows.shape[1] - 2
     per_rank = all_gather_rows(rows)
     table = np.concatenate(per_rank, axis=0)
     order = np.argsort(table[:, 0], kind='stable')          # frame-id order (already sorted for contiguous blocks)
@@ -105,8 +161,7 @@ def merge_direct(folder_path, base_filename, rank=None, world=None, records=None
     if rank == 0:
         with open(os.path.join(folder_path, '%s_part%03d' % (base_filename, 0)), 'rb') as src, open(target, 'wb') as out:
             out.write(src.read(head_len))
-            for row in table[order]:
-                out.write(struct.pack('<%dI' % n_md, *[int(v) for v in row[2:]]))
+            out.write(np.ascontiguousarray(table[order, 2:], dtype='<u4').tobytes())
             out.seek(hdr.get_field_position_in_bytes('nz'))
             out.write(int(nz).to_bytes(hdr.get_definition('nz')['bytes'], 'little'))
             out.truncate(data_start + int(sizes.sum()))
@@ -114,8 +169,25 @@ def merge_direct(folder_path, base_filename, rank=None, world=None, records=None
         dist.barrier()                                      # the file exists and is sized before anyone pwrite()s
     fd = os.open(target, os.O_WRONLY)
     try:
-        for fid, md, data in recs:
-            os.pwrite(fd, data, data_start + pos_of[fid])
+        if records is not None:
+            for fid, md, data in records:
+                os.pwrite(fd, data, data_start + pos_of[fid])
+        elif rows.shape[0]:
+            src_fd = os.open(part, os.O_RDONLY)
+            try:
+                # consecutive frames whose data is consecutive in both files go in one copy (mode-0 records with no
+                # metadata; otherwise every record's header sits in between and frames are copied one by one)
+                i, n = 0, rows.shape[0]
+                while i < n:
+                    s_off, d_off, cnt = int(pos[i]), data_start + pos_of[int(rows[i, 0])], int(rows[i, 1])
+                    j = i + 1
+                    while j < n and int(pos[j]) == s_off + cnt and data_start + pos_of[int(rows[j, 0])] == d_off + cnt:
+                        cnt += int(rows[j, 1])
+                        j += 1
+                    _copy_range(src_fd, fd, s_off, d_off, cnt)
+                    i = j
+            finally:
+                os.close(src_fd)
     finally:
         os.close(fd)
     if dist is not None and world > 1:
@@ -142,11 +214,12 @@ def write_sharded(image_filename, data, dark_data, output_directory, input_param
                      device_id=device_id)
     w.start()
     metrics = w.run(data)
+    index = w.frame_index()   # what this rank wrote, and where: the merge reads nothing back but the frame data it copies
     w.close()
     if dist is not None and world > 1:
         dist.barrier()  # every part file is complete before anyone reads part 000's header
     nz = None
     if merge:
         base = '%s.rc%d' % (Path(image_filename).stem, int(input_params.reduction_level))
-        nz = merge_direct(output_directory, base, rank=rank, world=world)
+        nz = merge_direct(output_directory, base, rank=rank, world=world, index=index)
     return metrics, nz

@@ -270,41 +270,44 @@ class ReCoDeReader:
 
 
 def merge_parts(folder_path, base_filename, num_parts):
-    """Merge `<base>_partNNN` files into `<base>` (reference :495-595): header of part 000 (nz patched), the
-    source header, one metadata row per frame (frame_id dropped), then the frame data blobs in frame-id order."""
+    """Merge `<base>_partNNN` files into `<base>` (reference :495-595): header of part 000 (nz patched), the source header,
+    one metadata row per frame (frame_id dropped), then the frame data blobs in frame-id order.  Two passes like the
+    reference's, with bounded memory: the first reads the record headers only (frame data skipped), the second copies each
+    frame's data from its part file to its place."""
+    from .parallel import _copy_range, part_index
     paths = [os.path.join(folder_path, '%s_part%03d' % (base_filename, i)) for i in range(num_parts)]
-    readers = []
+    hdrs, tables, offsets = [], [], []
     for p in paths:
-        r = ReCoDeReader(p, is_intermediate=True)
-        r.open(print_header=False)
-        readers.append(r)
-    first = readers[0]
-    rc_header = first.get_header()
+        h, rows, pos = part_index(p)
+        hdrs.append(h)
+        tables.append(rows)
+        offsets.append(pos)
+    rc_header = hdrs[0]
     header = rc_header.as_dict()
+    n_md = max((t.shape[1] - 2 for t in tables if t.shape[0]), default=0)
 
     def stream(idx):
-        r = readers[idx]
-        while True:
-            f = r.get_next_frame_raw()
-            if f is None:
-                return
-            (frame_id, body), = f.items()
-            yield int(frame_id), idx, body
+        for k in range(tables[idx].shape[0]):
+            yield int(tables[idx][k, 0]), idx, k
 
-    metadata, blobs = [], []
-    for frame_id, _, body in heapq.merge(*(stream(i) for i in range(num_parts))):
-        metadata.append(body['metadata'])
-        blobs.append(b''.join(body['data'][k] for k in body['data']))
+    order = list(heapq.merge(*(stream(i) for i in range(num_parts))))
+    head_len = rc_header.recode_header_length + int(header['source_header_length'])
     with open(os.path.join(folder_path, base_filename), 'wb') as target:
         with open(paths[0], 'rb') as src:
-            target.write(src.read(rc_header.recode_header_length + int(header['source_header_length'])))
-        for md in metadata:
-            for name, value in md.items():
-                if name != 'frame_id':
-                    target.write(struct.pack('<I', int(value)))
-        for blob in blobs:
-            target.write(blob)
+            target.write(src.read(head_len))
+        for _, idx, k in order:
+            target.write(np.ascontiguousarray(tables[idx][k, 2:2 + n_md], dtype='<u4').tobytes())
+        target.flush()
+        fds = [os.open(p, os.O_RDONLY) for p in paths]
+        try:
+            out_fd = target.fileno()
+            dst = head_len + len(order) * 4 * n_md
+            for _, idx, k in order:
+                size = int(tables[idx][k, 1])
+                _copy_range(fds[idx], out_fd, int(offsets[idx][k]), dst, size)
+                dst += size
+        finally:
+            for fd in fds:
+                os.close(fd)
         target.seek(rc_header.get_field_position_in_bytes('nz'), 0)
-        target.write(len(metadata).to_bytes(rc_header.get_definition('nz')['bytes'], 'little'))
-    for r in readers:
-        r.close()
+        target.write(len(order).to_bytes(rc_header.get_definition('nz')['bytes'], 'little'))

@@ -163,6 +163,11 @@ class ReCoDeWriter:
         self._out = np.empty(self._ctx.out_capacity(self._batch_size), np.uint8)
         self._chunk_offset = 0
         self._num_frames_in_part = 0
+        # per frame written: [frame_id, data bytes, metadata fields...] and where its data starts in the part file - what the
+        # direct merge needs (parallel.merge_direct) without reading the part file back
+        self._n_md = len(self._structures.standard_frame_metadata_structure_for(ip.reduction_level, ip.rc_operation_mode))
+        self._index_rows, self._index_pos = [], []
+        self._file_pos = None
         self._vc_roi['nx'], self._vc_roi['ny'] = min(nx, 128), min(ny, 128)
         self._vc_roi['x_start'] = math.floor((nx - self._vc_roi['nx']) / 2.0)
         self._vc_roi['y_start'] = math.floor((ny - self._vc_roi['ny']) / 2.0)
@@ -252,6 +257,7 @@ class ReCoDeWriter:
                 for rec in records:
                     if self._buffer_sz - len(self._rct_buffer) < len(rec):
                         self._offload_buffer()
+                    self._note_host_record(self._intermediate_file.tell() + len(self._rct_buffer), rec)
                     self._rct_buffer += rec
                 for i in range(batch.shape[0]):
                     if (first_id + i) % gap == 0:
@@ -330,10 +336,15 @@ class ReCoDeWriter:
             ctx.pipe_fetch_wait(i % slots)
             n, rec, md, total = info[i]
             buf = self._pin_out[i % slots].array
+            pos = self._intermediate_file.tell()
             if self._host_compress:
                 for z in range(n):
-                    self._intermediate_file.write(self._host_compress_record(buf[int(rec[z]):int(rec[z + 1])].tobytes(), metrics))
+                    r = self._host_compress_record(buf[int(rec[z]):int(rec[z + 1])].tobytes(), metrics)
+                    self._note_host_record(pos, r)
+                    self._intermediate_file.write(r)
+                    pos += len(r)
             else:
+                self._note_records(pos, n, rec, md, first_id + i * B)
                 self._intermediate_file.write(memoryview(buf)[:total])
             info[i] = None
 
@@ -455,6 +466,27 @@ class ReCoDeWriter:
         if self._ctx is not None:
             self._ctx.close()
             self._ctx = None
+
+    def frame_index(self):
+        """(rows int64[n, 2 + n_md] = [frame_id, data bytes, metadata...], data offsets int64[n]) of the frames written so far."""
+        rows = np.array(self._index_rows, dtype=np.int64).reshape(len(self._index_rows), 2 + self._n_md)
+        return rows, np.array(self._index_pos, dtype=np.int64)
+
+    def _note_host_record(self, pos, r):
+        """One finished record (bytes) about to be written at file position pos."""
+        hdr = 4 + 4 * self._n_md
+        vals = struct.unpack_from('<%dI' % (1 + self._n_md), r, 0)
+        self._index_rows.append([vals[0], len(r) - hdr] + list(vals[1:]))
+        self._index_pos.append(pos + hdr)
+
+    def _note_records(self, pos, n, rec, md, first_id, lengths=None):
+        """Bookkeeping for frame_index(): n records starting at file position pos; rec = offsets inside the batch."""
+        hdr = 4 + 4 * self._n_md
+        for z in range(n):
+            lo = int(rec[z])
+            size = (int(rec[z + 1]) - lo) if lengths is None else lengths[z]
+            self._index_rows.append([first_id + z, size - hdr] + [int(v) for v in md[z][:self._n_md]])
+            self._index_pos.append(pos + lo + hdr)
 
     def _offload_buffer(self):
         self._intermediate_file.write(self._rct_buffer)

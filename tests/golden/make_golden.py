@@ -20,6 +20,7 @@ Fixture groups:
   G3  whole part files + merged file           (recode_writer.py:184-607, recode_reader.py:495-595)
   G4  512-byte header bytes                    (recode_header.py:58-94, 257-275)
   G5  get_frame_sparse triplets                (pyrecode.cpp:95-119, reader.h:10-68)
+  G6  321-byte v0.1 header                     (recode_header.py:27-56, 98-127, 257-275)
 """
 import contextlib
 import io
@@ -219,7 +220,32 @@ def g5():
     print("g5:", len(out), "arrays")
 
 
+def g6():
+    """A version-0.1 header as the reference itself writes it: ReCoDeHeader(version=0.1).create(...).serialize(...)."""
+    from pyrecode.params import InitParams
+    tmp = tempfile.mkdtemp()
+    try:
+        ip, cfg = make_params(tmp, num_frames=7, num_rows=40, num_cols=56, num_threads=1, compression_scheme=0,
+                              calibration_threshold_epsilon=3, frame_offset=2, source_bit_depth=12, target_bit_depth=12)
+        init = InitParams("batch", tmp, image_filename="legacy_stack.bin", calibration_filename="legacy_dark.bin")
+        h = ReCoDeHeader(version=0.1)
+        quiet(h.create, init, ip, True)
+        path = os.path.join(FILES, "g6_header_v01.bin")
+        quiet(h.serialize, path)
+        d = h.as_dict()
+        keys = [k for k in d if not isinstance(d[k], (str, np.ndarray))]
+        np.savez_compressed(os.path.join(HERE, "g6_header_v01.npz"), keys=np.array(keys), vals=np.array([int(d[k]) for k in keys], np.int64),
+                            source_file_name=np.array(str(d["source_file_name"])), calibration_file_name=np.array(str(d["calibration_file_name"])))
+        print("g6: %d bytes, %d scalar fields" % (os.path.getsize(path), len(keys)))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    g1_g2()
-    g3_g4()
-    g5()
+    if len(sys.argv) > 1 and sys.argv[1] == "g6":
+        g6()
+    else:
+        g1_g2()
+        g3_g4()
+        g5()
+        g6()

@@ -166,3 +166,64 @@ def test_blosc1_from_spec_decoder_on_a_hand_built_chunk():
     assert orc.blosc1_decode(chunk) == data.tobytes()
     mem = bytes([2, 1, 0x36, 8]) + struct.pack("<iii", 5, 5, 21) + b"hello"
     assert orc.blosc1_decode(mem) == b"hello"
+
+
+def test_blosc1_from_spec_decoder_on_compressed_bitshuffled_blocks():
+    """The path the device encoder actually emits for scheme 8: bit-shuffled blocks that ARE LZ4-compressed.  Block 0's LZ4
+    bytes are derived by hand from lz4_Block_format.md (an all-zero shuffled block: one literal, one 506-byte overlapping
+    match, the five mandatory trailing literals); block 1 is compressed by the stock liblz4 block API when the library is
+    installed (an encoder that shares nothing with this repository)."""
+    import ctypes as C
+    import ctypes.util
+    import struct
+    rng = np.random.default_rng(4)
+
+    def shuffle(blk):
+        S = (blk.size // 8) & ~7
+        bits = np.unpackbits(blk[:S * 8].reshape(S, 8), axis=1, bitorder="little")
+        return np.concatenate([np.packbits(bits.T, axis=1, bitorder="little").reshape(-1), blk[S * 8:]])
+
+    blk0 = np.zeros(512, np.uint8)
+    lz0 = bytes([0x1F, 0x00, 0x01, 0x00, 0xFF, 0xE8, 0x50, 0, 0, 0, 0, 0])   # token(1 lit, ml 15+) 00 | off 1 | +255 +232 | token(5 lit) 00*5
+    assert orc.lz4_block_decode(lz0, 512) == bytes(512)
+    blk1 = np.zeros(512, np.uint8)                      # sparse, like a packed binary map: a few single-bit bytes
+    blk1[rng.choice(512, 20, replace=False)] = 1 << rng.integers(0, 8, 20).astype(np.uint8)
+    sh1 = shuffle(blk1).tobytes()
+    name = ctypes.util.find_library("lz4")
+    if name:
+        L = C.CDLL(name)
+        L.LZ4_compress_default.restype = C.c_int
+        L.LZ4_compress_default.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        dst = C.create_string_buffer(1024)
+        n = L.LZ4_compress_default(sh1, dst, len(sh1), 1024)
+        assert 0 < n < 512
+        lz1 = dst.raw[:n]
+    else:
+        lz1 = sh1                                        # stored (csize == size)
+    blocks = [struct.pack("<i", len(lz0)) + lz0, struct.pack("<i", len(lz1)) + lz1]
+    tab = 16 + 8
+    body = struct.pack("<2i", tab, tab + len(blocks[0])) + b"".join(blocks)
+    chunk = bytes([2, 1, 0x34, 8]) + struct.pack("<iii", 1024, 512, 16 + len(body)) + body
+    assert orc.blosc1_decode(chunk) == blk0.tobytes() + blk1.tobytes()
+
+
+def test_v01_header_written_by_the_reference_loads():
+    """G6: a 321-byte version-0.1 header serialised by the reference's ReCoDeHeader(version=0.1) (tests/golden/make_golden.py
+    g6) must load with every field the reference stored (reference recode_header.py:27-56, 188-249)."""
+    from pyrecode_amd.recode_header import ReCoDeHeader
+    g = load_npz("g6_header_v01.npz")
+    path = os.path.join(GOLDEN, "files", "g6_header_v01.bin")
+    assert os.path.getsize(path) == 321
+    h = ReCoDeHeader()
+    h.load(path)
+    d = h.as_dict()
+    assert h.recode_header_length == 321
+    for k, v in zip(g["keys"].tolist(), g["vals"].tolist()):
+        assert int(d[k]) == v, k
+    assert d["version_major"] == 0 and d["version_minor"] == 1 and d["nx"] == 56 and d["ny"] == 40 and d["nz"] == 7
+    assert str(d["source_file_name"]).strip() == str(g["source_file_name"]).strip()
+    assert str(d["calibration_file_name"]).strip() == str(g["calibration_file_name"]).strip()
+    # what a v0.1 file implies for the fields it does not carry (reference :236-243)
+    assert d["is_bit_packed"] == 1 and d["source_header_length"] == 0 and d["source_dtype"] == 0 and d["target_dtype"] == 0
+    # and the table round-trips byte for byte
+    assert h.to_bytes() == open(path, "rb").read()

@@ -61,3 +61,49 @@ def test_two_rank_direct_merge_matches_reference(base, nz, tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
     assert (tmp_path / base).read_bytes() == open(os.path.join(FILES, base), "rb").read()
+
+
+# ---- cfg-3 proportions without a GPU: fabricated part files (reference layout, arbitrary payload bytes) -------------------
+def _fabricate_parts(tmp_path, base, n_frames, world, seed):
+    """Part files in the reference's layout for n_frames frames split by the contiguous-block rule: header copied from a
+    reference-written fixture (nz patched), records `u32 frame_id | u32 cb | u32 cp | u32 npk | blob`.  Returns the merged
+    file's expected bytes, assembled independently of the code under test."""
+    import struct
+    from pyrecode_amd.parallel import frame_block
+    from pyrecode_amd.recode_header import ReCoDeHeader
+    rng = np.random.default_rng(seed)
+    head = open(os.path.join(FILES, "g3_l1z16.rc1_part000"), "rb").read(512)   # L1, mode 1: three metadata fields
+    h = ReCoDeHeader()
+    nz_pos, nz_len = h.get_field_position_in_bytes("nz") if hasattr(h, "get_field_position_in_bytes") else 23, 4
+    table, blobs = [], []
+    for r in range(world):
+        lo, cnt = frame_block(n_frames, world, r)
+        with open(tmp_path / ("%s_part%03d" % (base, r)), "wb") as f:
+            f.write(head[:nz_pos] + int(cnt).to_bytes(nz_len, "little") + head[nz_pos + nz_len:])
+            for fid in range(lo, lo + cnt):
+                cb, cp = int(rng.integers(1, 4000)), int(rng.integers(0, 3000))
+                blob = rng.integers(0, 256, cb + cp, dtype=np.uint8).tobytes()
+                f.write(struct.pack("<IIII", fid, cb, cp, cp + 7) + blob)
+                table.append((cb, cp, cp + 7))
+                blobs.append(blob)
+    import struct as _s
+    return (head[:nz_pos] + int(n_frames).to_bytes(nz_len, "little") + head[nz_pos + nz_len:] +
+            b"".join(_s.pack("<III", *row) for row in table) + b"".join(blobs))
+
+
+@pytest.mark.parametrize("n_frames", [150, 1])   # 75 frames per rank; one frame: rank 1's part file is empty
+def test_two_rank_direct_merge_at_scale_and_with_an_empty_rank(n_frames, tmp_path):
+    from pyrecode_amd.recode_reader import merge_parts
+    base = "fab.rc1"
+    want = _fabricate_parts(tmp_path, base, n_frames, 2, 11 + n_frames)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(repo=REPO, folder=str(tmp_path), base=base, nz=n_frames))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31500 + os.getpid() % 2000), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert (tmp_path / base).read_bytes() == want
+    os.remove(tmp_path / base)
+    merge_parts(str(tmp_path), base, 2)          # the file-based merge (streaming, two passes) must agree
+    assert (tmp_path / base).read_bytes() == want

@@ -203,6 +203,24 @@ uint64_t rc_compress_bound(uint32_t scheme, uint64_t n);
 int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_depth, const uint8_t *bitmap,
                                const uint8_t *pixvals, uint64_t pixvals_bytes, uint64_t *out,
                                uint64_t out_cap_triplets, uint32_t reduction_level);
+/* Batched form of the reader's per-frame work: n stored frames -> decompress both streams -> sparse expand, in one call
+ * with no host round trip in between.  Replaces, for n frames at once, ReCoDeReader._get_frame_sparse
+ * (pyrecode/recode_reader.py:379-471: de_compress on the binary-map stream and on the value stream,
+ * recode_compressors.py:40-79, then c_recode get_frame_sparse, pyrecode.cpp:95-119).
+ *   nx, ny, bit_depth, reduction_level (1 or 3), op_mode, scheme    header fields of the file
+ *   data          host memory: the n frames' data blobs back to back, as they lie in a merged file (per frame: the
+ *                 binary-map stream, then the value stream)
+ *   sizes         uint32[n][3]: bytes of the binary-map stream, bytes of the value stream, bytes of the DEcompressed value
+ *                 stream (the rows of the file's metadata table; mode 0: {nb, n_packed, n_packed})
+ *   nnz_prefix    uint64[n+1] out: exclusive prefix of the frames' set-pixel counts (frame i's triplets are
+ *                 [nnz_prefix[i], nnz_prefix[i+1]))
+ *   triplets      uint64[cap][3] out (host or device): (row, col, value) in row-major order per frame, frames in order;
+ *                 may be NULL with cap 0 (a counting call)
+ * Device decoders: mode 0 (stored pieces), LZ4 frames with independent blocks, zstd frames inside the subset this library
+ * writes (rc_zstd_dec.h).  Anything else returns RC_ERR_UNSUPPORTED before any work is done and the caller falls back to
+ * the per-frame path with the stock decoder.  RC_ERR_OUT_TOO_SMALL: nnz_prefix is valid, triplets untouched. */
+int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t reduction_level, uint32_t op_mode, uint32_t scheme,
+                     const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap);
 /* bit_pack_pixel_intensities -> _bit_pack_pixel_intensities (reader.h:105-140) with the intended semantics of
  * the numba _bit_pack (recode_writer.py:637-652): zero, then LSB-first d-bit fields.  out_n = ceil(n*d/8). */
 int rc_bit_pack(const uint16_t *pixvals, uint64_t n, uint32_t bit_depth, uint8_t *out, uint64_t out_n);

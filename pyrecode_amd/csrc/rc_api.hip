@@ -15,6 +15,7 @@
 #include "rc_expand.h"
 #include "rc_launch.h"
 #include "rc_zstd_block.h"
+#include "rc_zstd_dec.h"
 
 #define RC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -871,6 +872,8 @@ struct Util {
     uint8_t *w = nullptr; uint64_t w_cap = 0;   // work
     uint64_t *h_scalar = nullptr;               // pinned
     void *ztab = nullptr;                       // zstd FSE tables
+    uint8_t *x[10] = {}; uint64_t x_cap[10] = {};   // rc_expand_frames: data, bitmaps, values, tables, block lists, counters
+    void *zd_predef = nullptr;                  // predefined zstd decoding tables
 };
 constexpr int RC_MAX_DEV = 64;
 Util g_utils[RC_MAX_DEV];
@@ -970,6 +973,206 @@ RC_EXPORT int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_
     if (out_host) HIP_TRY(hipMemcpyAsync(out, d_out, nnz * 24, hipMemcpyDeviceToHost, u.stream));
     HIP_TRY(hipStreamSynchronize(u.stream));
     return (int64_t)nnz;
+}
+
+// ---- seam 3, batched: decode + expand n stored frames ---------------------------------------------------------------------
+namespace {
+// LZ4 frame of independent blocks -> block table (compressed blocks in `comp`, stored ones in `raw`); expect: bytes every
+// compressed block regenerates (the last one the rest)
+int lz4_index_frame(const uint8_t *base, uint64_t off, uint64_t n, uint32_t frame_idx, uint32_t expect, uint64_t total_expected,
+                    std::vector<rc::ZdBlock> &comp, std::vector<rc::ZdBlock> &raw, uint64_t *total)
+{
+    using namespace rc;
+    const uint8_t *p = base + off;
+    auto rd32 = [&](uint64_t q) { return (uint32_t)p[q] | ((uint32_t)p[q + 1] << 8) | ((uint32_t)p[q + 2] << 16) | ((uint32_t)p[q + 3] << 24); };
+    if (n < 11 || rd32(0) != 0x184D2204u) return ZD_CORRUPT;
+    const uint32_t flg = p[4], bd = p[5];
+    if ((flg >> 6) != 1 || (flg & 2) || (bd & 0x8F)) return ZD_CORRUPT;
+    if (!((flg >> 5) & 1)) return ZD_FOREIGN;                          // linked blocks: a serial chain
+    const int bsum = (flg >> 4) & 1, csize = (flg >> 3) & 1, csum = (flg >> 2) & 1, dict = flg & 1;
+    uint64_t q = 6 + (csize ? 8 : 0) + (dict ? 4 : 0) + 1, out = 0;
+    for (;;) {
+        if (q + 4 > n) return ZD_CORRUPT;
+        uint32_t bs = rd32(q);
+        q += 4;
+        if (bs == 0) break;
+        const bool stored = bs >> 31;
+        bs &= 0x7FFFFFFFu;
+        if (q + bs > n) return ZD_CORRUPT;
+        ZdBlock b;
+        memset(&b, 0, sizeof b);
+        b.frame = frame_idx; b.src = off + q; b.csize = bs; b.dst = (uint32_t)out;
+        if (stored) { b.type = 0; b.regen = bs; raw.push_back(b); }
+        else {
+            if (!expect) return ZD_FOREIGN;
+            b.type = 2;
+            b.regen = (uint32_t)std::min<uint64_t>(expect, total_expected - out);
+            comp.push_back(b);
+        }
+        out += b.regen;
+        if (out > total_expected) return ZD_CORRUPT;
+        q += bs + (bsum ? 4 : 0);
+    }
+    if (csum) q += 4;
+    if (q != n) return ZD_CORRUPT;
+    *total = out;
+    return ZD_OK;
+}
+}  // namespace
+
+RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode, uint32_t scheme,
+                               const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap)
+{
+    using namespace rc;
+    if (!data || !sizes || !nnz_prefix || n == 0 || nx == 0 || ny == 0 || (!triplets && cap)) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
+    if (level != 1 && level != 3) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: reduction level 1 or 3");
+    if (level == 1 && (bit_depth == 0 || bit_depth > 64)) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..64");
+    const int codec = op_mode == 0 ? 0 : (scheme == RC_SCHEME_LZ4 ? 2 : (scheme == RC_SCHEME_ZSTD ? 1 : -1));
+    if (codec < 0) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: scheme has no batched device decoder");
+    const uint64_t N = (uint64_t)nx * ny, nb = (N + 7) / 8, nb8 = (nb + 7) / 8;
+    // ---- host: walk the frames, build block tables and decoding tables ----
+    std::vector<ZdBlock> bm_comp, pv_comp, raw;          // Compressed blocks of the two streams, stored / RLE blocks of both
+    std::vector<ZdTables> bm_tab(codec == 1 ? n : 0), pv_tab(codec == 1 ? n : 0);
+    std::vector<uint32_t> bm_first(n + 1, 0), pv_first(n + 1, 0), pv_bytes(n, 0);
+    std::vector<uint64_t> bm_base(n), pv_base(n);
+    const uint64_t bm_stride = nb8 * 8 + 8;
+    uint64_t pv_stride = 16, off = 0, total_in = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        const uint32_t npk = level == 1 ? sizes[3 * f + 2] : 0;
+        pv_stride = std::max<uint64_t>(pv_stride, ((uint64_t)npk + 15) & ~15ull);
+        total_in += (uint64_t)sizes[3 * f] + (level == 1 ? sizes[3 * f + 1] : 0);
+    }
+    pv_stride += 16;
+    uint32_t bm_max = 0, pv_max = 0, raw_max_regen = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        const uint64_t cb = sizes[3 * f], cp = level == 1 ? sizes[3 * f + 1] : 0, npk = level == 1 ? sizes[3 * f + 2] : 0;
+        bm_base[f] = (uint64_t)f * bm_stride;
+        pv_base[f] = (uint64_t)n * bm_stride + (uint64_t)f * pv_stride;   // the value streams lie behind the bitmaps in ONE output buffer
+        pv_bytes[f] = (uint32_t)npk;
+        bm_first[f] = (uint32_t)bm_comp.size();
+        pv_first[f] = (uint32_t)pv_comp.size();
+        int r = ZD_OK;
+        uint64_t got = 0;
+        if (codec == 0) {
+            if (cb != nb || cp != npk) return fail(RC_ERR_CORRUPT, "rc_expand_frames: mode-0 sizes disagree with the frame shape");
+            ZdBlock b;
+            memset(&b, 0, sizeof b);
+            b.frame = f; b.src = off; b.csize = b.regen = (uint32_t)nb; b.dst = 0;
+            raw.push_back(b);
+            if (npk) { b.src = off + cb; b.csize = b.regen = (uint32_t)npk; b.frame = n + f; raw.push_back(b); }
+        } else if (codec == 2) {
+            const size_t r0 = raw.size();
+            r = lz4_index_frame(data, off, cb, f, TILE_BM, nb, bm_comp, raw, &got);
+            if (r == ZD_OK && got != nb) r = ZD_CORRUPT;
+            if (r == ZD_OK && level == 1) {
+                const size_t r1 = raw.size();
+                std::vector<ZdBlock> none;
+                r = lz4_index_frame(data, off + cb, cp, n + f, 0, npk, none, raw, &got);
+                if (r == ZD_OK && got != npk) r = ZD_CORRUPT;
+                (void)r1;
+            }
+            (void)r0;
+        } else {
+            std::vector<ZdBlock> all;
+            r = zd_index_frame(data, off, cb, f, TILE_BM, nb, all, bm_tab[f], &got);
+            if (r == ZD_OK && got != nb) r = ZD_CORRUPT;
+            for (const ZdBlock &b : all) (b.type == 2 ? bm_comp : raw).push_back(b);
+            if (r == ZD_OK && level == 1) {
+                all.clear();
+                r = zd_index_frame(data, off + cb, cp, n + f, 0, npk, all, pv_tab[f], &got);
+                if (r == ZD_OK && got != npk) r = ZD_CORRUPT;
+                for (ZdBlock b : all) {
+                    if (b.type == 2) { if (b.regen > 1024) { r = ZD_FOREIGN; break; } b.frame = f; pv_comp.push_back(b); }
+                    else raw.push_back(b);
+                }
+            }
+        }
+        if (r == ZD_FOREIGN) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: stream outside the device decoders' subset (use the stock decoder)");
+        if (r != ZD_OK) return fail(RC_ERR_CORRUPT, "rc_expand_frames: malformed compressed stream");
+        bm_max = std::max<uint32_t>(bm_max, (uint32_t)bm_comp.size() - bm_first[f]);
+        pv_max = std::max<uint32_t>(pv_max, (uint32_t)pv_comp.size() - pv_first[f]);
+        off += cb + cp;
+    }
+    bm_first[n] = (uint32_t)bm_comp.size();
+    pv_first[n] = (uint32_t)pv_comp.size();
+    for (const ZdBlock &b : raw) raw_max_regen = std::max(raw_max_regen, b.regen);
+    // raw blocks address their frame through out_base[b.frame]: frames 0..n-1 = bitmaps, n..2n-1 = value streams
+    std::vector<uint64_t> base2(2 * (size_t)n);
+    for (uint32_t f = 0; f < n; ++f) { base2[f] = bm_base[f]; base2[n + f] = pv_base[f]; }
+    // ---- device ----
+    UtilScope util_scope;
+    int r = util_scope.enter();
+    if (r != RC_OK) return r;
+    Util &u = g_util;
+    hipStream_t s = u.stream;
+    const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
+    const uint64_t out_bytes = (uint64_t)n * (bm_stride + (level == 1 ? pv_stride : 0)) + 64;
+    auto need = [&](int i, uint64_t bytes) { return ensure(u.x[i], u.x_cap[i], bytes); };
+    const uint64_t sz_blocks = (bm_comp.size() + pv_comp.size() + raw.size()) * sizeof(ZdBlock) + 64;
+    const uint64_t sz_tabs = (bm_tab.size() + pv_tab.size()) * sizeof(ZdTables) + 64;
+    const uint64_t sz_idx = ((uint64_t)(n + 1) * 2 * 4 + (uint64_t)n * 4 + (uint64_t)n * 4 * 8 + 64 + 15) & ~15ull;
+    if ((r = need(0, total_in + 64)) != RC_OK || (r = need(1, out_bytes)) != RC_OK || (r = need(2, sz_blocks)) != RC_OK ||
+        (r = need(3, sz_tabs)) != RC_OK || (r = need(4, sz_idx)) != RC_OK || (r = need(5, (uint64_t)n * nblk * 8 + (uint64_t)(2 * n + 2) * 8 + 64)) != RC_OK)
+        return r;
+    if (!u.zd_predef) {
+        std::vector<uint8_t> t(zd_tables_bytes());
+        zd_predefined_tables(t.data());
+        HIP_TRY(hipMalloc(&u.zd_predef, t.size()));
+        HIP_TRY(hipMemcpy(u.zd_predef, t.data(), t.size(), hipMemcpyHostToDevice));
+    }
+    uint8_t *d_data = u.x[0], *d_out = u.x[1];
+    ZdBlock *d_bm_blk = reinterpret_cast<ZdBlock *>(u.x[2]), *d_pv_blk = d_bm_blk + bm_comp.size(), *d_raw = d_pv_blk + pv_comp.size();
+    ZdTables *d_bm_tab = reinterpret_cast<ZdTables *>(u.x[3]), *d_pv_tab = d_bm_tab + bm_tab.size();
+    uint32_t *d_bm_first = reinterpret_cast<uint32_t *>(u.x[4]), *d_pv_first = d_bm_first + (n + 1), *d_pv_bytes = d_pv_first + (n + 1);
+    uint64_t *d_base2 = reinterpret_cast<uint64_t *>(u.x[4] + (((uint64_t)(n + 1) * 8 + (uint64_t)n * 4 + 15) & ~15ull));
+    uint64_t *d_pvbase = d_base2 + 2 * (uint64_t)n;   // out_base of the value-stream decoder: per frame
+    uint32_t *d_blk_cnt = reinterpret_cast<uint32_t *>(u.x[5]), *d_blk_off = d_blk_cnt + (uint64_t)n * nblk;
+    uint64_t *d_fnnz = reinterpret_cast<uint64_t *>(d_blk_off + (uint64_t)n * nblk), *d_fbase = d_fnnz + n;
+    int *d_err = reinterpret_cast<int *>(d_fbase + n + 1);
+    HIP_TRY(hipMemcpyAsync(d_data, data, total_in, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, s));   // bitmap padding and value-stream tails read as zero
+    HIP_TRY(hipMemsetAsync(d_err, 0, 4, s));
+    auto up = [&](void *dst, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess; };
+    HIP_TRY(up(d_bm_blk, bm_comp.data(), bm_comp.size() * sizeof(ZdBlock)));
+    HIP_TRY(up(d_pv_blk, pv_comp.data(), pv_comp.size() * sizeof(ZdBlock)));
+    HIP_TRY(up(d_raw, raw.data(), raw.size() * sizeof(ZdBlock)));
+    HIP_TRY(up(d_bm_tab, bm_tab.data(), bm_tab.size() * sizeof(ZdTables)));
+    HIP_TRY(up(d_pv_tab, pv_tab.data(), pv_tab.size() * sizeof(ZdTables)));
+    HIP_TRY(up(d_bm_first, bm_first.data(), (n + 1) * 4));
+    HIP_TRY(up(d_pv_first, pv_first.data(), (n + 1) * 4));
+    HIP_TRY(up(d_pv_bytes, pv_bytes.data(), n * 4));
+    HIP_TRY(up(d_base2, base2.data(), 2 * (size_t)n * 8));
+    HIP_TRY(up(d_pvbase, pv_base.data(), (size_t)n * 8));
+    if (!bm_comp.empty()) launch_block_decode(codec == 1 ? 1 : 2, TILE_BM, d_data, d_bm_blk, d_bm_first, n, bm_max, d_bm_tab, u.zd_predef, d_out, d_base2, d_err, s);
+    if (!pv_comp.empty()) launch_block_decode(1, 1024, d_data, d_pv_blk, d_pv_first, n, pv_max, d_pv_tab, u.zd_predef, d_out, d_pvbase, d_err, s);
+    launch_block_copy(d_data, d_raw, (uint32_t)raw.size(), raw_max_regen, d_out, d_base2, s);
+    const uint8_t *d_bm = d_out, *d_pv = d_out + (uint64_t)n * bm_stride;
+    launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s);
+    HIP_TRY(hipGetLastError());
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(nnz_prefix, d_fbase, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (err) return fail(RC_ERR_CORRUPT, "rc_expand_frames: a block does not decode to its expected size");
+    const uint64_t total = nnz_prefix[n];
+    if (!triplets) return RC_OK;
+    if (total > cap) return fail(RC_ERR_OUT_TOO_SMALL, "rc_expand_frames: triplets holds fewer entries than the frames have set pixels");
+    if (level == 1)
+        for (uint32_t f = 0; f < n; ++f)
+            if (((nnz_prefix[f + 1] - nnz_prefix[f]) * bit_depth + 7) / 8 > pv_bytes[f])
+                return fail(RC_ERR_CORRUPT, "rc_expand_frames: value stream shorter than popcount(bitmap) * bit_depth bits");
+    if (total == 0) return RC_OK;
+    uint64_t *d_trip = triplets;
+    const bool out_host = !is_device_ptr(triplets);
+    if (out_host) {
+        if ((r = need(6, total * 24)) != RC_OK) return r;
+        d_trip = reinterpret_cast<uint64_t *>(u.x[6]);
+    }
+    launch_expand_batch_emit(d_bm, bm_stride, nb8, N, nx, n, d_blk_off, d_fbase, d_pv, pv_stride, d_pv_bytes, bit_depth, level, total, d_trip, s);
+    HIP_TRY(hipGetLastError());
+    if (out_host) HIP_TRY(hipMemcpyAsync(triplets, d_trip, total * 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RC_OK;
 }
 
 RC_EXPORT int rc_bit_pack(const uint16_t *pixvals, uint64_t n, uint32_t bit_depth, uint8_t *out, uint64_t out_n)

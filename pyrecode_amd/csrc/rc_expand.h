@@ -8,6 +8,20 @@ void launch_expand_count(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, u
 void launch_expand_emit(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, uint32_t nx, const uint32_t *blk_off,
                         const uint8_t *pix, uint64_t pix_bytes, uint32_t d, uint32_t level, uint64_t cap, uint64_t *out,
                         hipStream_t s);
+void launch_expand_batch_count(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t n, uint32_t *blk_cnt, uint32_t *blk_off,
+                               uint64_t *frame_nnz, uint64_t *frame_base, hipStream_t s);
+void launch_expand_batch_emit(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx, uint32_t n, const uint32_t *blk_off,
+                              const uint64_t *frame_base, const uint8_t *pv, uint64_t pv_stride, const uint32_t *pv_bytes, uint32_t d,
+                              uint32_t level, uint64_t cap, uint64_t *out, hipStream_t s);
+// rc_zstd_dec.hip: block decoders of the batched reader
+void launch_block_decode(int codec, int row, const uint8_t *data, const void *blocks, const uint32_t *frame_first, uint32_t nframes,
+                         uint32_t max_blocks_per_frame, const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base, int *err,
+                         hipStream_t s);
+void launch_block_copy(const uint8_t *data, const void *blocks, uint32_t nblocks, uint32_t max_regen, uint8_t *out, const uint64_t *out_base,
+                       hipStream_t s);
+size_t zd_tables_bytes();
+size_t zd_block_bytes();
+void zd_predefined_tables(void *dst);
 void launch_bit_pack(const uint16_t *vals, uint64_t n, uint32_t d, uint8_t *out, uint64_t out_n, hipStream_t s);
 void launch_bit_unpack(const uint8_t *packed, uint64_t nbytes, uint64_t n, uint32_t d, uint64_t *out, hipStream_t s);
 void launch_synth_dark(uint32_t seed, uint64_t N, uint16_t *dark, hipStream_t s);

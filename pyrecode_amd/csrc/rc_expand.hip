@@ -103,6 +103,91 @@ void launch_expand_emit(const uint8_t *bitmap_pad8, uint64_t nb8, uint64_t N, ui
                        cap, out);
 }
 
+// ---- batched form (rc_expand_frames): n frames' decoded bitmaps / value streams, frame f at bm + f * bm_stride ------------------
+__global__ __launch_bounds__(WG) void k_expand_count_b(const uint8_t *__restrict__ bm, uint64_t bm_stride, uint64_t nb8, uint64_t N,
+                                                         uint32_t nblk, uint32_t *__restrict__ blk_cnt)
+{
+    __shared__ uint32_t sm[WAVES + 1];
+    const uint32_t f = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    const uint32_t c = (uint32_t)__builtin_popcountll(expand_word(bm + f * bm_stride, nb8, N, i));
+    uint32_t tot;
+    (void)block_excl_scan(c, sm, &tot);
+    if (threadIdx.x == 0) blk_cnt[(uint64_t)f * nblk + blockIdx.x] = tot;
+}
+// one workgroup per frame: blk_cnt row -> exclusive prefix (in place into blk_off), frame_nnz[f]
+__global__ __launch_bounds__(WG) void k_expand_scan_b(const uint32_t *__restrict__ blk_cnt, uint32_t *__restrict__ blk_off, uint32_t nblk,
+                                                        uint64_t *__restrict__ frame_nnz)
+{
+    __shared__ uint32_t sm[WAVES + 1];
+    const uint32_t f = blockIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += WG) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < nblk ? blk_cnt[(uint64_t)f * nblk + b] : 0;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, sm, &tot);
+        if (b < nblk) blk_off[(uint64_t)f * nblk + b] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) frame_nnz[f] = carry;
+}
+// single workgroup: frame_nnz[0..n) -> frame_base[0..n] (exclusive prefix, total at [n])
+__global__ __launch_bounds__(WG) void k_expand_bases(const uint64_t *__restrict__ frame_nnz, uint64_t *__restrict__ frame_base, uint32_t n)
+{
+    __shared__ uint64_t part[WG];
+    const uint32_t per = (n + WG - 1) / WG, lo = threadIdx.x * per, hi = min(lo + per, n);
+    uint64_t s = 0;
+    for (uint32_t f = lo; f < hi; ++f) s += frame_nnz[f];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    uint64_t base = 0;
+    for (uint32_t i = 0; i < threadIdx.x; ++i) base += part[i];
+    for (uint32_t f = lo; f < hi; ++f) { frame_base[f] = base; base += frame_nnz[f]; }
+    if (threadIdx.x == WG - 1) frame_base[n] = base;
+}
+__global__ __launch_bounds__(WG) void k_expand_emit_b(const uint8_t *__restrict__ bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx,
+                                                        uint32_t nblk, const uint32_t *__restrict__ blk_off, const uint64_t *__restrict__ frame_base,
+                                                        const uint8_t *__restrict__ pv, uint64_t pv_stride, const uint32_t *__restrict__ pv_bytes,
+                                                        uint32_t d, uint32_t level, uint64_t cap, uint64_t *__restrict__ out)
+{
+    __shared__ uint32_t sm[WAVES + 1];
+    const uint32_t f = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t bits = expand_word(bm + f * bm_stride, nb8, N, i);
+    const uint64_t k0 = i * 64;
+    uint32_t tot;
+    uint64_t rank = blk_off[(uint64_t)f * nblk + blockIdx.x] + block_excl_scan((uint32_t)__builtin_popcountll(bits), sm, &tot);
+    const uint64_t base = frame_base[f];
+    const uint8_t *pix = pv + f * pv_stride;
+    const uint64_t pix_bytes = level == 1 ? pv_bytes[f] : 0;
+    for (; bits; bits &= bits - 1, ++rank) {
+        if (base + rank >= cap) break;
+        const uint64_t k = k0 + (uint64_t)__builtin_ctzll(bits);
+        const uint32_t row = (uint32_t)(k / nx), col = (uint32_t)(k - (uint64_t)row * nx);
+        uint64_t *o = out + 3 * (base + rank);
+        o[0] = row;
+        o[1] = col;
+        o[2] = level == 1 ? read_field(pix, pix_bytes, rank, d) : 1ull;
+    }
+}
+void launch_expand_batch_count(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t n, uint32_t *blk_cnt, uint32_t *blk_off,
+                               uint64_t *frame_nnz, uint64_t *frame_base, hipStream_t s)
+{
+    const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
+    hipLaunchKernelGGL(k_expand_count_b, dim3(nblk, n), dim3(WG), 0, s, bm, bm_stride, nb8, N, nblk, blk_cnt);
+    hipLaunchKernelGGL(k_expand_scan_b, dim3(n), dim3(WG), 0, s, blk_cnt, blk_off, nblk, frame_nnz);
+    hipLaunchKernelGGL(k_expand_bases, dim3(1), dim3(WG), 0, s, frame_nnz, frame_base, n);
+}
+void launch_expand_batch_emit(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx, uint32_t n, const uint32_t *blk_off,
+                              const uint64_t *frame_base, const uint8_t *pv, uint64_t pv_stride, const uint32_t *pv_bytes, uint32_t d,
+                              uint32_t level, uint64_t cap, uint64_t *out, hipStream_t s)
+{
+    const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
+    hipLaunchKernelGGL(k_expand_emit_b, dim3(nblk, n), dim3(WG), 0, s, bm, bm_stride, nb8, N, nx, nblk, blk_off, frame_base, pv, pv_stride,
+                       pv_bytes, d, level, cap, out);
+}
+
 // ---- stand-alone pack / unpack ------------------------------------------------------------------------------
 __global__ void k_bit_pack(const uint16_t *__restrict__ vals, uint64_t n, uint32_t d, uint8_t *__restrict__ out, uint64_t out_n)
 {

@@ -15,6 +15,7 @@ import numpy as np
 from scipy.sparse import coo_matrix
 
 from . import recode_compressors as compressors
+from . import _lib
 from . import c_recode
 from .misc import map_dtype
 from .recode_header import ReCoDeHeader
@@ -171,6 +172,68 @@ class ReCoDeReader:
         out = self._pack(z, self._frame_metadata[z], self._get_frame_sparse(self._frame_metadata[z]))
         if out is not None:
             self._current_frame_index = z + 1
+        return out
+
+    # ---- batched access (device-resident decode + expand; no counterpart in the reference, which reads frame by frame) ------
+    def get_frames_triplets(self, z0, n):
+        """Frames z0 .. z0+n-1 of a merged file in ONE device call (rc_expand_frames): both streams of every frame are
+        decompressed and expanded on the GPU without a host round trip in between.  Returns (nnz_prefix uint64[n+1],
+        triplets uint64[total, 3]) - frame i's (row, col, value) rows are triplets[nnz_prefix[i]:nnz_prefix[i+1]], in the
+        reference's row-major order (pyrecode.cpp:95-119).  Falls back to the per-frame path (stock decoder on the host) for
+        streams outside the device decoders' subset, for level 2 and for host-only schemes."""
+        if self._is_intermediate:
+            raise ValueError("Random acceess is not available for intermediate files")
+        h = self._header
+        nz = int(h['nz'])
+        if z0 < 0 or n <= 0 or z0 + n > nz:
+            raise ValueError('Requested frame index is greater than number of frames in dataset')
+        level, mode, scheme = int(h['reduction_level']), int(h['rc_operation_mode']), int(h['compression_scheme'])
+        fast = level in (1, 3) and (mode == 0 or scheme in (1, 2))
+        if fast:
+            sizes = np.zeros((n, 3), np.uint32)
+            for i in range(n):
+                md = self._frame_metadata[z0 + i]
+                sz_map, sz_val = self._stream_sizes(md)
+                sizes[i, 0] = sz_map
+                if level == 1:
+                    sizes[i, 1] = sz_val
+                    sizes[i, 2] = int(md['bytes_in_packed_pixvals'])
+            lo = self._frame_data_start_position + int(self._seek_table[z0, 1])
+            total = int(self._seek_table[z0:z0 + n, 0].sum())
+            self._fp.seek(lo, 0)
+            blob = np.frombuffer(self._fp.read(total), np.uint8)
+            prefix = np.zeros(n + 1, np.uint64)
+            L = _lib.lib()
+            args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, mode, scheme, _lib.ptr(blob), _lib.ptr(sizes), n)
+            st = L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0)            # counting call: sizes the output
+            if st == _lib.RC_OK:
+                trip = np.empty((max(int(prefix[n]), 1), 3), np.uint64)
+                _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0]), 'rc_expand_frames')
+                self._current_frame_index = z0 + n
+                self.last_batch_path = 'device'
+                return prefix, trip[:int(prefix[n])]
+            if st != _lib.RC_ERR_UNSUPPORTED:
+                _lib.check(st, 'rc_expand_frames')
+        # per-frame path
+        self.last_batch_path = 'per-frame'  
+        parts, prefix = [], np.zeros(n + 1, np.uint64)
+        for i in range(n):
+            coo = self.get_frame(z0 + i)[z0 + i]['data']
+            coo = coo[0] if isinstance(coo, tuple) else coo
+            t = np.stack([coo.row.astype(np.uint64), coo.col.astype(np.uint64), coo.data.astype(np.uint64)], axis=1) if coo is not None and coo.nnz \
+                else np.zeros((0, 3), np.uint64)
+            parts.append(t)
+            prefix[i + 1] = prefix[i] + t.shape[0]
+        return prefix, np.concatenate(parts) if parts else np.zeros((0, 3), np.uint64)
+
+    def get_frames(self, z0, n):
+        """{frame index: {'metadata', 'data': COO}} for n consecutive frames, decoded in one device call."""
+        prefix, trip = self.get_frames_triplets(z0, n)
+        out = {}
+        for i in range(n):
+            d = trip[int(prefix[i]):int(prefix[i + 1])]
+            coo = coo_matrix((d[:, 2], (d[:, 0], d[:, 1])), shape=(int(self._header['ny']), int(self._header['nx'])), dtype=self._numpy_dtype)
+            out[z0 + i] = {'metadata': self._frame_metadata[z0 + i], 'data': coo}
         return out
 
     def _next_header(self):

@@ -376,3 +376,35 @@ class _no_warning:
 
     def __exit__(self, *a):
         return False
+
+
+@pytest.mark.parametrize("scheme,clevel,mode,level,d", [(1, 1, 1, 1, 12), (1, 1, 1, 1, 16), (1, 0, 1, 1, 12), (2, 1, 1, 1, 12), (2, 1, 1, 3, 12),
+                                                       (1, 1, 1, 3, 12), (0, 1, 0, 1, 12), (0, 1, 1, 1, 12)])
+def test_batched_reader_equals_per_frame_reader(tmp_path, scheme, clevel, mode, level, d):
+    """ReCoDeReader.get_frames_triplets (rc_expand_frames: every frame's two streams decoded and expanded on the GPU in one
+    call - device zstd / LZ4 decoders for this library's own frames, the per-frame stock-decoder path for zlib) must return
+    exactly what the reference-shaped per-frame reader returns, frame by frame, in row-major order."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, nz = 150, 260, 7
+    dark, frames = synth_frames(50 + scheme + d, nz, ny, nx, 0.04, d)
+    frames[3] = dark // 2                       # an empty frame in the middle
+    g = load_npz("g3_l1z12.npz")
+    over = dict(num_rows=ny, num_cols=nx, num_frames=nz, num_threads=2, compression_scheme=scheme, compression_level=clevel,
+                rc_operation_mode=mode, reduction_level=level, source_bit_depth=d, target_bit_depth=d)
+    _write_parts(tmp_path, "bt", dark, frames, 2, g, batch_size=3, **over)
+    base = "bt.rc%d" % level
+    merge_parts(str(tmp_path), base, 2)
+    rd = ReCoDeReader(str(tmp_path / base))
+    rd.open(print_header=False)
+    prefix, trip = rd.get_frames_triplets(1, nz - 1)
+    assert prefix[0] == 0 and prefix[-1] == trip.shape[0]
+    assert rd.last_batch_path == ("per-frame" if (mode == 1 and scheme == 0) else "device")   # zlib: host library, like the reference
+    want = np.where(frames > dark, frames - dark if level == 1 else 1, 0)
+    for i, z in enumerate(range(1, nz)):
+        t = trip[int(prefix[i]):int(prefix[i + 1])]
+        rows, cols = np.nonzero(want[z])
+        assert np.array_equal(t[:, 0], rows.astype(np.uint64)) and np.array_equal(t[:, 1], cols.astype(np.uint64)), z
+        assert np.array_equal(t[:, 2], want[z][rows, cols].astype(np.uint64)), z
+    fr = rd.get_frames(0, 2)
+    assert np.array_equal(np.asarray(fr[1]["data"].todense()), want[1].astype(np.uint16))
+    rd.close()

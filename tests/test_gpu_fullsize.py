@@ -200,4 +200,13 @@ def test_direct_electron_size_zstd_write_read_config5(env, tmp_path):
         got = np.asarray(rd.get_frame(z)[z]["data"].todense())
         want = np.where(frames[z] > dark, frames[z] - dark, 0).astype(np.uint16)
         assert np.array_equal(got, want)
+    # the batched path (rc_expand_frames: device zstd decode of both streams + expand, all frames in one call)
+    prefix, trip = rd.get_frames_triplets(0, nz)
+    assert rd.last_batch_path == "device"
+    for z in range(nz):
+        t = trip[int(prefix[z]):int(prefix[z + 1])]
+        want = np.where(frames[z] > dark, frames[z] - dark, 0).astype(np.uint16)
+        rows, cols = np.nonzero(want)
+        assert np.array_equal(t[:, 0], rows.astype(np.uint64)) and np.array_equal(t[:, 1], cols.astype(np.uint64))
+        assert np.array_equal(t[:, 2], want[rows, cols].astype(np.uint64))
     rd.close()

@@ -103,7 +103,7 @@ struct rc_ctx {
     int last = 0;                         // set of the most recent batch
     hipStream_t pstream = nullptr;        // carries everything behind the reduce kernel: one of the two below
     hipStream_t pstream_all = nullptr, pstream_masked = nullptr;
-    hipEvent_t ev_red[2] = {}, ev_post[2] = {};
+    hipEvent_t ev_red[2] = {}, ev_post[2] = {}, ev_in[2] = {};
     bool post_pending[2] = {false, false};
     bool pipelined = false;
     bool thr_set = false;
@@ -289,6 +289,7 @@ static int ctx_alloc(rc_ctx *c)
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev_red) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->ev_post) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : c->ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return RC_OK;
 }
 
@@ -379,7 +380,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
                     c->d_md, c->d_ztab, c->d_model, c->d_sample, c->l2.pos, c->l2.val, c->l2.parent, c->l2.stat, c->l2.word_rank, c->l2.frame_base};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
-    hipEvent_t sync_ev[] = {c->ev_red[0], c->ev_red[1], c->ev_post[0], c->ev_post[1]};
+    hipEvent_t sync_ev[] = {c->ev_red[0], c->ev_red[1], c->ev_post[0], c->ev_post[1], c->ev_in[0], c->ev_in[1]};
     for (hipEvent_t e : sync_ev)
         if (e) (void)hipEventDestroy(e);
     if (c->pstream_all) (void)hipStreamDestroy(c->pstream_all);
@@ -519,7 +520,13 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     // every device codec's block encoder runs inside the reduce kernel (LZ4; blosc = bit-shuffle + LZ4; zstd: the
     // byte-parallel half - literals, sequence tokens - with the serial FSE half lane-per-block behind it)
     const bool fitted_seq = c->modelled && (c->h_model->valid & 4u);
-    launch_reduce(sc, frames_dev, n, c->level, c->modelled ? 3u : c->emit, c->keep_bitmap || c->emit == 0, c->depth, s);
+    hipStream_t tail = nullptr;
+    if (sc.N % TILE_PX) {   // a partial last tile: its small launch goes to the second-stage stream, behind "the frames are there"
+        HIP_TRY(hipEventRecord(c->ev_in[k], s));
+        HIP_TRY(hipStreamWaitEvent(ps, c->ev_in[k], 0));
+        tail = ps;
+    }
+    launch_reduce(sc, frames_dev, n, c->level, c->modelled ? 3u : c->emit, c->keep_bitmap || c->emit == 0, c->depth, s, tail);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);

@@ -71,7 +71,7 @@ void launch_threshold(const uint16_t *dark, int64_t eps, uint64_t N, uint16_t *t
 // level: 1 residuals, 2 raw values of the set pixels (input of launch_l2), 3 bitmap only.  depth < 16 (level 1 only):
 // every tile's residuals are left in its slot already bit-packed (tile-local LSB-first stream of depth-bit fields)
 void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
-                   uint32_t depth, hipStream_t s);
+                   uint32_t depth, hipStream_t s, hipStream_t s_tail = nullptr);
 // rc_l2.hip
 void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s);
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);

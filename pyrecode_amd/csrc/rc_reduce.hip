@@ -164,6 +164,33 @@ __device__ __forceinline__ void pack_stage(uint16_t *pix, uint32_t cnt, uint32_t
     const int lane = lane_id();
     const uint32_t nbits = cnt * d;
     const uint32_t ndw = (((nbits + 31) >> 5) + 31u) & ~31u;
+    if (d == 12) {
+        // the common detector depth: 8 values = 3 dwords per lane and step, one 16-byte LDS read, no inner loop.  In place is
+        // safe for the same reason as below (12g <= 16g: a group's output lies at or in front of its input, and a step's
+        // reads all happen before its writes); the padding up to the line boundary is zeroed behind.
+        uint32_t *out = reinterpret_cast<uint32_t *>(pix);
+        const uint32_t ngrp = (cnt + 7) >> 3;
+        for (uint32_t g0 = 0; g0 < ngrp; g0 += 64) {
+            const uint32_t g = g0 + lane;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (g < ngrp) v = *reinterpret_cast<const u32x4 *>(pix + 8 * g);
+            uint32_t x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t h = (j & 1) ? (v[j >> 1] >> 16) : (v[j >> 1] & 0xFFFFu);
+                x[j] = 8 * g + j < cnt ? (h & 0xFFFu) : 0u;
+            }
+            const uint32_t w0 = x[0] | (x[1] << 12) | (x[2] << 24);
+            const uint32_t w1 = (x[2] >> 8) | (x[3] << 4) | (x[4] << 16) | (x[5] << 28);
+            const uint32_t w2 = (x[5] >> 4) | (x[6] << 8) | (x[7] << 20);
+            __builtin_amdgcn_wave_barrier();
+            if (g < ngrp) { out[3 * g] = w0; out[3 * g + 1] = w1; out[3 * g + 2] = w2; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (uint32_t w = 3 * ngrp + lane; w < ndw; w += 64) out[w] = 0;
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     const uint32_t inv = 0xFFFFFFFFu / d + 1u;  // floor(n / d) = umulhi(n, inv) for n * d < 2^32
     const uint32_t dmask = (1u << d) - 1u;
     uint32_t *out = reinterpret_cast<uint32_t *>(pix);
@@ -491,7 +518,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 }
 
 template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW>
-static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t depth, hipStream_t s)
+static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
     const uint32_t ngroups = (B + BZ - 1) / BZ;
     auto grid_for = [&](uint32_t nt) { return (((nt + WAVES - 1) / WAVES + 7) / 8) * 8 * ngroups; };
@@ -503,43 +530,46 @@ static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t 
         hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, AL, L1, CODEC, KEEP, RAW>), dim3(grid_for(nfull)), dim3(WG), 0, s, frames, sc.thr, sc.N,
                            sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
                            sc.blk_size, depth, sc.status, zm);
-    if (nfull < sc.ntiles)
-        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(WG), 0, s, frames,
+    if (nfull < sc.ntiles)   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
+        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(WG), 0, nfull ? s_tail : s, frames,
                            sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
                            sc.blk_slots, sc.blk_size, depth, sc.status, zm);
 }
 template <int BZ, bool AL, bool L1, bool RAW>
-static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s)
+static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
     // raw-value (level 2) instantiations always keep the bitmap: the labelling kernels read it
     if (RAW) keep = true;
 #define RC_CODEC(C)                                                                                          \
     do {                                                                                                     \
-        if (keep) launch_reduce_t<BZ, AL, L1, C, true, RAW>(sc, frames, B, depth, s);                        \
-        else if (!RAW && C != 0) launch_reduce_t<BZ, AL, L1, C, false, false>(sc, frames, B, depth, s);      \
+        if (keep) launch_reduce_t<BZ, AL, L1, C, true, RAW>(sc, frames, B, depth, s, s_tail);                \
+        else if (!RAW && C != 0) launch_reduce_t<BZ, AL, L1, C, false, false>(sc, frames, B, depth, s, s_tail); \
     } while (0)
     if (codec == 2) RC_CODEC(2);
     else if (codec == 1) RC_CODEC(1);
     else if (codec == 3) RC_CODEC(3);
     else if (codec == 8) RC_CODEC(8);
-    else launch_reduce_t<BZ, AL, L1, 0, true, RAW>(sc, frames, B, depth, s);
+    else launch_reduce_t<BZ, AL, L1, 0, true, RAW>(sc, frames, B, depth, s, s_tail);
 #undef RC_CODEC
 }
 template <int BZ, bool AL>
 static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep,
-                            uint32_t depth, hipStream_t s)
+                            uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
-    if (level == 2) launch_reduce_c<BZ, AL, true, true>(sc, frames, B, codec, keep, depth, s);
-    else if (level == 1) launch_reduce_c<BZ, AL, true, false>(sc, frames, B, codec, keep, depth, s);
-    else launch_reduce_c<BZ, AL, false, false>(sc, frames, B, codec, keep, depth, s);
+    if (level == 2) launch_reduce_c<BZ, AL, true, true>(sc, frames, B, codec, keep, depth, s, s_tail);
+    else if (level == 1) launch_reduce_c<BZ, AL, true, false>(sc, frames, B, codec, keep, depth, s, s_tail);
+    else launch_reduce_c<BZ, AL, false, false>(sc, frames, B, codec, keep, depth, s, s_tail);
 }
+// s_tail (optional): the stream for the small launch over a frame's partial last tile; it must already be ordered behind
+// whatever produced the frames
 void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
-                   uint32_t depth, hipStream_t s)
+                   uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
     if (depth == 0 || depth > 16) depth = 16;
+    if (!s_tail) s_tail = s;
     const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
-    if (aligned) launch_reduce_a<4, true>(sc, frames, B, level, codec, keep_bitmap, depth, s);
-    else launch_reduce_a<4, false>(sc, frames, B, level, codec, keep_bitmap, depth, s);
+    if (aligned) launch_reduce_a<4, true>(sc, frames, B, level, codec, keep_bitmap, depth, s, s_tail);
+    else launch_reduce_a<4, false>(sc, frames, B, level, codec, keep_bitmap, depth, s, s_tail);
 }
 
 // ---- per-frame scans over tiles ---------------------------------------------------------------------------

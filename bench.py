@@ -86,12 +86,17 @@ def cpu_baseline(frames_h, thr_h, depth, scheme):
     t_one = time.perf_counter() - t0
     threads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))  # every core this process may use
     nfr = frames_h.shape[0]
-    total = max(threads, int(round(15.0 * threads / max(t_one, 1e-4))))  # ~15 s of wall clock with every core busy
+    budget_s = 12.0                      # wall-clock bound: every worker runs until the deadline and counts its frames
+    done = [0] * threads
 
-    def work(i):   # worker i takes items i, i + threads, ...; item j is frame j % nfr
+    def work(i):   # worker i takes frames i, i + threads, ... (mod nfr) until the deadline
         scratch = np.empty(bound, np.uint8)
-        for j in range(i, total, threads):
+        j, k = i, 0
+        while time.perf_counter() < deadline:
             one(frames_h[j % nfr], scratch)
+            j += threads
+            k += 1
+        done[i] = k
 
     # single core first (short), then all workers
     t0 = time.perf_counter()
@@ -102,11 +107,13 @@ def cpu_baseline(frames_h, thr_h, depth, scheme):
     single = n1 / (time.perf_counter() - t0)
     ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
     t0 = time.perf_counter()
+    deadline = t0 + budget_s
     for t in ths:
         t.start()
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
+    total = sum(done)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):

@@ -140,9 +140,16 @@ __global__ __launch_bounds__(WG) void k_pix_gather(Scratch sc, uint32_t B, uint3
     for (uint32_t c = blockIdx.x * WAVES + w; c < nch; c += gridDim.x * WAVES) {
         const uint64_t fc = (uint64_t)f * sc.nchunk_max + c;
         const uint32_t size = sc.chunk_size[fc], off = sc.chunk_off[fc];
-        const uint8_t *src = sc.pix_chunks + fc * PIX_SLOT;
-        uint8_t *dst = pf + 6 + off;
-        for (uint32_t i = lane; i < size; i += 64) dst[i] = src[i];
+        const uint8_t *src = sc.pix_chunks + fc * PIX_SLOT;   // 4-byte aligned (slots are PIX_SLOT apart)
+        uint8_t *dst = pf + 6 + off;                          // any alignment
+        // aligned dword stores: destination dword j = source bytes [head + 4j, +4) = the byte funnel of source dwords j, j+1
+        const uint32_t head = min(size, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
+        const uint32_t nd = (size - head) >> 2, tail = (size - head) & 3u;
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+        for (uint32_t j = lane; j < nd; j += 64)
+            reinterpret_cast<uint32_t *>(dst + head)[j] = __builtin_amdgcn_alignbyte(s32[j + 1], s32[j], head);
+        if ((uint32_t)lane < head) dst[lane] = src[lane];
+        if ((uint32_t)lane < tail) dst[head + 4 * nd + lane] = src[head + 4 * nd + lane];
         if (c == 0 && lane == 0) {   // magic, Frame_Header_Descriptor 0, 1 KiB window (blocks regenerate <= 1008 bytes)
             pf[0] = 0x28; pf[1] = 0xB5; pf[2] = 0x2F; pf[3] = 0xFD; pf[4] = 0; pf[5] = 0;
         }

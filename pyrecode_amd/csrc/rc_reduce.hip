@@ -645,14 +645,20 @@ __device__ __forceinline__ void zstd_place_defs(const uint32_t *__restrict__ row
     __shared__ __attribute__((aligned(16))) uint8_t s_img[PIX_SLOT + 16];
     if (threadIdx.x < 2) s_first[threadIdx.x] = 0xFFFFFFFFu;
     __syncthreads();
-    uint32_t mt = 0xFFFFFFFFu, mq = 0xFFFFFFFFu;
-    for (uint32_t t = threadIdx.x; t < n; t += SCAN_T) {
-        const uint32_t w = row[t];
-        if ((w & ZW_TREE) && t < mt) mt = t;
-        if ((w & ZW_SEQ) && t < mq) mq = t;
+    const uint32_t w0 = row[0];
+    const bool both0 = (w0 & ZW_TREE) && ((w0 & ZW_SEQ) || !sdesc_len);   // the usual case: the frame's first block takes both
+    if (both0) {
+        if (threadIdx.x == 0) { s_first[0] = 0; if (sdesc_len) s_first[1] = 0; }
+    } else {
+        uint32_t mt = 0xFFFFFFFFu, mq = 0xFFFFFFFFu;
+        for (uint32_t t = threadIdx.x; t < n; t += SCAN_T) {
+            const uint32_t w = row[t];
+            if ((w & ZW_TREE) && t < mt) mt = t;
+            if ((w & ZW_SEQ) && t < mq) mq = t;
+        }
+        if (mt != 0xFFFFFFFFu) atomicMin(&s_first[0], mt);
+        if (mq != 0xFFFFFFFFu) atomicMin(&s_first[1], mq);
     }
-    if (mt != 0xFFFFFFFFu) atomicMin(&s_first[0], mt);
-    if (mq != 0xFFFFFFFFu) atomicMin(&s_first[1], mq);
     __syncthreads();
     const uint32_t t_tree = s_first[0], t_seq = s_first[1];
     const uint32_t tl = t_tree != 0xFFFFFFFFu ? tree_len : 0u, sl = t_seq != 0xFFFFFFFFu ? sdesc_len : 0u;

@@ -37,8 +37,9 @@ typedef enum rc_status {
     RC_ERR_RECORD_TOO_LARGE = -5, /* a record exceeds the raw frame size; python: ValueError('Buffer size smaller
                                      than compressed data size') (recode_writer.py:565-566) */
     RC_ERR_CORRUPT = -6,          /* malformed compressed stream / bitmap-vs-pixvals mismatch on the read side */
-    RC_ERR_WORKSPACE = -7         /* reduction level 2: more foreground pixels in the batch than the ctx's workspace holds
-                                     (sized for 12.5 % mean density); python: ValueError */
+    RC_ERR_WORKSPACE = -7         /* reduction level 2: more foreground pixels in the batch than the ctx's workspace holds - only
+                                     when the full-size workspace could not be allocated at rc_ctx_create; the synchronous
+                                     entry point then grows it and retries, the asynchronous ones report; python: ValueError */
 } rc_status;
 
 /* compression_scheme codes of the reference (recode_compressors.py:3-4, config/README.md). Device codecs:
@@ -188,7 +189,13 @@ int rc_ctx_get_profile(rc_ctx *ctx, double sum_ms[5], uint64_t *batches);
  * compress()/de_compress() of pyrecode/recode_compressors.py:82-120 / :40-79 for the device codecs.
  * Host or device pointers.  *out_n receives the produced byte count; rc_decompress also sets it to the required size
  * when it returns RC_ERR_OUT_TOO_SMALL (dst may then be NULL with dst_cap 0: a size query).
- * Uses GPU `RC_DEVICE` (env, default 0). */
+ * Every scheme rc_scheme_on_device() reports (LZ4, zstd, blosc-lz4) is both encoded and decoded here.  Decoding covers
+ * what this library writes and the stock encoders' frames of the same kind: LZ4 frames (independent or linked blocks),
+ * blosc1-LZ4 chunks; zstd frames inside the device decoder's subset (rc_zstd_dec.h: single-stream Huffman or raw literals,
+ * predefined / described / repeated sequence tables, repeat-offset matches) - for a zstd frame outside it (a stock
+ * encoder's 4-stream literals, real offsets) rc_decompress returns RC_ERR_UNSUPPORTED before doing any work and the caller
+ * uses the stock decoder (pyrecode_amd/recode_compressors.py::de_compress does).
+ * Runs on the caller's current GPU, or on `RC_DEVICE` (env) when that is set. */
 int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap,
                 uint64_t *out_n);
 int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n);

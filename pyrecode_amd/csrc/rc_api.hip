@@ -218,10 +218,32 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
     return RC_OK;
 }
 
+// (re)allocate the level-2 workspace for `cap` set pixels per batch
+static int l2_alloc(rc_ctx *c, uint64_t cap)
+{
+    using namespace rc;
+    L2Work &w = c->l2;
+    void *old[] = {w.pos, w.val, w.parent, w.stat};
+    for (void *b : old) if (b) HIP_TRY(hipFree(b));
+    w.pos = nullptr; w.val = nullptr; w.parent = nullptr; w.stat = nullptr;
+    const uint64_t all = (uint64_t)c->max_batch * c->sc.N;
+    w.cap = std::min<uint64_t>(std::min<uint64_t>(cap, all), 0xFFFFFFF0ull);
+    HIP_TRY(hipMalloc((void **)&w.pos, w.cap * 4));
+    HIP_TRY(hipMalloc((void **)&w.val, w.cap * 2));
+    HIP_TRY(hipMalloc((void **)&w.parent, w.cap * 4));
+    HIP_TRY(hipMalloc((void **)&w.stat, w.cap * 4));
+    if (!w.word_rank) {
+        w.words_per_frame = (uint64_t)c->sc.ntiles * (TILE_PX / 64);
+        HIP_TRY(hipMalloc((void **)&w.word_rank, (uint64_t)c->max_batch * w.words_per_frame * 4));
+        HIP_TRY(hipMalloc((void **)&w.frame_base, ((uint64_t)c->max_batch + 1) * 8));
+    }
+    return RC_OK;
+}
+
 static int ctx_alloc(rc_ctx *c)
 {
     using namespace rc;
-    const uint64_t B = c->max_batch, T = c->sc.ntiles;
+    const uint64_t B = c->max_batch;
     RC_ON_DEVICE(c->device);
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->pstream_all, hipStreamNonBlocking));
@@ -256,17 +278,16 @@ static int ctx_alloc(rc_ctx *c)
         if (r != RC_OK) return r;
     }
     c->sc = c->sets[0];
-    if (c->level == 2) {  // compact-pixel workspace: 12.5 % mean foreground over the batch (RC_ERR_WORKSPACE beyond that)
-        L2Work &w = c->l2;
-        w.cap = std::max<uint64_t>(B * c->sc.N / 8, 1ull << 16);
-        if (w.cap > 0xFFFFFFF0ull) w.cap = 0xFFFFFFF0ull;
-        w.words_per_frame = T * (TILE_PX / 64);
-        HIP_TRY(hipMalloc((void **)&w.pos, w.cap * 4));
-        HIP_TRY(hipMalloc((void **)&w.val, w.cap * 2));
-        HIP_TRY(hipMalloc((void **)&w.parent, w.cap * 4));
-        HIP_TRY(hipMalloc((void **)&w.stat, w.cap * 4));
-        HIP_TRY(hipMalloc((void **)&w.word_rank, B * w.words_per_frame * 4));
-        HIP_TRY(hipMalloc((void **)&w.frame_base, (B + 1) * 8));
+    if (c->level == 2) {
+        // compact-pixel workspace: room for EVERY pixel of a batch (14 bytes each - 7.5 GB for 32 frames of 4096^2, nothing
+        // next to 288 GB), so that no batch can exceed it; should that allocation fail, 12.5 % mean foreground, grown on demand
+        // by the synchronous entry point (RC_ERR_WORKSPACE from the asynchronous ones)
+        int r = getenv("RC_L2_SMALL_WORKSPACE") ? RC_ERR_DEVICE : l2_alloc(c, B * c->sc.N);   // (the env switch: tests of the growth path)
+        if (r != RC_OK) {
+            (void)hipGetLastError();
+            r = l2_alloc(c, std::max<uint64_t>(B * c->sc.N / 8, 1ull << 16));
+        }
+        if (r != RC_OK) return r;
     }
     if (c->emit == RC_SCHEME_ZSTD) {
         std::vector<uint8_t> tab(zstd_tables_bytes());
@@ -660,6 +681,18 @@ RC_EXPORT int rc_reduce_compress_batch(rc_ctx *c, const uint16_t *frames, uint32
     r = enqueue_batch(c, fdev, n, first_frame_id, odev, cap, c->d_rec_off, c->d_md, true);
     if (r != RC_OK) return r;
     r = rc_ctx_sync(c);
+    if (r == RC_ERR_WORKSPACE && c->level == 2) {
+        // more foreground than the level-2 workspace holds: the batch's total is known now - grow (with headroom) and run it again
+        uint64_t total = 0;
+        HIP_TRY(hipMemcpy(&total, c->l2.frame_base + n, 8, hipMemcpyDeviceToHost));
+        if (total > c->l2.cap) {
+            r = l2_alloc(c, total + total / 4 + 4096);
+            if (r != RC_OK) return r;
+            r = enqueue_batch(c, fdev, n, first_frame_id, odev, cap, c->d_rec_off, c->d_md, true);
+            if (r != RC_OK) return r;
+            r = rc_ctx_sync(c);
+        }
+    }
     for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&c->stage_ms[4], c->ev[0], c->ev[4]);
     if (r != RC_OK) return r;
@@ -1583,15 +1616,91 @@ static int blosc_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64
     return RC_OK;
 }
 
+// zstd frame of the subset the device decoders cover (rc_zstd_dec.h: everything rc_compress / the ctx write): the host walks
+// the block headers and builds the tables, one lane decodes one block.  The decoded size is not in the frame: the last block
+// is decoded "up to" a block's size and reports what it produced.
+static int zstd_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
+{
+    using namespace rc;
+    Util &u = g_util;
+    std::vector<uint8_t> hsrc;
+    const uint8_t *h = src;
+    if (is_device_ptr(src)) {
+        hsrc.resize(n);
+        HIP_TRY(hipMemcpy(hsrc.data(), src, n, hipMemcpyDeviceToHost));
+        h = hsrc.data();
+    }
+    std::vector<ZdBlock> all, comp, raw;
+    ZdTables T;
+    uint64_t bound = 0;
+    const int zr = zd_index_frame(h, 0, n, 0, TILE_BM, ~0ull, all, T, &bound);
+    if (zr == ZD_FOREIGN) return fail(RC_ERR_UNSUPPORTED, "rc_decompress: zstd stream outside the device decoder's subset (use the stock decoder)");
+    if (zr != ZD_OK) return fail(RC_ERR_CORRUPT, "malformed zstd frame");
+    uint32_t raw_max = 0;
+    for (const ZdBlock &b : all) {
+        if (b.type == 2) { if (b.regen > 1024) return fail(RC_ERR_UNSUPPORTED, "rc_decompress: zstd block larger than the device decoder's rows"); comp.push_back(b); }
+        else { raw.push_back(b); raw_max = std::max(raw_max, b.regen); }
+    }
+    uint32_t row = TILE_BM;
+    for (const ZdBlock &b : comp) if (b.regen > (uint32_t)TILE_BM) row = 1024;
+    const uint8_t *d_src = nullptr;
+    int r = stage_in(src, n, u.a, u.a_cap, d_src);
+    if (r != RC_OK) return r;
+    const uint64_t sz_blk = (comp.size() + raw.size()) * sizeof(ZdBlock) + 64;
+    if ((r = ensure(u.x[2], u.x_cap[2], sz_blk)) != RC_OK || (r = ensure(u.x[3], u.x_cap[3], sizeof(ZdTables) + 64)) != RC_OK ||
+        (r = ensure(u.x[4], u.x_cap[4], 256)) != RC_OK || (r = ensure(u.x[1], u.x_cap[1], bound + 64)) != RC_OK)
+        return r;
+    if (!u.zd_predef) {
+        std::vector<uint8_t> t(zd_tables_bytes());
+        zd_predefined_tables(t.data());
+        HIP_TRY(hipMalloc(&u.zd_predef, t.size()));
+        HIP_TRY(hipMemcpy(u.zd_predef, t.data(), t.size(), hipMemcpyHostToDevice));
+    }
+    hipStream_t s = u.stream;
+    ZdBlock *d_comp = reinterpret_cast<ZdBlock *>(u.x[2]), *d_raw = d_comp + comp.size();
+    uint32_t *d_first = reinterpret_cast<uint32_t *>(u.x[4]);
+    uint64_t *d_base = reinterpret_cast<uint64_t *>(u.x[4] + 16);
+    int *d_err = reinterpret_cast<int *>(u.x[4] + 32);
+    uint32_t *d_prod = reinterpret_cast<uint32_t *>(u.x[4] + 40);
+    const uint32_t first[2] = {0u, (uint32_t)comp.size()};
+    const uint64_t base0 = 0;
+    const uint32_t none = 0xFFFFFFFFu;
+    if (!comp.empty()) HIP_TRY(hipMemcpyAsync(d_comp, comp.data(), comp.size() * sizeof(ZdBlock), hipMemcpyHostToDevice, s));
+    if (!raw.empty()) HIP_TRY(hipMemcpyAsync(d_raw, raw.data(), raw.size() * sizeof(ZdBlock), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(u.x[3], &T, sizeof T, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_first, first, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_base, &base0, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 4, s));
+    HIP_TRY(hipMemcpyAsync(d_prod, &none, 4, hipMemcpyHostToDevice, s));
+    if (!comp.empty()) launch_block_decode(1, (int)row, d_src, d_comp, d_first, 1, (uint32_t)comp.size(), u.x[3], u.zd_predef, u.x[1], d_base, d_err, s, d_prod);
+    launch_block_copy(d_src, d_raw, (uint32_t)raw.size(), raw_max, u.x[1], d_base, s);
+    HIP_TRY(hipGetLastError());
+    int err = 0;
+    uint32_t prod = none;
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&prod, d_prod, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (err) return fail(RC_ERR_CORRUPT, "malformed zstd block");
+    uint64_t total = bound;
+    if (prod != none) {   // the flexible last block produced `prod` of the `regen` bytes it was given
+        for (const ZdBlock &b : comp) if (b.flex) total = bound - (b.regen - prod);
+    }
+    *out_n = total;
+    if (total > dst_cap) return fail(RC_ERR_OUT_TOO_SMALL, "rc_decompress: dst too small");
+    if (total) HIP_TRY(hipMemcpy(dst, u.x[1], total, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return RC_OK;
+}
+
 RC_EXPORT int rc_decompress(uint32_t scheme, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
 {
     if (!src || !out_n || (!dst && dst_cap)) return fail(RC_ERR_BAD_ARG, "NULL argument");
-    if (scheme != RC_SCHEME_LZ4 && scheme != RC_SCHEME_BLOSC_LZ4)  // zstd decoding stays with the stock library on the host, like the reference (recode_compressors.py:46)
+    if (scheme != RC_SCHEME_LZ4 && scheme != RC_SCHEME_BLOSC_LZ4 && scheme != RC_SCHEME_ZSTD)
         return fail(RC_ERR_UNSUPPORTED, "rc_decompress: compression scheme not implemented on device");
     UtilScope util_scope;
     int r = util_scope.enter();
     if (r != RC_OK) return r;
-    return scheme == RC_SCHEME_LZ4 ? lz4_decompress(src, n, dst, dst_cap, out_n) : blosc_decompress(src, n, dst, dst_cap, out_n);
+    if (scheme == RC_SCHEME_ZSTD) return zstd_decompress(src, n, dst, dst_cap, out_n);   // RC_ERR_UNSUPPORTED for foreign frames: the
+    return scheme == RC_SCHEME_LZ4 ? lz4_decompress(src, n, dst, dst_cap, out_n) : blosc_decompress(src, n, dst, dst_cap, out_n);   // caller's stock decoder
 }
 RC_EXPORT uint64_t rc_compress_bound(uint32_t scheme, uint64_t n)
 {

@@ -169,7 +169,8 @@ template <int ROW, int CODEC, int T>
 __global__ __launch_bounds__(64) void k_block_decode(const uint8_t *__restrict__ data, const ZdBlock *__restrict__ blocks,
                                                        const uint32_t *__restrict__ frame_first, const ZdTables *__restrict__ tables,
                                                        const ZdTables *__restrict__ predef, uint8_t *__restrict__ out,
-                                                       const uint64_t *__restrict__ out_base, int *__restrict__ err)
+                                                       const uint64_t *__restrict__ out_base, int *__restrict__ err,
+                                                       uint32_t *__restrict__ produced_out)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_row[T][ROW + 4];
     __shared__ ZdTables s_t;
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(64) void k_block_decode(const uint8_t *__restrict__
                                          fr ? s_t.ml : s_pml, fr ? s_t.ml_log : 6u, s_row[lane], b.regen, &e);
         } else
             produced = lz4_block_decode_row(data + b.src, b.csize, s_row[lane], b.regen, &e);
-        if (produced != b.regen) e = 1;
+        if (b.flex ? produced > b.regen : produced != b.regen) e = 1;
+        if (b.flex && produced_out) produced_out[0] = produced;   // (at most one such block per call: a single stream's last)
         if (e) *err = 1;
     }
     __syncthreads();
@@ -237,16 +239,16 @@ __global__ __launch_bounds__(WG) void k_block_copy(const uint8_t *__restrict__ d
 
 void launch_block_decode(int codec, int row, const uint8_t *data, const void *blocks, const uint32_t *frame_first, uint32_t nframes,
                          uint32_t max_blocks_per_frame, const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base, int *err,
-                         hipStream_t s)
+                         hipStream_t s, uint32_t *produced_out)
 {
     if (!max_blocks_per_frame) return;
     const dim3 blk(64);
     const dim3 g64((max_blocks_per_frame + 63) / 64, nframes), g32((max_blocks_per_frame + 31) / 32, nframes);
     const ZdBlock *b = reinterpret_cast<const ZdBlock *>(blocks);
     const ZdTables *t = reinterpret_cast<const ZdTables *>(tables), *p = reinterpret_cast<const ZdTables *>(predef);
-    if (codec == 1 && row <= 512) hipLaunchKernelGGL((k_block_decode<512, 1, 64>), g64, blk, 0, s, data, b, frame_first, t, p, out, out_base, err);
-    else if (codec == 1) hipLaunchKernelGGL((k_block_decode<1024, 1, 32>), g32, blk, 0, s, data, b, frame_first, t, p, out, out_base, err);
-    else hipLaunchKernelGGL((k_block_decode<512, 2, 64>), g64, blk, 0, s, data, b, frame_first, t, p, out, out_base, err);
+    if (codec == 1 && row <= 512) hipLaunchKernelGGL((k_block_decode<512, 1, 64>), g64, blk, 0, s, data, b, frame_first, t, p, out, out_base, err, produced_out);
+    else if (codec == 1) hipLaunchKernelGGL((k_block_decode<1024, 1, 32>), g32, blk, 0, s, data, b, frame_first, t, p, out, out_base, err, produced_out);
+    else hipLaunchKernelGGL((k_block_decode<512, 2, 64>), g64, blk, 0, s, data, b, frame_first, t, p, out, out_base, err, produced_out);
 }
 void launch_block_copy(const uint8_t *data, const void *blocks, uint32_t nblocks, uint32_t max_regen, uint8_t *out, const uint64_t *out_base,
                        hipStream_t s)

@@ -31,7 +31,8 @@ def _on_device(scheme):
     return bool(_lib.lib().rc_scheme_on_device(int(scheme)))
 
 
-_DEVICE_DECODERS = (2, 8)  # LZ4 frames and blosc1-LZ4 chunks are also DEcoded on the GPU; zstd frames by the stock library on the host
+_DEVICE_DECODERS = (2, 8)  # LZ4 frames and blosc1-LZ4 chunks are always DEcoded on the GPU; zstd frames when they lie inside the
+# device decoder's subset (everything this library writes; rc_decompress says RC_ERR_UNSUPPORTED otherwise), else by the stock library
 
 
 def _zstd_host_decompress(data, decompressor_context=None):
@@ -133,6 +134,11 @@ def de_compress(compression_scheme, compressed_data, decompressor_context):
     if s == 0:
         return zlib.decompress(compressed_data)
     if s == 1:
+        if len(compressed_data):
+            try:
+                return device_decompress(1, compressed_data)
+            except NotImplementedError:   # a foreign encoder's frame (4-stream literals, real offsets, ...): the stock decoder
+                pass
         return _zstd_host_decompress(compressed_data, decompressor_context)
     if s == 3:
         return _need('snappy').decompress(compressed_data)

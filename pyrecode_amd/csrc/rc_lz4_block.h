@@ -61,9 +61,11 @@ __device__ __forceinline__ void table_put2(uint16_t *table, uint32_t k, uint32_t
 
 // Wave-collective.  Precondition: L.raw holds the block in position order (written by this wavefront) and `own` is this
 // lane's 8 bytes raw[8*lane .. 8*lane+8), little-endian.  n: valid bytes (1..512).
-// Returns the compressed size (wave-uniform); the payload is in L.out[0..size) only when size < n.
+// Returns the compressed size (wave-uniform); the payload is in L.out[4 .. 4 + size) only when size < n (the four bytes in
+// front of it take the block's size word: lz4_stage_slot completes the image of the tile's slot in place).
 __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, Lz4Lds &L)
 {
+    uint8_t *const pay = L.out + 4;
     const int lane = lane_id();
     const int base = 8 * lane;
     // ---- phase 1: per-lane masks over the 8 owned positions -------------------------------------------------------
@@ -129,27 +131,27 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
         if ((uint32_t)rd < nrounds && seq_ll[rd] != 0xFFFFFFFFu) {
             uint32_t o = seq_o[rd];
             const uint32_t ll = seq_ll[rd], ml4 = seq_ml4[rd], fs = seq_fs[rd];
-            L.out[o++] = (uint8_t)((min(ll, 15u) << 4) | (ml4 == 0xFFFFu ? 0u : min(ml4, 15u)));
-            if (ll >= 15) o = lz4_emit_len(L.out, o, ll - 15);
+            pay[o++] = (uint8_t)((min(ll, 15u) << 4) | (ml4 == 0xFFFFu ? 0u : min(ml4, 15u)));
+            if (ll >= 15) o = lz4_emit_len(pay, o, ll - 15);
             // literals: 4 bytes per step from two aligned dwords of the block image (one LDS round trip per step; a
             // byte-by-byte copy pays one per byte, and the longest literal run of the block sets the trip count)
             {
                 const uint32_t *raw32 = reinterpret_cast<const uint32_t *>(L.raw);
                 for (uint32_t i = 0; i < ll; i += 4) {
                     const uint32_t a = (fs + i) >> 2;
-                    const uint32_t v = __builtin_amdgcn_alignbyte(raw32[a + 1], raw32[a], (fs + i) & 3u);  // (a + 1 may be L.out[0..3]: unused bytes)
+                    const uint32_t v = __builtin_amdgcn_alignbyte(raw32[a + 1], raw32[a], (fs + i) & 3u);  // (a + 1 may be pay[0..3]: unused bytes)
                     const uint32_t rem = ll - i;
-                    L.out[o + i] = (uint8_t)v;
-                    if (rem > 1) L.out[o + i + 1] = (uint8_t)(v >> 8);
-                    if (rem > 2) L.out[o + i + 2] = (uint8_t)(v >> 16);
-                    if (rem > 3) L.out[o + i + 3] = (uint8_t)(v >> 24);
+                    pay[o + i] = (uint8_t)v;
+                    if (rem > 1) pay[o + i + 1] = (uint8_t)(v >> 8);
+                    if (rem > 2) pay[o + i + 2] = (uint8_t)(v >> 16);
+                    if (rem > 3) pay[o + i + 3] = (uint8_t)(v >> 24);
                 }
             }
             o += ll;
             if (ml4 != 0xFFFFu) {
-                L.out[o++] = 1;  // offset 1, little-endian
-                L.out[o++] = 0;
-                if (ml4 >= 15) o = lz4_emit_len(L.out, o, ml4 - 15);
+                pay[o++] = 1;  // offset 1, little-endian
+                pay[o++] = 0;
+                if (ml4 >= 15) o = lz4_emit_len(pay, o, ml4 - 15);
             }
         }
     }
@@ -193,35 +195,35 @@ __device__ __forceinline__ uint64_t bitshuffle_block(uint64_t elem, uint32_t n, 
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// Wave-collective: write the block to its slot = [u32 LZ4F block word][payload]; returns slot bytes used.  *nst (optional)
-// is increased by the number of vector store instructions issued, or by FEWER when that is not certain: the reduce kernel
-// waits for its prefetched loads with `s_waitcnt vmcnt(nst)` (rc_reduce.hip), where an over-estimate would be an error and an
-// under-estimate only waits a little longer.
-__device__ __forceinline__ uint32_t lz4_store_block(uint8_t *slot, uint64_t own, uint32_t n, uint32_t csize, const Lz4Lds &L,
-                                                    uint32_t *nst = nullptr)
+// Wave-collective: complete the image of the tile's slot in L.out = [u32 block word][payload]: the word in front of a compressed
+// payload (already at L.out + 4), or word + the raw bytes for a block that did not shrink.  LZ4 frame: bit 31 of the word marks
+// a stored block; blosc: a stored block is marked by word == n.  Returns the image's bytes (4 + payload).
+__device__ __forceinline__ uint32_t lz4_stage_slot(uint64_t own, uint32_t n, uint32_t csize, Lz4Lds &L, bool blosc = false)
 {
-    uint32_t *slot32 = reinterpret_cast<uint32_t *>(slot);
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(L.out);
     const int lane = lane_id();
-    if (csize >= n) {  // stored block: bit 31 of the size word
-        if (lane == 0) slot32[0] = n | 0x80000000u;
-        if ((uint32_t)(8 * lane) < n) {
-            slot32[1 + 2 * lane] = (uint32_t)own;
-            slot32[2 + 2 * lane] = (uint32_t)(own >> 32);
-        }
-        if (nst) *nst += 2;  // the size word + at least one store of the payload (n >= 1: lane 0 takes part)
+    if (csize >= n) {
+        if (lane == 0) out32[0] = blosc ? n : (n | 0x80000000u);
+        if ((uint32_t)(8 * lane) < n) { out32[1 + 2 * lane] = (uint32_t)own; out32[2 + 2 * lane] = (uint32_t)(own >> 32); }
+        __builtin_amdgcn_wave_barrier();
         return 4 + n;
     }
-    // [size word][payload] written as whole 128-byte lines (slots are 128-byte aligned, BLK_SLOT is a multiple of 128): the
-    // bytes behind the payload are unused slot space, and partial-line writes cost a read-modify-write at the memory side
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(L.out);
-    const uint32_t ndw = ((1u + (csize + 3) / 4) + 31u) & ~31u;   // >= 32: every round below stores with lanes active
-#if defined(RC_ABLATE) && (RC_ABLATE & 2)
-    for (uint32_t i = lane; i < ndw; i += 64) if ((i == 0 ? csize : p[i - 1]) == 0x9E3779B9u) slot32[i] = 1;
-#else
-    for (uint32_t i = lane; i < ndw; i += 64) slot32[i] = i == 0 ? csize : p[i - 1];
-    if (nst) *nst += (ndw + 63u) >> 6;
-#endif
+    if (lane == 0) out32[0] = csize;
+    __builtin_amdgcn_wave_barrier();
     return 4 + csize;
+}
+
+// Wave-collective: stage + write the slot as whole 128-byte lines (slots are 128-byte aligned, BLK_SLOT is a multiple of 128;
+// the bytes behind the image are unused slot space, and partial-line writes cost a read-modify-write at the memory side).
+// Returns slot bytes used.  (The fused reduce kernel stages here and writes through its own combined store, rc_reduce.hip.)
+__device__ __forceinline__ uint32_t lz4_store_block(uint8_t *slot, uint64_t own, uint32_t n, uint32_t csize, Lz4Lds &L, bool blosc = false)
+{
+    const uint32_t used = lz4_stage_slot(own, n, csize, L, blosc);
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(L.out);
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(slot);
+    const uint32_t ndw = min((((used + 3) >> 2) + 31u) & ~31u, (uint32_t)BLK_SLOT / 4);
+    for (uint32_t i = lane_id(); i < ndw; i += 64) slot32[i] = p[i];
+    return used;
 }
 
 }  // namespace rc

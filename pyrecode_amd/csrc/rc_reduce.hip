@@ -212,50 +212,78 @@ __device__ __forceinline__ void pack_stage(uint16_t *pix, uint32_t cnt, uint32_t
     }
 }
 
-// Returns the number of vector store instructions issued (never more than were: see lz4_store_block).
+// All line-sized results of one (tile, frame) - the residual stream's lines and the encoded block's lines, both complete images
+// in the wave's LDS - leave through ONE kind of store: every lane moves 16 bytes (ds_read_b128 + global_store_dwordx4), the
+// first q0 lanes from segment 0, the next q1 from segment 1, each lane with its own address; 1 KiB per instruction, i.e. one
+// instruction for the usual 1 + 2 lines.  Only whole 128-byte lines are written (the tails are unused slot space: partial-line
+// writes cost a read-modify-write at the memory side).  The two 4-byte results (count, block size) share one instruction as
+// well (lanes 0 and 1, different arrays).  Fewer vector-memory instructions matter here: under the saturated read stream every
+// one of them waits for a slot in the CU's memory queue (profiles/r02_reduce_stores.md).
+// Returns the number of vector store instructions issued - NEVER more than were issued (vm_wait_loads).
+__device__ __forceinline__ uint32_t store_lines2(const uint8_t *s0, uint8_t *d0, uint32_t q0, const uint8_t *s1, uint8_t *d1, uint32_t q1)
+{
+    const uint32_t total = q0 + q1, lane = (uint32_t)lane_id();
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t i = base + lane;
+        if (i < total) {
+            const bool second = i >= q0;
+            const uint32_t j = second ? i - q0 : i;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>((second ? s1 : s0) + 16 * j);
+            *reinterpret_cast<u32x4 *>((second ? d1 : d0) + 16 * j) = v;
+        }
+    }
+    return (total + 63u) >> 6;
+}
+
 template <bool LEVEL1, int CODEC, bool KEEP_BITMAP>
 __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t tile, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                   uint64_t nb_stride, uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
-                                                  uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, const Lz4Lds *lz,
+                                                  uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, Lz4Lds *lz,
                                                   const WaveStage *st)
 {
     if (!p.valid) return 0;
     const int lane = lane_id();
     uint32_t nst = 0;
+    // segment 0: the residual lines; segment 1: the encoded block's lines
+    const uint8_t *s0 = nullptr, *s1 = nullptr;
+    uint8_t *d0 = nullptr, *d1 = nullptr;
+    uint32_t q0 = 0, q1 = 0, bsz = 0;
     if (LEVEL1) {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(pix_slots + p.ft * TILE_PX);   // slots are 8 KiB aligned
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.buf);
-        // whole 128-byte lines only (the tail of the last line is unused slot space): partial-line writes cost a
-        // read-modify-write at the memory side
-        const uint32_t ndw = (((p.cnt * p.depth + 31) >> 5) + 31u) & ~31u;
-        for (uint32_t i = lane; i < ndw; i += 64) RC_ST(1, dst[i], src[i]);
-        if (lane == 0) RC_ST(4, tile_cnt[p.ft], p.cnt);
-        if (!(RC_ABLATE & 1)) nst += (ndw + 63u) >> 6;
-        if (!(RC_ABLATE & 4)) nst += 1;
+        s0 = reinterpret_cast<const uint8_t *>(p.buf);
+        d0 = reinterpret_cast<uint8_t *>(pix_slots + p.ft * TILE_PX);   // slots are 8 KiB aligned
+        q0 = ((((p.cnt * p.depth + 31) >> 5) + 31u) & ~31u) >> 2;       // whole lines, in 16-byte units
     }
+    if (CODEC == 2 || CODEC == 8) {
+        const uint64_t bytes = CODEC == 2 ? ((uint64_t)p.own[0] | ((uint64_t)p.own[1] << 32)) : p.cown;
+        bsz = lz4_stage_slot(bytes, n_blk, p.csize, *lz, CODEC == 8);
+    }
+    if (CODEC == 1 || CODEC == 3) {
+        (void)zstd_stage_slot(n_blk, p.last, p.staged, *lz);
+        bsz = p.staged ? p.staged : 4u;
+    }
+    if (CODEC) {
+        s1 = lz->out;
+        d1 = blk_slots + p.ft * BLK_SLOT;
+        q1 = min((((bsz + 3) >> 2) + 31u) & ~31u, (uint32_t)BLK_SLOT / 4) >> 2;
+    }
+    if (!(RC_ABLATE & 1) && !(RC_ABLATE & 2)) { if (q0 + q1) nst += store_lines2(s0, d0, q0, s1, d1, q1); }
+    else if (!(RC_ABLATE & 1)) { if (q0) nst += store_lines2(s0, d0, q0, s1, d1, 0); }
+    else if (!(RC_ABLATE & 2)) { if (q1) nst += store_lines2(s1, d1, q1, s0, d0, 0); }
     if (KEEP_BITMAP) {
         *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)p.f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = p.own;
         nst += 1;
     }
-    if (CODEC == 2) {
-        const uint64_t bytes = (uint64_t)p.own[0] | ((uint64_t)p.own[1] << 32);
-        const uint32_t used = lz4_store_block(blk_slots + p.ft * BLK_SLOT, bytes, n_blk, p.csize, *lz, &nst);
-        if (lane == 0) RC_ST(4, blk_size[p.ft], used);
-        if (!(RC_ABLATE & 4)) nst += 1;
-    }
-    if (CODEC == 1 || CODEC == 3) {
-        zstd_store_block(blk_slots + p.ft * BLK_SLOT, n_blk, p.last, p.csize, p.staged, *lz, &nst);
-        if (lane == 0) blk_size[p.ft] = p.csize;
-        nst += 1;
-    }
-    if (CODEC == 8) {
-        uint8_t *slot = blk_slots + p.ft * BLK_SLOT;
-        const uint32_t used = lz4_store_block(slot, p.cown, n_blk, p.csize, *lz, &nst);
-        if (lane == 0) {
-            if (p.csize >= n_blk) reinterpret_cast<uint32_t *>(slot)[0] = n_blk;  // blosc marks a stored block by csize == size
-            blk_size[p.ft] = used;
+    // the 4-byte results: lane 0 the count, lane 1 the block's size word, one instruction
+    if ((LEVEL1 || CODEC) && !(RC_ABLATE & 4)) {
+        const uint32_t word = CODEC == 1 || CODEC == 3 ? p.csize : bsz;   // zstd: the tokenizer's word (k_zstd_fse finishes the block)
+        if (LEVEL1 && CODEC) {
+            if (lane < 2) *(lane == 0 ? &tile_cnt[p.ft] : &blk_size[p.ft]) = lane == 0 ? p.cnt : word;
+        } else if (LEVEL1) {
+            if (lane == 0) tile_cnt[p.ft] = p.cnt;
+        } else {
+            if (lane == 0) blk_size[p.ft] = word;
         }
-        nst += 1;   // (the rewritten size word of a stored block is not counted: fewer is safe)
+        nst += 1;
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)nst);
 }

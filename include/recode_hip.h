@@ -161,6 +161,12 @@ int rc_pipe_result(rc_ctx *ctx, uint32_t slot, uint64_t *rec_offsets, uint32_t *
 int rc_pipe_fetch(rc_ctx *ctx, uint32_t slot, uint8_t *dst_host, uint64_t bytes);
 int rc_pipe_fetch_wait(rc_ctx *ctx, uint32_t slot);
 
+/* zstd, modelled encoder (compression_level >= 1): the ctx fits its entropy tables to a sample of the FIRST batch it sees and
+ * keeps them (every frame carries the tables it was coded with, so any model is valid for any data - only the ratio suffers when
+ * the data drifts away from the sample).  rc_ctx_refit_model makes the NEXT batch the sample again (one synchronous step), e.g.
+ * after a change of dose or detector mode; a no-op for other schemes.  No counterpart in the reference (libzstd adapts per call). */
+int rc_ctx_refit_model(rc_ctx *ctx);
+
 /* Packed binary map (ceil(nx*ny/8) bytes, LSB-first) of frame i of the most recent batch: what the third element
  * of _reduce_compress's return value carries for validation frames (recode_writer.py:386,402-415,557). */
 int rc_get_binary_map(rc_ctx *ctx, uint32_t i, uint8_t *bitmap_out);

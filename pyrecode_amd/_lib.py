@@ -41,6 +41,7 @@ SIGNATURES = {
     "rc_ctx_sync": (C.c_int, [C.c_void_p]),
     "rc_ctx_set_pipelined": (C.c_int, [C.c_void_p, C.c_int]),
     "rc_ctx_wait_results": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rc_ctx_refit_model": (C.c_int, [C.c_void_p]),
     "rc_get_binary_map": (C.c_int, [C.c_void_p, C.c_uint32, _u8p]),
     "rc_ctx_keep_binary_maps": (C.c_int, [C.c_void_p, C.c_int]),
     "rc_ctx_set_l2_statistics": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -242,6 +243,10 @@ class ReduceContext:
 
     def pipe_fetch_wait(self, slot):
         check(lib().rc_pipe_fetch_wait(self._h, slot), "rc_pipe_fetch_wait")
+
+    def refit_model(self):
+        """zstd, modelled encoder: fit the entropy tables again to the next batch (include/recode_hip.h)."""
+        check(lib().rc_ctx_refit_model(self._h), "rc_ctx_refit_model")
 
     def binary_map(self, i):
         out = np.empty(self.bitmap_bytes, np.uint8)

@@ -849,6 +849,13 @@ RC_EXPORT int rc_pipe_fetch_wait(rc_ctx *c, uint32_t slot)
     return RC_OK;
 }
 
+RC_EXPORT int rc_ctx_refit_model(rc_ctx *c)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    c->model_ready = false;
+    return RC_OK;
+}
+
 RC_EXPORT int rc_get_binary_map(rc_ctx *c, uint32_t i, uint8_t *bitmap_out)
 {
     if (!c || !bitmap_out) return fail(RC_ERR_BAD_ARG, "NULL argument");

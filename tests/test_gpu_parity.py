@@ -416,6 +416,15 @@ def test_zstd_modelled_frames_unlike_the_sample(hip, orc, d):
     out, rec, md = ctx.reduce_compress_batch(batch, first_frame_id=10)
     for z in range(4):
         _check_zstd_record(orc, out[int(rec[z]):int(rec[z + 1])].tobytes(), batch[z], thr, d, 10 + z)
+    # refit: the next batch becomes the sample; dense frames then compress no worse than under the sparse model
+    _, dense4 = synth_frames(79, 4, ny, nx, 0.25, d)
+    out, rec, md = ctx.reduce_compress_batch(dense4, first_frame_id=20)
+    before = int(rec[4])
+    ctx.refit_model()
+    out, rec, md = ctx.reduce_compress_batch(dense4, first_frame_id=20)
+    for z in range(4):
+        _check_zstd_record(orc, out[int(rec[z]):int(rec[z + 1])].tobytes(), dense4[z], thr, d, 20 + z)
+    assert int(rec[4]) <= before
     ctx.close()
 
 

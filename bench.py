@@ -192,7 +192,9 @@ def bench_read(a):
     for z in range(B):
         blobs.append(out[int(rec[z]) + hdr:int(rec[z + 1])])
         sizes[z] = md[z] if a.level == 1 else (md[z][0], 0, 0)
-    blob = np.concatenate(blobs)
+    pinned = hip.PinnedBuffer(sum(b.size for b in blobs))   # what a reader holds: the file's bytes in page-locked memory
+    blob = pinned.array
+    np.concatenate(blobs, out=blob)
     prefix = np.zeros(B + 1, np.uint64)
     args = (a.nx, a.ny, a.depth, a.level, 1, a.scheme, hip.ptr(blob), hip.ptr(sizes), B)
     hip.check(L.rc_expand_frames(*args, hip.ptr(prefix), None, 0), "rc_expand_frames")

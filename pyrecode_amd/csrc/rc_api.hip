@@ -9,6 +9,7 @@
 #include <new>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/recode_hip.h"
@@ -1091,54 +1092,73 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     }
     pv_stride += 16;
     uint32_t bm_max = 0, pv_max = 0, raw_max_regen = 0;
-    for (uint32_t f = 0; f < n; ++f) {
+    // per frame, independently (a few host threads): walk the two streams' block headers, build the frame's tables
+    struct FrameIndex { std::vector<ZdBlock> bm, pv, raw; int status = ZD_OK; const char *what = nullptr; };
+    std::vector<FrameIndex> fi(n);
+    std::vector<uint64_t> foff(n);
+    for (uint32_t f = 0; f < n; ++f) { foff[f] = off; off += (uint64_t)sizes[3 * f] + (level == 1 ? sizes[3 * f + 1] : 0); }
+    auto index_frame = [&](uint32_t f) {
+        FrameIndex &F = fi[f];
         const uint64_t cb = sizes[3 * f], cp = level == 1 ? sizes[3 * f + 1] : 0, npk = level == 1 ? sizes[3 * f + 2] : 0;
-        bm_base[f] = (uint64_t)f * bm_stride;
-        pv_base[f] = (uint64_t)n * bm_stride + (uint64_t)f * pv_stride;   // the value streams lie behind the bitmaps in ONE output buffer
-        pv_bytes[f] = (uint32_t)npk;
-        bm_first[f] = (uint32_t)bm_comp.size();
-        pv_first[f] = (uint32_t)pv_comp.size();
-        int r = ZD_OK;
+        const uint64_t o = foff[f];
         uint64_t got = 0;
+        int r = ZD_OK;
         if (codec == 0) {
-            if (cb != nb || cp != npk) return fail(RC_ERR_CORRUPT, "rc_expand_frames: mode-0 sizes disagree with the frame shape");
+            if (cb != nb || cp != npk) { F.status = ZD_CORRUPT; F.what = "rc_expand_frames: mode-0 sizes disagree with the frame shape"; return; }
             ZdBlock b;
             memset(&b, 0, sizeof b);
-            b.frame = f; b.src = off; b.csize = b.regen = (uint32_t)nb; b.dst = 0;
-            raw.push_back(b);
-            if (npk) { b.src = off + cb; b.csize = b.regen = (uint32_t)npk; b.frame = n + f; raw.push_back(b); }
+            b.frame = f; b.src = o; b.csize = b.regen = (uint32_t)nb; b.dst = 0;
+            F.raw.push_back(b);
+            if (npk) { b.src = o + cb; b.csize = b.regen = (uint32_t)npk; b.frame = n + f; F.raw.push_back(b); }
         } else if (codec == 2) {
-            const size_t r0 = raw.size();
-            r = lz4_index_frame(data, off, cb, f, TILE_BM, nb, bm_comp, raw, &got);
+            r = lz4_index_frame(data, o, cb, f, TILE_BM, nb, F.bm, F.raw, &got);
             if (r == ZD_OK && got != nb) r = ZD_CORRUPT;
             if (r == ZD_OK && level == 1) {
-                const size_t r1 = raw.size();
                 std::vector<ZdBlock> none;
-                r = lz4_index_frame(data, off + cb, cp, n + f, 0, npk, none, raw, &got);
+                r = lz4_index_frame(data, o + cb, cp, n + f, 0, npk, none, F.raw, &got);
                 if (r == ZD_OK && got != npk) r = ZD_CORRUPT;
-                (void)r1;
             }
-            (void)r0;
         } else {
             std::vector<ZdBlock> all;
-            r = zd_index_frame(data, off, cb, f, TILE_BM, nb, all, bm_tab[f], &got);
+            r = zd_index_frame(data, o, cb, f, TILE_BM, nb, all, bm_tab[f], &got);
             if (r == ZD_OK && got != nb) r = ZD_CORRUPT;
-            for (const ZdBlock &b : all) (b.type == 2 ? bm_comp : raw).push_back(b);
+            for (const ZdBlock &b : all) (b.type == 2 ? F.bm : F.raw).push_back(b);
             if (r == ZD_OK && level == 1) {
                 all.clear();
-                r = zd_index_frame(data, off + cb, cp, n + f, 0, npk, all, pv_tab[f], &got);
+                r = zd_index_frame(data, o + cb, cp, n + f, 0, npk, all, pv_tab[f], &got);
                 if (r == ZD_OK && got != npk) r = ZD_CORRUPT;
                 for (ZdBlock b : all) {
-                    if (b.type == 2) { if (b.regen > 1024) { r = ZD_FOREIGN; break; } b.frame = f; pv_comp.push_back(b); }
-                    else raw.push_back(b);
+                    if (b.type == 2) { if (b.regen > 1024) { r = ZD_FOREIGN; break; } b.frame = f; F.pv.push_back(b); }
+                    else F.raw.push_back(b);
                 }
             }
         }
-        if (r == ZD_FOREIGN) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: stream outside the device decoders' subset (use the stock decoder)");
-        if (r != ZD_OK) return fail(RC_ERR_CORRUPT, "rc_expand_frames: malformed compressed stream");
-        bm_max = std::max<uint32_t>(bm_max, (uint32_t)bm_comp.size() - bm_first[f]);
-        pv_max = std::max<uint32_t>(pv_max, (uint32_t)pv_comp.size() - pv_first[f]);
-        off += cb + cp;
+        F.status = r;
+    };
+    {
+        const uint32_t nthr = std::min<uint32_t>(n, 8);
+        if (nthr <= 1) { for (uint32_t f = 0; f < n; ++f) index_frame(f); }
+        else {
+            std::vector<std::thread> pool;
+            for (uint32_t t = 0; t < nthr; ++t)
+                pool.emplace_back([&, t] { for (uint32_t f = t; f < n; f += nthr) index_frame(f); });
+            for (auto &th : pool) th.join();
+        }
+    }
+    for (uint32_t f = 0; f < n; ++f) {
+        FrameIndex &F = fi[f];
+        if (F.status == ZD_FOREIGN) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: stream outside the device decoders' subset (use the stock decoder)");
+        if (F.status != ZD_OK) return fail(RC_ERR_CORRUPT, F.what ? F.what : "rc_expand_frames: malformed compressed stream");
+        bm_base[f] = (uint64_t)f * bm_stride;
+        pv_base[f] = (uint64_t)n * bm_stride + (uint64_t)f * pv_stride;   // the value streams lie behind the bitmaps in ONE output buffer
+        pv_bytes[f] = level == 1 ? sizes[3 * f + 2] : 0;
+        bm_first[f] = (uint32_t)bm_comp.size();
+        pv_first[f] = (uint32_t)pv_comp.size();
+        bm_comp.insert(bm_comp.end(), F.bm.begin(), F.bm.end());
+        pv_comp.insert(pv_comp.end(), F.pv.begin(), F.pv.end());
+        raw.insert(raw.end(), F.raw.begin(), F.raw.end());
+        bm_max = std::max<uint32_t>(bm_max, (uint32_t)F.bm.size());
+        pv_max = std::max<uint32_t>(pv_max, (uint32_t)F.pv.size());
     }
     bm_first[n] = (uint32_t)bm_comp.size();
     pv_first[n] = (uint32_t)pv_comp.size();

@@ -607,7 +607,9 @@ void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32
 // The workgroup is deliberately small: in pipelined mode this kernel is dispatched while the next batch's reduce kernel
 // owns the chip, and a 1024-thread workgroup (16 waves that must start on one CU together) waited there for hundreds of
 // microseconds (rocprofv3: 74 us with LZ4, 355 us with zstd, against 10 us when alone).
-constexpr int SCAN_T = 256, SCAN_W = SCAN_T / 64, SCAN_I = 16;
+constexpr int SCAN_T = 256, SCAN_W = SCAN_T / 64;
+// entries per thread and round: 16 (one round for 4096 tiles), 32 for frames with many more tiles (half the rounds, each of which is a
+// dependent global round trip + two barriers: 11520x8184 has 23 018 tiles)
 
 __device__ __forceinline__ uint32_t scan_block_excl(uint32_t v, uint32_t *sm, uint32_t *total)
 {
@@ -629,6 +631,7 @@ __device__ __forceinline__ uint32_t scan_block_excl(uint32_t v, uint32_t *sm, ui
 
 // adj (optional): {tile a, bytes added to a, tile b, bytes added to b}: the row's size words are read without their flag bits,
 // the two additions applied, and the clean sizes written back
+template <int SCAN_I>
 __device__ __forceinline__ void scan_row(uint32_t *__restrict__ row, uint32_t *__restrict__ orow, uint32_t n,
                                          uint32_t *__restrict__ total, uint32_t *sm, const uint32_t *adj = nullptr)
 {
@@ -724,13 +727,14 @@ __global__ __launch_bounds__(SCAN_T) void k_pix_scan(Scratch sc, uint32_t depth)
     const uint32_t nch = npk ? (npk + PIX_CHUNK - 1) / PIX_CHUNK : 1u;
     uint32_t *row = sc.chunk_size + (uint64_t)f * sc.nchunk_max;
     zstd_place_defs(row, nch, sc.pix_chunks + (uint64_t)f * sc.nchunk_max * PIX_SLOT, PIX_SLOT, M->pix_desc, M->pix_desc_len, nullptr, 0, s_adj);
-    scan_row(row, sc.chunk_off + (uint64_t)f * sc.nchunk_max, nch, sc.frame_pbytes + f, sm, s_adj);
+    scan_row<16>(row, sc.chunk_off + (uint64_t)f * sc.nchunk_max, nch, sc.frame_pbytes + f, sm, s_adj);
 }
 void launch_pix_scan(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t s)
 {
     hipLaunchKernelGGL(k_pix_scan, dim3(B), dim3(SCAN_T), 0, s, sc, depth);
 }
 
+template <int SCAN_I>
 __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_counts, int with_blocks)
 {
     __shared__ uint32_t sm[SCAN_W];
@@ -744,11 +748,11 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_cou
             zstd_place_defs(sc.blk_size + fr, n, sc.blk_slots + fr * BLK_SLOT, BLK_SLOT, M->lit_desc, M->lit_desc_len, M->seq_desc,
                             M->seq_desc_len, s_adj);
         }
-        scan_row(sc.blk_size + fr, sc.blk_off + fr, n, sc.frame_cbytes + f, sm, sc.zm_model ? s_adj : nullptr);
+        scan_row<SCAN_I>(sc.blk_size + fr, sc.blk_off + fr, n, sc.frame_cbytes + f, sm, sc.zm_model ? s_adj : nullptr);
     }
     if (!with_counts) return;
     uint32_t *row = sc.tile_cnt + fr;
-    scan_row(row, sc.tile_off + fr, n, sc.frame_nnz + f, sm);
+    scan_row<SCAN_I>(row, sc.tile_off + fr, n, sc.frame_nnz + f, sm);
     // suffix pass, rounds from the end: next non-empty tile
     uint32_t *nrow = sc.tile_next + fr;
     if (threadIdx.x == 0) s_carry = n;
@@ -799,7 +803,8 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_cou
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s)
 {
     if (!with_counts && !with_blocks) return;
-    hipLaunchKernelGGL(k_scan_frames, dim3(B), dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
+    if (sc.ntiles > 8192) hipLaunchKernelGGL(k_scan_frames<32>, dim3(B), dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
+    else hipLaunchKernelGGL(k_scan_frames<16>, dim3(B), dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
 }
 
 // ---- record layout: sizes, offsets, metadata, status ------------------------------------------------------------

@@ -124,7 +124,8 @@ __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlo
             if (llen == 0 || op + llen + mlen > cap) { *err = 1; return op; }   // offset code 0 means "previous byte" only behind a literal
             for (uint32_t k = 0; k < llen; ++k) row[op++] = (uint8_t)L.next(err);
             const uint8_t prev = row[op - 1];
-            for (uint32_t k = 0; k < mlen; ++k) row[op++] = prev;
+            if (prev == 0) op += mlen;   // the rows start out zeroed: a run of zeros (what these matches are in a bitmap) costs nothing
+            else for (uint32_t k = 0; k < mlen; ++k) row[op++] = prev;
             if (i + 1 < nseq) {                                               // state updates: literal length, match length, (offset)
                 sl = (el >> 16) + fb.read((el >> 8) & 0xFFu);
                 sm = (em >> 16) + fb.read((em >> 8) & 0xFFu);
@@ -187,6 +188,8 @@ __global__ __launch_bounds__(64) void k_block_decode(const uint8_t *__restrict__
         s_pml[lane] = predef->ml[lane];
         __syncthreads();
     }
+    for (uint32_t i = lane; i < (uint32_t)(T * (ROW + 4)) / 4; i += 64) reinterpret_cast<uint32_t *>(&s_row[0][0])[i] = 0;
+    __syncthreads();
     const uint32_t bi = i0 + lane;
     ZdBlock b;
     uint32_t produced = 0;

@@ -132,6 +132,9 @@ class ReCoDeReader:
 
     def close(self):
         self._fp.close()
+        if getattr(self, '_pin_blob', None) is not None:
+            self._pin_blob.close()
+            self._pin_blob = None
 
     def seek_to_frame_data(self):
         self._frame_data_start_position = self._rc_header.get_frame_data_offset(self._is_intermediate,
@@ -201,7 +204,13 @@ class ReCoDeReader:
             lo = self._frame_data_start_position + int(self._seek_table[z0, 1])
             total = int(self._seek_table[z0:z0 + n, 0].sum())
             self._fp.seek(lo, 0)
-            blob = np.frombuffer(self._fp.read(total), np.uint8)
+            if getattr(self, '_pin_blob', None) is None or self._pin_blob.nbytes < total:   # file -> page-locked memory, no copy in between
+                if getattr(self, '_pin_blob', None) is not None:
+                    self._pin_blob.close()
+                self._pin_blob = _lib.PinnedBuffer(max(int(total * 1.25), 1 << 20))
+            blob = self._pin_blob.array[:total]
+            if self._fp.readinto(memoryview(blob)) != total:
+                raise ValueError('file shorter than its seek table says')
             prefix = np.zeros(n + 1, np.uint64)
             L = _lib.lib()
             args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, mode, scheme, _lib.ptr(blob), _lib.ptr(sizes), n)

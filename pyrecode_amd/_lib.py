@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librecode_hip.so")
+LIB_PATH = os.environ.get("RC_LIB_PATH") or os.path.join(_HERE, "librecode_hip.so")   # (RC_LIB_PATH: A/B runs of two builds, tools/ab.sh)
 
 RC_OK = 0
 RC_ERR_BAD_ARG = -1

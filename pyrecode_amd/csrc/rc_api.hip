@@ -247,6 +247,7 @@ static int ctx_alloc(rc_ctx *c)
     const uint64_t B = c->max_batch;
     RC_ON_DEVICE(c->device);
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    // (a high-priority second-stage stream was measured: no gain with LZ4 or zstd, 2 % slower at 11520x8184 - tools/ab_bench.sh)
     HIP_TRY(hipStreamCreateWithFlags(&c->pstream_all, hipStreamNonBlocking));
     {
         // Experiment knob, off by default.  In pipelined mode the second stage runs next to the following batch's reduce

@@ -21,6 +21,7 @@ constexpr int BLK_SLOT = TILE_BM + 128;    // per-tile scratch slot for an encod
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
 // ---- wavefront primitives (64 lanes) ------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

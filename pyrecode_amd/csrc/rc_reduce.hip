@@ -309,10 +309,14 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
         const u32x4 tt = t[r];
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[r][k] = pk_sub_sat_u16(x[r][k], tt[k]);
+        // 0 / 1 per pixel (packed min with 1), then four chained 16-bit dot products with the bit weights: pixel j -> bit j
         const uint32_t one = 0x00010001u;
-        const uint32_t M = pk_min_u16(x[r][0], one) | (pk_min_u16(x[r][1], one) << 2) | (pk_min_u16(x[r][2], one) << 4) |
-                           (pk_min_u16(x[r][3], one) << 6);  // pixel 2k -> bit 2k, pixel 2k+1 -> bit 16+2k
-        m8[r] = (M | (M >> 15)) & 0xFFu;
+        uint32_t M = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k)
+            M = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pk_min_u16(x[r][k], one)),
+                                       __builtin_bit_cast(u16x2, (uint32_t)((1u << (2 * k)) | (2u << (2 * k + 16)))), M, false);
+        m8[r] = M;
     }
     // this frame's data has arrived (the subtract above consumed it): start the NEXT frame's loads now, into the other
     // register set, so that they fly during the whole compaction + encoding of this frame ...
@@ -360,23 +364,27 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
         // prefix sum of the per-lane popcounts places everything, and each lane moves its own set pixels from `val` to
         // `out`, two per step (both LDS reads in flight together).  [The group-by-group alternative below needs three
         // packed scans and eight divergent loops per frame: 0.10 ms of the kernel at 1 % sparsity, measured against level 3.]
-        uint64_t q = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(q);
+        const uint32_t cnt = (uint32_t)__builtin_popcount(pend.own[0]) + (uint32_t)__builtin_popcount(pend.own[1]);
         const uint32_t inc = wave_incl_scan(cnt);
         const uint32_t wave_total = wave_last(inc);
         if (wave_total <= (uint32_t)STAGE_CAP) {
-            const uint16_t *mine = st->val + 64 * lane;
-            uint32_t o = inc - cnt;
-            while (q) {
-                const uint32_t i0 = (uint32_t)__builtin_ctzll(q);
-                q &= q - 1;
-                const bool two = q != 0;
-                const uint32_t i1 = two ? (uint32_t)__builtin_ctzll(q) : i0;
-                q &= q - 1;                       // (0 & anything: stays 0)
-                const uint16_t v0 = mine[i0], v1 = mine[i1];
-                st->out[o] = v0;
-                if (two) st->out[o + 1] = v1;
-                o += 2;
+            // (the two 32-pixel halves one after the other: 32-bit bit scans, half the instructions of a 64-bit loop body)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint16_t *mine = st->val + 64 * lane + 32 * h;
+                uint32_t qh = pend.own[h];
+                uint32_t o = inc - cnt + (h ? (uint32_t)__builtin_popcount(pend.own[0]) : 0u);
+                while (qh) {
+                    const uint32_t i0 = (uint32_t)__builtin_ctz(qh);
+                    qh &= qh - 1;
+                    const bool two = qh != 0;
+                    const uint32_t i1 = two ? (uint32_t)__builtin_ctz(qh) : i0;
+                    qh &= qh - 1;                       // (0 & anything: stays 0)
+                    const uint16_t v0 = mine[i0], v1 = mine[i1];
+                    st->out[o] = v0;
+                    if (two) st->out[o + 1] = v1;
+                    o += 2;
+                }
             }
         } else {
             // dense tile: exclusive prefix of the per-lane popcounts in (group, lane) order, three groups per packed scan
@@ -464,8 +472,14 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 // ASMLOAD instantiation (aligned frames, every tile of the launch lies wholly inside the frame): the frames are read through
 // vm_issue_loads / vm_wait_loads, see Pending.  The other instantiation (the last, partial tile of a frame; unaligned frames)
 // leaves loads and waits to the compiler.  tile0: first tile of this launch.
+// Workgroup = RWAVES wavefronts.  The wavefronts of this kernel never talk to each other, so the workgroup size is free
+// (measurements in launch_reduce_t).
+#ifndef RC_REDUCE_WAVES
+#define RC_REDUCE_WAVES 4
+#endif
+constexpr int RWAVES = RC_REDUCE_WAVES, RWG = 64 * RWAVES;
 template <int BZ, bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
+__global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(3))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t tile0, uint32_t tile_end,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
@@ -478,20 +492,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
     if (blockIdx.x == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
     __shared__ uint16_t s_code[CODEC == 3 ? 256 : 2];                                           // modelled zstd: Huffman code table
     if (CODEC == 3) {   // (the only barrier of the kernel, in front of every early exit)
-        if (threadIdx.x < 128) reinterpret_cast<uint32_t *>(s_code)[threadIdx.x] = reinterpret_cast<const uint32_t *>(zm.lit_code)[threadIdx.x];
+        for (uint32_t i = threadIdx.x; i < 128; i += RWG) reinterpret_cast<uint32_t *>(s_code)[i] = reinterpret_cast<const uint32_t *>(zm.lit_code)[i];
         __syncthreads();
         zm.lit_code = s_code;
     }
-    __shared__ Lz4Lds s_lz[CODEC ? WAVES : 1];                                                  // codec working set
-    __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : WAVES][CODEC ? 16 : TILE_BM];  // transpose only
-    __shared__ WaveStage s_stage[LEVEL1 ? WAVES : 1];                                           // compacted residuals
+    __shared__ Lz4Lds s_lz[CODEC ? RWAVES : 1];                                                  // codec working set
+    __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : RWAVES][CODEC ? 16 : TILE_BM];  // transpose only
+    __shared__ WaveStage s_stage[LEVEL1 ? RWAVES : 1];                                           // compacted residuals
 
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t grp = j % ngroups;
     const uint32_t tblock = (j / ngroups) * 8u + xcd;
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t tile = tile0 + tblock * WAVES + w;
+    const uint32_t tile = tile0 + tblock * RWAVES + w;
     if (tile >= tile_end) return;  // whole wavefront leaves; nothing below synchronises across wavefronts
     const uint64_t lane_px0 = (uint64_t)tile * TILE_PX + (uint64_t)lane * 8;
     const uint32_t f0 = grp * BZ;
@@ -549,17 +563,24 @@ template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW>
 static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
     const uint32_t ngroups = (B + BZ - 1) / BZ;
-    auto grid_for = [&](uint32_t nt) { return (((nt + WAVES - 1) / WAVES + 7) / 8) * 8 * ngroups; };
+    // Workgroup size, measured (bench.py, pipelined, same box; tools/build_def.sh + tools/ab_bench.sh).  With ONE wavefront per
+    // workgroup a retiring wavefront frees exactly what the next one needs on its SIMD, and the kernel no longer slows down next to
+    // the second stage of the previous batch (11520x8184 5 %: 0.67 ms instead of 0.81; LZ4 1 %: 0.43 instead of 0.46) - because the
+    // second stage, whose workgroups need several free slots of one CU at once, is then starved until the reduce kernel has
+    // drained: the step gets LONGER (0.97 ms vs 0.83; LZ4 0.483 vs 0.478).  Shrinking the second stage's workgroups to one
+    // wavefront as well brings the interference back in full (0.465 ms, step 0.478).  Two wavefronts: in between.  The work is
+    // conserved; four wavefronts per workgroup overlaps it best.
+    auto grid_for = [&](uint32_t nt) { return (((nt + RWAVES - 1) / RWAVES + 7) / 8) * 8 * ngroups; };
     // aligned frames: the tiles that lie wholly inside the frame go through the explicit-wait instantiation; a partial last
     // tile (N not a multiple of TILE_PX) gets a second, tiny launch of the plain one
     const uint32_t nfull = AL ? (uint32_t)(sc.N / TILE_PX) : 0u;
     const ZmParams zm{reinterpret_cast<const uint16_t *>(sc.zm_lit_code), sc.zm_valid, sc.zm_budget, sc.zm_seq_bits};
     if (nfull)
-        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, AL, L1, CODEC, KEEP, RAW>), dim3(grid_for(nfull)), dim3(WG), 0, s, frames, sc.thr, sc.N,
+        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, AL, L1, CODEC, KEEP, RAW>), dim3(grid_for(nfull)), dim3(RWG), 0, s, frames, sc.thr, sc.N,
                            sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
                            sc.blk_size, depth, sc.status, zm);
     if (nfull < sc.ntiles)   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
-        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(WG), 0, nfull ? s_tail : s, frames,
+        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(RWG), 0, nfull ? s_tail : s, frames,
                            sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
                            sc.blk_slots, sc.blk_size, depth, sc.status, zm);
 }
@@ -607,7 +628,10 @@ void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32
 // The workgroup is deliberately small: in pipelined mode this kernel is dispatched while the next batch's reduce kernel
 // owns the chip, and a 1024-thread workgroup (16 waves that must start on one CU together) waited there for hundreds of
 // microseconds (rocprofv3: 74 us with LZ4, 355 us with zstd, against 10 us when alone).
-constexpr int SCAN_T = 256, SCAN_W = SCAN_T / 64;
+#ifndef RC_SCAN_T
+#define RC_SCAN_T 256
+#endif
+constexpr int SCAN_T = RC_SCAN_T, SCAN_W = SCAN_T / 64;
 // entries per thread and round: 16 (one round for 4096 tiles), 32 for frames with many more tiles (half the rounds, each of which is a
 // dependent global round trip + two barriers: 11520x8184 has 23 018 tiles)
 
@@ -840,17 +864,21 @@ __host__ __device__ inline uint32_t stored_size(const FrameFmt &ff, uint32_t n)
     return ff.hdr + n + ff.chunk_hdr * stored_chunks(ff, n) + ff.end;
 }
 
-__global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ frame_nnz,
+#ifndef RC_SMALL_WG
+#define RC_SMALL_WG 0
+#endif
+constexpr int LWG = RC_SMALL_WG ? 64 : WG, AWAVES = RC_SMALL_WG ? 1 : WAVES, AWG = 64 * AWAVES;
+__global__ __launch_bounds__(LWG) void k_layout(const uint32_t *__restrict__ frame_nnz,
                                                  const uint32_t *__restrict__ frame_cbytes, const uint32_t *__restrict__ frame_pbytes,
                                                  RecordParams rp, uint64_t nb,
                                                  uint32_t ntiles, uint32_t B, uint64_t out_cap, uint64_t *__restrict__ rec_off,
                                                  uint32_t *__restrict__ md, BatchStatus *__restrict__ st)
 {
-    __shared__ uint64_t s_part[WG];
+    __shared__ uint64_t s_part[LWG];
     __shared__ uint32_t s_bad;
     if (threadIdx.x == 0) s_bad = 0xFFFFFFFFu;
     __syncthreads();
-    const uint32_t per = (B + WG - 1) / WG;
+    const uint32_t per = (B + LWG - 1) / LWG;
     const uint32_t lo = threadIdx.x * per;
     const uint32_t hi = min(lo + per, B);
     uint64_t sum = 0;
@@ -886,9 +914,9 @@ __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ fram
     }
     if (threadIdx.x == 0) rec_off[0] = 0;
     __syncthreads();
-    if (threadIdx.x == WG - 1) {
+    if (threadIdx.x == LWG - 1) {
         uint64_t total = 0;
-        for (uint32_t i = 0; i < WG; ++i) total += s_part[i];
+        for (uint32_t i = 0; i < LWG; ++i) total += s_part[i];
         st->total = total;
         if (s_bad != 0xFFFFFFFFu) { st->code = -5; st->frame = s_bad; }        // RC_ERR_RECORD_TOO_LARGE
         else if (total > out_cap) { st->code = -2; st->frame = 0; }            // RC_ERR_OUT_TOO_SMALL
@@ -898,7 +926,7 @@ __global__ __launch_bounds__(WG) void k_layout(const uint32_t *__restrict__ fram
 void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
                    uint32_t *md, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(WG), 0, s, sc.frame_nnz, sc.frame_cbytes, sc.frame_pbytes, rp, sc.nb, sc.ntiles, B, out_cap,
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(LWG), 0, s, sc.frame_nnz, sc.frame_cbytes, sc.frame_pbytes, rp, sc.nb, sc.ntiles, B, out_cap,
                        rec_off, md, sc.status);
 }
 
@@ -993,7 +1021,7 @@ constexpr uint32_t ASM_TPW = 4 * ASM_PASSES;  // tiles per wavefront
 // hold tile-local packed streams of d-bit fields (rc_reduce's pack_stage; plain uint16 = the d = 16 case), so the copy is a
 // bit-granular funnel shift; the byte a tile shares with its successor is completed from the successor's first bits.
 // Value lists that are still uint16 and need packing (level-2 statistics with d < 16) take the byte-granular path at the end.
-__global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, uint32_t B, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, uint32_t B, uint8_t *__restrict__ out,
                                                    const uint64_t *__restrict__ rec_off, uint32_t lz4f_hdr_bitmap,
                                                    uint32_t lz4f_hdr_pix, uint32_t batch_seq)
 {
@@ -1009,7 +1037,7 @@ __global__ __launch_bounds__(WG) void k_assemble(Scratch sc, RecordParams rp, ui
     }
     const uint32_t f = blockIdx.y;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t t0 = (blockIdx.x * WAVES + w) * ASM_TPW;
+    const uint32_t t0 = (blockIdx.x * AWAVES + w) * ASM_TPW;
     const int lane = lane_id();
     if (t0 >= sc.ntiles) return;
     // pix_mode 1: ONLY the packed residual stream, flat (no container), into the frame's row of sc.pixraw - record offsets do
@@ -1306,8 +1334,8 @@ void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint
 {
     static const uint32_t hdr_bitmap = lz4f_descriptor(0x40);  // 64 KiB max block (blocks are <= 2 KiB)
     static const uint32_t hdr_pix = lz4f_descriptor(0x70);     // 4 MiB max block (stored chunks)
-    const uint32_t per_wg = WAVES * ASM_TPW;
-    const dim3 grid((sc.ntiles + per_wg - 1) / per_wg, B), block(WG);
+    const uint32_t per_wg = AWAVES * ASM_TPW;
+    const dim3 grid((sc.ntiles + per_wg - 1) / per_wg, B), block(AWG);
     hipLaunchKernelGGL(k_assemble, grid, block, 0, s, sc, rp, B, out, rec_off, hdr_bitmap, hdr_pix, batch_seq);
 }
 

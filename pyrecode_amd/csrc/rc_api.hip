@@ -9,7 +9,12 @@
 #include <new>
 #include <algorithm>
 #include <string>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/recode_hip.h"
@@ -561,23 +566,30 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
         launch_scans(sc, n, true, false, ps);
         launch_l2(sc, c->l2, n, c->nx, c->l2_sum ? (1u << c->depth) - 1u : 0u, ps);
     }
-    if (c->emit == RC_SCHEME_ZSTD) launch_zstd_fse(sc, n, fitted_seq ? (const void *)&c->d_model->seq : c->d_ztab, fitted_seq, ps);
+#ifdef RC_DEV_SKIP   // development builds only (tools/build_def.sh): leave second-stage kernels out (WRONG records) to see what each costs the
+                     // reduce kernel running next to it - bits: 1 FSE, 2 scans, 4 residual Huffman chain, 8 layout, 16 assemble, 32 gather
+    static const unsigned skip = getenv("RC_DEV_SKIP_BITS") ? (unsigned)atoi(getenv("RC_DEV_SKIP_BITS")) : 0u;
+#else
+    constexpr unsigned skip = 0;
+#endif
+    if (c->emit == RC_SCHEME_ZSTD && !(skip & 1)) launch_zstd_fse(sc, n, fitted_seq ? (const void *)&c->d_model->seq : c->d_ztab, fitted_seq, ps);
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], ps));
-    launch_scans(sc, n, c->level == 1, c->emit != 0, ps);  // (level 2: k_l2_emit has already described its value list)
+    if (!(skip & 2)) launch_scans(sc, n, c->level == 1, c->emit != 0, ps);  // (level 2: k_l2_emit has already described its value list)
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], ps));
     // modelled zstd, level 1: the residual stream is laid out flat, Huffman-coded in chunks, and placed behind the bitmap stream
     // (rc_pix_huff.hip); its encoded size is part of the record layout
     const bool pix_huff = c->modelled && c->level == 1 && (c->h_model->valid & 2u) && sc.pixraw;
-    if (pix_huff) {
+    if (pix_huff && !(skip & 4)) {
         rp.pix_mode = 1;
         launch_assemble(sc, rp, n, out_dev, rec_off_dev, c->batch_seq, ps);
         launch_pix_huff(sc, n, c->depth, ps);
         launch_pix_scan(sc, n, c->depth, ps);
         rp.pix_mode = 2;
     }
-    launch_layout(sc, rp, n, out_cap, rec_off_dev, md_dev, ps);
-    launch_assemble(sc, rp, n, out_dev, rec_off_dev, c->batch_seq++, ps);
-    if (pix_huff) launch_pix_gather(sc, n, c->depth, 16, out_dev, rec_off_dev, ps);
+    if (!(skip & 8)) launch_layout(sc, rp, n, out_cap, rec_off_dev, md_dev, ps);
+    if (!(skip & 16)) launch_assemble(sc, rp, n, out_dev, rec_off_dev, c->batch_seq, ps);
+    ++c->batch_seq;
+    if (pix_huff && !(skip & 32)) launch_pix_gather(sc, n, c->depth, 16, out_dev, rec_off_dev, ps);
     if (ev) HIP_TRY(hipEventRecord(ev[4], ps));
     HIP_TRY(hipEventRecord(c->ev_post[k], ps));
     c->post_pending[k] = true;
@@ -911,10 +923,87 @@ RC_EXPORT int rc_get_stage_ms(rc_ctx *c, float ms[5])
 // One per GPU, created on first use.  A call runs on RC_DEVICE (env) when that is set, otherwise on the CALLER'S CURRENT
 // device - in a one-process-per-GPU job that is the rank's own GPU - and leaves the current device as it found it.
 namespace {
+// A few worker threads that stay around between calls (rc_expand_frames indexes its frames on them: starting 15 threads per call
+// cost more than the indexing itself - 0.5 of 0.7 ms for 64 frames).  run(n, fn) calls fn(0..n-1), fn(0) on the calling thread, and
+// returns when all are done; one run at a time (the callers hold the device's Util lock).  Never destroyed: the workers sleep on a
+// condition variable and end with the process.  A forked child starts its own.
+struct WorkerPool {
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(uint32_t)> fn;
+    uint64_t generation = 0;
+    uint32_t want = 0, done = 0;
+    int started = 0;
+    pid_t pid = 0;
+    void worker(uint32_t id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(uint32_t)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                if (id >= want) continue;
+                f = fn;
+            }
+            f(id);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ++done;
+            }
+            cv_done.notify_one();
+        }
+    }
+    void run(uint32_t n, const std::function<void(uint32_t)> &f)
+    {
+        if (n <= 1) { if (n) f(0); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (pid != getpid()) { started = 0; pid = getpid(); }   // (after a fork the parent's workers do not exist here)
+            for (; started + 1 < (int)n; ++started) std::thread(&WorkerPool::worker, this, (uint32_t)started + 1).detach();
+            fn = f;
+            want = n;
+            done = 1;   // id 0 runs here
+            ++generation;
+        }
+        cv_go.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return done >= want; });
+    }
+};
+WorkerPool *g_pool = new WorkerPool;
+
+// Growable array in page-locked host memory (a hipMemcpyAsync from it is a real asynchronous copy; capacity is kept).
+template <class T>
+struct PinnedVec {
+    T *p = nullptr; size_t n = 0, cap = 0;
+    bool ok = true;                     // false: an allocation failed (checked by the caller after the indexing threads have joined)
+    void clear() { n = 0; ok = true; }
+    size_t size() const { return n; }
+    const T *data() const { return p; }
+    void push_back(const T &v)
+    {
+        if (n == cap) {
+            const size_t nc = cap ? cap * 2 : 8192;
+            T *q = nullptr;
+            if (hipHostMalloc((void **)&q, nc * sizeof(T), hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
+            if (n) memcpy(q, p, n * sizeof(T));
+            if (p) (void)hipHostFree(p);
+            p = q; cap = nc;
+        }
+        p[n++] = v;
+    }
+};
+constexpr int RC_READ_THREADS = 16;
+
 struct Util {
     std::mutex mu;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;              // rc_expand_frames: the two streams' decoders run side by side
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     uint8_t *a = nullptr; uint64_t a_cap = 0;   // input 1
     uint8_t *b = nullptr; uint64_t b_cap = 0;   // input 2
     uint8_t *o = nullptr; uint64_t o_cap = 0;   // output
@@ -923,6 +1012,10 @@ struct Util {
     void *ztab = nullptr;                       // zstd FSE tables
     uint8_t *x[10] = {}; uint64_t x_cap[10] = {};   // rc_expand_frames: data, bitmaps, values, tables, block lists, counters
     void *zd_predef = nullptr;                  // predefined zstd decoding tables
+    // rc_expand_frames, host side (kept between calls: no allocation, no first-touch page faults in steady state)
+    PinnedVec<rc::ZdBlock> rd_bm[RC_READ_THREADS], rd_pv[RC_READ_THREADS], rd_raw[RC_READ_THREADS];   // per indexing thread, page-locked
+    std::vector<rc::ZdBlock> rd_tmp[RC_READ_THREADS];
+    uint8_t *rd_head = nullptr; uint64_t rd_head_cap = 0;   // page-locked: decoding tables + per-frame index arrays
 };
 constexpr int RC_MAX_DEV = 64;
 Util g_utils[RC_MAX_DEV];
@@ -949,6 +1042,9 @@ struct UtilScope {
         HIP_TRY(guard.enter(dev));
         if (t_util->device < 0) {
             HIP_TRY(hipStreamCreateWithFlags(&t_util->stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&t_util->stream2, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&t_util->ev_a, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&t_util->ev_b, hipEventDisableTiming));
             HIP_TRY(hipHostMalloc((void **)&t_util->h_scalar, 64, hipHostMallocDefault));
             t_util->device = dev;
         }
@@ -1028,8 +1124,9 @@ RC_EXPORT int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_
 namespace {
 // LZ4 frame of independent blocks -> block table (compressed blocks in `comp`, stored ones in `raw`); expect: bytes every
 // compressed block regenerates (the last one the rest)
+template <class VC, class VR>
 int lz4_index_frame(const uint8_t *base, uint64_t off, uint64_t n, uint32_t frame_idx, uint32_t expect, uint64_t total_expected,
-                    std::vector<rc::ZdBlock> &comp, std::vector<rc::ZdBlock> &raw, uint64_t *total)
+                    VC &comp, VR &raw, uint64_t *total)
 {
     using namespace rc;
     const uint8_t *p = base + off;
@@ -1048,6 +1145,9 @@ int lz4_index_frame(const uint8_t *base, uint64_t off, uint64_t n, uint32_t fram
         const bool stored = bs >> 31;
         bs &= 0x7FFFFFFFu;
         if (q + bs > n) return ZD_CORRUPT;
+        // the walk is a chain of dependent cache misses (a header per few lines): ask for the lines a few blocks ahead, assuming
+        // blocks of about this size
+        if (bs < 2048) { __builtin_prefetch(p + q + 4 * (uint64_t)(bs + 4)); __builtin_prefetch(p + q + 4 * (uint64_t)(bs + 4) + 64); }
         ZdBlock b;
         memset(&b, 0, sizeof b);
         b.frame = frame_idx; b.src = off + q; b.csize = bs; b.dst = (uint32_t)out;
@@ -1079,95 +1179,20 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     const int codec = op_mode == 0 ? 0 : (scheme == RC_SCHEME_LZ4 ? 2 : (scheme == RC_SCHEME_ZSTD ? 1 : -1));
     if (codec < 0) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: scheme has no batched device decoder");
     const uint64_t N = (uint64_t)nx * ny, nb = (N + 7) / 8, nb8 = (nb + 7) / 8;
-    // ---- host: walk the frames, build block tables and decoding tables ----
-    std::vector<ZdBlock> bm_comp, pv_comp, raw;          // Compressed blocks of the two streams, stored / RLE blocks of both
-    std::vector<ZdTables> bm_tab(codec == 1 ? n : 0), pv_tab(codec == 1 ? n : 0);
-    std::vector<uint32_t> bm_first(n + 1, 0), pv_first(n + 1, 0), pv_bytes(n, 0);
-    std::vector<uint64_t> bm_base(n), pv_base(n);
+    static const bool timing = getenv("RC_READ_TIMING") != nullptr;   // development: phase times on stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = now();
+    // ---- sizes known without looking at the streams; the copy-in of the compressed bytes starts before the host walks them ----
     const uint64_t bm_stride = nb8 * 8 + 8;
-    uint64_t pv_stride = 16, off = 0, total_in = 0;
+    uint64_t pv_stride = 16, total_in = 0;
+    std::vector<uint64_t> foff(n);
     for (uint32_t f = 0; f < n; ++f) {
         const uint32_t npk = level == 1 ? sizes[3 * f + 2] : 0;
         pv_stride = std::max<uint64_t>(pv_stride, ((uint64_t)npk + 15) & ~15ull);
+        foff[f] = total_in;
         total_in += (uint64_t)sizes[3 * f] + (level == 1 ? sizes[3 * f + 1] : 0);
     }
     pv_stride += 16;
-    uint32_t bm_max = 0, pv_max = 0, raw_max_regen = 0;
-    // per frame, independently (a few host threads): walk the two streams' block headers, build the frame's tables
-    struct FrameIndex { std::vector<ZdBlock> bm, pv, raw; int status = ZD_OK; const char *what = nullptr; };
-    std::vector<FrameIndex> fi(n);
-    std::vector<uint64_t> foff(n);
-    for (uint32_t f = 0; f < n; ++f) { foff[f] = off; off += (uint64_t)sizes[3 * f] + (level == 1 ? sizes[3 * f + 1] : 0); }
-    auto index_frame = [&](uint32_t f) {
-        FrameIndex &F = fi[f];
-        const uint64_t cb = sizes[3 * f], cp = level == 1 ? sizes[3 * f + 1] : 0, npk = level == 1 ? sizes[3 * f + 2] : 0;
-        const uint64_t o = foff[f];
-        uint64_t got = 0;
-        int r = ZD_OK;
-        if (codec == 0) {
-            if (cb != nb || cp != npk) { F.status = ZD_CORRUPT; F.what = "rc_expand_frames: mode-0 sizes disagree with the frame shape"; return; }
-            ZdBlock b;
-            memset(&b, 0, sizeof b);
-            b.frame = f; b.src = o; b.csize = b.regen = (uint32_t)nb; b.dst = 0;
-            F.raw.push_back(b);
-            if (npk) { b.src = o + cb; b.csize = b.regen = (uint32_t)npk; b.frame = n + f; F.raw.push_back(b); }
-        } else if (codec == 2) {
-            r = lz4_index_frame(data, o, cb, f, TILE_BM, nb, F.bm, F.raw, &got);
-            if (r == ZD_OK && got != nb) r = ZD_CORRUPT;
-            if (r == ZD_OK && level == 1) {
-                std::vector<ZdBlock> none;
-                r = lz4_index_frame(data, o + cb, cp, n + f, 0, npk, none, F.raw, &got);
-                if (r == ZD_OK && got != npk) r = ZD_CORRUPT;
-            }
-        } else {
-            std::vector<ZdBlock> all;
-            r = zd_index_frame(data, o, cb, f, TILE_BM, nb, all, bm_tab[f], &got);
-            if (r == ZD_OK && got != nb) r = ZD_CORRUPT;
-            for (const ZdBlock &b : all) (b.type == 2 ? F.bm : F.raw).push_back(b);
-            if (r == ZD_OK && level == 1) {
-                all.clear();
-                r = zd_index_frame(data, o + cb, cp, n + f, 0, npk, all, pv_tab[f], &got);
-                if (r == ZD_OK && got != npk) r = ZD_CORRUPT;
-                for (ZdBlock b : all) {
-                    if (b.type == 2) { if (b.regen > 1024) { r = ZD_FOREIGN; break; } b.frame = f; F.pv.push_back(b); }
-                    else F.raw.push_back(b);
-                }
-            }
-        }
-        F.status = r;
-    };
-    {
-        const uint32_t nthr = std::min<uint32_t>(n, 8);
-        if (nthr <= 1) { for (uint32_t f = 0; f < n; ++f) index_frame(f); }
-        else {
-            std::vector<std::thread> pool;
-            for (uint32_t t = 0; t < nthr; ++t)
-                pool.emplace_back([&, t] { for (uint32_t f = t; f < n; f += nthr) index_frame(f); });
-            for (auto &th : pool) th.join();
-        }
-    }
-    for (uint32_t f = 0; f < n; ++f) {
-        FrameIndex &F = fi[f];
-        if (F.status == ZD_FOREIGN) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: stream outside the device decoders' subset (use the stock decoder)");
-        if (F.status != ZD_OK) return fail(RC_ERR_CORRUPT, F.what ? F.what : "rc_expand_frames: malformed compressed stream");
-        bm_base[f] = (uint64_t)f * bm_stride;
-        pv_base[f] = (uint64_t)n * bm_stride + (uint64_t)f * pv_stride;   // the value streams lie behind the bitmaps in ONE output buffer
-        pv_bytes[f] = level == 1 ? sizes[3 * f + 2] : 0;
-        bm_first[f] = (uint32_t)bm_comp.size();
-        pv_first[f] = (uint32_t)pv_comp.size();
-        bm_comp.insert(bm_comp.end(), F.bm.begin(), F.bm.end());
-        pv_comp.insert(pv_comp.end(), F.pv.begin(), F.pv.end());
-        raw.insert(raw.end(), F.raw.begin(), F.raw.end());
-        bm_max = std::max<uint32_t>(bm_max, (uint32_t)F.bm.size());
-        pv_max = std::max<uint32_t>(pv_max, (uint32_t)F.pv.size());
-    }
-    bm_first[n] = (uint32_t)bm_comp.size();
-    pv_first[n] = (uint32_t)pv_comp.size();
-    for (const ZdBlock &b : raw) raw_max_regen = std::max(raw_max_regen, b.regen);
-    // raw blocks address their frame through out_base[b.frame]: frames 0..n-1 = bitmaps, n..2n-1 = value streams
-    std::vector<uint64_t> base2(2 * (size_t)n);
-    for (uint32_t f = 0; f < n; ++f) { base2[f] = bm_base[f]; base2[n + f] = pv_base[f]; }
-    // ---- device ----
     UtilScope util_scope;
     int r = util_scope.enter();
     if (r != RC_OK) return r;
@@ -1176,12 +1201,21 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
     const uint64_t out_bytes = (uint64_t)n * (bm_stride + (level == 1 ? pv_stride : 0)) + 64;
     auto need = [&](int i, uint64_t bytes) { return ensure(u.x[i], u.x_cap[i], bytes); };
-    const uint64_t sz_blocks = (bm_comp.size() + pv_comp.size() + raw.size()) * sizeof(ZdBlock) + 64;
-    const uint64_t sz_tabs = (bm_tab.size() + pv_tab.size()) * sizeof(ZdTables) + 64;
-    const uint64_t sz_idx = ((uint64_t)(n + 1) * 2 * 4 + (uint64_t)n * 4 + (uint64_t)n * 4 * 8 + 64 + 15) & ~15ull;
-    if ((r = need(0, total_in + 64)) != RC_OK || (r = need(1, out_bytes)) != RC_OK || (r = need(2, sz_blocks)) != RC_OK ||
-        (r = need(3, sz_tabs)) != RC_OK || (r = need(4, sz_idx)) != RC_OK || (r = need(5, (uint64_t)n * nblk * 8 + (uint64_t)(2 * n + 2) * 8 + 64)) != RC_OK)
+    // head: [ZdTables bitmap x n][ZdTables values x n] (zstd) [block lists: bitmap x n, values x n, stored x threads][pv_bytes n] [base2 2n][pv_base n], the
+    // same layout in page-locked host memory and on the device: one copy
+    const uint64_t ntab = codec == 1 ? 2 * (uint64_t)n : 0;
+    const uint64_t o_first = ntab * sizeof(ZdTables);
+    const uint64_t o_base2 = (o_first + (2 * (uint64_t)n + RC_READ_THREADS) * sizeof(ZdFrameList) + (uint64_t)n * 4 + 15) & ~15ull;
+    const uint64_t sz_head = o_base2 + (uint64_t)n * 3 * 8;
+    if ((r = need(0, total_in + 64)) != RC_OK || (r = need(1, out_bytes)) != RC_OK || (r = need(3, sz_head)) != RC_OK ||
+        (r = need(5, (uint64_t)n * nblk * 8 + (uint64_t)(2 * n + 2) * 8 + 64)) != RC_OK)
         return r;
+    if (u.rd_head_cap < sz_head) {
+        if (u.rd_head) HIP_TRY(hipHostFree(u.rd_head));
+        u.rd_head = nullptr; u.rd_head_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&u.rd_head, sz_head, hipHostMallocDefault));
+        u.rd_head_cap = sz_head;
+    }
     if (!u.zd_predef) {
         std::vector<uint8_t> t(zd_tables_bytes());
         zd_predefined_tables(t.data());
@@ -1189,31 +1223,124 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
         HIP_TRY(hipMemcpy(u.zd_predef, t.data(), t.size(), hipMemcpyHostToDevice));
     }
     uint8_t *d_data = u.x[0], *d_out = u.x[1];
-    ZdBlock *d_bm_blk = reinterpret_cast<ZdBlock *>(u.x[2]), *d_pv_blk = d_bm_blk + bm_comp.size(), *d_raw = d_pv_blk + pv_comp.size();
-    ZdTables *d_bm_tab = reinterpret_cast<ZdTables *>(u.x[3]), *d_pv_tab = d_bm_tab + bm_tab.size();
-    uint32_t *d_bm_first = reinterpret_cast<uint32_t *>(u.x[4]), *d_pv_first = d_bm_first + (n + 1), *d_pv_bytes = d_pv_first + (n + 1);
-    uint64_t *d_base2 = reinterpret_cast<uint64_t *>(u.x[4] + (((uint64_t)(n + 1) * 8 + (uint64_t)n * 4 + 15) & ~15ull));
-    uint64_t *d_pvbase = d_base2 + 2 * (uint64_t)n;   // out_base of the value-stream decoder: per frame
     uint32_t *d_blk_cnt = reinterpret_cast<uint32_t *>(u.x[5]), *d_blk_off = d_blk_cnt + (uint64_t)n * nblk;
     uint64_t *d_fnnz = reinterpret_cast<uint64_t *>(d_blk_off + (uint64_t)n * nblk), *d_fbase = d_fnnz + n;
     int *d_err = reinterpret_cast<int *>(d_fbase + n + 1);
     HIP_TRY(hipMemcpyAsync(d_data, data, total_in, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, s));   // bitmap padding and value-stream tails read as zero
     HIP_TRY(hipMemsetAsync(d_err, 0, 4, s));
-    auto up = [&](void *dst, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess; };
-    HIP_TRY(up(d_bm_blk, bm_comp.data(), bm_comp.size() * sizeof(ZdBlock)));
-    HIP_TRY(up(d_pv_blk, pv_comp.data(), pv_comp.size() * sizeof(ZdBlock)));
-    HIP_TRY(up(d_raw, raw.data(), raw.size() * sizeof(ZdBlock)));
-    HIP_TRY(up(d_bm_tab, bm_tab.data(), bm_tab.size() * sizeof(ZdTables)));
-    HIP_TRY(up(d_pv_tab, pv_tab.data(), pv_tab.size() * sizeof(ZdTables)));
-    HIP_TRY(up(d_bm_first, bm_first.data(), (n + 1) * 4));
-    HIP_TRY(up(d_pv_first, pv_first.data(), (n + 1) * 4));
-    HIP_TRY(up(d_pv_bytes, pv_bytes.data(), n * 4));
-    HIP_TRY(up(d_base2, base2.data(), 2 * (size_t)n * 8));
-    HIP_TRY(up(d_pvbase, pv_base.data(), (size_t)n * 8));
-    if (!bm_comp.empty()) launch_block_decode(codec == 1 ? 1 : 2, TILE_BM, d_data, d_bm_blk, d_bm_first, n, bm_max, d_bm_tab, u.zd_predef, d_out, d_base2, d_err, s);
-    if (!pv_comp.empty()) launch_block_decode(1, 1024, d_data, d_pv_blk, d_pv_first, n, pv_max, d_pv_tab, u.zd_predef, d_out, d_pvbase, d_err, s);
-    launch_block_copy(d_data, d_raw, (uint32_t)raw.size(), raw_max_regen, d_out, d_base2, s);
+    // ---- host: walk the frames, build block tables and decoding tables (a few threads, each a contiguous range of frames) ----
+    // (the copy-in reads the caller's memory: no return from here on without waiting for it)
+    auto bail = [&](int code, const char *msg) { (void)hipStreamSynchronize(s); return fail(code, msg); };
+    ZdTables *bm_tab = reinterpret_cast<ZdTables *>(u.rd_head), *pv_tab = bm_tab + (codec == 1 ? n : 0);
+    // The block lists stay where the indexing threads wrote them, in page-locked host memory: the decoders read every entry once,
+    // over the link (uploading them meant 3 small copies per thread, each a fixed ~15 us of stream time: 0.7 ms per call).
+    ZdFrameList *bm_list = reinterpret_cast<ZdFrameList *>(u.rd_head + o_first), *pv_list = bm_list + n, *raw_list = pv_list + n;
+    uint32_t *pv_bytes = reinterpret_cast<uint32_t *>(raw_list + RC_READ_THREADS);
+    uint64_t *base2 = reinterpret_cast<uint64_t *>(u.rd_head + o_base2), *pv_base = base2 + 2 * (uint64_t)n;
+    struct FrameIndex { uint32_t bm0 = 0, bm_n = 0, pv0 = 0, pv_n = 0; int status = ZD_OK; const char *what = nullptr; };
+    std::vector<FrameIndex> fi(n);
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    static const uint32_t thr_env = getenv("RC_READ_THREADS") ? (uint32_t)atoi(getenv("RC_READ_THREADS")) : 0u;   // (development: 1..16)
+    const uint32_t nthr = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(n, thr_env ? std::min<uint32_t>(thr_env, RC_READ_THREADS) : RC_READ_THREADS), hw));
+    const int dev_now = u.device;
+    auto index_range = [&](uint32_t t) {
+        if (t) (void)hipSetDevice(dev_now);   // (a worker thread: page-locked memory it allocates belongs to this device's context)
+        auto &BM = u.rd_bm[t]; auto &PV = u.rd_pv[t]; auto &RAW = u.rd_raw[t]; auto &all = u.rd_tmp[t];
+        BM.clear(); PV.clear(); RAW.clear();
+        for (uint32_t f = (uint32_t)((uint64_t)n * t / nthr); f < (uint32_t)((uint64_t)n * (t + 1) / nthr); ++f) {
+            FrameIndex &F = fi[f];
+            const uint64_t cb = sizes[3 * f], cp = level == 1 ? sizes[3 * f + 1] : 0, npk = level == 1 ? sizes[3 * f + 2] : 0;
+            const uint64_t o = foff[f];
+            uint64_t got = 0;
+            int rr = ZD_OK;
+            F.bm0 = (uint32_t)BM.size(); F.pv0 = (uint32_t)PV.size();
+            if (codec == 0) {
+                if (cb != nb || cp != npk) { F.status = ZD_CORRUPT; F.what = "rc_expand_frames: mode-0 sizes disagree with the frame shape"; continue; }
+                ZdBlock b;
+                memset(&b, 0, sizeof b);
+                b.frame = f; b.src = o; b.csize = b.regen = (uint32_t)nb; b.dst = 0;
+                RAW.push_back(b);
+                if (npk) { b.src = o + cb; b.csize = b.regen = (uint32_t)npk; b.frame = n + f; RAW.push_back(b); }
+            } else if (codec == 2) {
+                rr = lz4_index_frame(data, o, cb, f, TILE_BM, nb, BM, RAW, &got);
+                if (rr == ZD_OK && got != nb) rr = ZD_CORRUPT;
+                if (rr == ZD_OK && level == 1) {
+                    all.clear();   // (a value stream holds stored chunks only: a compressed block there is outside the subset)
+                    rr = lz4_index_frame(data, o + cb, cp, n + f, 0, npk, all, RAW, &got);
+                    if (rr == ZD_OK && got != npk) rr = ZD_CORRUPT;
+                }
+            } else {
+                // (Compressed blocks to the stream's list, stored / RLE ones to the copy list, as the walk finds them)
+                struct Route {
+                    PinnedVec<ZdBlock> &comp, &raw;
+                    bool values; uint32_t frame; bool too_long = false;
+                    void push_back(const ZdBlock &b)
+                    {
+                        if (b.type != 2) { raw.push_back(b); return; }
+                        if (!values) { comp.push_back(b); return; }
+                        if (b.regen > 1024) { too_long = true; return; }   // a value-stream block the chunk decoder is not built for
+                        ZdBlock c = b;
+                        c.frame = frame;
+                        comp.push_back(c);
+                    }
+                };
+                Route rb{BM, RAW, false, f}, rp{PV, RAW, true, f};
+                rr = zd_index_frame(data, o, cb, f, TILE_BM, nb, rb, bm_tab[f], &got);
+                if (rr == ZD_OK && got != nb) rr = ZD_CORRUPT;
+                if (rr == ZD_OK && level == 1) {
+                    rr = zd_index_frame(data, o + cb, cp, n + f, 0, npk, rp, pv_tab[f], &got);
+                    if (rr == ZD_OK && got != npk) rr = ZD_CORRUPT;
+                    if (rr == ZD_OK && rp.too_long) rr = ZD_FOREIGN;
+                }
+            }
+            F.bm_n = (uint32_t)BM.size() - F.bm0; F.pv_n = (uint32_t)PV.size() - F.pv0;
+            F.status = rr;
+        }
+    };
+    g_pool->run(nthr, index_range);
+    const double t_1 = now();
+    uint64_t n_bm = 0, n_pv = 0, n_raw = 0;
+    uint32_t bm_max = 0, pv_max = 0, raw_max_regen = 0;
+    for (uint32_t t = 0; t < nthr; ++t) {
+        if (!u.rd_bm[t].ok || !u.rd_pv[t].ok || !u.rd_raw[t].ok) return bail(RC_ERR_DEVICE, "rc_expand_frames: page-locked host memory exhausted");
+        for (uint32_t f = (uint32_t)((uint64_t)n * t / nthr); f < (uint32_t)((uint64_t)n * (t + 1) / nthr); ++f) {
+            const FrameIndex &F = fi[f];
+            if (F.status == ZD_FOREIGN) return bail(RC_ERR_UNSUPPORTED, "rc_expand_frames: stream outside the device decoders' subset (use the stock decoder)");
+            if (F.status != ZD_OK) return bail(RC_ERR_CORRUPT, F.what ? F.what : "rc_expand_frames: malformed compressed stream");
+            bm_list[f].p = u.rd_bm[t].data() + F.bm0; bm_list[f].n = F.bm_n; bm_list[f].pad = 0;
+            pv_list[f].p = u.rd_pv[t].data() + F.pv0; pv_list[f].n = F.pv_n; pv_list[f].pad = 0;
+            pv_bytes[f] = level == 1 ? sizes[3 * f + 2] : 0;
+            base2[f] = (uint64_t)f * bm_stride;                                        // stored blocks: frames 0..n-1 = bitmaps,
+            base2[n + f] = pv_base[f] = (uint64_t)n * bm_stride + (uint64_t)f * pv_stride;   // n..2n-1 = value streams (behind the bitmaps)
+            bm_max = std::max(bm_max, F.bm_n);
+            pv_max = std::max(pv_max, F.pv_n);
+            n_bm += F.bm_n; n_pv += F.pv_n;
+        }
+        raw_list[t].p = u.rd_raw[t].data(); raw_list[t].n = (uint32_t)u.rd_raw[t].size(); raw_list[t].pad = 0;
+        n_raw += u.rd_raw[t].size();
+        const ZdBlock *rb = u.rd_raw[t].data();
+        for (size_t i = 0; i < u.rd_raw[t].size(); ++i) raw_max_regen = std::max(raw_max_regen, rb[i].regen);
+    }
+    if (n_raw >= (1ull << 31)) return bail(RC_ERR_UNSUPPORTED, "rc_expand_frames: too many blocks in one call");
+    const double t_2 = now();
+    // ---- device ----
+    ZdTables *d_bm_tab = reinterpret_cast<ZdTables *>(u.x[3]), *d_pv_tab = d_bm_tab + (codec == 1 ? n : 0);
+    const ZdFrameList *d_bm_list = reinterpret_cast<const ZdFrameList *>(u.x[3] + o_first), *d_pv_list = d_bm_list + n, *d_raw_list = d_pv_list + n;
+    uint32_t *d_pv_bytes = reinterpret_cast<uint32_t *>(u.x[3] + o_first + (2 * (uint64_t)n + RC_READ_THREADS) * sizeof(ZdFrameList));
+    uint64_t *d_base2 = reinterpret_cast<uint64_t *>(u.x[3] + o_base2), *d_pvbase = d_base2 + 2 * (uint64_t)n;
+    HIP_TRY(hipMemcpyAsync(u.x[3], u.rd_head, sz_head, hipMemcpyHostToDevice, s));
+    const double t_3 = now();
+    // the value streams' chunks (few, long serial chains) decode next to the binary maps' blocks (many, short), on a second stream
+    if (n_pv) {
+        HIP_TRY(hipEventRecord(u.ev_a, s));
+        HIP_TRY(hipStreamWaitEvent(u.stream2, u.ev_a, 0));
+        launch_block_decode(1, 1024, d_data, d_pv_list, n, pv_max, d_pv_tab, u.zd_predef, d_out, d_pvbase, d_err, u.stream2);
+        HIP_TRY(hipEventRecord(u.ev_b, u.stream2));
+    }
+    if (n_bm) launch_block_decode(codec == 1 ? 1 : 2, TILE_BM, d_data, d_bm_list, n, bm_max, d_bm_tab, u.zd_predef, d_out, d_base2, d_err, s);
+    launch_block_copy(d_data, d_raw_list, nthr, (uint32_t)n_raw, raw_max_regen, d_out, d_base2, s);
+    if (n_pv) HIP_TRY(hipStreamWaitEvent(s, u.ev_b, 0));
     const uint8_t *d_bm = d_out, *d_pv = d_out + (uint64_t)n * bm_stride;
     launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s);
     HIP_TRY(hipGetLastError());
@@ -1221,6 +1348,7 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     HIP_TRY(hipMemcpyAsync(nnz_prefix, d_fbase, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    const double t_4 = now();
     if (err) return fail(RC_ERR_CORRUPT, "rc_expand_frames: a block does not decode to its expected size");
     const uint64_t total = nnz_prefix[n];
     if (!triplets) return RC_OK;
@@ -1240,6 +1368,9 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     HIP_TRY(hipGetLastError());
     if (out_host) HIP_TRY(hipMemcpyAsync(triplets, d_trip, total * 24, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (timing)
+        fprintf(stderr, "rc_expand_frames: index %.3f ms, merge %.3f, enqueue copies %.3f, decode+count (to sync) %.3f, emit %.3f\n", t_1 - t_0, t_2 - t_1,
+                t_3 - t_2, t_4 - t_3, now() - t_4);
     return RC_OK;
 }
 
@@ -1686,22 +1817,23 @@ static int zstd_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_
     }
     hipStream_t s = u.stream;
     ZdBlock *d_comp = reinterpret_cast<ZdBlock *>(u.x[2]), *d_raw = d_comp + comp.size();
-    uint32_t *d_first = reinterpret_cast<uint32_t *>(u.x[4]);
-    uint64_t *d_base = reinterpret_cast<uint64_t *>(u.x[4] + 16);
-    int *d_err = reinterpret_cast<int *>(u.x[4] + 32);
-    uint32_t *d_prod = reinterpret_cast<uint32_t *>(u.x[4] + 40);
-    const uint32_t first[2] = {0u, (uint32_t)comp.size()};
+    ZdFrameList *d_lists = reinterpret_cast<ZdFrameList *>(u.x[4]);   // [0] compressed, [1] stored / RLE
+    uint64_t *d_base = reinterpret_cast<uint64_t *>(u.x[4] + 32);
+    int *d_err = reinterpret_cast<int *>(u.x[4] + 48);
+    uint32_t *d_prod = reinterpret_cast<uint32_t *>(u.x[4] + 56);
+    const ZdFrameList lists[2] = {{d_comp, (uint32_t)comp.size(), 0}, {d_raw, (uint32_t)raw.size(), 0}};
     const uint64_t base0 = 0;
     const uint32_t none = 0xFFFFFFFFu;
     if (!comp.empty()) HIP_TRY(hipMemcpyAsync(d_comp, comp.data(), comp.size() * sizeof(ZdBlock), hipMemcpyHostToDevice, s));
     if (!raw.empty()) HIP_TRY(hipMemcpyAsync(d_raw, raw.data(), raw.size() * sizeof(ZdBlock), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(u.x[3], &T, sizeof T, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_first, first, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_lists, lists, sizeof lists, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_base, &base0, 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(d_err, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(u.x[1], 0, bound + 64, s));   // the decoders store only what is not zero
     HIP_TRY(hipMemcpyAsync(d_prod, &none, 4, hipMemcpyHostToDevice, s));
-    if (!comp.empty()) launch_block_decode(1, (int)row, d_src, d_comp, d_first, 1, (uint32_t)comp.size(), u.x[3], u.zd_predef, u.x[1], d_base, d_err, s, d_prod);
-    launch_block_copy(d_src, d_raw, (uint32_t)raw.size(), raw_max, u.x[1], d_base, s);
+    if (!comp.empty()) launch_block_decode(1, (int)row, d_src, d_lists, 1, (uint32_t)comp.size(), u.x[3], u.zd_predef, u.x[1], d_base, d_err, s, d_prod);
+    launch_block_copy(d_src, d_lists + 1, 1, (uint32_t)raw.size(), raw_max, u.x[1], d_base, s);
     HIP_TRY(hipGetLastError());
     int err = 0;
     uint32_t prod = none;

@@ -14,11 +14,11 @@ void launch_expand_batch_emit(const uint8_t *bm, uint64_t bm_stride, uint64_t nb
                               const uint64_t *frame_base, const uint8_t *pv, uint64_t pv_stride, const uint32_t *pv_bytes, uint32_t d,
                               uint32_t level, uint64_t cap, uint64_t *out, hipStream_t s);
 // rc_zstd_dec.hip: block decoders of the batched reader
-void launch_block_decode(int codec, int row, const uint8_t *data, const void *blocks, const uint32_t *frame_first, uint32_t nframes,
-                         uint32_t max_blocks_per_frame, const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base, int *err,
-                         hipStream_t s, uint32_t *produced_out = nullptr);
-void launch_block_copy(const uint8_t *data, const void *blocks, uint32_t nblocks, uint32_t max_regen, uint8_t *out, const uint64_t *out_base,
-                       hipStream_t s);
+void launch_block_decode(int codec, int row, const uint8_t *data, const void *frame_lists, uint32_t nframes, uint32_t max_blocks_per_frame,
+                         const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base, int *err, hipStream_t s,
+                         uint32_t *produced_out = nullptr);
+void launch_block_copy(const uint8_t *data, const void *lists, uint32_t nlists, uint32_t nblocks, uint32_t max_regen, uint8_t *out,
+                       const uint64_t *out_base, hipStream_t s);
 size_t zd_tables_bytes();
 size_t zd_block_bytes();
 void zd_predefined_tables(void *dst);

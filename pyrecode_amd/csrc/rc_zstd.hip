@@ -45,10 +45,16 @@ __global__ __launch_bounds__(WG) void k_zstd_buffer(Scratch sc)
 // The bitstream is collected in a per-lane LDS row and written out afterwards.  A lane whose bitstream outgrows its row
 // (dense blocks) re-runs the chain with stores straight into the slot, in place: a sequence costs at most 29 bits and its
 // token is 32, so the write position never passes the read position.
-constexpr int FSE_ROW = 48;  // dwords of bitstream kept in LDS per lane (192 bytes; a 1 %-sparsity block needs about 15)
+#ifndef RC_FSE_ROW
+#define RC_FSE_ROW 48
+#endif
+#ifndef RC_FSE_T
+#define RC_FSE_T 128
+#endif
+constexpr int FSE_ROW = RC_FSE_ROW;  // dwords of bitstream kept in LDS per lane (192 bytes; a 1 %-sparsity block needs about 15)
 // 128 threads = 25 KB of LDS per workgroup: in pipelined mode this kernel is dispatched while the next batch's reduce kernel
 // fills the CUs (3 workgroups x 39.5 KB of the 160 KB), and a 50 KB workgroup would have to wait for one of them to leave
-constexpr int FSE_T = 128;
+constexpr int FSE_T = RC_FSE_T;
 
 // fitted != 0: the tables are a ctx's fitted ones and the blocks' sequences are in Repeat_Mode (ZW_SEQ is reported in the
 // size word, next to the tokenizer's ZW_TREE, for k_scan_frames to place the frame's definitions).

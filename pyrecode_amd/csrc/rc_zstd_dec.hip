@@ -4,8 +4,8 @@
 // recode_compressors.py:40-79) for frames inside the subset rc_zstd_dec.h describes (everything this library writes).
 // The host has walked the frames' block headers and built the tables; here ONE LANE decodes ONE BLOCK - the entropy-coded
 // streams of a block are serial chains (Huffman: one table step per literal; FSE: one per sequence), so blocks, not bytes,
-// are the unit of parallelism, exactly as in the encoder's k_zstd_fse.  A lane regenerates its block into its own row of the
-// workgroup's LDS (rows start in different banks), the wavefront then writes the rows out with coalesced stores.
+// are the unit of parallelism, exactly as in the encoder's k_zstd_fse.  A workgroup stages the compressed bytes of its blocks in
+// LDS; a lane regenerates its block straight into (zeroed) global memory, storing only what is not zero (k_block_decode).
 #include <algorithm>
 
 #include "rc_launch.h"
@@ -23,31 +23,45 @@ __device__ __constant__ uint16_t c_ml_base[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 1
 __device__ __constant__ uint8_t c_ml_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                                  0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 
-struct BackBits {   // backward bit reader over global memory: `bit` unread bits below the current position
-    const uint8_t *p;
-    int32_t bit;
+// Backward bit reader.  The stream is read through ALIGNED dwords, two of them (64 bits around the position) kept in registers
+// and one new dword fetched per 32 bits consumed; `p` may point into LDS or global memory (generic address).  Bits below the
+// stream's first are whatever lies there: a valid stream never depends on them (a Huffman step is decided by the code's own
+// bits, an FSE read never crosses the start), a corrupt one runs into `bit < 0`, which the callers check.
+struct BackBits {
+    const uint32_t *pa;   // the stream's first byte, rounded down to a dword
+    int32_t bit;          // unread bits, counted from bit 0 of pa[0]
+    int32_t first;        // the stream's first bit in the same count (8 * misalignment)
+    uint32_t hi, lo, nx;  // dwords pa[ci], pa[ci - 1]; pa[ci - 2], requested ahead of its use
+    int32_t ci;
     __device__ bool init(const uint8_t *src, uint32_t n)
     {
-        if (n == 0 || src[n - 1] == 0) return false;
-        p = src;
-        bit = (int32_t)(n - 1) * 8 + (31 - __clz((int)src[n - 1]));
+        if (n == 0) return false;
+        const uint32_t lastb = src[n - 1];
+        if (lastb == 0) return false;
+        const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+        pa = reinterpret_cast<const uint32_t *>(src - mis);
+        first = 8 * (int32_t)mis;
+        bit = first + (int32_t)(n - 1) * 8 + (31 - __clz((int)lastb));
+        ci = -2;
+        hi = lo = nx = 0;
         return true;
     }
-    // the nb <= 24 bits just below the position, without consuming (positions below 0 read as zero)
-    __device__ uint32_t peek(uint32_t nb) const
+    __device__ int32_t left() const { return bit - first; }   // < 0: the stream was over-read
+    // the nb <= 24 bits just below the position, without consuming
+    __device__ uint32_t peek(uint32_t nb)
     {
-        const int32_t lo = bit - (int32_t)nb;
-        uint32_t v = 0;
-        const int32_t b0 = lo >> 3;   // may be negative
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int32_t b = b0 + i;
-            const uint32_t byte = b >= 0 && b <= ((bit - 1) >> 3) ? p[b] : 0u;
-            const int32_t sh = 8 * i - (lo & 7);
-            if (sh >= 0) { if (sh < 32) v |= byte << sh; }
-            else v |= byte >> (-sh);
+        const int32_t i = max((bit - 1) >> 5, 0);
+        if (i != ci) {
+            // (the lanes of a wavefront cross dword boundaries at different symbols: almost every step has SOME lane in here, so
+            // the usual case must not wait for memory - it takes the dword requested at the previous crossing)
+            if (i == ci - 1) { hi = lo; lo = nx; }
+            else { hi = pa[i]; lo = i > 0 ? pa[i - 1] : 0u; }
+            ci = i;
+            nx = i > 1 ? pa[i - 2] : 0u;
         }
-        return nb >= 32 ? v : (v & ((1u << nb) - 1u));
+        const int32_t sh = max(bit - (int32_t)nb - 32 * (i - 1), 0);
+        const uint64_t w = ((uint64_t)hi << 32) | lo;
+        return (uint32_t)(w >> sh) & ((1u << nb) - 1u);
     }
     __device__ uint32_t read(uint32_t nb)
     {
@@ -73,27 +87,66 @@ struct LitSource {   // the block's literals, delivered one at a time in order
         if (mode == 1) return *raw;
         const uint32_t e = dt[hb.peek(log)];
         hb.bit -= (int32_t)(e >> 8);
-        if (hb.bit < 0) *err = 1;
+        if (hb.left() < 0) *err = 1;
         return e & 0xFFu;
     }
 };
 
-// regenerate one Compressed block into `row` (cap bytes); returns the bytes produced
+// Where a lane's regenerated bytes go: straight to the block's place in global memory, which the caller has ZEROED.
+//   SPARSE (binary maps): only non-zero bytes are stored - a zero literal or a run of zeros costs nothing;
+//   dense (value streams): bytes are collected eight at a time and leave as one 8-byte store when the destination is 8-byte aligned.
+template <bool SPARSE>
+struct Sink {
+    uint8_t *g;
+    uint32_t op;
+    uint64_t acc;
+    bool al;
+    __device__ void init(uint8_t *dst) { g = dst; op = 0; acc = 0; al = ((uintptr_t)dst & 7u) == 0; }
+    __device__ void put(uint32_t v)
+    {
+        if (SPARSE) { if (v) g[op] = (uint8_t)v; ++op; return; }
+        acc |= (uint64_t)v << (8 * (op & 7u));
+        ++op;
+        if ((op & 7u) == 0) flush8();
+    }
+    __device__ void flush8()   // the eight bytes in front of op
+    {
+        if (al) *reinterpret_cast<uint64_t *>(g + op - 8) = acc;
+        else for (int j = 0; j < 8; ++j) g[op - 8 + j] = (uint8_t)(acc >> (8 * j));
+        acc = 0;
+    }
+    __device__ void fill(uint32_t v, uint32_t n)   // n copies of v
+    {
+        if (SPARSE) { if (v) for (uint32_t k = 0; k < n; ++k) g[op + k] = (uint8_t)v; op += n; return; }
+        for (uint32_t k = 0; k < n; ++k) put(v);
+    }
+    __device__ void finish()
+    {
+        if (SPARSE) return;
+        const uint32_t k = op & 7u;
+        for (uint32_t j = 0; j < k; ++j) g[op - k + j] = (uint8_t)(acc >> (8 * j));
+    }
+};
+
+// regenerate one Compressed block (content c, bs bytes; generic address) into the sink, at most cap bytes; returns the bytes produced
+template <bool SPARSE>
 __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlock &b, const uint16_t *huf, uint32_t huf_log,
-                                      const uint32_t *ll, uint32_t ll_log, const uint32_t *ml, uint32_t ml_log, uint8_t *row, uint32_t cap,
-                                      int *err)
+                                      const uint32_t *ll, uint32_t ll_log, const uint32_t *ml, uint32_t ml_log, const uint32_t *llx,
+                                      const uint32_t *mlx, Sink<SPARSE> &o, uint32_t cap, int *err)
 {
-    const uint32_t lt = c[0] & 3u, sf = (c[0] >> 2) & 3u;
+    const uint32_t c0 = c[0];
+    const uint32_t lt = c0 & 3u, sf = (c0 >> 2) & 3u;
     uint32_t lhs, nlit, lit_c;
     if (lt < 2) {
-        if (sf == 0 || sf == 2) { lhs = 1; nlit = c[0] >> 3; }
-        else if (sf == 1) { lhs = 2; nlit = (c[0] >> 4) | ((uint32_t)c[1] << 4); }
-        else { lhs = 3; nlit = (c[0] >> 4) | ((uint32_t)c[1] << 4) | ((uint32_t)c[2] << 12); }
+        if (sf == 0 || sf == 2) { lhs = 1; nlit = c0 >> 3; }
+        else if (sf == 1) { lhs = 2; nlit = (c0 >> 4) | ((uint32_t)c[1] << 4); }
+        else { lhs = 3; nlit = (c0 >> 4) | ((uint32_t)c[1] << 4) | ((uint32_t)c[2] << 12); }
         lit_c = lt == 0 ? nlit : 1;
     } else {
-        const uint32_t lh = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+        const uint32_t lh = c0 | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
         lhs = 3; nlit = (lh >> 4) & 0x3FFu; lit_c = lh >> 14;
     }
+    if (lhs + lit_c + 1 > bs) { *err = 1; return 0; }
     LitSource L;
     L.mode = lt < 2 ? lt : 2u;
     L.raw = c + lhs;
@@ -107,7 +160,7 @@ __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlo
     const uint8_t *sq = c + lhs + lit_c;
     uint32_t nseq = sq[0], nsb = 1;
     if (nseq >= 128) { nseq = ((nseq - 128) << 8) + sq[1]; nsb = 2; }
-    uint32_t op = 0;
+    uint32_t prev = 0;
     if (nseq) {
         const uint8_t *bsrc = sq + nsb + 1 + b.seq_skip;
         const uint32_t blen = (uint32_t)(c + bs - bsrc);
@@ -118,118 +171,138 @@ __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlo
         for (uint32_t i = 0; i < nseq; ++i) {
             const uint32_t el = ll[sl], em = ml[sm];
             const uint32_t llc = el & 0xFFu, mlc = em & 0xFFu;
-            if (llc > 35 || mlc > 52) { *err = 1; return op; }
-            const uint32_t mlen = c_ml_base[mlc] + fb.read(c_ml_bits[mlc]);   // extra bits: (offset: none), match length, literal length
-            const uint32_t llen = c_ll_base[llc] + fb.read(c_ll_bits[llc]);
-            if (llen == 0 || op + llen + mlen > cap) { *err = 1; return op; }   // offset code 0 means "previous byte" only behind a literal
-            for (uint32_t k = 0; k < llen; ++k) row[op++] = (uint8_t)L.next(err);
-            const uint8_t prev = row[op - 1];
-            if (prev == 0) op += mlen;   // the rows start out zeroed: a run of zeros (what these matches are in a bitmap) costs nothing
-            else for (uint32_t k = 0; k < mlen; ++k) row[op++] = prev;
+            if (llc > 35 || mlc > 52) { *err = 1; return o.op; }
+            const uint32_t mx = mlx[mlc], lx = llx[llc];                      // base | extra bits << 16
+            const uint32_t mlen = (mx & 0xFFFFu) + fb.read(mx >> 16);         // extra bits: (offset: none), match length, literal length
+            const uint32_t llen = (lx & 0xFFFFu) + fb.read(lx >> 16);
+            if (llen == 0 || o.op + llen + mlen > cap) { *err = 1; return o.op; }   // offset code 0 means "previous byte" only behind a literal
+            for (uint32_t k = 0; k < llen; ++k) { prev = L.next(err); o.put(prev); }
+            o.fill(prev, mlen);   // (a run of zeros - what these matches are in a binary map - costs nothing in the sparse sink)
             if (i + 1 < nseq) {                                               // state updates: literal length, match length, (offset)
                 sl = (el >> 16) + fb.read((el >> 8) & 0xFFu);
                 sm = (em >> 16) + fb.read((em >> 8) & 0xFFu);
             }
-            if (fb.bit < 0) { *err = 1; return op; }
+            if (fb.left() < 0) { *err = 1; return o.op; }
         }
     }
-    if (op + L.left > cap) { *err = 1; return op; }
-    while (L.left) row[op++] = (uint8_t)L.next(err);
-    return op;
+    if (o.op + L.left > cap) { *err = 1; return o.op; }
+    while (L.left) o.put(L.next(err));
+    o.finish();
+    return o.op;
 }
 
-// LZ4 block into a row (lz4_Block_format.md); the block may not reference anything in front of itself
-__device__ uint32_t lz4_block_decode_row(const uint8_t *src, uint32_t n, uint8_t *row, uint32_t cap, int *err)
+// LZ4 block (lz4_Block_format.md) into the sparse sink; the block may not reference anything in front of itself.  A match is
+// read back from the lane's own earlier output (bytes it skipped read as the zeros the caller put there).
+__device__ uint32_t lz4_block_decode(const uint8_t *src, uint32_t n, Sink<true> &o, uint32_t cap, int *err)
 {
-    uint32_t ip = 0, op = 0;
+    uint32_t ip = 0;
+    uint32_t prev = 0;
     while (ip < n) {
         const uint32_t token = src[ip++];
         uint32_t lit = token >> 4;
-        if (lit == 15) { uint32_t x; do { if (ip >= n) { *err = 1; return op; } x = src[ip++]; lit += x; } while (x == 255); }
-        if (ip + lit > n || op + lit > cap) { *err = 1; return op; }
-        for (uint32_t i = 0; i < lit; ++i) row[op + i] = src[ip + i];
-        ip += lit; op += lit;
+        if (lit == 15) { uint32_t x; do { if (ip >= n) { *err = 1; return o.op; } x = src[ip++]; lit += x; } while (x == 255); }
+        if (ip + lit > n || o.op + lit > cap) { *err = 1; return o.op; }
+        for (uint32_t i = 0; i < lit; ++i) { prev = src[ip + i]; o.put(prev); }
+        ip += lit;
         if (ip >= n) break;
-        if (ip + 2 > n) { *err = 1; return op; }
+        if (ip + 2 > n) { *err = 1; return o.op; }
         const uint32_t off = src[ip] | ((uint32_t)src[ip + 1] << 8);
         ip += 2;
         uint32_t ml = token & 15u;
-        if (ml == 15) { uint32_t x; do { if (ip >= n) { *err = 1; return op; } x = src[ip++]; ml += x; } while (x == 255); }
+        if (ml == 15) { uint32_t x; do { if (ip >= n) { *err = 1; return o.op; } x = src[ip++]; ml += x; } while (x == 255); }
         ml += 4;
-        if (off == 0 || off > op || op + ml > cap) { *err = 1; return op; }
-        for (uint32_t i = 0; i < ml; ++i) row[op + i] = row[op + i - off];
-        op += ml;
+        if (off == 0 || off > o.op || o.op + ml > cap) { *err = 1; return o.op; }
+        if (off == 1 && lit) o.fill(prev, ml);   // the byte just written, repeated: known without reading anything back
+        else {
+            for (uint32_t i = 0; i < ml; ++i) { prev = o.g[o.op - off]; o.put(prev); }
+        }
     }
-    return op;
+    return o.op;
 }
 
-// ROW: row capacity in bytes (multiple of 4); T: blocks (= decoding lanes) per workgroup, so that T rows + the tables fit
-// the 64 KiB of static LDS.  CODEC 1: zstd Compressed blocks, 2: LZ4 compressed blocks.
-// Blocks are grouped by frame (grid.y); frame_first[f] .. frame_first[f + 1] index `blocks`.
-template <int ROW, int CODEC, int T>
-__global__ __launch_bounds__(64) void k_block_decode(const uint8_t *__restrict__ data, const ZdBlock *__restrict__ blocks,
-                                                       const uint32_t *__restrict__ frame_first, const ZdTables *__restrict__ tables,
-                                                       const ZdTables *__restrict__ predef, uint8_t *__restrict__ out,
-                                                       const uint64_t *__restrict__ out_base, int *__restrict__ err,
-                                                       uint32_t *__restrict__ produced_out)
+// ONE LANE decodes ONE BLOCK, T blocks of one frame (grid.y) per workgroup; lists[f] = the frame's block list (which may lie in
+// page-locked HOST memory: every entry is read once).
+// The blocks of a workgroup are neighbours in the stored stream: their compressed bytes - one contiguous span, the 3-byte headers
+// in between included - are first copied into LDS with coalesced 16-byte loads, and every lane reads ITS block from there (a lane
+// whose block does not lie inside the staged span reads global memory instead: same code, generic addresses).  This is what
+// makes the kernel fast: a block's decoding is a chain of some hundred dependent reads of its compressed bytes, and from global
+// memory each of them is a full memory latency.  (Before: rows of regenerated bytes in LDS, compressed bytes from global memory -
+// 1.18 ms for the 262 144 binary-map blocks of 64 frames of 4096 x 4096.)  The regenerated bytes go straight to global memory
+// (Sink), which the caller has zeroed.
+// CODEC 1: zstd Compressed blocks, 2: LZ4 compressed blocks.  SPAN: staged bytes (multiple of 16).
+template <int CODEC, bool SPARSE, int T, int SPAN>
+__global__ __launch_bounds__(T) void k_block_decode(const uint8_t *__restrict__ data, const ZdFrameList *__restrict__ lists,
+                                                      const ZdTables *__restrict__ tables,
+                                                      const ZdTables *__restrict__ predef, uint8_t *__restrict__ out,
+                                                      const uint64_t *__restrict__ out_base, int *__restrict__ err,
+                                                      uint32_t *__restrict__ produced_out)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_row[T][ROW + 4];
+    __shared__ u32x4 s_span[SPAN / 16];
     __shared__ ZdTables s_t;
     __shared__ uint32_t s_pll[64], s_pml[64];
+    __shared__ uint32_t s_llx[36], s_mlx[53];   // code -> base | extra bits << 16 (from constant memory each lookup was a vector load)
     const uint32_t f = blockIdx.y;
-    const uint32_t lo = frame_first[f], hi = frame_first[f + 1];
-    const uint32_t i0 = lo + blockIdx.x * T;
+    const ZdBlock *__restrict__ blocks = lists[f].p;
+    const uint32_t hi = lists[f].n;
+    const uint32_t i0 = blockIdx.x * T;
     if (i0 >= hi) return;
-    const int lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     if (CODEC == 1) {
+        if (tid < 36) s_llx[tid] = c_ll_base[tid] | ((uint32_t)c_ll_bits[tid] << 16);
+        if (tid < 53) s_mlx[tid] = c_ml_base[tid] | ((uint32_t)c_ml_bits[tid] << 16);
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + f);
-        for (uint32_t i = lane; i < sizeof(ZdTables) / 4; i += 64) reinterpret_cast<uint32_t *>(&s_t)[i] = src[i];
-        s_pll[lane] = predef->ll[lane];
-        s_pml[lane] = predef->ml[lane];
-        __syncthreads();
+        for (uint32_t i = tid; i < sizeof(ZdTables) / 4; i += T) reinterpret_cast<uint32_t *>(&s_t)[i] = src[i];
+        if (tid < 64) { s_pll[tid] = predef->ll[tid]; s_pml[tid] = predef->ml[tid]; }
     }
-    for (uint32_t i = lane; i < (uint32_t)(T * (ROW + 4)) / 4; i += 64) reinterpret_cast<uint32_t *>(&s_row[0][0])[i] = 0;
+    const uint32_t ilast = min(i0 + (uint32_t)T, hi) - 1;
+    const uint64_t span0 = blocks[i0].src & ~15ull;
+    const uint64_t span_end = blocks[ilast].src + blocks[ilast].csize;
+    const uint32_t staged = span_end > span0 ? (uint32_t)min<uint64_t>((span_end - span0 + 15) & ~15ull, (uint64_t)SPAN) : 0u;
+    {
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(data + span0);   // (data is an allocation's start: 16-byte aligned)
+        for (uint32_t i = tid; i < staged / 16; i += T) s_span[i] = g[i];
+    }
     __syncthreads();
-    const uint32_t bi = i0 + lane;
-    ZdBlock b;
-    uint32_t produced = 0;
+    const uint32_t bi = i0 + tid;
+    if (bi >= hi) return;
+    const ZdBlock b = blocks[bi];
     int e = 0;
-    if (lane < T && bi < hi) {
-        b = blocks[bi];
-        if (b.regen > ROW) e = 1;
-        else if (CODEC == 1) {
+    const bool in_lds = b.src >= span0 && b.src - span0 + b.csize <= staged;
+    Sink<SPARSE> o;
+    o.init(out + out_base[f] + b.dst);
+    uint32_t produced = 0;
+    // Two copies of the decoder, one per address space of the compressed bytes: with ONE generic pointer every read would be a
+    // flat load, which is ordered behind the lane's outstanding global stores (flat and global memory instructions share vmcnt) -
+    // a full store latency per few symbols (measured: 300 ns per literal of a value-stream chunk).
+    auto run = [&](const uint8_t *c) {
+        if (CODEC == 1) {
             const bool fr = b.seq_tables != 0;
-            produced = zstd_block_decode(data + b.src, b.csize, b, s_t.huf, s_t.huf_log, fr ? s_t.ll : s_pll, fr ? s_t.ll_log : 6u,
-                                         fr ? s_t.ml : s_pml, fr ? s_t.ml_log : 6u, s_row[lane], b.regen, &e);
-        } else
-            produced = lz4_block_decode_row(data + b.src, b.csize, s_row[lane], b.regen, &e);
-        if (b.flex ? produced > b.regen : produced != b.regen) e = 1;
-        if (b.flex && produced_out) produced_out[0] = produced;   // (at most one such block per call: a single stream's last)
-        if (e) *err = 1;
-    }
-    __syncthreads();
-    // rows -> global: lanes sweep one row at a time
-    for (uint32_t r = 0; r < (uint32_t)T && i0 + r < hi; ++r) {
-        const ZdBlock q = blocks[i0 + r];
-        uint8_t *dst = out + out_base[f] + q.dst;
-        const uint8_t *src = s_row[r];
-        const uint32_t n = q.regen <= (uint32_t)ROW ? q.regen : 0u;
-        if (((uintptr_t)dst & 3u) == 0) {
-            for (uint32_t i = lane; i < n / 4; i += 64) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
-            for (uint32_t i = (n & ~3u) + lane; i < n; i += 64) dst[i] = src[i];
-        } else
-            for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
-    }
+            return zstd_block_decode<SPARSE>(c, b.csize, b, s_t.huf, s_t.huf_log, fr ? s_t.ll : s_pll, fr ? s_t.ll_log : 6u, fr ? s_t.ml : s_pml,
+                                             fr ? s_t.ml_log : 6u, s_llx, s_mlx, o, b.regen, &e);
+        } else {
+            if constexpr (SPARSE) return lz4_block_decode(c, b.csize, o, b.regen, &e);
+            else return 0u;
+        }
+    };
+    if (b.csize == 0) e = 1;
+    else if (in_lds) produced = run(reinterpret_cast<const uint8_t *>(s_span) + (uint32_t)(b.src - span0));
+    else produced = run(data + b.src);
+    if (b.flex ? produced > b.regen : produced != b.regen) e = 1;
+    if (b.flex && produced_out) produced_out[0] = produced;   // (at most one such block per call: a single stream's last)
+    if (e) *err = 1;
 }
 
 // Raw / RLE blocks (and stored LZ4 blocks) of any size: one wavefront per 4 KiB piece
-__global__ __launch_bounds__(WG) void k_block_copy(const uint8_t *__restrict__ data, const ZdBlock *__restrict__ blocks, uint32_t nblocks,
+__global__ __launch_bounds__(WG) void k_block_copy(const uint8_t *__restrict__ data, const ZdFrameList *__restrict__ lists, uint32_t nlists,
                                                      uint8_t *__restrict__ out, const uint64_t *__restrict__ out_base, uint32_t pieces_per_block)
 {
     const uint32_t w = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    const uint32_t bi = w / pieces_per_block, piece = w % pieces_per_block;
-    if (bi >= nblocks) return;
-    const ZdBlock b = blocks[bi];
+    uint32_t bi = w / pieces_per_block;
+    const uint32_t piece = w % pieces_per_block;
+    uint32_t l = 0;
+    while (l < nlists && bi >= lists[l].n) { bi -= lists[l].n; ++l; }   // (a handful of lists: one per indexing thread)
+    if (l >= nlists) return;
+    const ZdBlock b = lists[l].p[bi];
     const int lane = lane_id();
     uint8_t *dst = out + out_base[b.frame] + b.dst;
     const uint8_t *src = data + b.src;
@@ -240,26 +313,31 @@ __global__ __launch_bounds__(WG) void k_block_copy(const uint8_t *__restrict__ d
     }
 }
 
-void launch_block_decode(int codec, int row, const uint8_t *data, const void *blocks, const uint32_t *frame_first, uint32_t nframes,
-                         uint32_t max_blocks_per_frame, const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base, int *err,
-                         hipStream_t s, uint32_t *produced_out)
+// row: the largest number of bytes a block regenerates (<= 512: the blocks of a binary map; more: the chunks of a value stream,
+// few and large - fewer lanes per workgroup so that their compressed bytes still fit the LDS span).  `out` must be zeroed.
+void launch_block_decode(int codec, int row, const uint8_t *data, const void *frame_lists, uint32_t nframes, uint32_t max_blocks_per_frame,
+                         const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base, int *err, hipStream_t s,
+                         uint32_t *produced_out)
 {
     if (!max_blocks_per_frame) return;
-    const dim3 blk(64);
-    const dim3 g64((max_blocks_per_frame + 63) / 64, nframes), g32((max_blocks_per_frame + 31) / 32, nframes);
-    const ZdBlock *b = reinterpret_cast<const ZdBlock *>(blocks);
+    const ZdFrameList *l = reinterpret_cast<const ZdFrameList *>(frame_lists);
     const ZdTables *t = reinterpret_cast<const ZdTables *>(tables), *p = reinterpret_cast<const ZdTables *>(predef);
-    if (codec == 1 && row <= 512) hipLaunchKernelGGL((k_block_decode<512, 1, 64>), g64, blk, 0, s, data, b, frame_first, t, p, out, out_base, err, produced_out);
-    else if (codec == 1) hipLaunchKernelGGL((k_block_decode<1024, 1, 32>), g32, blk, 0, s, data, b, frame_first, t, p, out, out_base, err, produced_out);
-    else hipLaunchKernelGGL((k_block_decode<512, 2, 64>), g64, blk, 0, s, data, b, frame_first, t, p, out, out_base, err, produced_out);
+    auto grid = [&](uint32_t per) { return dim3((max_blocks_per_frame + per - 1) / per, nframes); };
+    if (codec == 1 && row <= 512)
+        hipLaunchKernelGGL((k_block_decode<1, true, 256, 20480>), grid(256), dim3(256), 0, s, data, l, t, p, out, out_base, err, produced_out);
+    else if (codec == 1)
+        hipLaunchKernelGGL((k_block_decode<1, false, 64, 55296>), grid(64), dim3(64), 0, s, data, l, t, p, out, out_base, err, produced_out);
+    else
+        hipLaunchKernelGGL((k_block_decode<2, true, 128, 32768>), grid(128), dim3(128), 0, s, data, l, t, p, out, out_base, err, produced_out);
 }
-void launch_block_copy(const uint8_t *data, const void *blocks, uint32_t nblocks, uint32_t max_regen, uint8_t *out, const uint64_t *out_base,
-                       hipStream_t s)
+// lists: nlists block lists with nblocks entries in all
+void launch_block_copy(const uint8_t *data, const void *lists, uint32_t nlists, uint32_t nblocks, uint32_t max_regen, uint8_t *out,
+                       const uint64_t *out_base, hipStream_t s)
 {
     if (!nblocks) return;
     const uint32_t ppb = std::max(1u, std::min(64u, (max_regen + 16383u) / 16384u));
     const uint32_t waves = nblocks * ppb;
-    hipLaunchKernelGGL(k_block_copy, dim3((waves + WAVES - 1) / WAVES), dim3(WG), 0, s, data, reinterpret_cast<const ZdBlock *>(blocks), nblocks,
+    hipLaunchKernelGGL(k_block_copy, dim3((waves + WAVES - 1) / WAVES), dim3(WG), 0, s, data, reinterpret_cast<const ZdFrameList *>(lists), nlists,
                        out, out_base, ppb);
 }
 

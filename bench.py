@@ -229,7 +229,7 @@ def bench_read(a):
                                % (a.ny, a.nx, a.sparsity_ppm / 1e4, a.level, a.scheme, a.clevel, a.depth, B, blob.size / B)},
         "roofline": {"bound": "hbm", "achieved": round(alg * a.steps / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg * a.steps / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                     "algorithmic_bytes_per_call": alg, "note": "whole call incl. host-side block indexing and the copy-in of the compressed blobs; the decoders are serial-chain-per-block (latency bound), not bandwidth bound"},
+                     "algorithmic_bytes_per_call": alg, "note": "whole call incl. host-side block indexing and the copy-in of the compressed blobs over the link (%.0f B/frame: the link alone allows about %.0f k frames/s); the decoders are serial chains per block (latency bound), not bandwidth bound" % (blob.size / B, 57e9 / (blob.size / B) / 1e3)},
         "nnz_per_frame": round(nnz / B, 1)}), flush=True)
 
 

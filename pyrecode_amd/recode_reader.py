@@ -214,10 +214,18 @@ class ReCoDeReader:
             prefix = np.zeros(n + 1, np.uint64)
             L = _lib.lib()
             args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, mode, scheme, _lib.ptr(blob), _lib.ptr(sizes), n)
-            st = L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0)            # counting call: sizes the output
+            if level == 1:
+                # a frame's packed stream holds one depth-bit field per set pixel: its size bounds the count, one call does it all
+                d = int(h['target_bit_depth'])
+                cap = max(int((sizes[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
+                trip = np.empty((cap, 3), np.uint64)
+                st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), cap)
+            else:
+                st = L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0)        # level 3: a counting call sizes the output
+                if st == _lib.RC_OK:
+                    trip = np.empty((max(int(prefix[n]), 1), 3), np.uint64)
+                    st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0])
             if st == _lib.RC_OK:
-                trip = np.empty((max(int(prefix[n]), 1), 3), np.uint64)
-                _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0]), 'rc_expand_frames')
                 self._current_frame_index = z0 + n
                 self.last_batch_path = 'device'
                 return prefix, trip[:int(prefix[n])]

@@ -120,3 +120,31 @@ def test_emfile_rejects_other_types(tmp_path):
     bad.write_bytes(bytes(2048))
     with pytest.raises(ValueError):
         SEQReader(str(bad))
+
+
+def test_mrc_reader_against_mrcfile_when_installed(tmp_path):
+    """Cross-check against the stock package the reference wraps (pyrecode/em_reader.py); skipped where mrcfile is absent (this image)."""
+    mrcfile = pytest.importorskip("mrcfile")
+    rng = np.random.default_rng(11)
+    stack = rng.integers(0, 4096, (3, 20, 24)).astype(np.uint16)
+    path = tmp_path / "stock.mrc"
+    with mrcfile.new(str(path), overwrite=True) as m:
+        m.set_data(stack)
+    with emfile(str(path), rc.FILE_TYPE_MRC) as r:
+        assert r.shape == stack.shape
+        for z in range(3):
+            assert np.array_equal(r[z][0], stack[z])
+
+
+def test_seq_reader_against_pims_when_installed(tmp_path):
+    """Cross-check against pims.NorpixSeq (what the reference wraps); skipped where pims is absent (this image)."""
+    pims = pytest.importorskip("pims")
+    rng = np.random.default_rng(12)
+    stack = rng.integers(0, 4096, (3, 16, 20)).astype(np.uint16)
+    path = tmp_path / "stock.seq"
+    write_seq(path, stack)
+    theirs = pims.NorpixSeq(str(path))
+    assert len(theirs) == 3
+    with emfile(str(path), rc.FILE_TYPE_SEQ) as ours:
+        for z in range(3):
+            assert np.array_equal(np.asarray(theirs[z]), ours[z][0])

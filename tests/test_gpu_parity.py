@@ -221,6 +221,25 @@ def test_blosc_lz4_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
     ctx.close()
 
 
+def test_blosc_chunks_against_stock_blosc_when_installed(hip, orc):
+    """The same chunks through c-blosc itself (python-blosc), which is what a reference reader would call (recode_compressors.py:66);
+    skipped where the package is absent (this image)."""
+    blosc = pytest.importorskip("blosc")
+    ny, nx, d = 96, 128, 12
+    dark, frames = synth_frames(77, 2, ny, nx, 0.02, d)
+    thr = orc.threshold(dark, 0)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 8, 1, 0, max_batch=2)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+    for z in range(2):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        binary, pix = orc.binarize_l1(frames[z], thr)
+        assert blosc.decompress(r[16:16 + cb]) == orc.pack_binary_frame(binary).tobytes()
+        assert blosc.decompress(r[16 + cb:]) == orc.bit_pack(pix, d).tobytes()
+    ctx.close()
+
+
 @pytest.mark.parametrize("mode,scheme", [(0, 0), (1, 2), (1, 0), (1, 1), (1, 8)])
 def test_l3_records(hip, orc, mode, scheme):
     ny, nx = 200, 333
@@ -331,6 +350,42 @@ def test_sparse_expand(hip, orc, ny, nx, s, d, level):
     if n > 1:
         with pytest.raises(ValueError):
             hip.check(hip.lib().rc_unpack_frame_sparse(nx, ny, d, hip.ptr(bitmap), hip.ptr(pk), packed.size, hip.ptr(out), n - 1, level))
+
+
+def test_sparse_expand_ignores_stray_padding_bits(hip, orc):
+    """A foreign / damaged bitmap with bits set at or behind pixel N (the padding of its last byte, or whole padding bytes): count
+    and emit agree - the returned nnz is the number of triplets written, and the packed-stream length check uses that count."""
+    ny, nx, d = 5, 13, 12   # N = 65: the last byte has 7 padding bits
+    N = ny * nx
+    rng = np.random.default_rng(65)
+    binary = rng.random(N) < 0.3
+    n = int(binary.sum())
+    vals = rng.integers(1, 1 << d, n).astype(np.uint16)
+    bitmap = np.packbits(binary, bitorder="little")
+    packed = orc.bit_pack(vals, d)
+    want = orc.unpack_frame_sparse(nx, ny, d, bitmap, packed, 1)
+    dirty = bitmap.copy()
+    dirty[-1] |= 0xFE           # every padding bit of the last byte set
+    out = np.zeros((n + 8, 3), np.uint64)
+    got = hip.lib().rc_unpack_frame_sparse(nx, ny, d, hip.ptr(dirty), hip.ptr(packed), packed.size, hip.ptr(out), n + 8, 1)
+    assert got == n
+    assert np.array_equal(out[:n], want)
+    assert not out[n:].any()
+
+
+def test_stateless_entry_points_leave_the_current_device_alone(hip):
+    """Every entry point binds to its device for the duration of the call only (one process per GPU: a reader call on rank r must not
+    move the thread's current device).  With one visible GPU this checks the restore path: the device torch sees stays the same, and a
+    ctx created here keeps working after stateless calls in between."""
+    import torch
+    from pyrecode_amd import recode_compressors as rcomp
+    before = torch.cuda.current_device()
+    src = (np.arange(4096) % 7).astype(np.uint8)
+    comp = rcomp.device_compress(2, 1, src)
+    assert rcomp.device_decompress(2, comp, src.size) == src.tobytes()
+    assert torch.cuda.current_device() == before
+    x = torch.ones(8, device="cuda")
+    assert int(x.sum().item()) == 8 and x.device.index == before
 
 
 @pytest.mark.parametrize("d", [1, 5, 8, 9, 10, 12, 13, 15, 16])

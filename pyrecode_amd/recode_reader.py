@@ -229,7 +229,10 @@ class ReCoDeReader:
                 self._current_frame_index = z0 + n
                 self.last_batch_path = 'device'
                 return prefix, trip[:int(prefix[n])]
-            if st != _lib.RC_ERR_UNSUPPORTED:
+            # Outside the device decoders' subset - or a stream they could not make sense of (a foreign encoder's independent 64 KiB
+            # LZ4 blocks look like that): the per-frame path below decodes with the stock library, which is also the judge of whether
+            # the file is really damaged.
+            if st not in (_lib.RC_ERR_UNSUPPORTED, _lib.RC_ERR_CORRUPT):
                 _lib.check(st, 'rc_expand_frames')
         # per-frame path
         self.last_batch_path = 'per-frame'  

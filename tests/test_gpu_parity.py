@@ -554,6 +554,42 @@ def test_expand_frames_rejects_damaged_and_foreign_streams(hip, orc):
                 fs[zf, j] = k
             fs[zf, 2] = len(streams[1])
         assert call(np.concatenate(parts), fs) == hip.RC_ERR_UNSUPPORTED
+    # a stock liblz4 frame of INDEPENDENT 64 KiB blocks with real matches: inside the LZ4 decoder's format subset but not the
+    # 512-byte-block shape the binary-map decoder is launched for - refused (either code), nothing written out of bounds, and
+    # ReCoDeReader.get_frames_triplets then takes its per-frame path
+    name = ctypes.util.find_library("lz4")
+    if name:
+        lz = C.CDLL(name)
+
+        class FrameInfo(C.Structure):
+            _fields_ = [("blockSizeID", C.c_int), ("blockMode", C.c_int), ("contentChecksumFlag", C.c_int), ("frameType", C.c_int),
+                        ("contentSize", C.c_ulonglong), ("dictID", C.c_uint), ("blockChecksumFlag", C.c_int)]
+
+        class Prefs(C.Structure):
+            _fields_ = [("frameInfo", FrameInfo), ("compressionLevel", C.c_int), ("autoFlush", C.c_uint), ("favorDecSpeed", C.c_uint),
+                        ("reserved", C.c_uint * 3)]
+        lz.LZ4F_compressFrameBound.restype = C.c_size_t
+        lz.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+        lz.LZ4F_compressFrame.restype = C.c_size_t
+        lz.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        prefs = Prefs()
+        prefs.frameInfo.blockSizeID = 4    # 64 KiB
+        prefs.frameInfo.blockMode = 1      # independent
+        parts, fs = [], np.zeros((2, 3), np.uint32)
+        for zf in range(2):
+            binary, pix = orc.binarize_l1(frames[zf], thr)
+            streams = [orc.pack_binary_frame(binary).tobytes(), orc.bit_pack(pix, d).tobytes()]
+            for j, sdata in enumerate(streams):
+                cap = lz.LZ4F_compressFrameBound(len(sdata), C.byref(prefs))
+                dst = C.create_string_buffer(cap)
+                k = lz.LZ4F_compressFrame(dst, cap, sdata, len(sdata), C.byref(prefs))
+                assert k < cap
+                parts.append(np.frombuffer(dst.raw[:k], np.uint8))
+                fs[zf, j] = k
+            fs[zf, 2] = len(streams[1])
+        b = np.ascontiguousarray(np.concatenate(parts))
+        st = L.rc_expand_frames(nx, ny, d, 1, 1, 2, hip.ptr(b), hip.ptr(fs), 2, hip.ptr(prefix), None, 0)
+        assert st in (hip.RC_ERR_UNSUPPORTED, hip.RC_ERR_CORRUPT)
 
 
 # ---- reduction level 2: specification by intent, checked against scipy.ndimage.label + numpy -----------------

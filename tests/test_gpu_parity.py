@@ -511,6 +511,37 @@ def test_seam2_zstd_compress_decompress_agree(hip):
         assert rcomp.de_compress(1, foreign, None) == text
 
 
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_expand_frames_blob_in_device_memory(hip, orc, scheme):
+    """rc_expand_frames with the compressed bytes already in device memory (decoded in place, or copied when the buffer's end lies too
+    close to a page boundary for the decoders' wide loads) gives what the host-memory call gives."""
+    import torch
+    ny, nx, d, n = 64, 512, 12, 3
+    dark, frames = synth_frames(5, n, ny, nx, 0.03, d)
+    thr = orc.threshold(dark, 0)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, scheme, 1, 0, max_batch=n)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, 0)
+    ctx.close()
+    L = hip.lib()
+    blob = np.ascontiguousarray(np.concatenate([out[int(rec[z]) + 16:int(rec[z + 1])] for z in range(n)]))
+    sizes = np.ascontiguousarray(md[:, :3], dtype=np.uint32)
+    nnz = int((frames > thr).sum())
+    want_prefix, want = np.zeros(n + 1, np.uint64), np.zeros((nnz, 3), np.uint64)
+    hip.check(L.rc_expand_frames(nx, ny, d, 1, 1, scheme, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(want_prefix), hip.ptr(want), nnz))
+    assert int(want_prefix[n]) == nnz
+    for pad in (0, 4096 - (blob.size % 4096) - 8):      # an ordinary end, and an end 8 bytes in front of a page boundary
+        dev = torch.zeros(blob.size + 8192, dtype=torch.uint8, device="cuda")
+        off = (4096 - (blob.size + pad) % 4096 - 8) % 4096 if pad else 0
+        off -= off % 16
+        view = dev[off:off + blob.size]
+        view.copy_(torch.from_numpy(blob))
+        prefix, got = np.zeros(n + 1, np.uint64), torch.zeros((nnz, 3), dtype=torch.int64, device="cuda")
+        hip.check(L.rc_expand_frames(nx, ny, d, 1, 1, scheme, view.data_ptr(), hip.ptr(sizes), n, hip.ptr(prefix), got.data_ptr(), nnz))
+        assert np.array_equal(prefix, want_prefix)
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+
+
 def test_expand_frames_rejects_damaged_and_foreign_streams(hip, orc):
     """rc_expand_frames: a truncated / bit-flipped stream is RC_ERR_CORRUPT (ValueError), a stream from a foreign encoder is
     RC_ERR_UNSUPPORTED (the reader then uses its per-frame path); neither writes past its buffers or hangs."""

@@ -1250,18 +1250,24 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     ZdFrameList *bm_list = reinterpret_cast<ZdFrameList *>(u.rd_head + o_first), *pv_list = bm_list + n, *raw_list = pv_list + n;
     uint32_t *pv_bytes = reinterpret_cast<uint32_t *>(raw_list + RC_READ_THREADS);
     uint64_t *base2 = reinterpret_cast<uint64_t *>(u.rd_head + o_base2), *pv_base = base2 + 2 * (uint64_t)n;
-    struct FrameIndex { uint32_t bm0 = 0, bm_n = 0, pv0 = 0, pv_n = 0; int status = ZD_OK; const char *what = nullptr; };
+    struct FrameIndex { uint32_t bm0 = 0, bm_n = 0, pv0 = 0, pv_n = 0, thread = 0; int status = ZD_OK; const char *what = nullptr; };
     std::vector<FrameIndex> fi(n);
     const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
     static const uint32_t thr_env = getenv("RC_READ_THREADS") ? (uint32_t)atoi(getenv("RC_READ_THREADS")) : 0u;   // (development: 1..16)
     const uint32_t nthr = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(n, thr_env ? std::min<uint32_t>(thr_env, RC_READ_THREADS) : RC_READ_THREADS), hw));
     const int dev_now = u.device;
+    // frames are claimed one at a time: the calling thread starts at once, the pool's workers join in as they wake up (their
+    // wake-up, not the walk - 30 us per frame - is what a static split waited for)
+    std::atomic<uint32_t> next_frame{0};
     auto index_range = [&](uint32_t t) {
         if (t) (void)hipSetDevice(dev_now);   // (a worker thread: page-locked memory it allocates belongs to this device's context)
         auto &BM = u.rd_bm[t]; auto &PV = u.rd_pv[t]; auto &RAW = u.rd_raw[t]; auto &all = u.rd_tmp[t];
         BM.clear(); PV.clear(); RAW.clear();
-        for (uint32_t f = (uint32_t)((uint64_t)n * t / nthr); f < (uint32_t)((uint64_t)n * (t + 1) / nthr); ++f) {
+        for (;;) {
+            const uint32_t f = next_frame.fetch_add(1, std::memory_order_relaxed);
+            if (f >= n) break;
             FrameIndex &F = fi[f];
+            F.thread = t;
             const uint64_t cb = sizes[3 * f], cp = level == 1 ? sizes[3 * f + 1] : 0, npk = level == 1 ? sizes[3 * f + 2] : 0;
             const uint64_t o = foff[f];
             uint64_t got = 0;
@@ -1316,23 +1322,24 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     uint32_t bm_max = 0, pv_max = 0, raw_max_regen = 0;
     for (uint32_t t = 0; t < nthr; ++t) {
         if (!u.rd_bm[t].ok || !u.rd_pv[t].ok || !u.rd_raw[t].ok) return bail(RC_ERR_DEVICE, "rc_expand_frames: page-locked host memory exhausted");
-        for (uint32_t f = (uint32_t)((uint64_t)n * t / nthr); f < (uint32_t)((uint64_t)n * (t + 1) / nthr); ++f) {
-            const FrameIndex &F = fi[f];
-            if (F.status == ZD_FOREIGN) return bail(RC_ERR_UNSUPPORTED, "rc_expand_frames: stream outside the device decoders' subset (use the stock decoder)");
-            if (F.status != ZD_OK) return bail(RC_ERR_CORRUPT, F.what ? F.what : "rc_expand_frames: malformed compressed stream");
-            bm_list[f].p = u.rd_bm[t].data() + F.bm0; bm_list[f].n = F.bm_n; bm_list[f].pad = 0;
-            pv_list[f].p = u.rd_pv[t].data() + F.pv0; pv_list[f].n = F.pv_n; pv_list[f].pad = 0;
-            pv_bytes[f] = level == 1 ? sizes[3 * f + 2] : 0;
-            base2[f] = (uint64_t)f * bm_stride;                                        // stored blocks: frames 0..n-1 = bitmaps,
-            base2[n + f] = pv_base[f] = (uint64_t)n * bm_stride + (uint64_t)f * pv_stride;   // n..2n-1 = value streams (behind the bitmaps)
-            bm_max = std::max(bm_max, F.bm_n);
-            pv_max = std::max(pv_max, F.pv_n);
-            n_bm += F.bm_n; n_pv += F.pv_n;
-        }
         raw_list[t].p = u.rd_raw[t].data(); raw_list[t].n = (uint32_t)u.rd_raw[t].size(); raw_list[t].pad = 0;
         n_raw += u.rd_raw[t].size();
         const ZdBlock *rb = u.rd_raw[t].data();
         for (size_t i = 0; i < u.rd_raw[t].size(); ++i) raw_max_regen = std::max(raw_max_regen, rb[i].regen);
+    }
+    for (uint32_t f = 0; f < n; ++f) {
+        const FrameIndex &F = fi[f];
+        const uint32_t t = F.thread;
+        if (F.status == ZD_FOREIGN) return bail(RC_ERR_UNSUPPORTED, "rc_expand_frames: stream outside the device decoders' subset (use the stock decoder)");
+        if (F.status != ZD_OK) return bail(RC_ERR_CORRUPT, F.what ? F.what : "rc_expand_frames: malformed compressed stream");
+        bm_list[f].p = u.rd_bm[t].data() + F.bm0; bm_list[f].n = F.bm_n; bm_list[f].pad = 0;
+        pv_list[f].p = u.rd_pv[t].data() + F.pv0; pv_list[f].n = F.pv_n; pv_list[f].pad = 0;
+        pv_bytes[f] = level == 1 ? sizes[3 * f + 2] : 0;
+        base2[f] = (uint64_t)f * bm_stride;                                        // stored blocks: frames 0..n-1 = bitmaps,
+        base2[n + f] = pv_base[f] = (uint64_t)n * bm_stride + (uint64_t)f * pv_stride;   // n..2n-1 = value streams (behind the bitmaps)
+        bm_max = std::max(bm_max, F.bm_n);
+        pv_max = std::max(pv_max, F.pv_n);
+        n_bm += F.bm_n; n_pv += F.pv_n;
     }
     if (n_raw >= (1ull << 31)) return bail(RC_ERR_UNSUPPORTED, "rc_expand_frames: too many blocks in one call");
     const double t_2 = now();

@@ -176,7 +176,18 @@ __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlo
             const uint32_t mlen = (mx & 0xFFFFu) + fb.read(mx >> 16);         // extra bits: (offset: none), match length, literal length
             const uint32_t llen = (lx & 0xFFFFu) + fb.read(lx >> 16);
             if (llen == 0 || o.op + llen + mlen > cap) { *err = 1; return o.op; }   // offset code 0 means "previous byte" only behind a literal
-            for (uint32_t k = 0; k < llen; ++k) { prev = L.next(err); o.put(prev); }
+            if (L.mode == 2) {   // Huffman-coded literals: the bare table step (the lanes wait for each other in this loop: keep it short)
+                if (L.left < llen) { *err = 1; return o.op; }
+                for (uint32_t k = 0; k < llen; ++k) {
+                    const uint32_t e = L.dt[L.hb.peek(L.log)];
+                    L.hb.bit -= (int32_t)(e >> 8);
+                    prev = e & 0xFFu;
+                    o.put(prev);
+                }
+                L.left -= llen;
+                if (L.hb.left() < 0) { *err = 1; return o.op; }
+            } else
+                for (uint32_t k = 0; k < llen; ++k) { prev = L.next(err); o.put(prev); }
             o.fill(prev, mlen);   // (a run of zeros - what these matches are in a binary map - costs nothing in the sparse sink)
             if (i + 1 < nseq) {                                               // state updates: literal length, match length, (offset)
                 sl = (el >> 16) + fb.read((el >> 8) & 0xFFu);

@@ -925,10 +925,10 @@ RC_EXPORT int rc_get_stage_ms(rc_ctx *c, float ms[5])
 namespace {
 // A few worker threads that stay around between calls (rc_expand_frames indexes its frames on them: starting 15 threads per call
 // cost more than the indexing itself - 0.5 of 0.7 ms for 64 frames).  run(n, fn) calls fn(0..n-1), fn(0) on the calling thread, and
-// returns when all are done; one run at a time (the callers hold the device's Util lock).  Never destroyed: the workers sleep on a
-// condition variable and end with the process.  A forked child starts its own.
+// returns when all are done; runs are serialised (callers on different devices share the pool).  Never destroyed: the workers sleep
+// on a condition variable and end with the process.  A forked child starts its own.
 struct WorkerPool {
-    std::mutex mu;
+    std::mutex mu, run_mu;
     std::condition_variable cv_go, cv_done;
     std::function<void(uint32_t)> fn;
     uint64_t generation = 0;
@@ -958,6 +958,7 @@ struct WorkerPool {
     void run(uint32_t n, const std::function<void(uint32_t)> &f)
     {
         if (n <= 1) { if (n) f(0); return; }
+        std::lock_guard<std::mutex> one_run(run_mu);
         {
             std::lock_guard<std::mutex> lk(mu);
             if (pid != getpid()) { started = 0; pid = getpid(); }   // (after a fork the parent's workers do not exist here)

@@ -542,6 +542,64 @@ def test_expand_frames_blob_in_device_memory(hip, orc, scheme):
         assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
 
 
+def test_expand_frames_decodes_stock_lz4_blocks_with_real_matches(hip, orc):
+    """LZ4 frames of independent 512-byte blocks compressed by STOCK liblz4 (its hash-table matcher emits matches at arbitrary offsets,
+    which this library's own encoder never does): inside the device decoder's subset, so rc_expand_frames must decode them - each lane
+    reading matches back from its own earlier output - to the oracle's triplets."""
+    import ctypes as C
+    import ctypes.util
+    xxhash = pytest.importorskip("xxhash")
+    name = ctypes.util.find_library("lz4")
+    if not name:
+        pytest.skip("no liblz4")
+    lz = C.CDLL(name)
+    lz.LZ4_compress_default.restype = C.c_int
+    lz.LZ4_compress_default.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    ny, nx, d, n = 64, 512, 12, 2
+    rng = np.random.default_rng(9)
+    dark = rng.integers(90, 110, (ny, nx)).astype(np.uint16)
+    frames = np.repeat(dark[None], n, 0).copy()
+    # repeated small motifs: plenty of non-trivial matches inside every 512-byte bitmap block
+    for z in range(n):
+        for y in range(0, ny, 2):
+            frames[z, y, (7 * y + 3 * z) % 16::16] += 300
+            frames[z, y, (5 * y + z) % 48::48] += 40
+    thr = orc.threshold(dark, 0)
+    hdr = bytes([0x04, 0x22, 0x4D, 0x18, 0x60, 0x40])
+    hdr += bytes([(xxhash.xxh32(hdr[4:6]).intdigest() >> 8) & 0xFF])
+    parts, sizes, want, prefix = [], np.zeros((n, 3), np.uint32), [], [0]
+    nmatch_blocks = 0
+    for z in range(n):
+        binary, pix = orc.binarize_l1(frames[z], thr)
+        bitmap = orc.pack_binary_frame(binary).tobytes()
+        packed = orc.bit_pack(pix, d).tobytes()
+        bm = bytearray(hdr)
+        for o in range(0, len(bitmap), 512):
+            chunk = bitmap[o:o + 512]
+            dst = C.create_string_buffer(1024)
+            k = lz.LZ4_compress_default(chunk, dst, len(chunk), 1024)
+            assert 0 < k
+            if k < len(chunk):
+                bm += struct.pack("<I", k) + dst.raw[:k]
+                nmatch_blocks += 1
+            else:
+                bm += struct.pack("<I", len(chunk) | 0x80000000) + chunk
+        bm += struct.pack("<I", 0)
+        pv = bytearray(hdr) + struct.pack("<I", len(packed) | 0x80000000) + packed + struct.pack("<I", 0)
+        parts += [bytes(bm), bytes(pv)]
+        sizes[z] = (len(bm), len(pv), len(packed))
+        t = orc.unpack_frame_sparse(nx, ny, d, np.frombuffer(bitmap, np.uint8), np.frombuffer(packed, np.uint8), 1)
+        want.append(t)
+        prefix.append(prefix[-1] + t.shape[0])
+    assert nmatch_blocks > n * 4
+    blob = np.frombuffer(b"".join(parts), np.uint8).copy()
+    total = prefix[-1]
+    got_prefix, got = np.zeros(n + 1, np.uint64), np.zeros((total, 3), np.uint64)
+    hip.check(hip.lib().rc_expand_frames(nx, ny, d, 1, 1, 2, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(got_prefix), hip.ptr(got), total))
+    assert list(got_prefix) == prefix
+    assert np.array_equal(got, np.concatenate(want))
+
+
 def test_expand_frames_rejects_damaged_and_foreign_streams(hip, orc):
     """rc_expand_frames: a truncated / bit-flipped stream is RC_ERR_CORRUPT (ValueError), a stream from a foreign encoder is
     RC_ERR_UNSUPPORTED (the reader then uses its per-frame path); neither writes past its buffers or hangs."""

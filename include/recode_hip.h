@@ -221,8 +221,9 @@ int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_depth, con
  * (pyrecode/recode_reader.py:379-471: de_compress on the binary-map stream and on the value stream,
  * recode_compressors.py:40-79, then c_recode get_frame_sparse, pyrecode.cpp:95-119).
  *   nx, ny, bit_depth, reduction_level (1 or 3), op_mode, scheme    header fields of the file
- *   data          host memory: the n frames' data blobs back to back, as they lie in a merged file (per frame: the
- *                 binary-map stream, then the value stream)
+ *   data          host or device memory: the n frames' data blobs back to back, as they lie in a merged file (per frame: the
+ *                 binary-map stream, then the value stream).  Host memory is copied in while the streams' block headers are
+ *                 walked (page-locked memory - rc_host_alloc - makes that copy asynchronous); device memory is decoded where it lies
  *   sizes         uint32[n][3]: bytes of the binary-map stream, bytes of the value stream, bytes of the DEcompressed value
  *                 stream (the rows of the file's metadata table; mode 0: {nb, n_packed, n_packed})
  *   nnz_prefix    uint64[n+1] out: exclusive prefix of the frames' set-pixel counts (frame i's triplets are
@@ -231,7 +232,11 @@ int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_depth, con
  *                 may be NULL with cap 0 (a counting call)
  * Device decoders: mode 0 (stored pieces), LZ4 frames with independent blocks, zstd frames inside the subset this library
  * writes (rc_zstd_dec.h).  Anything else returns RC_ERR_UNSUPPORTED before any work is done and the caller falls back to
- * the per-frame path with the stock decoder.  RC_ERR_OUT_TOO_SMALL: nnz_prefix is valid, triplets untouched. */
+ * the per-frame path with the stock decoder; a stream that is inside the subset on its face but does not decode to the frame's
+ * shape (a foreign encoder's larger blocks, or damage) returns RC_ERR_CORRUPT - callers that can fall back should do so for both
+ * codes and let the stock decoder judge.  RC_ERR_OUT_TOO_SMALL: nnz_prefix is valid, triplets untouched.  At reduction level 1
+ * sum(8 * sizes[i][2] / bit_depth) bounds the count, so one call with that capacity does (ReCoDeReader.get_frames_triplets).
+ * The host walk runs on a small pool of worker threads that stays with the process. */
 int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t reduction_level, uint32_t op_mode, uint32_t scheme,
                      const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap);
 /* bit_pack_pixel_intensities -> _bit_pack_pixel_intensities (reader.h:105-140) with the intended semantics of

@@ -1362,31 +1362,42 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     launch_block_copy(d_data, d_raw_list, nthr, (uint32_t)n_raw, raw_max_regen, d_out, d_base2, s);
     if (n_pv) HIP_TRY(hipStreamWaitEvent(s, u.ev_b, 0));
     const uint8_t *d_bm = d_out, *d_pv = d_out + (uint64_t)n * bm_stride;
-    launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s);
+    // Triplets wanted in DEVICE memory: the emit kernel is queued right behind the count - no host round trip in between; the kernel that
+    // finishes the count (k_expand_bases) checks what the host otherwise would (total <= cap, value streams long enough) and the emit
+    // kernel writes nothing once any check or decoder has raised *d_err.  Host memory: the output is staged, so its size must be known
+    // first (one more synchronisation).
+    const bool dev_out = triplets && is_device_ptr(triplets);
+    if (dev_out) {
+        launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s, d_pv_bytes, bit_depth, level, cap, d_err);
+        launch_expand_batch_emit(d_bm, bm_stride, nb8, N, nx, n, d_blk_off, d_fbase, d_pv, pv_stride, d_pv_bytes, bit_depth, level, cap, triplets, s, d_err);
+    } else
+        launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s);
     HIP_TRY(hipGetLastError());
     int err = 0;
     HIP_TRY(hipMemcpyAsync(nnz_prefix, d_fbase, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const double t_4 = now();
-    if (err) return fail(RC_ERR_CORRUPT, "rc_expand_frames: a block does not decode to its expected size");
+    if (err & 1) return fail(RC_ERR_CORRUPT, "rc_expand_frames: a block does not decode to its expected size");
     const uint64_t total = nnz_prefix[n];
     if (!triplets) return RC_OK;
-    if (total > cap) return fail(RC_ERR_OUT_TOO_SMALL, "rc_expand_frames: triplets holds fewer entries than the frames have set pixels");
+    if (total > cap || (err & 2)) return fail(RC_ERR_OUT_TOO_SMALL, "rc_expand_frames: triplets holds fewer entries than the frames have set pixels");
     if (level == 1)
         for (uint32_t f = 0; f < n; ++f)
             if (((nnz_prefix[f + 1] - nnz_prefix[f]) * bit_depth + 7) / 8 > pv_bytes[f])
                 return fail(RC_ERR_CORRUPT, "rc_expand_frames: value stream shorter than popcount(bitmap) * bit_depth bits");
-    if (total == 0) return RC_OK;
-    uint64_t *d_trip = triplets;
-    const bool out_host = !is_device_ptr(triplets);
-    if (out_host) {
-        if ((r = need(6, total * 24)) != RC_OK) return r;
-        d_trip = reinterpret_cast<uint64_t *>(u.x[6]);
+    if (dev_out) {
+        if (timing)
+            fprintf(stderr, "rc_expand_frames: index %.3f ms, merge %.3f, enqueue copies %.3f, decode+count+emit (to sync) %.3f\n", t_1 - t_0, t_2 - t_1,
+                    t_3 - t_2, t_4 - t_3);
+        return RC_OK;
     }
+    if (total == 0) return RC_OK;
+    if ((r = need(6, total * 24)) != RC_OK) return r;
+    uint64_t *d_trip = reinterpret_cast<uint64_t *>(u.x[6]);
     launch_expand_batch_emit(d_bm, bm_stride, nb8, N, nx, n, d_blk_off, d_fbase, d_pv, pv_stride, d_pv_bytes, bit_depth, level, total, d_trip, s);
     HIP_TRY(hipGetLastError());
-    if (out_host) HIP_TRY(hipMemcpyAsync(triplets, d_trip, total * 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(triplets, d_trip, total * 24, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (timing)
         fprintf(stderr, "rc_expand_frames: index %.3f ms, merge %.3f, enqueue copies %.3f, decode+count (to sync) %.3f, emit %.3f\n", t_1 - t_0, t_2 - t_1,

@@ -132,26 +132,39 @@ __global__ __launch_bounds__(WG) void k_expand_scan_b(const uint32_t *__restrict
     }
     if (threadIdx.x == 0) frame_nnz[f] = carry;
 }
-// single workgroup: frame_nnz[0..n) -> frame_base[0..n] (exclusive prefix, total at [n])
-__global__ __launch_bounds__(WG) void k_expand_bases(const uint64_t *__restrict__ frame_nnz, uint64_t *__restrict__ frame_base, uint32_t n)
+// single workgroup: frame_nnz[0..n) -> frame_base[0..n] (exclusive prefix, total at [n]).  With err != NULL it is also the gate of the
+// emit kernel that may already be queued behind it: a total above cap sets bit 1 of *err, a frame whose value stream is shorter
+// than its set pixels need (level 1: pv_bytes) bit 2; k_expand_emit_b writes nothing once *err is set.
+__global__ __launch_bounds__(WG) void k_expand_bases(const uint64_t *__restrict__ frame_nnz, uint64_t *__restrict__ frame_base, uint32_t n,
+                                                       const uint32_t *__restrict__ pv_bytes, uint32_t d, uint32_t level, uint64_t cap,
+                                                       int *__restrict__ err)
 {
     __shared__ uint64_t part[WG];
     const uint32_t per = (n + WG - 1) / WG, lo = threadIdx.x * per, hi = min(lo + per, n);
     uint64_t s = 0;
-    for (uint32_t f = lo; f < hi; ++f) s += frame_nnz[f];
+    for (uint32_t f = lo; f < hi; ++f) {
+        const uint64_t c = frame_nnz[f];
+        s += c;
+        if (err && level == 1 && (c * d + 7) / 8 > pv_bytes[f]) atomicOr(err, 4);
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     uint64_t base = 0;
     for (uint32_t i = 0; i < threadIdx.x; ++i) base += part[i];
     for (uint32_t f = lo; f < hi; ++f) { frame_base[f] = base; base += frame_nnz[f]; }
-    if (threadIdx.x == WG - 1) frame_base[n] = base;
+    if (threadIdx.x == WG - 1) {
+        frame_base[n] = base;
+        if (err && base > cap) atomicOr(err, 2);
+    }
 }
 __global__ __launch_bounds__(WG) void k_expand_emit_b(const uint8_t *__restrict__ bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx,
                                                         uint32_t nblk, const uint32_t *__restrict__ blk_off, const uint64_t *__restrict__ frame_base,
                                                         const uint8_t *__restrict__ pv, uint64_t pv_stride, const uint32_t *__restrict__ pv_bytes,
-                                                        uint32_t d, uint32_t level, uint64_t cap, uint64_t *__restrict__ out)
+                                                        uint32_t d, uint32_t level, uint64_t cap, uint64_t *__restrict__ out,
+                                                        const int *__restrict__ err)
 {
     __shared__ uint32_t sm[WAVES + 1];
+    if (err && *err) return;   // (workgroup-uniform: k_expand_bases, a decoder or nobody has set it before this kernel started)
     const uint32_t f = blockIdx.y;
     const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t bits = expand_word(bm + f * bm_stride, nb8, N, i);
@@ -172,20 +185,21 @@ __global__ __launch_bounds__(WG) void k_expand_emit_b(const uint8_t *__restrict_
     }
 }
 void launch_expand_batch_count(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t n, uint32_t *blk_cnt, uint32_t *blk_off,
-                               uint64_t *frame_nnz, uint64_t *frame_base, hipStream_t s)
+                               uint64_t *frame_nnz, uint64_t *frame_base, hipStream_t s, const uint32_t *pv_bytes, uint32_t d, uint32_t level,
+                               uint64_t cap, int *err)
 {
     const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
     hipLaunchKernelGGL(k_expand_count_b, dim3(nblk, n), dim3(WG), 0, s, bm, bm_stride, nb8, N, nblk, blk_cnt);
     hipLaunchKernelGGL(k_expand_scan_b, dim3(n), dim3(WG), 0, s, blk_cnt, blk_off, nblk, frame_nnz);
-    hipLaunchKernelGGL(k_expand_bases, dim3(1), dim3(WG), 0, s, frame_nnz, frame_base, n);
+    hipLaunchKernelGGL(k_expand_bases, dim3(1), dim3(WG), 0, s, frame_nnz, frame_base, n, pv_bytes, d, level, cap, err);
 }
 void launch_expand_batch_emit(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx, uint32_t n, const uint32_t *blk_off,
                               const uint64_t *frame_base, const uint8_t *pv, uint64_t pv_stride, const uint32_t *pv_bytes, uint32_t d,
-                              uint32_t level, uint64_t cap, uint64_t *out, hipStream_t s)
+                              uint32_t level, uint64_t cap, uint64_t *out, hipStream_t s, const int *err)
 {
     const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
     hipLaunchKernelGGL(k_expand_emit_b, dim3(nblk, n), dim3(WG), 0, s, bm, bm_stride, nb8, N, nx, nblk, blk_off, frame_base, pv, pv_stride,
-                       pv_bytes, d, level, cap, out);
+                       pv_bytes, d, level, cap, out, err);
 }
 
 // ---- stand-alone pack / unpack ------------------------------------------------------------------------------

@@ -540,6 +540,11 @@ def test_expand_frames_blob_in_device_memory(hip, orc, scheme):
         hip.check(L.rc_expand_frames(nx, ny, d, 1, 1, scheme, view.data_ptr(), hip.ptr(sizes), n, hip.ptr(prefix), got.data_ptr(), nnz))
         assert np.array_equal(prefix, want_prefix)
         assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+    # device triplets, capacity one short: refused, and nothing written (the emit kernel was already queued behind the count)
+    small = torch.full((nnz - 1, 3), -7, dtype=torch.int64, device="cuda")
+    st = L.rc_expand_frames(nx, ny, d, 1, 1, scheme, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(prefix), small.data_ptr(), nnz - 1)
+    assert st == hip.RC_ERR_OUT_TOO_SMALL and int(prefix[n]) == nnz
+    assert bool((small == -7).all())
 
 
 def test_expand_frames_decodes_stock_lz4_blocks_with_real_matches(hip, orc):

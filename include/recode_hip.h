@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 2
+#define RC_ABI_VERSION 3
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -239,6 +239,18 @@ int64_t rc_unpack_frame_sparse(uint32_t nx, uint32_t ny, uint32_t bit_depth, con
  * The host walk runs on a small pool of worker threads that stays with the process. */
 int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t reduction_level, uint32_t op_mode, uint32_t scheme,
                      const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap);
+/* The same work in two halves, for a reader that streams through a file: _submit queues one batch (host walk of the block headers,
+ * copy-in, decoders, count, emit) on one of two slots and returns; _wait(slot) blocks until that batch is done and reports like
+ * rc_expand_frames.  With two batches in flight the host walk and copy-in of one run while the device decodes the other.
+ *   slot            0 or 1; a slot holds one batch at a time (_submit on a slot with a batch waiting: RC_ERR_BAD_ARG)
+ *   triplets_dev    device memory, or page-locked host memory (rc_host_alloc: the emit kernel writes it over the link), cap entries
+ *                   (level 1: sum(8 * sizes[i][2] / bit_depth) bounds the count)
+ *   data            must stay valid until _wait(slot) returns; sizes is consumed by _submit
+ * Streams outside the device decoders' subset are reported by _submit (RC_ERR_UNSUPPORTED / RC_ERR_CORRUPT, nothing left pending);
+ * what only the device can see (a block that does not decode to its size, cap too small) by _wait. */
+int rc_expand_frames_submit(uint32_t slot, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t reduction_level, uint32_t op_mode,
+                            uint32_t scheme, const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *triplets_dev, uint64_t cap);
+int rc_expand_frames_wait(uint32_t slot, uint64_t *nnz_prefix);
 /* bit_pack_pixel_intensities -> _bit_pack_pixel_intensities (reader.h:105-140) with the intended semantics of
  * the numba _bit_pack (recode_writer.py:637-652): zero, then LSB-first d-bit fields.  out_n = ceil(n*d/8). */
 int rc_bit_pack(const uint16_t *pixvals, uint64_t n, uint32_t bit_depth, uint8_t *out, uint64_t out_n);

@@ -62,6 +62,8 @@ SIGNATURES = {
     "rc_compress_bound": (C.c_uint64, [C.c_uint32, C.c_uint64]),
     "rc_unpack_frame_sparse": (C.c_int64, [C.c_uint32, C.c_uint32, C.c_uint32, _u8p, _u8p, C.c_uint64, _u64p, C.c_uint64, C.c_uint32]),
     "rc_expand_frames": (C.c_int, [C.c_uint32] * 6 + [_u8p, _u32p, C.c_uint32, _u64p, _u64p, C.c_uint64]),
+    "rc_expand_frames_submit": (C.c_int, [C.c_uint32] * 7 + [_u8p, _u32p, C.c_uint32, _u64p, C.c_uint64]),
+    "rc_expand_frames_wait": (C.c_int, [C.c_uint32, _u64p]),
     "rc_bit_pack": (C.c_int, [_u16p, C.c_uint64, C.c_uint32, _u8p, C.c_uint64]),
     "rc_bit_unpack": (C.c_int, [_u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
     "rc_synth_dark": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, _u16p]),
@@ -93,7 +95,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here == header / library mismatch
             fn.restype, fn.argtypes = res, args
-        if L.rc_abi_version() != 2:
+        if L.rc_abi_version() != 3:
             raise RecodeHipError("librecode_hip.so ABI version mismatch")
         _lib = L
     return _lib

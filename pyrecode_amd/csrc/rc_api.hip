@@ -998,13 +998,30 @@ struct PinnedVec {
     }
 };
 constexpr int RC_READ_THREADS = 16;
+constexpr int RC_READ_SLOTS = 2;
+
+// Everything one batch of the batched reader owns while it is in flight (rc_expand_frames uses slot 0; rc_expand_frames_submit /
+// _wait alternate between the slots, so that the host walk and copy-in of one batch run while the device decodes the other).
+// Kept between calls: no allocation and no first-touch page faults in steady state.
+struct ReadRes {
+    hipStream_t stream = nullptr, stream2 = nullptr;       // the two streams' decoders run side by side
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, done = nullptr;
+    uint8_t *x[10] = {}; uint64_t x_cap[10] = {};          // device: data, decoded streams, -, head, -, counters, staged triplets
+    PinnedVec<rc::ZdBlock> rd_bm[RC_READ_THREADS], rd_pv[RC_READ_THREADS], rd_raw[RC_READ_THREADS];   // per indexing thread, page-locked
+    std::vector<rc::ZdBlock> rd_tmp[RC_READ_THREADS];
+    uint8_t *rd_head = nullptr; uint64_t rd_head_cap = 0;  // page-locked: decoding tables + per-frame index arrays
+    uint64_t *h_res = nullptr; uint64_t h_res_cap = 0;     // page-locked: nnz prefix (n + 1) and the error word, as the device left them
+    // a submitted batch waiting for its rc_expand_frames_wait
+    bool pending = false;
+    uint32_t n = 0, level = 0, bit_depth = 0;
+    uint64_t cap = 0;
+    std::vector<uint32_t> pv_bytes;
+};
 
 struct Util {
     std::mutex mu;
     int device = -1;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;              // rc_expand_frames: the two streams' decoders run side by side
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     uint8_t *a = nullptr; uint64_t a_cap = 0;   // input 1
     uint8_t *b = nullptr; uint64_t b_cap = 0;   // input 2
     uint8_t *o = nullptr; uint64_t o_cap = 0;   // output
@@ -1013,10 +1030,7 @@ struct Util {
     void *ztab = nullptr;                       // zstd FSE tables
     uint8_t *x[10] = {}; uint64_t x_cap[10] = {};   // rc_expand_frames: data, bitmaps, values, tables, block lists, counters
     void *zd_predef = nullptr;                  // predefined zstd decoding tables
-    // rc_expand_frames, host side (kept between calls: no allocation, no first-touch page faults in steady state)
-    PinnedVec<rc::ZdBlock> rd_bm[RC_READ_THREADS], rd_pv[RC_READ_THREADS], rd_raw[RC_READ_THREADS];   // per indexing thread, page-locked
-    std::vector<rc::ZdBlock> rd_tmp[RC_READ_THREADS];
-    uint8_t *rd_head = nullptr; uint64_t rd_head_cap = 0;   // page-locked: decoding tables + per-frame index arrays
+    ReadRes rr[RC_READ_SLOTS];                  // rc_expand_frames (slot 0) and its submit / wait form (both slots)
 };
 constexpr int RC_MAX_DEV = 64;
 Util g_utils[RC_MAX_DEV];
@@ -1043,9 +1057,6 @@ struct UtilScope {
         HIP_TRY(guard.enter(dev));
         if (t_util->device < 0) {
             HIP_TRY(hipStreamCreateWithFlags(&t_util->stream, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&t_util->stream2, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&t_util->ev_a, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&t_util->ev_b, hipEventDisableTiming));
             HIP_TRY(hipHostMalloc((void **)&t_util->h_scalar, 64, hipHostMallocDefault));
             t_util->device = dev;
         }
@@ -1170,11 +1181,12 @@ int lz4_index_frame(const uint8_t *base, uint64_t off, uint64_t n, uint32_t fram
 }
 }  // namespace
 
-RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode, uint32_t scheme,
-                               const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap)
+// slot, submit_only: rc_expand_frames = (0, false); rc_expand_frames_submit = (slot, true): returns once everything is queued.
+static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode, uint32_t scheme,
+                      const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap)
 {
     using namespace rc;
-    if (!data || !sizes || !nnz_prefix || n == 0 || nx == 0 || ny == 0 || (!triplets && cap)) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
+    if (!data || !sizes || (!nnz_prefix && !submit_only) || n == 0 || nx == 0 || ny == 0 || (!triplets && cap)) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
     if (level != 1 && level != 3) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: reduction level 1 or 3");
     if (level == 1 && (bit_depth == 0 || bit_depth > 64)) return fail(RC_ERR_BAD_ARG, "bit_depth must be 1..64");
     const int codec = op_mode == 0 ? 0 : (scheme == RC_SCHEME_LZ4 ? 2 : (scheme == RC_SCHEME_ZSTD ? 1 : -1));
@@ -1197,7 +1209,22 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     UtilScope util_scope;
     int r = util_scope.enter();
     if (r != RC_OK) return r;
-    Util &u = g_util;
+    Util &U = g_util;
+    ReadRes &u = U.rr[slot];
+    if (u.pending) return fail(RC_ERR_BAD_ARG, "rc_expand_frames: this slot holds a submitted batch - rc_expand_frames_wait first");
+    if (!u.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&u.stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&u.ev_a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&u.ev_b, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&u.done, hipEventDisableTiming));
+    }
+    if (u.h_res_cap < (uint64_t)n + 2) {
+        if (u.h_res) HIP_TRY(hipHostFree(u.h_res));
+        u.h_res = nullptr; u.h_res_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&u.h_res, ((uint64_t)n + 2) * 8, hipHostMallocDefault));
+        u.h_res_cap = (uint64_t)n + 2;
+    }
     hipStream_t s = u.stream;
     const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
     const uint64_t out_bytes = (uint64_t)n * (bm_stride + (level == 1 ? pv_stride : 0)) + 64;
@@ -1217,11 +1244,11 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
         HIP_TRY(hipHostMalloc((void **)&u.rd_head, sz_head, hipHostMallocDefault));
         u.rd_head_cap = sz_head;
     }
-    if (!u.zd_predef) {
+    if (!U.zd_predef) {
         std::vector<uint8_t> t(zd_tables_bytes());
         zd_predefined_tables(t.data());
-        HIP_TRY(hipMalloc(&u.zd_predef, t.size()));
-        HIP_TRY(hipMemcpy(u.zd_predef, t.data(), t.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&U.zd_predef, t.size()));
+        HIP_TRY(hipMemcpy(U.zd_predef, t.data(), t.size(), hipMemcpyHostToDevice));
     }
     // The compressed bytes: device memory is used where it lies; host memory is copied in, and the copy runs while the host walks the
     // streams.  (Letting the decoders read page-locked host memory in place - their staging loads as the transfer - was slower: the
@@ -1256,7 +1283,7 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
     static const uint32_t thr_env = getenv("RC_READ_THREADS") ? (uint32_t)atoi(getenv("RC_READ_THREADS")) : 0u;   // (development: 1..16)
     const uint32_t nthr = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(n, thr_env ? std::min<uint32_t>(thr_env, RC_READ_THREADS) : RC_READ_THREADS), hw));
-    const int dev_now = u.device;
+    const int dev_now = U.device;
     // frames are claimed one at a time: the calling thread starts at once, the pool's workers join in as they wake up (their
     // wake-up, not the walk - 30 us per frame - is what a static split waited for)
     std::atomic<uint32_t> next_frame{0};
@@ -1355,10 +1382,10 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     if (n_pv) {
         HIP_TRY(hipEventRecord(u.ev_a, s));
         HIP_TRY(hipStreamWaitEvent(u.stream2, u.ev_a, 0));
-        launch_block_decode(1, 1024, d_data, d_pv_list, n, pv_max, d_pv_tab, u.zd_predef, d_out, d_pvbase, d_err, u.stream2);
+        launch_block_decode(1, 1024, d_data, d_pv_list, n, pv_max, d_pv_tab, U.zd_predef, d_out, d_pvbase, d_err, u.stream2);
         HIP_TRY(hipEventRecord(u.ev_b, u.stream2));
     }
-    if (n_bm) launch_block_decode(codec == 1 ? 1 : 2, TILE_BM, d_data, d_bm_list, n, bm_max, d_bm_tab, u.zd_predef, d_out, d_base2, d_err, s);
+    if (n_bm) launch_block_decode(codec == 1 ? 1 : 2, TILE_BM, d_data, d_bm_list, n, bm_max, d_bm_tab, U.zd_predef, d_out, d_base2, d_err, s);
     launch_block_copy(d_data, d_raw_list, nthr, (uint32_t)n_raw, raw_max_regen, d_out, d_base2, s);
     if (n_pv) HIP_TRY(hipStreamWaitEvent(s, u.ev_b, 0));
     const uint8_t *d_bm = d_out, *d_pv = d_out + (uint64_t)n * bm_stride;
@@ -1366,17 +1393,36 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     // finishes the count (k_expand_bases) checks what the host otherwise would (total <= cap, value streams long enough) and the emit
     // kernel writes nothing once any check or decoder has raised *d_err.  Host memory: the output is staged, so its size must be known
     // first (one more synchronisation).
-    const bool dev_out = triplets && is_device_ptr(triplets);
+    // "device memory" includes page-locked host memory when the batch is submitted: the emit kernel then writes the triplets over the
+    // link itself, under the next batch's host walk and copy-in (the synchronous call stages host output in device memory instead:
+    // a kernel writing 64 MB over the link is slower than a copy, which only matters when nothing else can run meanwhile)
+    bool dev_out = triplets && is_device_ptr(triplets);
+    if (submit_only && !dev_out) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, triplets) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer) {
+            triplets = reinterpret_cast<uint64_t *>(a.devicePointer);
+            dev_out = true;
+        } else (void)hipGetLastError();
+    }
+    if (submit_only && !dev_out) return bail(RC_ERR_BAD_ARG, "rc_expand_frames_submit: triplets must be device or page-locked host memory");
     if (dev_out) {
         launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s, d_pv_bytes, bit_depth, level, cap, d_err);
         launch_expand_batch_emit(d_bm, bm_stride, nb8, N, nx, n, d_blk_off, d_fbase, d_pv, pv_stride, d_pv_bytes, bit_depth, level, cap, triplets, s, d_err);
     } else
         launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s);
     HIP_TRY(hipGetLastError());
-    int err = 0;
-    HIP_TRY(hipMemcpyAsync(nnz_prefix, d_fbase, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(u.h_res, d_fbase, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(u.h_res + n + 1, d_err, 4, hipMemcpyDeviceToHost, s));
+    if (submit_only) {   // (dev_out is a precondition, checked above)
+        HIP_TRY(hipEventRecord(u.done, s));
+        u.pending = true;
+        u.n = n; u.level = level; u.bit_depth = bit_depth; u.cap = cap;
+        u.pv_bytes.assign(pv_bytes, pv_bytes + n);
+        return RC_OK;
+    }
     HIP_TRY(hipStreamSynchronize(s));
+    const int err = (int)(uint32_t)u.h_res[n + 1];
+    memcpy(nnz_prefix, u.h_res, (size_t)(n + 1) * 8);
     const double t_4 = now();
     if (err & 1) return fail(RC_ERR_CORRUPT, "rc_expand_frames: a block does not decode to its expected size");
     const uint64_t total = nnz_prefix[n];
@@ -1402,6 +1448,39 @@ RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uin
     if (timing)
         fprintf(stderr, "rc_expand_frames: index %.3f ms, merge %.3f, enqueue copies %.3f, decode+count (to sync) %.3f, emit %.3f\n", t_1 - t_0, t_2 - t_1,
                 t_3 - t_2, t_4 - t_3, now() - t_4);
+    return RC_OK;
+}
+
+RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode, uint32_t scheme,
+                               const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap)
+{
+    return expand_run(0, false, nx, ny, bit_depth, level, op_mode, scheme, data, sizes, n, nnz_prefix, triplets, cap);
+}
+
+RC_EXPORT int rc_expand_frames_submit(uint32_t slot, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode,
+                                      uint32_t scheme, const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *triplets_dev, uint64_t cap)
+{
+    if (slot >= RC_READ_SLOTS) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_submit: slot 0 or 1");
+    if (!triplets_dev) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_submit: triplets must be device or page-locked host memory");
+    return expand_run(slot, true, nx, ny, bit_depth, level, op_mode, scheme, data, sizes, n, nullptr, triplets_dev, cap);
+}
+
+RC_EXPORT int rc_expand_frames_wait(uint32_t slot, uint64_t *nnz_prefix)
+{
+    if (slot >= RC_READ_SLOTS || !nnz_prefix) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_wait: slot 0 or 1, nnz_prefix");
+    UtilScope util_scope;
+    int r = util_scope.enter();
+    if (r != RC_OK) return r;
+    ReadRes &u = g_util.rr[slot];
+    if (!u.pending) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_wait: nothing was submitted to this slot");
+    u.pending = false;
+    HIP_TRY(hipEventSynchronize(u.done));
+    const uint32_t n = u.n;
+    const int err = (int)(uint32_t)u.h_res[n + 1];
+    memcpy(nnz_prefix, u.h_res, (size_t)(n + 1) * 8);
+    if (err & 1) return fail(RC_ERR_CORRUPT, "rc_expand_frames: a block does not decode to its expected size");
+    if (nnz_prefix[n] > u.cap || (err & 2)) return fail(RC_ERR_OUT_TOO_SMALL, "rc_expand_frames: triplets holds fewer entries than the frames have set pixels");
+    if (err & 4) return fail(RC_ERR_CORRUPT, "rc_expand_frames: value stream shorter than popcount(bitmap) * bit_depth bits");
     return RC_OK;
 }
 

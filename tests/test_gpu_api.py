@@ -407,4 +407,22 @@ def test_batched_reader_equals_per_frame_reader(tmp_path, scheme, clevel, mode, 
         assert np.array_equal(t[:, 2], want[z][rows, cols].astype(np.uint64)), z
     fr = rd.get_frames(0, 2)
     assert np.array_equal(np.asarray(fr[1]["data"].todense()), want[1].astype(np.uint16))
+    # the streaming form (two batches in flight) walks the whole file in batches of 3 and of 2 and yields the same triplets
+    for batch in (3, 2):
+        seen = 0
+        for a, pfx, t3 in rd.iter_frames_triplets(0, nz, batch=batch):
+            k = len(pfx) - 1
+            assert a == seen and k == min(batch, nz - a)
+            for i in range(k):
+                t = t3[int(pfx[i]):int(pfx[i + 1])]
+                rows, cols = np.nonzero(want[a + i])
+                assert np.array_equal(t[:, 0], rows.astype(np.uint64)) and np.array_equal(t[:, 1], cols.astype(np.uint64)), a + i
+                assert np.array_equal(t[:, 2], want[a + i][rows, cols].astype(np.uint64)), a + i
+            seen += k
+        assert seen == nz
+    it = rd.iter_frames_triplets(0, nz, batch=2)     # a consumer that stops after the first batch: the queued one is waited for
+    next(it)
+    it.close()
+    prefix2, trip2 = rd.get_frames_triplets(1, nz - 1)
+    assert np.array_equal(prefix2, prefix) and np.array_equal(trip2, trip)
     rd.close()

@@ -605,6 +605,57 @@ def test_expand_frames_decodes_stock_lz4_blocks_with_real_matches(hip, orc):
     assert np.array_equal(got, np.concatenate(want))
 
 
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_expand_frames_submit_wait_two_batches_in_flight(hip, orc, scheme):
+    """The streaming form of the batched reader: different batches on the two slots, in flight together, give what the one-call form
+    gives; a slot refuses a second batch before its wait; what only the device sees (capacity one short) is reported by the wait."""
+    import torch
+    ny, nx, d, n = 64, 512, 12, 3
+    L = hip.lib()
+    batches = []
+    for seed in (21, 22, 23):
+        dark, frames = synth_frames(seed, n, ny, nx, 0.02 + 0.01 * (seed % 3), d)
+        thr = orc.threshold(dark, 0)
+        ctx = hip.ReduceContext(nx, ny, d, 1, 1, scheme, 1, 0, max_batch=n)
+        ctx.set_threshold(thr)
+        out, rec, md = ctx.reduce_compress_batch(frames, 0)
+        ctx.close()
+        blob = hip.PinnedBuffer(int(rec[n]))
+        pos = 0
+        for z in range(n):
+            part = out[int(rec[z]) + 16:int(rec[z + 1])]
+            blob.array[pos:pos + part.size] = part
+            pos += part.size
+        sizes = np.ascontiguousarray(md[:, :3], dtype=np.uint32)
+        nnz = int((frames > thr).sum())
+        want_prefix, want = np.zeros(n + 1, np.uint64), np.zeros((nnz, 3), np.uint64)
+        hip.check(L.rc_expand_frames(nx, ny, d, 1, 1, scheme, hip.ptr(blob.array), hip.ptr(sizes), n, hip.ptr(want_prefix), hip.ptr(want), nnz))
+        batches.append((blob, sizes, nnz, want_prefix, want))
+    outs = [torch.zeros((b[2], 3), dtype=torch.int64, device="cuda") for b in batches]
+
+    def submit(k, slot, cap=None):
+        blob, sizes, nnz = batches[k][:3]
+        return L.rc_expand_frames_submit(slot, nx, ny, d, 1, 1, scheme, hip.ptr(blob.array), hip.ptr(sizes), n, outs[k].data_ptr(), nnz if cap is None else cap)
+    prefix = np.zeros(n + 1, np.uint64)
+    hip.check(submit(0, 0))
+    hip.check(submit(1, 1))
+    assert submit(2, 0) == hip.RC_ERR_BAD_ARG            # slot 0 still holds batch 0
+    hip.check(L.rc_expand_frames_wait(0, hip.ptr(prefix)))
+    assert np.array_equal(prefix, batches[0][3])
+    hip.check(submit(2, 0))
+    hip.check(L.rc_expand_frames_wait(1, hip.ptr(prefix)))
+    assert np.array_equal(prefix, batches[1][3])
+    hip.check(L.rc_expand_frames_wait(0, hip.ptr(prefix)))
+    assert np.array_equal(prefix, batches[2][3])
+    assert L.rc_expand_frames_wait(0, hip.ptr(prefix)) == hip.RC_ERR_BAD_ARG   # nothing submitted
+    for k in range(3):
+        assert np.array_equal(outs[k].cpu().numpy().view(np.uint64), batches[k][4])
+    hip.check(submit(1, 1, cap=batches[1][2] - 1))
+    assert L.rc_expand_frames_wait(1, hip.ptr(prefix)) == hip.RC_ERR_OUT_TOO_SMALL
+    for b in batches:
+        b[0].close()
+
+
 def test_expand_frames_rejects_damaged_and_foreign_streams(hip, orc):
     """rc_expand_frames: a truncated / bit-flipped stream is RC_ERR_CORRUPT (ValueError), a stream from a foreign encoder is
     RC_ERR_UNSUPPORTED (the reader then uses its per-frame path); neither writes past its buffers or hangs."""

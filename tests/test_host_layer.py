@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", hdr))
     assert declared and declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.lib()  # resolves every symbol; raises AttributeError on a mismatch
-    assert L.rc_abi_version() == 2
+    assert L.rc_abi_version() == 3
     assert L.rc_scheme_on_device(2) == 1 and L.rc_scheme_on_device(0) == 0
     assert L.rc_strerror(-5).decode() == "Buffer size smaller than compressed data size"
 

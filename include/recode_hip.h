@@ -243,7 +243,8 @@ int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t redu
  * copy-in, decoders, count, emit) on one of two slots and returns; _wait(slot) blocks until that batch is done and reports like
  * rc_expand_frames.  With two batches in flight the host walk and copy-in of one run while the device decodes the other.
  *   slot            0 or 1; a slot holds one batch at a time (_submit on a slot with a batch waiting: RC_ERR_BAD_ARG)
- *   triplets_dev    device memory, or page-locked host memory (rc_host_alloc: the emit kernel writes it over the link), cap entries
+ *   triplets_dev    device memory, or page-locked host memory (rc_host_alloc: staged on the device, then ONE asynchronous copy of all
+ *                   cap entries - keep cap tight; contents unspecified when _wait reports an error), cap entries
  *                   (level 1: sum(8 * sizes[i][2] / bit_depth) bounds the count)
  *   data            must stay valid until _wait(slot) returns; sizes is consumed by _submit
  * Streams outside the device decoders' subset are reported by _submit (RC_ERR_UNSUPPORTED / RC_ERR_CORRUPT, nothing left pending);

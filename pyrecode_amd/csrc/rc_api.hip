@@ -1393,14 +1393,17 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     // finishes the count (k_expand_bases) checks what the host otherwise would (total <= cap, value streams long enough) and the emit
     // kernel writes nothing once any check or decoder has raised *d_err.  Host memory: the output is staged, so its size must be known
     // first (one more synchronisation).
-    // "device memory" includes page-locked host memory when the batch is submitted: the emit kernel then writes the triplets over the
-    // link itself, under the next batch's host walk and copy-in (the synchronous call stages host output in device memory instead:
-    // a kernel writing 64 MB over the link is slower than a copy, which only matters when nothing else can run meanwhile)
+    // A submitted batch may also name PAGE-LOCKED host memory: the triplets are then staged in device memory and one asynchronous copy of
+    // cap entries follows the emit kernel (the copy engine moves 64 MB in 1.3 ms under the next batch's work; letting the emit kernel
+    // write over the link itself - 8-byte stores, 24 bytes apart - took 4 ms).
     bool dev_out = triplets && is_device_ptr(triplets);
+    uint64_t *host_async = nullptr;
     if (submit_only && !dev_out) {
         hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, triplets) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer) {
-            triplets = reinterpret_cast<uint64_t *>(a.devicePointer);
+        if (hipPointerGetAttributes(&a, triplets) == hipSuccess && a.type == hipMemoryTypeHost) {
+            if ((r = need(6, cap * 24 + 64)) != RC_OK) { (void)hipStreamSynchronize(s); return r; }
+            host_async = triplets;
+            triplets = reinterpret_cast<uint64_t *>(u.x[6]);
             dev_out = true;
         } else (void)hipGetLastError();
     }
@@ -1413,6 +1416,7 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(u.h_res, d_fbase, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(u.h_res + n + 1, d_err, 4, hipMemcpyDeviceToHost, s));
+    if (host_async && cap) HIP_TRY(hipMemcpyAsync(host_async, triplets, cap * 24, hipMemcpyDeviceToHost, s));
     if (submit_only) {   // (dev_out is a precondition, checked above)
         HIP_TRY(hipEventRecord(u.done, s));
         u.pending = true;

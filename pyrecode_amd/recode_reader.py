@@ -135,6 +135,40 @@ class ReCoDeReader:
         if getattr(self, '_pin_blob', None) is not None:
             self._pin_blob.close()
             self._pin_blob = None
+        for b in getattr(self, '_stream_bufs', None) or []:
+            if b is not None:
+                b.close()
+        self._stream_bufs = None
+        if getattr(self, '_read_pool', None) is not None:
+            self._read_pool.shutdown(wait=True)
+            self._read_pool = None
+
+    def _read_into(self, view, pos):
+        """file bytes [pos, pos + len(view)) -> view (page-locked memory), in a few pieces on worker threads: a read from the page
+        cache is a memcpy, and one thread moves 5-7 GB/s where the batched device reader takes 35 GB/s of compressed frames."""
+        total = view.nbytes
+        nthr = 4 if total >= (8 << 20) else 1
+        if nthr == 1:
+            self._fp.seek(pos, 0)
+            if self._fp.readinto(memoryview(view)) != total:
+                raise ValueError('file shorter than its seek table says')
+            return
+        if getattr(self, '_read_pool', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._read_pool = ThreadPoolExecutor(max_workers=4)
+        fd = self._fp.fileno()
+        step = -(-total // nthr)
+
+        def piece(i):
+            lo, hi = i * step, min((i + 1) * step, total)
+            got = 0
+            while lo + got < hi:
+                k = os.preadv(fd, [memoryview(view[lo + got:hi])], pos + lo + got)
+                if k <= 0:
+                    raise ValueError('file shorter than its seek table says')
+                got += k
+        list(self._read_pool.map(piece, range(nthr)))
+        self._fp.seek(pos + total, 0)      # (where a plain read would have left the file)
 
     def seek_to_frame_data(self):
         self._frame_data_start_position = self._rc_header.get_frame_data_offset(self._is_intermediate,
@@ -209,8 +243,7 @@ class ReCoDeReader:
                     self._pin_blob.close()
                 self._pin_blob = _lib.PinnedBuffer(max(int(total * 1.25), 1 << 20))
             blob = self._pin_blob.array[:total]
-            if self._fp.readinto(memoryview(blob)) != total:
-                raise ValueError('file shorter than its seek table says')
+            self._read_into(blob, lo)
             prefix = np.zeros(n + 1, np.uint64)
             L = _lib.lib()
             args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, mode, scheme, _lib.ptr(blob), _lib.ptr(sizes), n)
@@ -270,7 +303,9 @@ class ReCoDeReader:
             return
         L = _lib.lib()
         geom = (int(h['nx']), int(h['ny']), d, level, mode, scheme)
-        blobs, outs = [None, None], [None, None]
+        if getattr(self, '_stream_bufs', None) is None:
+            self._stream_bufs = [None, None, None, None]       # page-locked: two input blobs, two outputs; kept until close()
+        bufs = self._stream_bufs
 
         def pinned(buf, nbytes):
             if buf is None or buf.nbytes < nbytes:
@@ -290,14 +325,12 @@ class ReCoDeReader:
                 sizes[j, 0], sizes[j, 1] = self._stream_sizes(md)
                 sizes[j, 2] = int(md['bytes_in_packed_pixvals'])
             total = int(self._seek_table[a:a + k, 0].sum())
-            blobs[slot] = pinned(blobs[slot], total + 64)
-            blob = blobs[slot].array[:total]
-            self._fp.seek(self._frame_data_start_position + int(self._seek_table[a, 1]), 0)
-            if self._fp.readinto(memoryview(blob)) != total:
-                raise ValueError('file shorter than its seek table says')
+            bufs[slot] = pinned(bufs[slot], total + 64)
+            blob = bufs[slot].array[:total]
+            self._read_into(blob, self._frame_data_start_position + int(self._seek_table[a, 1]))
             cap = max(int((sizes[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
-            outs[slot] = pinned(outs[slot], cap * 24)
-            st = L.rc_expand_frames_submit(slot, *geom, _lib.ptr(blob), _lib.ptr(sizes), k, outs[slot]._p, cap)
+            bufs[2 + slot] = pinned(bufs[2 + slot], cap * 24)
+            st = L.rc_expand_frames_submit(slot, *geom, _lib.ptr(blob), _lib.ptr(sizes), k, bufs[2 + slot]._p, cap)
             if st in (_lib.RC_ERR_UNSUPPORTED, _lib.RC_ERR_CORRUPT):
                 return (a, k, slot, None)
             _lib.check(st, 'rc_expand_frames_submit')
@@ -313,7 +346,7 @@ class ReCoDeReader:
                 return (a,) + self.get_frames_triplets(a, k)
             _lib.check(st, 'rc_expand_frames_wait')
             total = int(prefix[k])
-            trip = outs[slot].array[:total * 24].view(np.uint64).reshape(total, 3)
+            trip = bufs[2 + slot].array[:total * 24].view(np.uint64).reshape(total, 3)
             return a, prefix, trip
         queued = None        # a batch submitted and not yet waited for
         try:
@@ -329,9 +362,6 @@ class ReCoDeReader:
             # a consumer that stops early leaves a batch queued: wait for it before its buffers go away
             if queued is not None and queued[3] is not None:
                 L.rc_expand_frames_wait(queued[2], _lib.ptr(np.zeros(queued[1] + 1, np.uint64)))
-            for b in blobs + outs:
-                if b is not None:
-                    b.close()
 
     def get_frames(self, z0, n):
         """{frame index: {'metadata', 'data': COO}} for n consecutive frames, decoded in one device call."""

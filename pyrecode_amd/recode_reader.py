@@ -430,11 +430,41 @@ class ReCoDeReader:
             out['pixvals'] = take(sz_val)
         return out
 
+    def _get_frame_sparse_fused(self, md, sz_map, sz_val):
+        h = self._header
+        d = int(h['target_bit_depth'])
+        npk = int(md['bytes_in_packed_pixvals'])
+        blob = np.frombuffer(self._fp.read(sz_map + sz_val), np.uint8)
+        if blob.size != sz_map + sz_val:
+            return NotImplemented
+        sizes = np.array([[sz_map, sz_val, npk]], np.uint32)
+        cap = (npk * 8) // d
+        if cap == 0:
+            return NotImplemented      # (an empty frame: the plain path knows the reference's conventions for it)
+        buf = np.empty((cap, 3), dtype=np.uint64)
+        prefix = np.zeros(2, np.uint64)
+        st = _lib.lib().rc_expand_frames(int(h['nx']), int(h['ny']), d, 1, int(h['rc_operation_mode']), int(h['compression_scheme']),
+                                         _lib.ptr(blob), _lib.ptr(sizes), 1, _lib.ptr(prefix), _lib.ptr(buf), cap)
+        if st != _lib.RC_OK:
+            return NotImplemented      # foreign or damaged: the stock decoder is the judge
+        n = int(prefix[1])
+        if n == 0:
+            return NotImplemented
+        return self._make_coo_frame(n, buf)
+
     def _get_frame_sparse(self, frame_metadata):
         """Read one frame's streams, decompress if needed, expand on the GPU, wrap as COO (reference :379-471)."""
         h = self._header
         level, mode = h['reduction_level'], h['rc_operation_mode']
         sz_map, sz_val = self._stream_sizes(frame_metadata)
+        if level == 1 and (mode == 0 or h['compression_scheme'] in (1, 2)) and not getattr(self, '_no_fused_frame', False):
+            # one device call for the whole frame (rc_expand_frames, n = 1): compressed streams in, triplets out - the decoded binary
+            # map and value stream never visit the host (the reference's three steps below remain for everything it does not take)
+            pos = self._fp.tell()
+            coo = self._get_frame_sparse_fused(frame_metadata, sz_map, sz_val)
+            if coo is not NotImplemented:
+                return coo
+            self._fp.seek(pos, 0)
         binary_map = self._fp.read(sz_map)
         values = self._fp.read(sz_val) if sz_val is not None else None
         if mode == 1:

@@ -78,6 +78,15 @@ try:
             total += int(pfx[-1])
         dt = time.perf_counter() - t0
         print("[read, file-inclusive] one call per batch scheme=%d rep=%d: %.0f frames/s (%d set pixels)" % (scheme, rep, nfr / dt, total))
+    for fused in (True, False):
+        rd._no_fused_frame = not fused
+        t0 = time.perf_counter()
+        k = min(nfr, 64)
+        tot = 0
+        for z in range(k):
+            tot += rd.get_frame(z)[z]['data'].nnz
+        dt = time.perf_counter() - t0
+        print("[read, file-inclusive] get_frame one by one (%s): %.0f frames/s (%d set pixels)" % ("one device call per frame" if fused else "reference's three steps", k / dt, tot))
     rd.close()
 finally:
     shutil.rmtree(out_dir, ignore_errors=True)

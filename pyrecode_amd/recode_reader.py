@@ -432,20 +432,26 @@ class ReCoDeReader:
 
     def _get_frame_sparse_fused(self, md, sz_map, sz_val):
         h = self._header
-        d = int(h['target_bit_depth'])
-        npk = int(md['bytes_in_packed_pixvals'])
+        d, level = int(h['target_bit_depth']), int(h['reduction_level'])
+        sz_val = sz_val if level == 1 else 0
+        npk = int(md['bytes_in_packed_pixvals']) if level == 1 else 0
         blob = np.frombuffer(self._fp.read(sz_map + sz_val), np.uint8)
-        if blob.size != sz_map + sz_val:
+        if blob.size != sz_map + sz_val or blob.size == 0:
             return NotImplemented
         sizes = np.array([[sz_map, sz_val, npk]], np.uint32)
-        cap = (npk * 8) // d
+        prefix = np.zeros(2, np.uint64)
+        args = (int(h['nx']), int(h['ny']), d, level, int(h['rc_operation_mode']), int(h['compression_scheme']), _lib.ptr(blob), _lib.ptr(sizes), 1)
+        L = _lib.lib()
+        if level == 1:
+            cap = (npk * 8) // d       # the packed stream's length bounds the count: one call
+        else:
+            if L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0) != _lib.RC_OK:     # bitmap only: a counting call first
+                return NotImplemented
+            cap = int(prefix[1])
         if cap == 0:
             return NotImplemented      # (an empty frame: the plain path knows the reference's conventions for it)
         buf = np.empty((cap, 3), dtype=np.uint64)
-        prefix = np.zeros(2, np.uint64)
-        st = _lib.lib().rc_expand_frames(int(h['nx']), int(h['ny']), d, 1, int(h['rc_operation_mode']), int(h['compression_scheme']),
-                                         _lib.ptr(blob), _lib.ptr(sizes), 1, _lib.ptr(prefix), _lib.ptr(buf), cap)
-        if st != _lib.RC_OK:
+        if L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(buf), cap) != _lib.RC_OK:
             return NotImplemented      # foreign or damaged: the stock decoder is the judge
         n = int(prefix[1])
         if n == 0:
@@ -457,7 +463,7 @@ class ReCoDeReader:
         h = self._header
         level, mode = h['reduction_level'], h['rc_operation_mode']
         sz_map, sz_val = self._stream_sizes(frame_metadata)
-        if level == 1 and (mode == 0 or h['compression_scheme'] in (1, 2)) and not getattr(self, '_no_fused_frame', False):
+        if level in (1, 3) and (mode == 0 or h['compression_scheme'] in (1, 2)) and not getattr(self, '_no_fused_frame', False):
             # one device call for the whole frame (rc_expand_frames, n = 1): compressed streams in, triplets out - the decoded binary
             # map and value stream never visit the host (the reference's three steps below remain for everything it does not take)
             pos = self._fp.tell()

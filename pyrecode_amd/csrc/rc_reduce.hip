@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
     const uint32_t sub = (uint32_t)lane >> 4, sl = (uint32_t)lane & 15u;
     const uint32_t d = rp.depth;
     // residual slots holding a tile-local packed stream of d-bit fields (level 1; uint16 values are the d = 16 case)
-    const bool pixp = rp.level == 1 && (rp.packed_slots || d == 16) && !skip_pix;
+    const bool pixp = rp.level == 1 && rp.packed_slots && !skip_pix;   // (level-2 statistics: one contiguous list, packed at the end of this kernel)
     const bool plain_pos = rp.emit == 0 || flat;   // residual byte b sits at offset b (no stored-chunk headers in between)
     uint8_t *pdst = rec + pix_pos;
     constexpr int BIT = 4, PIT = 2;  // unrolled 16-dword steps per segment: 256 B of block, 128 B of residuals; longer: loop
@@ -1278,34 +1278,27 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
     if (rp.level != 1 || pixp || skip_pix) return;
 
     // ---- uint16 value lists that still need packing (level 2 statistics with d < 16): bit-packed on the way, byte-wise -------
-    const uint32_t tl_ = t0 + (uint32_t)lane;
-    uint32_t cnt = 0, poff = 0;
-    if (tl_ < sc.ntiles) {
-        cnt = sc.tile_cnt[frow + tl_];
-        poff = sc.tile_off[frow + tl_];
-    }
-    // generic depth: per tile (wave-uniform metadata), lanes over the bytes whose first bit lies in the tile's values
+    // The list is ONE contiguous run of nnz values from the start of the frame's slots (k_l2_emit writes it that way and describes it
+    // as full pseudo-tiles), so every wavefront of the frame's launch row packs its own share of the output bytes.  (Tile by tile, as
+    // the description reads, all the work fell to the frame's first wavefront: 161 us for 24 KB per frame at 4096 x 4096, 0.1 %.)
+    const uint16_t *vals = sc.pix_slots + frow * TILE_PX;
+    const uint32_t wave_id = blockIdx.x * AWAVES + (uint32_t)w;
+    const uint32_t nwaves = (sc.ntiles + ASM_TPW - 1) / ASM_TPW;
+    const uint64_t per = (((uint64_t)npk + nwaves - 1) / nwaves + 63) & ~63ull;
+    const uint64_t b_end = min((uint64_t)npk, (uint64_t)(wave_id + 1) * per);
     const uint32_t dmask = (1u << d) - 1;
-    for (uint32_t k = 0; k < ntl; ++k) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)k);
-        if (c == 0) continue;
-        const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)poff, (int)k);
-        PixSrc ps{sc.pix_slots + frow * TILE_PX, sc.tile_cnt + frow, sc.tile_next + frow, sc.ntiles, t0 + k, P, c, nnz};
-        const uint64_t b_lo = ((uint64_t)P * d + 7) >> 3;
-        const uint64_t b_hi = ((uint64_t)(P + c) * d + 7) >> 3;
-        for (uint64_t b = b_lo + lane; b < b_hi; b += 64) {
-            const uint64_t bit0 = b * 8;
-            uint32_t v = (uint32_t)(bit0 / d);
-            const uint32_t o = (uint32_t)(bit0 - (uint64_t)v * d);
-            uint32_t acc = (pix_fetch(ps, v) & dmask) >> o;
-            uint32_t filled = d - o;
-            while (filled < 8) {
-                ++v;
-                acc |= (pix_fetch(ps, v) & dmask) << filled;
-                filled += d;
-            }
-            pdst[plain_pos ? b : stored_pos(ff, b)] = (uint8_t)acc;
+    for (uint64_t b = (uint64_t)wave_id * per + lane; b < b_end; b += 64) {
+        const uint64_t bit0 = b * 8;
+        uint32_t v = (uint32_t)(bit0 / d);
+        const uint32_t o = (uint32_t)(bit0 - (uint64_t)v * d);
+        uint32_t acc = ((v < nnz ? (uint32_t)vals[v] : 0u) & dmask) >> o;
+        uint32_t filled = d - o;
+        while (filled < 8) {
+            ++v;
+            acc |= ((v < nnz ? (uint32_t)vals[v] : 0u) & dmask) << filled;
+            filled += d;
         }
+        pdst[plain_pos ? b : stored_pos(ff, b)] = (uint8_t)acc;
     }
 }
 

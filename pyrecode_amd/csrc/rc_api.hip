@@ -1667,7 +1667,9 @@ static int lz4_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t
         d_out = u.o;
     }
     HIP_TRY(hipMemcpyAsync(d_offs, off.data(), offs, hipMemcpyHostToDevice, u.stream));
-    launch_lz4_decode(d_src, d_blks, nblk, nullptr, d_offs, d_out, total, linked, d_err, u.stream);
+    uint32_t max_stored = 0;
+    for (const Lz4Block &q : blks) if (q.raw) max_stored = std::max(max_stored, q.size);
+    launch_lz4_decode(d_src, d_blks, nblk, nullptr, d_offs, d_out, total, linked, d_err, u.stream, max_stored);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, u.stream));
     if (out_host) HIP_TRY(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, u.stream));
@@ -1872,7 +1874,9 @@ static int blosc_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64
     if (err) return fail(RC_ERR_CORRUPT, "malformed LZ4 block inside the blosc1 chunk");
     for (uint32_t i = 0; i < nb; ++i)
         if (sizes[i] != want[i]) return fail(RC_ERR_CORRUPT, "blosc1 block decodes to the wrong size");
-    launch_lz4_decode(d_src, d_blks, nb, nullptr, d_offs, u.b, nbytes, 0, d_err, u.stream);
+    uint32_t max_stored = 0;
+    for (const Lz4Block &q : blks) if (q.raw) max_stored = std::max(max_stored, q.size);
+    launch_lz4_decode(d_src, d_blks, nb, nullptr, d_offs, u.b, nbytes, 0, d_err, u.stream, max_stored);
     uint8_t *d_out = dst;
     const bool out_host = !is_device_ptr(dst);
     if (out_host) {

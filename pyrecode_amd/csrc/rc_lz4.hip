@@ -11,6 +11,8 @@
 //   encoded sizes are prefix-summed across the wavefront, and every lane writes the bytes of the positions it owns.
 //   Block-end rules (last 5 bytes literal, last match starts >= 12 bytes before the end) are met by never matching
 //   inside the last 12 bytes.  A block that would not shrink is stored raw (bit 31 of the block size word).
+#include <algorithm>
+
 #include "rc_launch.h"
 #include "rc_lz4_block.h"
 
@@ -145,19 +147,49 @@ __global__ void k_lz4_decode(const uint8_t *__restrict__ src, const Lz4Block *__
     }
     const uint64_t o = dst_off[b];
     if (q.raw) {
-        if (o + q.size > cap) { *err = 1; return; }
-        for (uint32_t i = 0; i < q.size; ++i) dst[o + i] = src[q.src_off + i];
+        if (o + q.size > cap) *err = 1;   // the bytes themselves: k_lz4_copy_stored (a stored block can be megabytes; one lane is no way to move it)
     } else {
         int e = 0;
         (void)lz4_block_walk(src + q.src_off, q.size, dst + o, 0, cap - o, true, &e);
         if (e) *err = 1;
     }
 }
+// stored blocks of a frame of independent blocks: one wavefront per 16 KiB piece (grid.y pieces per block), 16 bytes per lane where
+// source and destination allow it
+__global__ __launch_bounds__(WG) void k_lz4_copy_stored(const uint8_t *__restrict__ src, const Lz4Block *__restrict__ blks, uint32_t nblk,
+                                                          const uint64_t *__restrict__ dst_off, uint8_t *__restrict__ dst, uint64_t cap)
+{
+    const uint32_t b = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (b >= nblk) return;
+    const Lz4Block q = blks[b];
+    if (!q.raw) return;
+    const uint64_t o = dst_off[b];
+    if (o + q.size > cap) return;   // (k_lz4_decode has flagged it)
+    const int lane = lane_id();
+    const uint8_t *sp = src + q.src_off;
+    uint8_t *dp = dst + o;
+    for (uint64_t p0 = (uint64_t)blockIdx.y * 16384u; p0 < q.size; p0 += (uint64_t)gridDim.y * 16384u) {
+        const uint32_t n = (uint32_t)min<uint64_t>(16384u, q.size - p0);
+        if ((((uintptr_t)(sp + p0) | (uintptr_t)(dp + p0)) & 15u) == 0) {
+            const u32x4 *s4 = reinterpret_cast<const u32x4 *>(sp + p0);
+            u32x4 *d4 = reinterpret_cast<u32x4 *>(dp + p0);
+            for (uint32_t i = lane; i < n / 16; i += 64) d4[i] = s4[i];
+            for (uint32_t i = (n & ~15u) + lane; i < n; i += 64) dp[p0 + i] = sp[p0 + i];
+        } else
+            for (uint32_t i = lane; i < n; i += 64) dp[p0 + i] = sp[p0 + i];
+    }
+}
+
+// max_stored: size of the largest stored block (0: none) - only the decoding pass (dst != NULL) of an independent-block frame uses it
 void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
-                       uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s)
+                       uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s, uint32_t max_stored)
 {
     const uint32_t threads = 64, grid = linked ? 1 : (nblk + threads - 1) / threads;
     hipLaunchKernelGGL(k_lz4_decode, dim3(grid), dim3(threads), 0, s, src, blks, nblk, sizes, dst_off, dst, cap, linked, err);
+    if (!linked && dst && max_stored) {
+        const uint32_t pieces = std::min(256u, (max_stored + 16383u) / 16384u);
+        hipLaunchKernelGGL(k_lz4_copy_stored, dim3((nblk + WAVES - 1) / WAVES, pieces), dim3(WG), 0, s, src, blks, nblk, dst_off, dst, cap);
+    }
 }
 
 }  // namespace rc

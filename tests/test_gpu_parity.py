@@ -932,6 +932,30 @@ def test_random_shapes_depths_schemes_fuzz(hip, orc):
                         assert orc.blosc1_decode(stream) == expect, tag
             ctx.close()
             cases += 1
+            # ... and back: the batched device reader on the same records (its decoders see 1-pixel frames, partial last blocks,
+            # empty and nearly full frames here)
+            if scheme in (0, 1, 2):
+                hdr = (8 if level == 1 else 4) if mode == 0 else (16 if level == 1 else 8)
+                blob = np.ascontiguousarray(np.concatenate([out[int(rec[z]) + hdr:int(rec[z + 1])] for z in range(nz)]))
+                nbm = (ny * nx + 7) // 8
+                sizes = np.zeros((nz, 3), np.uint32)
+                wants = []
+                for z in range(nz):
+                    binary, pix = orc.binarize_l1(frames[z], dark)
+                    packed = orc.bit_pack(pix, d) if level == 1 else np.zeros(0, np.uint8)
+                    if mode == 0:
+                        sizes[z] = (nbm, packed.size, packed.size)
+                    else:
+                        sizes[z] = (md[z][0], md[z][1] if level == 1 else 0, packed.size)
+                    wants.append(orc.unpack_frame_sparse(nx, ny, d, orc.pack_binary_frame(binary), packed, level))
+                want = np.concatenate(wants) if wants else np.zeros((0, 3), np.uint64)
+                prefix = np.zeros(nz + 1, np.uint64)
+                got = np.zeros((max(want.shape[0], 1), 3), np.uint64)
+                if blob.size:
+                    hip.check(hip.lib().rc_expand_frames(nx, ny, d, level, mode, scheme, hip.ptr(blob), hip.ptr(sizes), nz, hip.ptr(prefix),
+                                                         hip.ptr(got), got.shape[0]), "rc_expand_frames " + tag)
+                    assert int(prefix[nz]) == want.shape[0], tag
+                    assert np.array_equal(got[:want.shape[0]], want), tag
     assert cases >= 30   # (the rest: records larger than their tiny raw frames, refused like the reference does)
 
 

@@ -3,6 +3,7 @@ binary map, residual order and values, d-bit packing, record framing; compressed
 to the bit-exact payload and their lengths must equal the metadata."""
 import ctypes as C
 import ctypes.util
+import os
 import struct
 import zlib
 
@@ -882,7 +883,7 @@ def test_random_shapes_depths_schemes_fuzz(hip, orc):
     """Seeded fuzz over tiny and odd geometries (1x1 upwards, pixel counts around multiples of 8 / 512 / 4096), every
     packing depth 9..16, reduce-only and the three device codecs, levels 1 and 3, random densities including 0 and
     near 1: every record is compared with the oracle (bit-exact pieces, compressed streams through the stock decoders)."""
-    rng = np.random.default_rng(20261003)
+    rng = np.random.default_rng(int(os.environ.get("RC_FUZZ_SEED", "20261003")))   # (other seeds: longer runs by hand)
     shapes = [(1, 1), (1, 7), (1, 8), (3, 3), (8, 1), (1, 9), (2, 255), (1, 511), (1, 512), (1, 513), (7, 585), (64, 64), (63, 65),
               (1, 4095), (1, 4096), (1, 4097), (5, 1639), (90, 91)]
     cases = 0

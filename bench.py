@@ -31,26 +31,48 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+# BASELINE.json `configs`, as bench.py arguments (per-GPU workload; config 3 / 5 are the 8-GPU jobs: --gpus 8 shards them)
+CONFIGS = {
+    1: dict(ny=512, nx=512, sparsity_ppm=145000, depth=12, scheme=0, level=1, batch=9, stack=9),   # minimal_read_write_test: zlib on the host
+    2: dict(ny=4096, nx=4096, sparsity_ppm=10000, depth=16, scheme=2, level=1),                     # the headline (defaults)
+    3: dict(ny=4096, nx=4096, sparsity_ppm=10000, depth=16, scheme=1, level=1),
+    4: dict(ny=4096, nx=4096, sparsity_ppm=1000, depth=16, scheme=8, level=2),
+    5: dict(ny=8184, nx=11520, sparsity_ppm=50000, depth=12, scheme=1, level=1, batch=32, stack=64),
+}
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="BASELINE.json configs[k-1] (1..5) as defaults for the workload flags below; 0 = the headline, configs[1]")
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--stack", type=int, default=256, help="distinct frames resident per GPU")
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--sparsity-ppm", type=int, default=10000)
     ap.add_argument("--depth", type=int, default=16)
+    ap.add_argument("--clustered", action="store_true", help="detector-like events: clusters of 1..6 pixels; --sparsity-ppm then counts SEEDS per million pixels (11000 = ~4.3 %% set pixels, the real acquisition the reference's notebook records)")
     ap.add_argument("--scheme", type=int, default=2, help="2 = LZ4 (headline), 1 = zstd, 8 = blosc-lz4, 0 = reduce-only pieces")
     ap.add_argument("--level", type=int, default=1, help="reduction level: 1 (headline), 2 = summary statistics, 3 = bitmap only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--read", action="store_true", help="measure the READER instead: stored frames -> device decode of both streams -> sparse expand (rc_expand_frames)")
+    ap.add_argument("--blob-on-device", action="store_true", help="--read: the stored frames' bytes already sit in device memory (the decoders without the link)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the extra ingest-inclusive measurement (host frames -> part file)")
     ap.add_argument("--no-pipeline", action="store_true", help="plain stream order: a batch's reduce kernel waits for the previous batch's records")
     ap.add_argument("--clevel", type=int, default=1, help="compression_level: 0 = the fast device encoders, >= 1 = the modelled zstd encoder")
-    ap.add_argument("--min-seconds", type=float, default=0.6, help="the K-step timed region is repeated until this much time has been measured (>= 3 repeats); the median repeat is reported")
-    return ap.parse_args()
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="the K-step timed region is repeated until this much time has been measured (>= 3 repeats); the median repeat is reported")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product); gloo only to rehearse on a box with fewer GPUs than ranks")
+    ap.add_argument("--shared-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses two ranks on one device)")
+    pre, _ = ap.parse_known_args(argv)
+    if pre.config:
+        ap.set_defaults(**CONFIGS[pre.config])
+    a = ap.parse_args(argv)
+    if a.shared_gpu and a.dist_backend == "nccl":
+        ap.error("--shared-gpu needs --dist-backend gloo")
+    return a
 
 
 def cpu_baseline(frames_h, thr_h, depth, scheme):
@@ -253,26 +275,102 @@ def bench_read(a):
         "nnz_per_frame": round(nnz / B, 1)}), flush=True)
 
 
-def main():
-    a = parse()
-    if a.read:
-        return bench_read(a)
+def launch_children(a, argv):
+    """`python bench.py --gpus N` with no rank in the environment: start the N ranks ourselves, as the reference's server starts
+    its N writer processes (recode_server.py:350-363).  This process has not touched the GPU (no torch import, no HIP call) and
+    never does: the ranks are CHILDREN (`python -m torch.distributed.run`), rank 0's one JSON line is relayed, and a failure
+    of any rank is this process's failure."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, RC_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank child job failed (exit code %d); its ranks' messages are above\n" % (a.gpus, rc))
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the child job printed no result line\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def verify_record(a, r, frame, thr_h, frame_id):
+    """One record against the oracle (CPU restatement): the stock decoder / the oracle's decoders must expand both streams to
+    the frame's exact binary map and value list.  Level 2 (no runnable reference): scipy.ndimage.label + numpy."""
+    import struct
+    from oracle import oracle as orc
+    bitmap, packed, nnz = orc.reduce_frame_l1(frame, thr_h, a.depth)
+    if a.level == 2:
+        import scipy.ndimage as nd
+        f2, t2 = frame.reshape(a.ny, a.nx), thr_h.reshape(a.ny, a.nx)
+        labels, n = nd.label(f2 > t2, structure=np.ones((3, 3), int))          # recode_writer.py:166,443
+        vals = nd.maximum(f2.astype(np.int64), labels, np.arange(1, n + 1)) if n else np.zeros(0)   # l2_statistics 0: max
+        packed = orc.bit_pack(np.minimum(np.asarray(vals, np.int64), (1 << a.depth) - 1).astype(np.uint16), a.depth)
+    bitmap, packed = bitmap.tobytes(), packed.tobytes()
+    if a.scheme == 2:
+        dec = lambda b, n: orc.lz4f_decode(b, n + 8)
+    elif a.scheme == 1:
+        from pyrecode_amd.recode_compressors import _zstd_host_decompress
+        dec = lambda b, n: _zstd_host_decompress(b)
+    elif a.scheme == 8:
+        dec = lambda b, n: orc.blosc1_decode(b)
+    else:
+        dec = None
+    if a.level in (1, 2):
+        if dec is None:   # reduce-only pieces (zlib & co. are the host library's call, as in the reference)
+            fid, npk = struct.unpack_from("<II", r, 0)
+            return fid == frame_id and r[8:] == bitmap + packed
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        return (fid == frame_id and npk == len(packed) and len(r) == 16 + cb + cp and dec(r[16:16 + cb], len(bitmap)) == bitmap
+                and dec(r[16 + cb:], npk) == packed)
+    if a.level == 3:
+        if dec is None:
+            return struct.unpack_from("<I", r, 0)[0] == frame_id and r[4:] == bitmap
+        fid, cb = struct.unpack_from("<II", r, 0)
+        return fid == frame_id and len(r) == 8 + cb and dec(r[8:], len(bitmap)) == bitmap
+    return None
+
+
+def run_rank(a):
     import torch
     import torch.distributed as dist
     from pyrecode_amd import _lib as hip
+    from pyrecode_amd.parallel import ShardedStepLoop
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (any world size)
+    if world != a.gpus:
+        raise SystemExit("rank %d: --gpus %d but WORLD_SIZE=%d" % (rank, a.gpus, world))
+    visible = torch.cuda.device_count()
+    if a.shared_gpu:      # rehearsal on a one-GPU box: every rank on cuda:0, collectives over gloo (RCCL refuses two ranks on one GPU)
+        local = 0
+    if local >= visible:
+        raise SystemExit("rank %d: --gpus %d needs one GPU per rank, but this node shows %d visible GPU(s) (local rank %d has none; "
+                         "RCCL does not take two ranks on one device - rehearse with --shared-gpu --dist-backend gloo)" % (rank, a.gpus, visible, local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (any world size)
+    backend = a.dist_backend
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     L = hip.lib()
     N = a.ny * a.nx
@@ -285,7 +383,10 @@ def main():
     hip.check(L.rc_synth_dark(local, seed, N, dark.data_ptr()))
     for lo in range(0, S, 64):
         n = min(64, S - lo)
-        hip.check(L.rc_synth_frames(local, seed, lo, n, N, a.sparsity_ppm, dark.data_ptr(), stack[lo].data_ptr()))
+        if a.clustered:
+            hip.check(L.rc_synth_frames_clustered(local, seed, lo, n, a.nx, a.ny, a.sparsity_ppm, dark.data_ptr(), stack[lo].data_ptr()))
+        else:
+            hip.check(L.rc_synth_frames(local, seed, lo, n, N, a.sparsity_ppm, dark.data_ptr(), stack[lo].data_ptr()))
 
     op_mode = 1
     ctx = hip.ReduceContext(a.nx, a.ny, a.depth, a.level, op_mode, a.scheme, a.clevel, local, max_batch=B)
@@ -294,36 +395,13 @@ def main():
     out_cap = B * (N // 2)  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
     out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
-    # the metadata rows are double-buffered: the all-gather of step i runs on a side stream while step i+1 computes
-    md2 = [torch.empty((B, 3), dtype=torch.int32, device=dev) for _ in range(2)]
-    md_all2 = [torch.empty((world * B, 3), dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
-    stream = torch.cuda.Stream(device=dev)
-    cstream = torch.cuda.Stream(device=dev) if use_dist else None
-    gathered = [None, None]
+    nb = S // B
+    # rank r's frames of step i carry the ids of its contiguous block of the job's frames (recode_writer.py:320-322,385)
+    loop = ShardedStepLoop(ctx, B, lambda i: (stack[(i % nb) * B].data_ptr(), rank * S + (i % nb) * B), out, rec, dev, collective=use_dist)
+    stream, md2 = loop.stream, loop.md2
     ctx.set_stream(stream.cuda_stream)
     ctx.set_pipelined(not a.no_pipeline)  # batch i+1's reduce kernel may overlap batch i's scans / layout / assembly
-
-    nb = S // B
-
-    def step(i):
-        lo = (i % nb) * B
-        k = i & 1
-        if use_dist and gathered[k] is not None:
-            stream.wait_event(gathered[k])   # md2[k] is rewritten below: its previous gather (step i-2) must have read it
-        ctx.enqueue(stack[lo].data_ptr(), B, lo, out.data_ptr(), out_cap, rec.data_ptr(), md2[k].data_ptr())
-        if use_dist:  # the path's one exchange step: every rank learns every frame's sizes
-            with torch.cuda.stream(cstream):
-                ctx.wait_results(cstream.cuda_stream)   # the collective's stream waits for this batch's metadata rows
-                dist.all_gather_into_tensor(md_all2[k], md2[k])
-                ev = torch.cuda.Event()
-                ev.record(cstream)
-                gathered[k] = ev
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    step, fence = loop.step, loop.fence
 
     # The timed region is EXACTLY a.steps steps between two fences (barrier + synchronize on both sides).  It is repeated
     # (>= 3 times, until --min-seconds of timed work): at 0.5 ms per step a single pass of the driver's --steps 20 lasts 10 ms,
@@ -334,7 +412,8 @@ def main():
         ctx.sync()
         ctx.set_profiling(True)
         times, k_ms_list, it = [], [], a.warmup
-        while len(times) < 3 or (sum(times) < a.min_seconds and len(times) < 1000):
+        more = True
+        while more:
             fence()
             t0 = time.perf_counter()
             for i in range(a.steps):
@@ -349,8 +428,9 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             if use_dist:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            times.append(float(t.item()))
+            times.append(float(t.item()))   # the same list on every rank, so every rank leaves the loop together
             k_ms_list.append((sums[0] / nbatches, sums[4] / nbatches, [v / nbatches for v in sums]))
+            more = len(times) < 3 or (sum(times) < a.min_seconds and len(times) < 1000)
     ctx.set_profiling(False)
     order = sorted(range(len(times)), key=lambda i: times[i])
     mid = order[len(order) // 2]
@@ -361,41 +441,29 @@ def main():
     frames_total = world * B * a.steps
     fps = frames_total / dt_max
     rec_h = rec.cpu().numpy()
-    md_h = md2[last_step & 1].cpu().numpy()
     assert rec_h[0] == 0 and rec_h[-1] > 0
+    gather_verified = loop.verify_gather()   # collective: every rank's block of the gathered table, on every rank
 
     def verify_last_batch():
-        """Outside the timing: one record of the last batch, decoded by the stock library / the oracle's decoder, must hold the
-        frame's exact bitmap and residuals as the oracle (CPU restatement) computes them."""
-        import struct
-        from oracle import oracle as orc
+        """Outside the timing: one record of the last batch against the oracle."""
         lo = (last_step % nb) * B
         z = B // 2
         frame = stack[lo + z].cpu().numpy().view(np.uint16)
         thr_h = dark.cpu().numpy().view(np.uint16)
         r = out[int(rec_h[z]):int(rec_h[z + 1])].cpu().numpy().tobytes()
-        bitmap, packed, nnz = orc.reduce_frame_l1(frame, thr_h, a.depth)
-        bitmap, packed = bitmap.tobytes(), packed.tobytes()
-        if a.level == 1 and a.scheme in (1, 2):
-            fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
-            if a.scheme == 2:
-                dec = lambda b, n: orc.lz4f_decode(b, n + 8)
-            else:
-                from pyrecode_amd.recode_compressors import _zstd_host_decompress
-                dec = lambda b, n: _zstd_host_decompress(b)
-            return fid == lo + z and npk == len(packed) and dec(r[16:16 + cb], len(bitmap)) == bitmap and dec(r[16 + cb:], npk) == packed
-        if a.level == 1 and a.scheme == 0:
-            fid, npk = struct.unpack_from("<II", r, 0)
-            return fid == lo + z and r[8:] == bitmap + packed
-        return None   # (level 2 / 3, blosc: covered by the test-suite, not re-checked here)
+        return verify_record(a, r, frame, thr_h, rank * S + lo + z)
 
-    result = None
+    try:
+        verified = verify_last_batch()
+    except Exception as e:   # a record the stock decoder rejects is a failed check, not a crashed bench
+        verified = False
+        print("rank %d: verification raised: %r" % (rank, e), file=sys.stderr)
+    if use_dist:   # every rank checks one of ITS records; the line reports the conjunction
+        v = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified = bool(int(v.item()) == 1)
+
     if rank == 0:
-        try:
-            verified = verify_last_batch()
-        except Exception as e:   # a record the stock decoder rejects is a failed check, not a crashed bench
-            verified = False
-            print("verification raised: %r" % (e,), file=sys.stderr)
         k_ms = sums[0] / max(nbatches, 1)
         achieved = B * N * 2 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_note = None, None
@@ -414,19 +482,27 @@ def main():
             "repeats": len(times), "timed_seconds_total": round(sum(times), 3),
             "ms_per_step_all_repeats": {"min": round(min(times) / a.steps * 1e3, 4), "median": round(dt_max / a.steps * 1e3, 4),
                                         "max": round(max(times) / a.steps * 1e3, 4)},
-            "verified": verified,
+            "verified": verified, "gather_verified": gather_verified,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {
-                "workload": "%dx%d uint16, %.2f%% sparsity, L%d + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
-                    a.ny, a.nx, a.sparsity_ppm / 1e4, a.level,
+                "workload": "%s%dx%d uint16, %s, L%d + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
+                    ("BASELINE configs[%d]: " % (a.config - 1)) if a.config else "", a.ny, a.nx,
+                    ("detector-like clusters of 1..6 pixels, %d seeds per million pixels" % a.sparsity_ppm) if a.clustered else "%.2f%% sparsity" % (a.sparsity_ppm / 1e4), a.level,
                     {2: "LZ4 frame", 1: "zstd frame (%s encoder)" % ("modelled" if a.clevel else "fast"), 8: "blosc-lz4 chunk",
-                     0: "reduce-only pieces"}.get(a.scheme, str(a.scheme)),
+                     0: "reduce-only pieces (the host library compresses them, as the reference does)"}.get(a.scheme, str(a.scheme)),
                     a.depth, B, S),
-                "parallelism": "dp%d (contiguous frame blocks per rank; per step one RCCL all-gather of the metadata rows, on a side stream under the next step)" % world,
+                "parallelism": "dp%d (contiguous frame blocks per rank; per step one %s all-gather of the metadata rows, on a side stream under the next step)" % (
+                    world, {"nccl": "RCCL"}.get(backend, backend) if use_dist else "(single process: no)"),
                 "record_bytes_per_frame": round(float(rec_h[-1]) / B, 1),
+                "launch": ("bench.py started its own ranks (child torch.distributed.run)" if os.environ.get("RC_BENCH_SELF_LAUNCHED")
+                           else ("torch.distributed.run" if use_dist else "single process")),
+                "collective_backend": (dist.get_backend() if use_dist else None), "collective_ranks": (dist.get_world_size() if use_dist else 1),
+                "shared_gpu_rehearsal": bool(a.shared_gpu),
             },
+            "rccl_ranks": (dist.get_world_size() if use_dist and backend == "nccl" else (1 if not use_dist else 0)),
             "roofline": {"bound": "hbm", "kernel": "k_reduce_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_ratio": (round(traffic / (B * N * 2), 4) if traffic else None),
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": B * N * 2,
                          "whole_path_frac": round(fps / world * N * 2 / 1e9 / HBM_PEAK_GBS, 4)},
             # only the events the roofline needs are recorded in the timed region (each costs stream time); the full
@@ -450,13 +526,23 @@ def main():
             except Exception as e:   # an extra: never lets the contract line fail
                 result["ingest_inclusive"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
+    ok = (gather_verified is not False)
     if use_dist:
-        if rank == 0:  # the gathered table must hold this rank's own rows at its block
-            k = last_step & 1
-            assert torch.equal(md_all2[k][:B].cpu(), md2[k].cpu())
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if not ok:
+        raise SystemExit("rank %d: the gathered metadata table does not hold every rank's rows" % rank)
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.read:
+        return bench_read(a)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_children(a, argv))
+    run_rank(a)
 
 
 if __name__ == "__main__":

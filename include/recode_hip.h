@@ -242,7 +242,8 @@ int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t redu
 /* The same work in two halves, for a reader that streams through a file: _submit queues one batch (host walk of the block headers,
  * copy-in, decoders, count, emit) on one of two slots and returns; _wait(slot) blocks until that batch is done and reports like
  * rc_expand_frames.  With two batches in flight the host walk and copy-in of one run while the device decodes the other.
- *   slot            0 or 1; a slot holds one batch at a time (_submit on a slot with a batch waiting: RC_ERR_BAD_ARG)
+ *   slot            0 or 1; a slot holds one batch at a time (_submit on a slot with a batch waiting: RC_ERR_BAD_ARG).  The synchronous
+ *                   rc_expand_frames owns resources of its own, so it may be called (e.g. to redo ONE batch) while batches are queued
  *   triplets_dev    device memory, or page-locked host memory (rc_host_alloc: staged on the device, then ONE asynchronous copy of all
  *                   cap entries - keep cap tight; contents unspecified when _wait reports an error), cap entries
  *                   (level 1: sum(8 * sizes[i][2] / bit_depth) bounds the count)
@@ -264,6 +265,11 @@ int rc_bit_unpack(const uint8_t *packed, uint64_t packed_bytes, uint64_t n, uint
 int rc_synth_dark(int device_id, uint32_t seed, uint64_t n_pixels, uint16_t *dark_dev);
 int rc_synth_frames(int device_id, uint32_t seed, uint32_t first_frame, uint32_t n_frames, uint64_t n_pixels,
                     uint32_t sparsity_ppm, const uint16_t *dark_dev, uint16_t *frames_dev);
+/* Detector-like variant: events come in clusters of 1..6 pixels (mean 4.1) inside a 2 x 3 window anchored at a seed pixel;
+ * seed_ppm = seeds per million pixels (10 700 gives ~4.3 % set pixels: the real acquisition the reference's notebook records,
+ * examples/Reading_ReCoDe_v0.1_Files.ipynb cells 7 / 17).  Same amplitudes and background as rc_synth_frames. */
+int rc_synth_frames_clustered(int device_id, uint32_t seed, uint32_t first_frame, uint32_t n_frames, uint32_t nx, uint32_t ny,
+                              uint32_t seed_ppm, const uint16_t *dark_dev, uint16_t *frames_dev);
 
 #ifdef __cplusplus
 }

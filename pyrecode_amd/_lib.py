@@ -68,6 +68,7 @@ SIGNATURES = {
     "rc_bit_unpack": (C.c_int, [_u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
     "rc_synth_dark": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, _u16p]),
     "rc_synth_frames": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _u16p, _u16p]),
+    "rc_synth_frames_clustered": (C.c_int, [C.c_int] + [C.c_uint32] * 6 + [_u16p, _u16p]),
 }
 
 _lib = None

@@ -1030,7 +1030,8 @@ struct Util {
     void *ztab = nullptr;                       // zstd FSE tables
     uint8_t *x[10] = {}; uint64_t x_cap[10] = {};   // rc_expand_frames: data, bitmaps, values, tables, block lists, counters
     void *zd_predef = nullptr;                  // predefined zstd decoding tables
-    ReadRes rr[RC_READ_SLOTS];                  // rc_expand_frames (slot 0) and its submit / wait form (both slots)
+    ReadRes rr[RC_READ_SLOTS + 1];              // the submit / wait form's two slots, then the synchronous rc_expand_frames' own:
+                                                // a synchronous call (e.g. the reader's fallback for ONE batch) never meets a queued batch
 };
 constexpr int RC_MAX_DEV = 64;
 Util g_utils[RC_MAX_DEV];
@@ -1181,7 +1182,7 @@ int lz4_index_frame(const uint8_t *base, uint64_t off, uint64_t n, uint32_t fram
 }
 }  // namespace
 
-// slot, submit_only: rc_expand_frames = (0, false); rc_expand_frames_submit = (slot, true): returns once everything is queued.
+// slot, submit_only: rc_expand_frames = (RC_READ_SLOTS - its own resources -, false); rc_expand_frames_submit = (slot, true): returns once everything is queued.
 static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode, uint32_t scheme,
                       const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap)
 {
@@ -1458,7 +1459,7 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
 RC_EXPORT int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode, uint32_t scheme,
                                const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap)
 {
-    return expand_run(0, false, nx, ny, bit_depth, level, op_mode, scheme, data, sizes, n, nnz_prefix, triplets, cap);
+    return expand_run(RC_READ_SLOTS, false, nx, ny, bit_depth, level, op_mode, scheme, data, sizes, n, nnz_prefix, triplets, cap);
 }
 
 RC_EXPORT int rc_expand_frames_submit(uint32_t slot, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode,
@@ -1918,6 +1919,8 @@ static int zstd_decompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_
         if (b.type == 2) { if (b.regen > 1024) return fail(RC_ERR_UNSUPPORTED, "rc_decompress: zstd block larger than the device decoder's rows"); comp.push_back(b); }
         else { raw.push_back(b); raw_max = std::max(raw_max, b.regen); }
     }
+    // nothing is allocated or zeroed beyond what the caller's buffer justifies: a few KB of RLE blocks can announce gigabytes
+    if (bound > dst_cap + 1024) { *out_n = bound; return fail(RC_ERR_OUT_TOO_SMALL, "rc_decompress: dst too small (out_n = an upper bound of the decoded size)"); }
     uint32_t row = TILE_BM;
     for (const ZdBlock &b : comp) if (b.regen > (uint32_t)TILE_BM) row = 1024;
     const uint8_t *d_src = nullptr;
@@ -1995,6 +1998,17 @@ RC_EXPORT int rc_synth_dark(int device_id, uint32_t seed, uint64_t n_pixels, uin
     if (!dark_dev) return fail(RC_ERR_BAD_ARG, "NULL argument");
     RC_ON_DEVICE(device_id);
     rc::launch_synth_dark(seed, n_pixels, dark_dev, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return RC_OK;
+}
+RC_EXPORT int rc_synth_frames_clustered(int device_id, uint32_t seed, uint32_t first_frame, uint32_t n_frames, uint32_t nx, uint32_t ny,
+                                        uint32_t seed_ppm, const uint16_t *dark_dev, uint16_t *frames_dev)
+{
+    if (!dark_dev || !frames_dev || n_frames == 0 || nx == 0 || ny == 0) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
+    if ((uint64_t)nx * ny > 0xFFFFFFFFull) return fail(RC_ERR_BAD_ARG, "rc_synth_frames_clustered: nx * ny must fit 32 bits");
+    RC_ON_DEVICE(device_id);
+    rc::launch_synth_frames_clustered(seed, first_frame, n_frames, nx, ny, seed_ppm, dark_dev, frames_dev, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return RC_OK;

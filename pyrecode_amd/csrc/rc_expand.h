@@ -26,6 +26,8 @@ void zd_predefined_tables(void *dst);
 void launch_bit_pack(const uint16_t *vals, uint64_t n, uint32_t d, uint8_t *out, uint64_t out_n, hipStream_t s);
 void launch_bit_unpack(const uint8_t *packed, uint64_t nbytes, uint64_t n, uint32_t d, uint64_t *out, hipStream_t s);
 void launch_synth_dark(uint32_t seed, uint64_t N, uint16_t *dark, hipStream_t s);
+void launch_synth_frames_clustered(uint32_t seed, uint32_t first_frame, uint32_t nframes, uint32_t nx, uint32_t ny, uint32_t seed_ppm,
+                                   const uint16_t *dark, uint16_t *frames, hipStream_t s);
 void launch_synth_frames(uint32_t seed, uint32_t first_frame, uint32_t nframes, uint64_t N, uint32_t sparsity_ppm,
                          const uint16_t *dark, uint16_t *frames, hipStream_t s);
 }  // namespace rc

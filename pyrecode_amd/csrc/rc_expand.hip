@@ -265,6 +265,41 @@ __global__ void k_synth_frames(uint32_t seed, uint32_t first_frame, uint32_t nfr
     }
     (void)nframes;
 }
+// Detector-like events (the one real-data anchor the reference records: 4096^2, 12 bit, ~4.3 % of the pixels set, in small
+// clusters - examples/Reading_ReCoDe_v0.1_Files.ipynb): pixel q is a SEED with probability thresh24 / 2^24; a seed lights itself
+// and each of the other five cells of the 2 x 3 window it anchors (top-left) with probability 5/8 (3 hash bits per cell), i.e.
+// clusters of 1..6 pixels, 4.1 on average.  A pixel is an event iff one of the six windows covering it lights it.
+__global__ void k_synth_frames_clustered(uint32_t seed, uint32_t first_frame, uint32_t nx, uint32_t ny, uint32_t thresh24,
+                                         const uint16_t *__restrict__ dark, uint16_t *__restrict__ frames)
+{
+    const uint32_t z = blockIdx.y;
+    const uint32_t fkey = mix32(seed + 0x9E3779B9u * (first_frame + z + 1u));
+    const uint64_t N = (uint64_t)nx * ny;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint16_t *fr = frames + (uint64_t)z * N;
+    for (; i < N; i += stride) {
+        const uint32_t y = (uint32_t)(i / nx), x = (uint32_t)(i - (uint64_t)y * nx);
+        bool ev = false;
+        for (uint32_t dy = 0; dy < 2 && dy <= y; ++dy)
+            for (uint32_t dx = 0; dx < 3 && dx <= x; ++dx) {
+                const uint32_t q = (uint32_t)(i - (uint64_t)dy * nx - dx);
+                const uint32_t hq = mix32(q ^ fkey);
+                if ((hq & 0xFFFFFFu) >= thresh24) continue;
+                const uint32_t cell = dy * 3 + dx;
+                ev |= cell == 0 || ((mix32(hq ^ 0x3C6EF372u) >> (3 * cell)) & 7u) < 5u;
+            }
+        const uint32_t h2 = mix32(mix32((uint32_t)i ^ fkey) ^ 0x68E31DA4u);
+        const uint32_t dk = dark[i];
+        fr[i] = (uint16_t)(ev ? dk + 1u + (h2 % 2047u) : (h2 % (dk + 1u)));
+    }
+}
+void launch_synth_frames_clustered(uint32_t seed, uint32_t first_frame, uint32_t nframes, uint32_t nx, uint32_t ny, uint32_t seed_ppm,
+                                   const uint16_t *dark, uint16_t *frames, hipStream_t s)
+{
+    const uint32_t thresh24 = (uint32_t)(((uint64_t)seed_ppm << 24) / 1000000ull);
+    hipLaunchKernelGGL(k_synth_frames_clustered, dim3(1024, nframes), dim3(256), 0, s, seed, first_frame, nx, ny, thresh24, dark, frames);
+}
 void launch_synth_dark(uint32_t seed, uint64_t N, uint16_t *dark, hipStream_t s)
 {
     hipLaunchKernelGGL(k_synth_dark, dim3(2048), dim3(256), 0, s, seed, N, dark);

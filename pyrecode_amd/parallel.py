@@ -31,16 +31,25 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
-def all_gather_rows(rows):
+def all_gather_rows(rows, device_id=None):
     """rows: int64 ndarray [k, w] (k may differ per rank).  Returns the list of every rank's rows, in rank order.
-    One collective for the payload (padded to the largest k) preceded by a tiny one for the counts."""
+    One collective for the payload (padded to the largest k) preceded by a tiny one for the counts.
+    With RCCL the tensors live on `device_id` (default: the caller's current device); a rank whose current device is not the
+    one its writer used would make two ranks meet on one GPU inside the collective, so that is refused here."""
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:
         return [rows]
     import torch
     world = dist.get_world_size()
     on_gpu = dist.get_backend() == 'nccl'
-    dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+    if on_gpu:
+        cur = torch.cuda.current_device()
+        if device_id is not None and int(device_id) != cur:
+            raise RuntimeError('rank %d: current device is cuda:%d but its frames were reduced on cuda:%d; call '
+                               'torch.cuda.set_device(local_rank) before the collective' % (dist.get_rank(), cur, int(device_id)))
+        dev = torch.device('cuda', cur)
+    else:
+        dev = torch.device('cpu')
     w = rows.shape[1]
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev))
@@ -113,7 +122,7 @@ def part_index(path):
     return hdr, np.array(rows, dtype=np.int64).reshape(len(rows), 2 + n_md), np.array(pos, dtype=np.int64)
 
 
-def merge_direct(folder_path, base_filename, rank=None, world=None, records=None, index=None):
+def merge_direct(folder_path, base_filename, rank=None, world=None, records=None, index=None, device_id=None):
     """Collective.  Every rank contributes its own frames to `<base>`; rank 0 also writes the header (copy of part 000's, nz
     patched) and the metadata table.  A rank describes its frames by, in order of preference: `index` = (rows, offsets)
     from ReCoDeWriter.frame_index() (nothing is read back), the headers of its part file (part_index: frame data skipped),
@@ -147,7 +156,7 @@ def merge_direct(folder_path, base_filename, rank=None, world=None, records=None
         n_md = len(ReCoDeStructures(h).standard_frame_metadata_structure_for(h['reduction_level'], h['rc_operation_mode']))
         rows = np.zeros((0, 2 + n_md), dtype=np.int64)
     n_md = rows.shape[1] - 2
-    per_rank = all_gather_rows(rows)
+    per_rank = all_gather_rows(rows, device_id=device_id)
     table = np.concatenate(per_rank, axis=0)
     order = np.argsort(table[:, 0], kind='stable')          # frame-id order (already sorted for contiguous blocks)
     sizes = table[order, 1]
@@ -213,6 +222,10 @@ def write_sharded(image_filename, data, dark_data, output_directory, input_param
                      mode='batch', validation_frame_gap=validation_frame_gap, node_id=rank, batch_size=batch_size,
                      device_id=device_id)
     w.start()
+    used_device = w.device_id()
+    if dist is not None and world > 1 and dist.get_backend() == 'nccl':
+        import torch
+        torch.cuda.set_device(used_device)   # the collective's tensors must live on the GPU this rank's frames were reduced on
     metrics = w.run(data)
     index = w.frame_index()   # what this rank wrote, and where: the merge reads nothing back but the frame data it copies
     w.close()
@@ -221,5 +234,99 @@ def write_sharded(image_filename, data, dark_data, output_directory, input_param
     nz = None
     if merge:
         base = '%s.rc%d' % (Path(image_filename).stem, int(input_params.reduction_level))
-        nz = merge_direct(output_directory, base, rank=rank, world=world, index=index)
+        nz = merge_direct(output_directory, base, rank=rank, world=world, index=index, device_id=used_device)
     return metrics, nz
+
+
+# ---- the weak-scaling step loop (bench.py --gpus N; tests/test_parallel_gloo.py drives it with two gloo ranks) -----------
+class _NullStream:
+    """Stand-in for a HIP stream where there is no device (CPU rehearsal over gloo): every operation completes at once."""
+    cuda_stream = 0
+
+    def wait_event(self, ev):
+        pass
+
+
+class _NullEvent:
+    def record(self, stream=None):
+        pass
+
+
+class ShardedStepLoop:
+    """One rank of the data-parallel hot path as the reference runs it (one writer per node, recode_server.py:350-363;
+    contiguous frame blocks, recode_writer.py:320-322): every step reduces `batch` frames on this rank's GPU and issues the
+    path's one exchange step, the all-gather of the per-frame metadata rows, on a SIDE stream so that it runs
+    under the next step's reduce kernel.  The rows are double-buffered: step i writes md2[i & 1] and gathers it into
+    md_all2[i & 1]; before step i + 2 rewrites md2[i & 1] the main stream waits for that gather's event.
+
+    ctx          the device boundary: enqueue(frames_ptr, n, first_frame_id, out_ptr, out_cap, rec_ptr, md_ptr) and
+                 wait_results(stream_handle) (pyrecode_amd._lib.ReduceContext; the CPU test passes a stand-in)
+    frames_of    step index -> (address of this rank's `batch` frames, their first frame id)
+    device       torch.device: cuda:<local rank> (HIP streams, RCCL) or cpu (no streams, gloo)
+    """
+
+    def __init__(self, ctx, batch, frames_of, out, rec, device, collective=True):
+        import torch
+        self._torch = torch
+        self.ctx, self.B, self.frames_of, self.out, self.rec, self.device = ctx, int(batch), frames_of, out, rec, device
+        self.dist = _dist() if collective else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.on_gpu = device.type == 'cuda'
+        if self.on_gpu:
+            if torch.cuda.current_device() != device.index:
+                raise RuntimeError('rank %d: current device cuda:%d is not the loop\'s device %s' % (self.rank, torch.cuda.current_device(), device))
+            if getattr(ctx, 'device_id', device.index) != device.index:
+                raise RuntimeError('rank %d: ctx lives on cuda:%s, loop on %s' % (self.rank, ctx.device_id, device))
+            self.stream = torch.cuda.Stream(device=device)
+            self.cstream = torch.cuda.Stream(device=device) if self.dist else None
+        else:
+            self.stream, self.cstream = _NullStream(), _NullStream()
+        self.md2 = [torch.zeros((self.B, 3), dtype=torch.int32, device=device) for _ in range(2)]
+        self.md_all2 = [torch.zeros((self.world * self.B, 3), dtype=torch.int32, device=device) for _ in range(2)] if self.dist else None
+        self.gathered = [None, None]
+        self.steps_done = 0
+
+    def _side(self):
+        import contextlib
+        return self._torch.cuda.stream(self.cstream) if self.on_gpu else contextlib.nullcontext()
+
+    def step(self, i):
+        k = i & 1
+        if self.dist and self.gathered[k] is not None:
+            self.stream.wait_event(self.gathered[k])   # md2[k] is rewritten below: its previous gather (step i-2) must have read it
+        frames_ptr, first_id = self.frames_of(i)
+        self.ctx.enqueue(frames_ptr, self.B, first_id, self.out.data_ptr(), self.out.numel(), self.rec.data_ptr(), self.md2[k].data_ptr())
+        if self.dist:  # every rank learns every frame's sizes
+            with self._side():
+                self.ctx.wait_results(self.cstream.cuda_stream)   # the collective's stream waits for this batch's metadata rows
+                self.dist.all_gather_into_tensor(self.md_all2[k], self.md2[k])
+                ev = self._torch.cuda.Event() if self.on_gpu else _NullEvent()
+                ev.record(self.cstream)
+                self.gathered[k] = ev
+        self.steps_done = i + 1
+
+    def fence(self):
+        """Barrier + device synchronize on both sides: what brackets a timed region."""
+        if self.on_gpu:
+            self._torch.cuda.synchronize(self.device)
+        if self.dist:
+            self.dist.barrier()
+        if self.on_gpu:
+            self._torch.cuda.synchronize(self.device)
+
+    def verify_gather(self):
+        """After fence(): the table the LAST step gathered asynchronously must hold EVERY rank's rows of that step at that
+        rank's block, on every rank.  Checked against a second, synchronous gather of the same rows; the verdicts are
+        combined (min over ranks), so every rank returns the same answer."""
+        if not self.dist:
+            return None
+        torch, k = self._torch, (self.steps_done - 1) & 1
+        mine = self.md2[k]
+        own = torch.equal(self.md_all2[k][self.rank * self.B:(self.rank + 1) * self.B], mine)
+        blocks = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(blocks, mine)
+        whole = torch.equal(self.md_all2[k], torch.cat(blocks, dim=0))
+        flag = torch.tensor([1 if (own and whole) else 0], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(int(flag.item()) == 1)

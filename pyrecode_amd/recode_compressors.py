@@ -137,7 +137,9 @@ def de_compress(compression_scheme, compressed_data, decompressor_context):
         if len(compressed_data):
             try:
                 return device_decompress(1, compressed_data)
-            except NotImplementedError:   # a foreign encoder's frame (4-stream literals, real offsets, ...): the stock decoder
+            except (NotImplementedError, ValueError):
+                # UNSUPPORTED: a frame outside the device decoder's subset.  CORRUPT: the device decoder could not follow the
+                # stream; whether the stream is damaged or merely foreign is the stock decoder's call (it raises on real damage).
                 pass
         return _zstd_host_decompress(compressed_data, decompressor_context)
     if s == 3:

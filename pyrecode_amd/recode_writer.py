@@ -278,8 +278,9 @@ class ReCoDeWriter:
         """Page-locked staging of the streaming form: three input buffers, PIPE_SLOTS output buffers (grown on demand)."""
         if self._pin_in is None:
             B = self._batch_size
-            self._pin_in = [_lib.PinnedBuffer(B * self._frame_sz) for _ in range(3)]
-            self._pin_out = [_lib.PinnedBuffer(max(B * self._frame_sz // 8, 1 << 20)) for _ in range(_lib.PIPE_SLOTS)]
+            staged = B * int(self._header['ny']) * int(self._header['nx']) * 2   # the kernel reads uint16, whatever the source dtype
+            self._pin_in = [_lib.PinnedBuffer(staged) for _ in range(3)]
+            self._pin_out = [_lib.PinnedBuffer(max(staged // 8, 1 << 20)) for _ in range(_lib.PIPE_SLOTS)]
 
     def _run_streamed(self, data, n_frames, first_id):
         """The frame loop of the reference (recode_writer.py:383-399) as a stream over batches (rc_pipe_*).  Four things run at
@@ -290,7 +291,7 @@ class ReCoDeWriter:
         own library call needs the pieces)."""
         from concurrent.futures import ThreadPoolExecutor
         ctx, B = self._ctx, self._batch_size
-        frame_bytes = self._frame_sz
+        frame_bytes = int(self._header['ny']) * int(self._header['nx']) * 2   # staged as uint16 (copyto casts other source dtypes)
         zero = timedelta(0)
         metrics = {k: zero for k in _STAGE_KEYS}
         if n_frames == 0:
@@ -466,6 +467,12 @@ class ReCoDeWriter:
         if self._ctx is not None:
             self._ctx.close()
             self._ctx = None
+
+    def device_id(self):
+        """HIP device ordinal this writer's frames are reduced on (valid after start())."""
+        if self._ctx is None:
+            raise RuntimeError('ReCoDeWriter.device_id(): call start() first')
+        return int(self._ctx.device_id)
 
     def frame_index(self):
         """(rows int64[n, 2 + n_md] = [frame_id, data bytes, metadata...], data offsets int64[n]) of the frames written so far."""

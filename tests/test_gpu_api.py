@@ -426,3 +426,70 @@ def test_batched_reader_equals_per_frame_reader(tmp_path, scheme, clevel, mode, 
     prefix2, trip2 = rd.get_frames_triplets(1, nz - 1)
     assert np.array_equal(prefix2, prefix) and np.array_equal(trip2, trip)
     rd.close()
+
+
+def test_reference_minimal_read_write_test_at_its_own_size(tmp_path, orc):
+    """BASELINE configs[0] literally (reference tests/minimal_read_write_test.py:16-43,82-119): 9 x 512x512 uint16 frames of
+    randint(0, 4096) - 3500 clipped at 0, zero dark frame, the reference's own parameter file (L1, zlib-1, 12 bit, 3 nodes,
+    validation_frame_gap 2), one writer per node -> part files -> merge_parts -> sequential and random-access read.  Every
+    record is compared byte for byte with the oracle's record (zlib through the same stdlib call the reference makes)."""
+    from pyrecode_amd.params import InputParams
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    shape = (9, 512, 512)
+    rng = np.random.RandomState(20261004)
+    data = rng.randint(0, high=4096, size=shape) - 3500
+    data[data < 0] = 0
+    data = data.astype(np.uint16)
+    calib = np.zeros(shape[1:], np.uint16)
+    ip = InputParams()
+    ip.load(os.path.join(FILES, "recode_params_minimal_read_write_test.txt"))
+    assert (ip.num_threads, ip.compression_scheme, ip.source_bit_depth, ip.num_frames) == (3, 0, 12, 9)
+    for node in range(3):
+        w = ReCoDeWriter("test_data", dark_data=calib, output_directory=str(tmp_path), input_params=ip, mode="batch",
+                         validation_frame_gap=2, log_filename=str(tmp_path / "recode.log"), run_name="minimal_read_write_test",
+                         verbosity=0, use_c=False, node_id=node)
+        w.start()
+        m = w.run(data)
+        w.close()
+        assert m["run_frames"] == 3
+        import scipy.ndimage as nd
+        want_rates = []
+        for z in range(3 * node, 3 * node + 3):
+            if z % 2 == 0:   # central 128 x 128 of the binary map, 8-connected components / ROI pixels (recode_writer.py:161,402-415)
+                roi = data[z, 192:320, 192:320] > 0
+                want_rates.append(nd.label(roi, structure=nd.generate_binary_structure(2, 2))[1] / (128 * 128))
+        assert list(m["run_dose_rates"]) == want_rates
+    thr = orc.threshold(calib, 0)
+    for node in range(3):
+        blob = (tmp_path / ("test_data.rc1_part%03d" % node)).read_bytes()
+        want = b"".join(orc.l1_record(data[z], thr, 12, z, mode=1) for z in range(3 * node, 3 * node + 3))
+        assert blob[512:] == want, "part %d" % node
+    # the reference's intermediate-file read loop (:82-93), with an exact comparison instead of its sum test
+    rd = ReCoDeReader(str(tmp_path / "test_data.rc1_part000"), is_intermediate=True)
+    rd.open(print_header=False)
+    hdr = rd.get_header().as_dict()
+    assert hdr["nz"] == 3
+    for _ in range(hdr["nz"]):
+        f = rd.get_next_frame()
+        fid = list(f.keys())[0]
+        assert np.sum(data[fid] - f[fid]["data"].todense()) == 0                # the reference's own check
+        assert np.array_equal(np.asarray(f[fid]["data"].todense()), data[fid])
+    rd.close()
+    merge_parts(str(tmp_path), "test_data.rc1", 3)
+    merged = (tmp_path / "test_data.rc1").read_bytes()
+    recs = [orc.l1_record(data[z], thr, 12, z, mode=1) for z in range(9)]
+    md = b"".join(r[4:16] for r in recs)
+    assert merged[512:] == md + b"".join(r[16:] for r in recs)
+    rd = ReCoDeReader(str(tmp_path / "test_data.rc1"), is_intermediate=False)
+    rd.open(print_header=False)
+    for i in range(9):
+        f = rd.get_next_frame()
+        assert np.array_equal(np.asarray(f[i]["data"].todense()), data[i])
+    for i in (7, 0, 4):
+        assert np.array_equal(np.asarray(rd.get_frame(i)[i]["data"].todense()), data[i])
+    rd.close()
+    # validation frames: raw frames whose absolute index is a multiple of the gap (recode_writer.py:402-415), one dose rate each
+    for node, ids in ((0, [0, 2]), (1, [4]), (2, [6, 8])):
+        v = np.fromfile(tmp_path / ("test_data.rc1_part%03d_validation_frames.bin" % node), np.uint16).reshape(-1, 512, 512)
+        assert v.shape[0] == len(ids) and all(np.array_equal(v[k], data[z]) for k, z in enumerate(ids))

@@ -24,7 +24,7 @@ def _run(cmd):
 @pytest.mark.gpu
 @pytest.mark.parametrize("launcher", ["plain", "torchrun"])
 def test_bench_contract(launcher):
-    args = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--stack", "64", "--no-cpu-baseline"]
+    args = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--stack", "64", "--no-cpu-baseline", "--min-seconds", "0.2"]
     if launcher == "plain":
         cmd = [sys.executable] + args
     else:
@@ -42,6 +42,30 @@ def test_bench_contract(launcher):
 
 @pytest.mark.gpu
 def test_bench_cpu_baseline_leg():
-    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--stack", "64"])
+    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--stack", "64", "--min-seconds", "0.2"])
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no rank in the environment starts two child ranks itself.  On a one-GPU box the product
+    form (RCCL) must fail in the CHILDREN with a message that names the cause; the rehearsal form (both ranks on cuda:0, gloo for
+    the collective) runs the whole two-rank step loop - double-buffered metadata rows, side-stream gather, every-rank check."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    base = [sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--stack", "64", "--batch", "16", "--min-seconds", "0.2"]
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run(base, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode != 0 and "needs one GPU per rank" in p.stderr.decode(), p.stderr.decode()[-2000:]
+        assert p.stdout.decode().strip() == ""
+    p = subprocess.run(base + ["--shared-gpu", "--dist-backend", "gloo"], cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["gather_verified"] is True
+    assert d["config"]["collective_ranks"] == 2 and d["config"]["collective_backend"] == "gloo" and d["config"]["shared_gpu_rehearsal"] is True
+    assert d["config"]["launch"].startswith("bench.py started its own ranks")
+    assert d["cpu_baseline"] is None

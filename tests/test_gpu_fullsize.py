@@ -210,3 +210,58 @@ def test_direct_electron_size_zstd_write_read_config5(env, tmp_path):
         assert np.array_equal(t[:, 0], rows.astype(np.uint64)) and np.array_equal(t[:, 1], cols.astype(np.uint64))
         assert np.array_equal(t[:, 2], want[rows, cols].astype(np.uint64))
     rd.close()
+
+
+@pytest.mark.parametrize("scheme", [2, 1])
+def test_4096_detector_like_clusters_full_oracle_compare(env, scheme):
+    """The one real-data anchor the reference records (examples/Reading_ReCoDe_v0.1_Files.ipynb cells 7 / 17: 4096^2, 12 bit,
+    ~4.3 % of the pixels set): events in 1..6-pixel clusters.  Exercises what Bernoulli frames never reach at speed - tiles
+    beyond the staged compaction's capacity (the dense-tile path) and literal-heavy bitmap blocks - frame for frame against
+    the oracle, then through the batched device reader."""
+    torch, hip, synth, orc = env
+    ny = nx = 4096
+    N, B, depth, seed_ppm = ny * nx, 4, 12, 11000
+    L = hip.lib()
+    dark_d = torch.empty(N, dtype=torch.int16, device="cuda")
+    frames_d = torch.empty((B, N), dtype=torch.int16, device="cuda")
+    hip.check(L.rc_synth_dark(0, 23, N, dark_d.data_ptr()))
+    hip.check(L.rc_synth_frames_clustered(0, 23, 0, B, nx, ny, seed_ppm, dark_d.data_ptr(), frames_d.data_ptr()))
+    thr = dark_d.cpu().numpy().view(np.uint16)
+    frames = frames_d.cpu().numpy().view(np.uint16)
+    assert np.array_equal(frames[1], synth.frames_clustered(23, 1, 1, nx, ny, seed_ppm, thr)[0])     # device generator == host mirror
+    # make two tiles of frame 0 denser than the staged compaction holds (> 1536 set pixels of 4096) and one tile solid
+    frames[0, 5 * 4096:6 * 4096:2] = thr[5 * 4096:6 * 4096:2] + 9
+    frames[0, 77 * 4096:78 * 4096] = thr[77 * 4096:78 * 4096] + 1
+    frames_d.copy_(torch.from_numpy(frames.view(np.int16)))
+    ctx = hip.ReduceContext(nx, ny, depth, 1, 1, scheme, 1, 0, max_batch=B)
+    ctx.set_dark(dark_d.data_ptr(), 0)
+    cap = B * N
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    rec = torch.empty(B + 1, dtype=torch.int64, device="cuda")
+    md = torch.empty((B, 3), dtype=torch.int32, device="cuda")
+    ctx.enqueue(frames_d.data_ptr(), B, 0, out.data_ptr(), cap, rec.data_ptr(), md.data_ptr())
+    ctx.sync()
+    rec_h, md_h = rec.cpu().numpy(), md.cpu().numpy()
+    out_h = out[:int(rec_h[-1])].cpu().numpy()
+    want_trip, blobs = [], []
+    for z in range(B):
+        r = out_h[int(rec_h[z]):int(rec_h[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        bitmap, packed, nnz = orc.reduce_frame_l1(frames[z], thr, depth)
+        assert fid == z and npk == packed.size and len(r) == 16 + cb + cp
+        assert 0.035 < nnz / N < 0.05
+        assert _decode(orc, scheme, r[16:16 + cb], bitmap.size + 8) == bitmap.tobytes()
+        assert _decode(orc, scheme, r[16 + cb:], packed.size + 8) == packed.tobytes()
+        want_trip.append(orc.unpack_frame_sparse(nx, ny, depth, bitmap, packed, 1))
+        blobs.append(np.frombuffer(r[16:], np.uint8))
+    ctx.close()
+    # reader: both streams of all frames decoded and expanded in one device call
+    blob = np.ascontiguousarray(np.concatenate(blobs))
+    sizes = np.ascontiguousarray(md_h.astype(np.uint32))
+    prefix = np.zeros(B + 1, np.uint64)
+    capt = int(sum(t.shape[0] for t in want_trip))
+    trip = np.empty((capt, 3), np.uint64)
+    hip.check(L.rc_expand_frames(nx, ny, depth, 1, 1, scheme, hip.ptr(blob), hip.ptr(sizes), B, hip.ptr(prefix), hip.ptr(trip), capt), "rc_expand_frames")
+    assert int(prefix[B]) == capt
+    for z in range(B):
+        assert np.array_equal(trip[int(prefix[z]):int(prefix[z + 1])], want_trip[z]), "frame %d" % z

@@ -107,3 +107,86 @@ def test_two_rank_direct_merge_at_scale_and_with_an_empty_rank(n_frames, tmp_pat
     os.remove(tmp_path / base)
     merge_parts(str(tmp_path), base, 2)          # the file-based merge (streaming, two passes) must agree
     assert (tmp_path / base).read_bytes() == want
+
+
+# ---- the bench's step loop (pyrecode_amd.parallel.ShardedStepLoop) with two ranks: device calls stubbed at the ReduceContext
+# boundary, so the double-buffered metadata rows, the side-"stream" gather and the every-rank check run with world = 2 ----
+LOOP_WORKER = textwrap.dedent("""
+    import ctypes, os, sys
+    import numpy as np
+    sys.path.insert(0, %(repo)r)
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyrecode_amd.parallel import ShardedStepLoop
+
+    B = 5
+
+    class StubCtx:                      # what _lib.ReduceContext offers the loop; rows are a function of (rank, step)
+        device_id = None
+        waits = 0
+
+        def enqueue(self, frames_ptr, n, first_id, out_ptr, out_cap, rec_ptr, md_ptr):
+            md = np.ctypeslib.as_array((ctypes.c_int32 * (n * 3)).from_address(md_ptr)).reshape(n, 3)
+            md[:, 0] = first_id + np.arange(n)
+            md[:, 1] = frames_ptr
+            md[:, 2] = rank + 1
+
+        def wait_results(self, stream_handle):
+            self.waits += 1
+
+    def rows(r, i):
+        t = np.zeros((B, 3), np.int32)
+        t[:, 0] = r * 1000 + i * B + np.arange(B)
+        t[:, 1] = 7 * i + r
+        t[:, 2] = r + 1
+        return t
+
+    ctx = StubCtx()
+    out, rec = torch.zeros(64, dtype=torch.uint8), torch.zeros(B + 1, dtype=torch.int64)
+    loop = ShardedStepLoop(ctx, B, lambda i: (7 * i + rank, rank * 1000 + i * B), out, rec, torch.device("cpu"))
+    assert loop.world == 2 and loop.rank == rank
+    nsteps = 7
+    loop.fence()
+    for i in range(nsteps):
+        loop.step(i)
+    loop.fence()
+    assert ctx.waits == nsteps
+    for i in (nsteps - 1, nsteps - 2):       # both buffers: the last step's table and the one before it
+        want = np.concatenate([rows(r, i) for r in range(world)])
+        assert np.array_equal(loop.md_all2[i & 1].numpy(), want), (rank, i)
+    assert loop.verify_gather() is True
+    if rank == 1:                            # one rank's table damaged: EVERY rank must learn it
+        loop.md_all2[(nsteps - 1) & 1][0, 0] += 1
+    assert loop.verify_gather() is False
+    dist.destroy_process_group()
+""")
+
+
+def _run_two_ranks(script_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() * 7 + 3) % 2000), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script_path)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r])
+
+
+def test_step_loop_two_ranks_over_gloo(tmp_path):
+    script = tmp_path / "loop_worker.py"
+    script.write_text(LOOP_WORKER % dict(repo=REPO))
+    _run_two_ranks(script)
+
+
+def test_bench_starts_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` with no rank in the environment must launch two CHILD ranks (never touching the GPU itself);
+    here there is no GPU, so both children refuse with a message of their own and the launcher's exit code says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = p.stderr.decode()
+    assert p.returncode != 0
+    assert "needs one GPU per rank" in err, err[-2000:]
+    assert "2-rank child job failed" in err
+    assert p.stdout.decode().strip() == ""

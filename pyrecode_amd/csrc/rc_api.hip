@@ -554,7 +554,9 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
         HIP_TRY(hipStreamWaitEvent(ps, c->ev_in[k], 0));
         tail = ps;
     }
-    launch_reduce(sc, frames_dev, n, c->level, c->modelled ? 3u : c->emit, c->keep_bitmap || c->emit == 0, c->depth, s, tail);
+    // codec of the fused block encoder: 1 zstd fast, 3 zstd modelled, 2 LZ4 runs (compression_level 0), 4 LZ4 events (>= 1), 8 blosc
+    const uint32_t codec = c->modelled ? 3u : (c->emit == RC_SCHEME_LZ4 && c->clevel != 0 ? 4u : c->emit);
+    launch_reduce(sc, frames_dev, n, c->level, codec, c->keep_bitmap || c->emit == 0, c->depth, s, tail);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);
@@ -1544,7 +1546,7 @@ RC_EXPORT int rc_bit_unpack(const uint8_t *packed, uint64_t packed_bytes, uint64
 }
 
 // ---- seam 2 ----------------------------------------------------------------------------------------------------
-static int lz4_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n)
+static int lz4_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *out_n, uint32_t level)
 {
     using namespace rc;
     Util &u = g_util;
@@ -1572,7 +1574,7 @@ static int lz4_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t d
     sc.blk_size = reinterpret_cast<uint32_t *>(u.w + T * BLK_SLOT);
     sc.blk_off = sc.blk_size + T;
     sc.frame_cbytes = sc.blk_off + T;
-    launch_lz4_encode_buffer(sc, u.stream);
+    launch_lz4_encode_buffer(sc, u.stream, level != 0);   // level 0: zero runs only; >= 1: the event parser (rc_lz4_block.h)
     launch_scans(sc, 1, false, true, u.stream);
     HIP_TRY(hipMemcpyAsync(u.h_scalar, sc.frame_cbytes, 4, hipMemcpyDeviceToHost, u.stream));
     HIP_TRY(hipStreamSynchronize(u.stream));
@@ -1784,7 +1786,8 @@ static int blosc_compress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t
 RC_EXPORT int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap,
                           uint64_t *out_n)
 {
-    (void)level;  // the device encoders have a single effort level
+    // level: LZ4 0 = the run parser, >= 1 = the event parser; zstd / blosc through this stateless seam: one effort (the ctx's zstd
+    // encoder has the modelled form for level >= 1)
     if (!dst || !out_n || (!src && n)) return fail(RC_ERR_BAD_ARG, "NULL argument");
     if (scheme == RC_SCHEME_BLOSC_LZ4) {
         UtilScope util_scope;
@@ -1797,7 +1800,7 @@ RC_EXPORT int rc_compress(uint32_t scheme, uint32_t level, const uint8_t *src, u
     UtilScope util_scope;
     int r = util_scope.enter();
     if (r != RC_OK) return r;
-    return scheme == RC_SCHEME_LZ4 ? lz4_compress(src, n, dst, dst_cap, out_n) : zstd_compress(src, n, dst, dst_cap, out_n);
+    return scheme == RC_SCHEME_LZ4 ? lz4_compress(src, n, dst, dst_cap, out_n, level) : zstd_compress(src, n, dst, dst_cap, out_n);
 }
 // blosc1 chunk with the LZ4 codec (what rc_compress(8) and python-blosc's cname='lz4' write): header and block table are
 // walked on the host, the LZ4 blocks are decoded on the GPU into an image of the shuffled chunk, a second kernel unshuffles.

@@ -87,7 +87,7 @@ void launch_pix_gather(const Scratch &sc, uint32_t B, uint32_t depth, uint32_t l
                        hipStream_t s);
 // rc_lz4.hip
 struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
-void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s);  // sc.bitmap = the buffer, sc.nb = its length
+void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s, bool events = false);  // sc.bitmap = the buffer, sc.nb = its length
 void launch_lz4f_gather(const Scratch &sc, uint32_t hdr3, uint8_t *out, hipStream_t s);
 void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
                        uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s, uint32_t max_stored = 0);

@@ -21,6 +21,7 @@ namespace rc {
 // grid ceil(ntiles/WAVES); wave w encodes block t = blockIdx.x*WAVES + w of the buffer sc.bitmap[0..sc.nb) (padded to whole
 // blocks): blk_slots[t] = [u32 LZ4F block-size word][payload], blk_size[t] = bytes used.  Same encoder as the fused
 // reduce kernel (rc_lz4_block.h).
+template <bool EVENTS>
 __global__ __launch_bounds__(WG) void k_lz4_buffer(Scratch sc)
 {
     __shared__ Lz4Lds s_lz[WAVES];
@@ -32,14 +33,15 @@ __global__ __launch_bounds__(WG) void k_lz4_buffer(Scratch sc)
     const u32x2 v = reinterpret_cast<const u32x2 *>(sc.bitmap + (uint64_t)f * sc.nb_stride + b0)[lane];  // rows are padded to whole blocks
     reinterpret_cast<u32x2 *>(s_lz[w].raw)[lane] = v;
     const uint64_t own = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
-    const uint32_t csize = lz4_encode_block(own, n, s_lz[w]);
+    const uint32_t csize = lz4_encode_block<EVENTS>(own, n, s_lz[w]);
     const uint64_t ft = (uint64_t)f * sc.ntiles + t;
     const uint32_t used = lz4_store_block(sc.blk_slots + ft * BLK_SLOT, own, n, csize, s_lz[w]);
     if (lane == 0) sc.blk_size[ft] = used;
 }
-void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s)
+void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s, bool events)
 {
-    hipLaunchKernelGGL(k_lz4_buffer, dim3((sc.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, s, sc);
+    if (events) hipLaunchKernelGGL(k_lz4_buffer<true>, dim3((sc.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, s, sc);
+    else hipLaunchKernelGGL(k_lz4_buffer<false>, dim3((sc.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, s, sc);
 }
 
 // ---- stand-alone LZ4 frame of an arbitrary byte buffer (seam 2: compress(), recode_compressors.py:91) -----------------

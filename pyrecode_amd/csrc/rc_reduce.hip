@@ -253,8 +253,8 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
         d0 = reinterpret_cast<uint8_t *>(pix_slots + p.ft * TILE_PX);   // slots are 8 KiB aligned
         q0 = ((((p.cnt * p.depth + 31) >> 5) + 31u) & ~31u) >> 2;       // whole lines, in 16-byte units
     }
-    if (CODEC == 2 || CODEC == 8) {
-        const uint64_t bytes = CODEC == 2 ? ((uint64_t)p.own[0] | ((uint64_t)p.own[1] << 32)) : p.cown;
+    if (CODEC == 2 || CODEC == 4 || CODEC == 8) {
+        const uint64_t bytes = CODEC != 8 ? ((uint64_t)p.own[0] | ((uint64_t)p.own[1] << 32)) : p.cown;
         bsz = lz4_stage_slot(bytes, n_blk, p.csize, *lz, CODEC == 8);
     }
     if (CODEC == 1 || CODEC == 3) {
@@ -433,7 +433,11 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
     }
     if (CODEC == 2) {
         const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
-        pend.csize = lz4_encode_block(bytes, n_blk, *s_lz);
+        pend.csize = lz4_encode_block<false>(bytes, n_blk, *s_lz);
+    }
+    if (CODEC == 4) {  // LZ4, compression_level >= 1: the event parser (rc_lz4_block.h)
+        const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
+        pend.csize = lz4_encode_block<true>(bytes, n_blk, *s_lz);
     }
     if (CODEC == 1) {
         const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
@@ -595,6 +599,7 @@ static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t 
         else if (!RAW && C != 0) launch_reduce_t<BZ, AL, L1, C, false, false>(sc, frames, B, depth, s, s_tail); \
     } while (0)
     if (codec == 2) RC_CODEC(2);
+    else if (codec == 4) RC_CODEC(4);
     else if (codec == 1) RC_CODEC(1);
     else if (codec == 3) RC_CODEC(3);
     else if (codec == 8) RC_CODEC(8);

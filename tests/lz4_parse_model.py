@@ -1,0 +1,118 @@
+"""Serial restatement (test infrastructure) of the two LZ4 block parses the device encoder implements
+(pyrecode_amd/csrc/rc_lz4_block.h): lz4_parse_runs (compression_level 0) and lz4_parse_events (>= 1).  Used two ways:
+on the CPU stock liblz4 must decode what the model emits (the PARSE is format-conformant, and its ratio is what DESIGN.md
+claims); on the GPU the device's bytes must equal the model's, block for block."""
+import numpy as np
+
+EV_MAX = 62
+
+
+def emit(block, matches):
+    """LZ4 block bytes of `block` with the given non-overlapping, position-ordered (start, length, offset) matches."""
+    n, out, pos = len(block), bytearray(), 0
+
+    def ext(v):
+        while v >= 255:
+            out.append(255)
+            v -= 255
+        out.append(v)
+    for s, l, off in matches:
+        ll = s - pos
+        out.append((min(ll, 15) << 4) | min(l - 4, 15))
+        if ll >= 15:
+            ext(ll - 15)
+        out += block[pos:s]
+        out += bytes([off & 255, off >> 8])
+        if l - 4 >= 15:
+            ext(l - 4 - 15)
+        pos = s + l
+    ll = n - pos
+    out.append(min(ll, 15) << 4)
+    if ll >= 15:
+        ext(ll - 15)
+    out += block[pos:]
+    return bytes(out)
+
+
+def parse_runs(block):
+    """every run of >= 5 zero bytes that lies in front of the block's last 12 bytes = [literal 00][match offset 1]"""
+    n = len(block)
+    z = np.frombuffer(block, np.uint8) == 0
+    z[max(n - 12, 0):] = False
+    matches, a = [], None
+    for i in range(n + 1):
+        if i < n and z[i]:
+            if a is None:
+                a = i
+        else:
+            if a is not None and i - a >= 5:
+                matches.append((a + 1, i - a - 1, 1))
+            a = None
+    return matches
+
+
+def parse_events(block):
+    """rc_lz4_block.h::lz4_parse_events, lane by lane.  None: more than EV_MAX events (the device takes the run parser)."""
+    n = len(block)
+    b = np.frombuffer(block, np.uint8)
+    ev = np.nonzero(b)[0].tolist()
+    if len(ev) > EV_MAX:
+        return None
+    P1 = [0] + [p + 1 for p in ev]                       # lane 0 = the block start
+    K = len(P1)
+    Pn = P1[1:] + [n + 1]
+    R = [Pn[k] - P1[k] - 1 for k in range(K)]
+    cls = [None] + [(int(b[p]).bit_length() - 1) if (b[p] & (b[p] - 1)) == 0 else None for p in ev]
+    best = {}                                            # value class -> (key, lane) of the best earlier event
+    has, trail, lead, J = [False] * K, [0] * K, [0] * K, [0] * K
+    for k in range(K):
+        c = cls[k]
+        if c is not None and c in best:
+            j = best[c][1]
+            t = min(R[k], R[j], n - 5 - P1[k])
+            if P1[k] + 11 <= n and t >= 3:
+                has[k], trail[k], J[k] = True, t, j
+        if c is not None:
+            key = (min(R[k], 127) << 6) | k
+            if c not in best or key > best[c][0]:
+                best[c] = (key, k)
+    d = [R[k] - trail[k] for k in range(K)]
+    for k in range(1, K):
+        if has[k]:
+            lead[k] = min(d[k - 1], R[J[k] - 1])
+    matches = []
+    for k in range(K):
+        if has[k]:
+            matches.append((P1[k] - 1 - lead[k], lead[k] + 1 + trail[k], P1[k] - P1[J[k]]))
+        leadn = lead[k + 1] if k + 1 < K else 0
+        gs = P1[k] + trail[k] + (0 if has[k] else 1)
+        ge = min(Pn[k] - 1 - leadn, n - 5)
+        if gs + 12 <= n and ge - gs >= 4:
+            matches.append((gs, ge - gs, 1))
+    return matches
+
+
+def encode_block(block, level):
+    """(size word, payload) as they stand in an LZ4 frame: the compressed block, or the block stored (bit 31) if that is not smaller"""
+    m = parse_events(block) if level else None
+    if m is None:
+        m = parse_runs(block)
+    enc = emit(block, m)
+    if len(enc) >= len(block):
+        return len(block) | 0x80000000, bytes(block)
+    return len(enc), enc
+
+
+def frame_blocks(frame):
+    """[(size word, payload)] of an LZ4 frame with a 7-byte header and no block checksums"""
+    out, q = [], 7
+    while True:
+        w = int.from_bytes(frame[q:q + 4], "little")
+        q += 4
+        if w == 0:
+            break
+        size = w & 0x7FFFFFFF
+        out.append((w, bytes(frame[q:q + size])))
+        q += size
+    assert q == len(frame)
+    return out

@@ -444,6 +444,9 @@ def test_reference_minimal_read_write_test_at_its_own_size(tmp_path, orc):
     calib = np.zeros(shape[1:], np.uint16)
     ip = InputParams()
     ip.load(os.path.join(FILES, "recode_params_minimal_read_write_test.txt"))
+    ip.nx, ip.ny, ip.nz = shape[1], shape[2], shape[0]      # as the reference's test does (:36-40)
+    ip.source_data_type = 0
+    ip.target_data_type = 0
     assert (ip.num_threads, ip.compression_scheme, ip.source_bit_depth, ip.num_frames) == (3, 0, 12, 9)
     for node in range(3):
         w = ReCoDeWriter("test_data", dark_data=calib, output_directory=str(tmp_path), input_params=ip, mode="batch",
@@ -463,7 +466,7 @@ def test_reference_minimal_read_write_test_at_its_own_size(tmp_path, orc):
     thr = orc.threshold(calib, 0)
     for node in range(3):
         blob = (tmp_path / ("test_data.rc1_part%03d" % node)).read_bytes()
-        want = b"".join(orc.l1_record(data[z], thr, 12, z, mode=1) for z in range(3 * node, 3 * node + 3))
+        want = b"".join(orc.l1_record(data[z], thr, 12, z, mode=1)[0] for z in range(3 * node, 3 * node + 3))
         assert blob[512:] == want, "part %d" % node
     # the reference's intermediate-file read loop (:82-93), with an exact comparison instead of its sum test
     rd = ReCoDeReader(str(tmp_path / "test_data.rc1_part000"), is_intermediate=True)
@@ -478,7 +481,7 @@ def test_reference_minimal_read_write_test_at_its_own_size(tmp_path, orc):
     rd.close()
     merge_parts(str(tmp_path), "test_data.rc1", 3)
     merged = (tmp_path / "test_data.rc1").read_bytes()
-    recs = [orc.l1_record(data[z], thr, 12, z, mode=1) for z in range(9)]
+    recs = [orc.l1_record(data[z], thr, 12, z, mode=1)[0] for z in range(9)]
     md = b"".join(r[4:16] for r in recs)
     assert merged[512:] == md + b"".join(r[16:] for r in recs)
     rd = ReCoDeReader(str(tmp_path / "test_data.rc1"), is_intermediate=False)
@@ -491,5 +494,5 @@ def test_reference_minimal_read_write_test_at_its_own_size(tmp_path, orc):
     rd.close()
     # validation frames: raw frames whose absolute index is a multiple of the gap (recode_writer.py:402-415), one dose rate each
     for node, ids in ((0, [0, 2]), (1, [4]), (2, [6, 8])):
-        v = np.fromfile(tmp_path / ("test_data.rc1_part%03d_validation_frames.bin" % node), np.uint16).reshape(-1, 512, 512)
+        v = np.fromfile(tmp_path / ("test_data_part%03d_validation_frames.bin" % node), np.uint16).reshape(-1, 512, 512)
         assert v.shape[0] == len(ids) and all(np.array_equal(v[k], data[z]) for k, z in enumerate(ids))

@@ -102,11 +102,12 @@ def test_reduce_only_records_bit_exact(hip, orc, ny, nx, s, d, eps):
     ctx.close()
 
 
+@pytest.mark.parametrize("clevel", [0, 1])   # 0: zero runs only, >= 1: the event parser (rc_lz4_block.h)
 @pytest.mark.parametrize("ny,nx,s,d,eps", SHAPES)
-def test_lz4_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps):
+def test_lz4_records_decode_bit_exact(hip, orc, ny, nx, s, d, eps, clevel):
     dark, frames = synth_frames(23 + nx, 4, ny, nx, s, d)
     thr = orc.threshold(dark, eps)
-    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 2, 1, 0, max_batch=4)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 2, clevel, 0, max_batch=4)
     ctx.set_threshold(thr)
     out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=7)
     for z in range(frames.shape[0]):
@@ -175,7 +176,7 @@ def _pattern_frames(ny, nx):
     return np.stack(frames).reshape(-1, ny, nx)
 
 
-@pytest.mark.parametrize("scheme,clevel", [(1, 0), (1, 1), (2, 1)])
+@pytest.mark.parametrize("scheme,clevel", [(1, 0), (1, 1), (2, 0), (2, 1)])
 @pytest.mark.parametrize("ny,nx", [(128, 256), (130, 250)])
 def test_codec_block_types(hip, orc, scheme, clevel, ny, nx):
     """Every block type of the fused encoders (zstd: RLE / Raw / Compressed incl. the in-place path for long bitstreams and
@@ -198,6 +199,56 @@ def test_codec_block_types(hip, orc, scheme, clevel, ny, nx):
             _check_lz4(orc, r[16:16 + cb], expect)
             _check_lz4(orc, r[16 + cb:], pix.tobytes())
     ctx.close()
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_lz4_device_blocks_equal_the_serial_parse_model(hip, orc, level):
+    """The device encoder's bytes against tests/lz4_parse_model.py (which stock liblz4 judges on the CPU, test_lz4_format_cpu.py),
+    block for block: through the stateless seam on a buffer of special blocks with a ragged tail, and through the fused reduce
+    kernel on frames of 0.2 % .. 12 % density (the event parser up to 62 events per block, the run parser beyond)."""
+    import lz4_parse_model as model
+    from test_lz4_format_cpu import _blocks
+    from pyrecode_amd.recode_compressors import device_compress
+    blocks = [b for b in _blocks() if len(b) == 512]
+    for tail in (b"", bytes(5), b"\x00" * 30 + b"\x04" + b"\x00" * 40, bytes(511)):
+        buf = b"".join(blocks) + tail
+        got = model.frame_blocks(device_compress(2, level, buf))
+        want = [model.encode_block(buf[i:i + 512], level) for i in range(0, len(buf), 512)]
+        assert len(got) == len(want)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g == w, "block %d of %d (tail %d)" % (i, len(want), len(tail))
+        assert orc.lz4f_decode(device_compress(2, level, buf), len(buf) + 8) == buf
+    ny, nx = 96, 512
+    for s in (0.002, 0.01, 0.04, 0.12):
+        dark, frames = synth_frames(int(s * 1000) + 5, 3, ny, nx, s, 12)
+        thr = orc.threshold(dark, 0)
+        ctx = hip.ReduceContext(nx, ny, 12, 1, 1, 2, level, 0, max_batch=3)
+        ctx.set_threshold(thr)
+        out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+        for z in range(3):
+            r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+            cb = struct.unpack_from("<I", r, 4)[0]
+            bitmap = orc.pack_binary_frame(frames[z] > thr).tobytes()
+            got = model.frame_blocks(r[16:16 + cb])
+            want = [model.encode_block(bitmap[i:i + 512], level) for i in range(0, len(bitmap), 512)]
+            assert got == want, "density %g frame %d" % (s, z)
+        ctx.close()
+
+
+def test_lz4_event_parser_ratio_on_bench_like_data(hip, orc):
+    """SURVEY 8d data at 1 %: the binary-map stream must come out below 0.30 of raw at compression_level >= 1 (the run parser:
+    0.375; stock liblz4 on the same bytes in one 64 KiB-block frame: 0.26)."""
+    ny = nx = 1024
+    dark, frames = synth_frames(99, 2, ny, nx, 0.01, 16)
+    thr = orc.threshold(dark, 0)
+    sizes = {}
+    for level in (0, 1):
+        ctx = hip.ReduceContext(nx, ny, 16, 1, 1, 2, level, 0, max_batch=2)
+        ctx.set_threshold(thr)
+        out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+        sizes[level] = float(md[:, 0].mean()) / (ny * nx // 8)
+        ctx.close()
+    assert 0.36 < sizes[0] < 0.39 and sizes[1] < 0.30, sizes
 
 
 @pytest.mark.parametrize("ny,nx,s,d,eps", SHAPES)

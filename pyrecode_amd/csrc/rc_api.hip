@@ -1011,6 +1011,7 @@ struct ReadRes {
     uint8_t *x[10] = {}; uint64_t x_cap[10] = {};          // device: data, decoded streams, -, head, -, counters, staged triplets
     PinnedVec<rc::ZdBlock> rd_bm[RC_READ_THREADS], rd_pv[RC_READ_THREADS], rd_raw[RC_READ_THREADS];   // per indexing thread, page-locked
     std::vector<rc::ZdBlock> rd_tmp[RC_READ_THREADS];
+    PinnedVec<uint32_t> rd_off[RC_READ_THREADS];           // compact lists of uniform binary-map streams: one header offset per block (k_bitmap_decode_c)
     uint8_t *rd_head = nullptr; uint64_t rd_head_cap = 0;  // page-locked: decoding tables + per-frame index arrays
     uint64_t *h_res = nullptr; uint64_t h_res_cap = 0;     // page-locked: nnz prefix (n + 1) and the error word, as the device left them
     // a submitted batch waiting for its rc_expand_frames_wait
@@ -1232,12 +1233,12 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
     const uint64_t out_bytes = (uint64_t)n * (bm_stride + (level == 1 ? pv_stride : 0)) + 64;
     auto need = [&](int i, uint64_t bytes) { return ensure(u.x[i], u.x_cap[i], bytes); };
-    // head: [ZdTables bitmap x n][ZdTables values x n] (zstd) [block lists: bitmap x n, values x n, stored x threads][pv_bytes n] [base2 2n][pv_base n], the
+    // head: [ZdTables bitmap x n][ZdTables values x n] (zstd) [block lists: bitmap x n, values x n, stored x threads, compact bitmap x n][pv_bytes n] [base2 2n][pv_base n][src_base n], the
     // same layout in page-locked host memory and on the device: one copy
     const uint64_t ntab = codec == 1 ? 2 * (uint64_t)n : 0;
     const uint64_t o_first = ntab * sizeof(ZdTables);
-    const uint64_t o_base2 = (o_first + (2 * (uint64_t)n + RC_READ_THREADS) * sizeof(ZdFrameList) + (uint64_t)n * 4 + 15) & ~15ull;
-    const uint64_t sz_head = o_base2 + (uint64_t)n * 3 * 8;
+    const uint64_t o_base2 = (o_first + (3 * (uint64_t)n + RC_READ_THREADS) * sizeof(ZdFrameList) + (uint64_t)n * 4 + 15) & ~15ull;
+    const uint64_t sz_head = o_base2 + (uint64_t)n * 4 * 8;
     if ((r = need(0, total_in + 64)) != RC_OK || (r = need(1, out_bytes)) != RC_OK || (r = need(3, sz_head)) != RC_OK ||
         (r = need(5, (uint64_t)n * nblk * 8 + (uint64_t)(2 * n + 2) * 8 + 64)) != RC_OK)
         return r;
@@ -1279,9 +1280,11 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     // The block lists stay where the indexing threads wrote them, in page-locked host memory: the decoders read every entry once,
     // over the link (uploading them meant 3 small copies per thread, each a fixed ~15 us of stream time: 0.7 ms per call).
     ZdFrameList *bm_list = reinterpret_cast<ZdFrameList *>(u.rd_head + o_first), *pv_list = bm_list + n, *raw_list = pv_list + n;
-    uint32_t *pv_bytes = reinterpret_cast<uint32_t *>(raw_list + RC_READ_THREADS);
-    uint64_t *base2 = reinterpret_cast<uint64_t *>(u.rd_head + o_base2), *pv_base = base2 + 2 * (uint64_t)n;
-    struct FrameIndex { uint32_t bm0 = 0, bm_n = 0, pv0 = 0, pv_n = 0, thread = 0; int status = ZD_OK; const char *what = nullptr; };
+    ZdFrameList *cbm_list = raw_list + RC_READ_THREADS;
+    uint32_t *pv_bytes = reinterpret_cast<uint32_t *>(cbm_list + n);
+    uint64_t *base2 = reinterpret_cast<uint64_t *>(u.rd_head + o_base2), *pv_base = base2 + 2 * (uint64_t)n, *src_base = pv_base + n;
+    // c0, c_n: the frame's range in its thread's compact offset list (c_n blocks = c_n + 1 offsets); c_skips: tree_skip | seq_skip << 8
+    struct FrameIndex { uint32_t bm0 = 0, bm_n = 0, pv0 = 0, pv_n = 0, thread = 0, c0 = 0, c_n = 0, c_skips = 0; int status = ZD_OK; const char *what = nullptr; };
     std::vector<FrameIndex> fi(n);
     const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
     static const uint32_t thr_env = getenv("RC_READ_THREADS") ? (uint32_t)atoi(getenv("RC_READ_THREADS")) : 0u;   // (development: 1..16)
@@ -1292,8 +1295,28 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     std::atomic<uint32_t> next_frame{0};
     auto index_range = [&](uint32_t t) {
         if (t) (void)hipSetDevice(dev_now);   // (a worker thread: page-locked memory it allocates belongs to this device's context)
-        auto &BM = u.rd_bm[t]; auto &PV = u.rd_pv[t]; auto &RAW = u.rd_raw[t]; auto &all = u.rd_tmp[t];
-        BM.clear(); PV.clear(); RAW.clear();
+        auto &BM = u.rd_bm[t]; auto &PV = u.rd_pv[t]; auto &RAW = u.rd_raw[t]; auto &all = u.rd_tmp[t]; auto &OFF = u.rd_off[t];
+        BM.clear(); PV.clear(); RAW.clear(); OFF.clear();
+        // A binary-map stream whose blocks all regenerate TILE_BM bytes (the last one the rest), lie back to back and keep to one
+        // set of sequence tables - what this library's encoders write - leaves one dword per block (k_bitmap_decode_c); any other
+        // stream inside the decoders' subset leaves full entries, Compressed blocks and stored ones apart, as before.
+        auto route_bitmap = [&](FrameIndex &F, uint64_t o, uint64_t cb, uint32_t hdr, bool one_table_set) {
+            bool uniform = one_table_set && !all.empty() && cb < (1ull << 32);
+            uint32_t skips = 0;
+            for (size_t i = 0; uniform && i < all.size(); ++i) {
+                const ZdBlock &b = all[i];
+                const uint64_t want = std::min<uint64_t>((uint64_t)TILE_BM, nb - std::min<uint64_t>(nb, (uint64_t)i * TILE_BM));
+                uniform = b.regen == want && b.dst == (uint64_t)i * TILE_BM && (i + 1 == all.size() || all[i + 1].src - hdr == b.src + b.csize);
+                if (b.tree_skip) skips |= b.tree_skip;
+                if (b.seq_skip > 1) skips |= (uint32_t)b.seq_skip << 8;     // (1 = the RLE offset byte of a block with predefined tables)
+            }
+            if (uniform) {
+                F.c0 = (uint32_t)OFF.size(); F.c_n = (uint32_t)all.size(); F.c_skips = skips;
+                for (const ZdBlock &b : all) OFF.push_back((uint32_t)(b.src - hdr - o));
+                OFF.push_back((uint32_t)(all.back().src + all.back().csize - o));
+            } else
+                for (const ZdBlock &b : all) { if (b.type == 2) BM.push_back(b); else RAW.push_back(b); }
+        };
         for (;;) {
             const uint32_t f = next_frame.fetch_add(1, std::memory_order_relaxed);
             if (f >= n) break;
@@ -1312,8 +1335,10 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
                 RAW.push_back(b);
                 if (npk) { b.src = o + cb; b.csize = b.regen = (uint32_t)npk; b.frame = n + f; RAW.push_back(b); }
             } else if (codec == 2) {
-                rr = lz4_index_frame(data, o, cb, f, TILE_BM, nb, BM, RAW, &got);
+                all.clear();
+                rr = lz4_index_frame(data, o, cb, f, TILE_BM, nb, all, all, &got);
                 if (rr == ZD_OK && got != nb) rr = ZD_CORRUPT;
+                if (rr == ZD_OK) route_bitmap(F, o, cb, 4, true);
                 if (rr == ZD_OK && level == 1) {
                     all.clear();   // (a value stream holds stored chunks only: a compressed block there is outside the subset)
                     rr = lz4_index_frame(data, o + cb, cp, n + f, 0, npk, all, RAW, &got);
@@ -1334,9 +1359,11 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
                         comp.push_back(c);
                     }
                 };
-                Route rb{BM, RAW, false, f}, rp{PV, RAW, true, f};
-                rr = zd_index_frame(data, o, cb, f, TILE_BM, nb, rb, bm_tab[f], &got);
+                Route rp{PV, RAW, true, f};
+                all.clear();
+                rr = zd_index_frame(data, o, cb, f, TILE_BM, nb, all, bm_tab[f], &got);
                 if (rr == ZD_OK && got != nb) rr = ZD_CORRUPT;
+                if (rr == ZD_OK) route_bitmap(F, o, cb, 3, !(bm_tab[f].has & 4u));
                 if (rr == ZD_OK && level == 1) {
                     rr = zd_index_frame(data, o + cb, cp, n + f, 0, npk, rp, pv_tab[f], &got);
                     if (rr == ZD_OK && got != npk) rr = ZD_CORRUPT;
@@ -1350,9 +1377,9 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     g_pool->run(nthr, index_range);
     const double t_1 = now();
     uint64_t n_bm = 0, n_pv = 0, n_raw = 0;
-    uint32_t bm_max = 0, pv_max = 0, raw_max_regen = 0;
+    uint32_t bm_max = 0, pv_max = 0, raw_max_regen = 0, cbm_max = 0;
     for (uint32_t t = 0; t < nthr; ++t) {
-        if (!u.rd_bm[t].ok || !u.rd_pv[t].ok || !u.rd_raw[t].ok) return bail(RC_ERR_DEVICE, "rc_expand_frames: page-locked host memory exhausted");
+        if (!u.rd_bm[t].ok || !u.rd_pv[t].ok || !u.rd_raw[t].ok || !u.rd_off[t].ok) return bail(RC_ERR_DEVICE, "rc_expand_frames: page-locked host memory exhausted");
         raw_list[t].p = u.rd_raw[t].data(); raw_list[t].n = (uint32_t)u.rd_raw[t].size(); raw_list[t].pad = 0;
         n_raw += u.rd_raw[t].size();
         const ZdBlock *rb = u.rd_raw[t].data();
@@ -1365,6 +1392,9 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
         if (F.status != ZD_OK) return bail(RC_ERR_CORRUPT, F.what ? F.what : "rc_expand_frames: malformed compressed stream");
         bm_list[f].p = u.rd_bm[t].data() + F.bm0; bm_list[f].n = F.bm_n; bm_list[f].pad = 0;
         pv_list[f].p = u.rd_pv[t].data() + F.pv0; pv_list[f].n = F.pv_n; pv_list[f].pad = 0;
+        cbm_list[f].p = reinterpret_cast<const ZdBlock *>(u.rd_off[t].data() + F.c0); cbm_list[f].n = F.c_n; cbm_list[f].pad = F.c_skips;
+        src_base[f] = foff[f];
+        cbm_max = std::max(cbm_max, F.c_n);
         pv_bytes[f] = level == 1 ? sizes[3 * f + 2] : 0;
         base2[f] = (uint64_t)f * bm_stride;                                        // stored blocks: frames 0..n-1 = bitmaps,
         base2[n + f] = pv_base[f] = (uint64_t)n * bm_stride + (uint64_t)f * pv_stride;   // n..2n-1 = value streams (behind the bitmaps)
@@ -1377,20 +1407,24 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     // ---- device ----
     ZdTables *d_bm_tab = reinterpret_cast<ZdTables *>(u.x[3]), *d_pv_tab = d_bm_tab + (codec == 1 ? n : 0);
     const ZdFrameList *d_bm_list = reinterpret_cast<const ZdFrameList *>(u.x[3] + o_first), *d_pv_list = d_bm_list + n, *d_raw_list = d_pv_list + n;
-    uint32_t *d_pv_bytes = reinterpret_cast<uint32_t *>(u.x[3] + o_first + (2 * (uint64_t)n + RC_READ_THREADS) * sizeof(ZdFrameList));
-    uint64_t *d_base2 = reinterpret_cast<uint64_t *>(u.x[3] + o_base2), *d_pvbase = d_base2 + 2 * (uint64_t)n;
+    const ZdFrameList *d_cbm_list = d_raw_list + RC_READ_THREADS;
+    uint32_t *d_pv_bytes = reinterpret_cast<uint32_t *>(u.x[3] + o_first + (3 * (uint64_t)n + RC_READ_THREADS) * sizeof(ZdFrameList));
+    uint64_t *d_base2 = reinterpret_cast<uint64_t *>(u.x[3] + o_base2), *d_pvbase = d_base2 + 2 * (uint64_t)n, *d_src_base = d_pvbase + n;
     HIP_TRY(hipMemcpyAsync(u.x[3], u.rd_head, sz_head, hipMemcpyHostToDevice, s));
     const double t_3 = now();
     // the value streams' chunks (few, long serial chains) decode next to the binary maps' blocks (many, short), on a second stream
-    if (n_pv) {
+    static const bool serial = getenv("RC_READ_SERIAL") != nullptr;   // development: both decoders on one stream (clean per-kernel times)
+    if (n_pv && serial) launch_block_decode(1, 1024, d_data, d_pv_list, n, pv_max, d_pv_tab, U.zd_predef, d_out, d_pvbase, d_err, s);
+    else if (n_pv) {
         HIP_TRY(hipEventRecord(u.ev_a, s));
         HIP_TRY(hipStreamWaitEvent(u.stream2, u.ev_a, 0));
         launch_block_decode(1, 1024, d_data, d_pv_list, n, pv_max, d_pv_tab, U.zd_predef, d_out, d_pvbase, d_err, u.stream2);
         HIP_TRY(hipEventRecord(u.ev_b, u.stream2));
     }
+    if (cbm_max) launch_bitmap_decode_compact(codec == 1 ? 1 : 2, d_data, d_cbm_list, d_src_base, n, cbm_max, d_bm_tab, U.zd_predef, d_out, d_base2, nb, d_err, s);
     if (n_bm) launch_block_decode(codec == 1 ? 1 : 2, TILE_BM, d_data, d_bm_list, n, bm_max, d_bm_tab, U.zd_predef, d_out, d_base2, d_err, s);
     launch_block_copy(d_data, d_raw_list, nthr, (uint32_t)n_raw, raw_max_regen, d_out, d_base2, s);
-    if (n_pv) HIP_TRY(hipStreamWaitEvent(s, u.ev_b, 0));
+    if (n_pv && !serial) HIP_TRY(hipStreamWaitEvent(s, u.ev_b, 0));
     const uint8_t *d_bm = d_out, *d_pv = d_out + (uint64_t)n * bm_stride;
     // Triplets wanted in DEVICE memory: the emit kernel is queued right behind the count - no host round trip in between; the kernel that
     // finishes the count (k_expand_bases) checks what the host otherwise would (total <= cap, value streams long enough) and the emit

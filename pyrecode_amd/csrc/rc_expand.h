@@ -18,6 +18,9 @@ void launch_expand_batch_emit(const uint8_t *bm, uint64_t bm_stride, uint64_t nb
 void launch_block_decode(int codec, int row, const uint8_t *data, const void *frame_lists, uint32_t nframes, uint32_t max_blocks_per_frame,
                          const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base, int *err, hipStream_t s,
                          uint32_t *produced_out = nullptr);
+void launch_bitmap_decode_compact(int codec, const uint8_t *data, const void *frame_lists, const uint64_t *src_base, uint32_t nframes,
+                                  uint32_t max_blocks_per_frame, const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base,
+                                  uint64_t nb, int *err, hipStream_t s);
 void launch_block_copy(const uint8_t *data, const void *lists, uint32_t nlists, uint32_t nblocks, uint32_t max_regen, uint8_t *out,
                        const uint64_t *out_base, hipStream_t s);
 size_t zd_tables_bytes();

@@ -23,16 +23,16 @@ __device__ __constant__ uint16_t c_ml_base[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 1
 __device__ __constant__ uint8_t c_ml_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                                  0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 
-// Backward bit reader.  The stream is read through ALIGNED dwords, two of them (64 bits around the position) kept in registers
-// and one new dword fetched per 32 bits consumed; `p` may point into LDS or global memory (generic address).  Bits below the
-// stream's first are whatever lies there: a valid stream never depends on them (a Huffman step is decided by the code's own
-// bits, an FSE read never crosses the start), a corrupt one runs into `bit < 0`, which the callers check.
+// Backward bit reader.  `p` may point into LDS or global memory (generic address; the kernels instantiate the decoder once per
+// address space).  EVERY read fetches the two aligned dwords around the position - no state, no branch: in a wavefront the lanes
+// cross dword boundaries at different symbols, so a reader that keeps dwords in registers and refills on demand executes its refill
+// path at almost every step anyway, under nested exec masks (measured: ~1000 cycles per Huffman symbol; this form: see DESIGN.md).
+// Bits below the stream's first are whatever lies there: a valid stream never depends on them (a Huffman step is decided by the
+// code's own bits, an FSE read never crosses the start), a corrupt one runs into `bit < 0`, which the callers check.
 struct BackBits {
     const uint32_t *pa;   // the stream's first byte, rounded down to a dword
     int32_t bit;          // unread bits, counted from bit 0 of pa[0]
     int32_t first;        // the stream's first bit in the same count (8 * misalignment)
-    uint32_t hi, lo, nx;  // dwords pa[ci], pa[ci - 1]; pa[ci - 2], requested ahead of its use
-    int32_t ci;
     __device__ bool init(const uint8_t *src, uint32_t n)
     {
         if (n == 0) return false;
@@ -42,31 +42,22 @@ struct BackBits {
         pa = reinterpret_cast<const uint32_t *>(src - mis);
         first = 8 * (int32_t)mis;
         bit = first + (int32_t)(n - 1) * 8 + (31 - __clz((int)lastb));
-        ci = -2;
-        hi = lo = nx = 0;
         return true;
     }
     __device__ int32_t left() const { return bit - first; }   // < 0: the stream was over-read
     // the nb <= 24 bits just below the position, without consuming
-    __device__ uint32_t peek(uint32_t nb)
+    __device__ uint32_t peek(uint32_t nb) const
     {
-        const int32_t i = max((bit - 1) >> 5, 0);
-        if (i != ci) {
-            // (the lanes of a wavefront cross dword boundaries at different symbols: almost every step has SOME lane in here, so
-            // the usual case must not wait for memory - it takes the dword requested at the previous crossing)
-            if (i == ci - 1) { hi = lo; lo = nx; }
-            else { hi = pa[i]; lo = i > 0 ? pa[i - 1] : 0u; }
-            ci = i;
-            nx = i > 1 ? pa[i - 2] : 0u;
-        }
-        const int32_t sh = max(bit - (int32_t)nb - 32 * (i - 1), 0);
-        const uint64_t w = ((uint64_t)hi << 32) | lo;
-        return (uint32_t)(w >> sh) & ((1u << nb) - 1u);
+        const int32_t i = max(((bit - 1) >> 5) - 1, 0);         // window = dwords i, i + 1: bits [32 i, 32 i + 64) hold [bit - nb, bit)
+        const uint32_t lo = pa[i], hi = pa[i + 1];
+        // fewer than nb bits left above dword 0 (a Huffman peek at a stream's very start): the bits that exist stay at the field's top
+        const int32_t s = bit - (int32_t)nb - 32 * i;
+        const uint64_t w = (((uint64_t)hi << 32) | lo) << (uint32_t)max(-s, 0);
+        return (uint32_t)(w >> (uint32_t)max(s, 0)) & ((1u << nb) - 1u);
     }
     __device__ uint32_t read(uint32_t nb)
     {
-        if (nb == 0) return 0;
-        const uint32_t v = peek(nb);
+        const uint32_t v = peek(nb);   // (nb == 0: mask 0)
         bit -= (int32_t)nb;
         return v;
     }
@@ -129,10 +120,14 @@ struct Sink {
 };
 
 // regenerate one Compressed block (content c, bs bytes; generic address) into the sink, at most cap bytes; returns the bytes produced
+// b.seq_tables == 2 (compact lists): the block's own modes byte decides - predefined tables (llm 0, one RLE offset byte behind the
+// modes), the frame's tables defined right here (llm 2: b.seq_skip bytes of descriptions) or repeated (llm 3); pll / pml then
+// hold the predefined tables and ll / ml the frame's.
 template <bool SPARSE>
 __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlock &b, const uint16_t *huf, uint32_t huf_log,
                                       const uint32_t *ll, uint32_t ll_log, const uint32_t *ml, uint32_t ml_log, const uint32_t *llx,
-                                      const uint32_t *mlx, Sink<SPARSE> &o, uint32_t cap, int *err)
+                                      const uint32_t *mlx, Sink<SPARSE> &o, uint32_t cap, int *err, const uint32_t *pll = nullptr,
+                                      const uint32_t *pml = nullptr)
 {
     const uint32_t c0 = c[0];
     const uint32_t lt = c0 & 3u, sf = (c0 >> 2) & 3u;
@@ -162,7 +157,13 @@ __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlo
     if (nseq >= 128) { nseq = ((nseq - 128) << 8) + sq[1]; nsb = 2; }
     uint32_t prev = 0;
     if (nseq) {
-        const uint8_t *bsrc = sq + nsb + 1 + b.seq_skip;
+        uint32_t seq_skip = b.seq_skip;
+        if (b.seq_tables == 2) {
+            const uint32_t llm = sq[nsb] >> 6;
+            if (llm == 0) { ll = pll; ml = pml; ll_log = ml_log = 6; seq_skip = 1; }
+            else if (llm == 3) seq_skip = 0;
+        }
+        const uint8_t *bsrc = sq + nsb + 1 + seq_skip;
         const uint32_t blen = (uint32_t)(c + bs - bsrc);
         BackBits fb;
         if ((int32_t)blen <= 0 || !fb.init(bsrc, blen)) { *err = 1; return 0; }
@@ -222,11 +223,13 @@ __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlo
 }
 
 // LZ4 block (lz4_Block_format.md) into the sparse sink; the block may not reference anything in front of itself.  A match is
-// read back from the lane's own earlier output (bytes it skipped read as the zeros the caller put there).
+// read back from the lane's own earlier output (bytes it skipped read as the zeros the caller put there), EIGHT bytes per load:
+// the event parser's matches (rc_lz4_block.h) sit at real offsets, and byte-wise read-back made every copied byte a dependent
+// round trip to L2 (0.87 ms for the 262 144 blocks of 64 binary maps; this form: see DESIGN.md).
 __device__ uint32_t lz4_block_decode(const uint8_t *src, uint32_t n, Sink<true> &o, uint32_t cap, int *err)
 {
     uint32_t ip = 0;
-    uint32_t prev = 0;
+    uint32_t prev = 0;   // the byte in front of o.op
     while (ip < n) {
         const uint32_t token = src[ip++];
         uint32_t lit = token >> 4;
@@ -242,9 +245,22 @@ __device__ uint32_t lz4_block_decode(const uint8_t *src, uint32_t n, Sink<true> 
         if (ml == 15) { uint32_t x; do { if (ip >= n) { *err = 1; return o.op; } x = src[ip++]; ml += x; } while (x == 255); }
         ml += 4;
         if (off == 0 || off > o.op || o.op + ml > cap) { *err = 1; return o.op; }
-        if (off == 1 && lit) o.fill(prev, ml);   // the byte just written, repeated: known without reading anything back
+        if (off == 1) o.fill(prev, ml);   // the byte in front, repeated: known without reading anything back
         else {
-            for (uint32_t i = 0; i < ml; ++i) { prev = o.g[o.op - off]; o.put(prev); }
+            for (uint32_t i = 0; i < ml;) {
+                const uint32_t k = min(min(8u, ml - i), off);   // (off < 8: the pattern repeats - only bytes already written are taken)
+                uint64_t v;
+                __builtin_memcpy(&v, o.g + o.op - off, 8);       // any alignment; may run past o.op, inside the (padded) output
+                v &= k == 8 ? ~0ull : ((1ull << (8 * k)) - 1ull);
+                prev = (uint32_t)(v >> (8 * (k - 1))) & 0xFFu;
+                for (uint64_t q = v; q;) {                       // store what is not zero
+                    const uint32_t j = (uint32_t)__builtin_ctzll(q) >> 3;
+                    o.g[o.op + j] = (uint8_t)(v >> (8 * j));
+                    q &= ~(0xFFull << (8 * j));
+                }
+                o.op += k;
+                i += k;
+            }
         }
     }
     return o.op;
@@ -322,6 +338,90 @@ __global__ __launch_bounds__(T) void k_block_decode(const uint8_t *__restrict__ 
     if (e) *err = 1;
 }
 
+// The binary-map streams of frames THIS library's shape of encoder wrote ("uniform": every block regenerates TILE_BM bytes, the
+// last one the rest; rc_api.hip checks that on the host) need no 32-byte entry per block: the host walk leaves ONE dword per block,
+// the offset of its header inside the frame's stream (n + 1 of them: the last is the stream's end), and the lane reads type, size and
+// table modes from the block itself.  The lists are read over the link (page-locked host memory, once): 1 MB instead of 8 MB per 64
+// frames of 4096 x 4096 - with full entries the link, not the decoder, set this kernel's time (315 us; entries in device memory: 159).
+//   lists[f].p   const uint32_t *: header offsets relative to src_base[f];  lists[f].pad = tree_skip | seq_skip << 8
+// CODEC 1: zstd (3-byte block headers; Raw and RLE blocks are handled in line), 2: LZ4 frame blocks (4-byte size words, bit 31 = stored).
+template <int CODEC, int T, int SPAN>
+__global__ __launch_bounds__(T) void k_bitmap_decode_c(const uint8_t *__restrict__ data, const ZdFrameList *__restrict__ lists,
+                                                         const uint64_t *__restrict__ src_base, const ZdTables *__restrict__ tables,
+                                                         const ZdTables *__restrict__ predef, uint8_t *__restrict__ out,
+                                                         const uint64_t *__restrict__ out_base, uint64_t nb, int *__restrict__ err)
+{
+    __shared__ u32x4 s_span[SPAN / 16];
+    __shared__ ZdTables s_t;
+    __shared__ uint32_t s_pll[64], s_pml[64];
+    __shared__ uint32_t s_llx[36], s_mlx[53];
+    const uint32_t f = blockIdx.y;
+    const uint32_t *__restrict__ offs = reinterpret_cast<const uint32_t *>(lists[f].p);
+    const uint32_t hi = lists[f].n, skips = lists[f].pad;
+    const uint32_t i0 = blockIdx.x * T;
+    if (i0 >= hi) return;
+    const uint32_t tid = threadIdx.x;
+    if (CODEC == 1) {
+        if (tid < 36) s_llx[tid] = c_ll_base[tid] | ((uint32_t)c_ll_bits[tid] << 16);
+        if (tid < 53) s_mlx[tid] = c_ml_base[tid] | ((uint32_t)c_ml_bits[tid] << 16);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + f);
+        for (uint32_t i = tid; i < sizeof(ZdTables) / 4; i += T) reinterpret_cast<uint32_t *>(&s_t)[i] = src[i];
+        if (tid < 64) { s_pll[tid] = predef->ll[tid]; s_pml[tid] = predef->ml[tid]; }
+    }
+    const uint64_t fb = src_base[f];
+    const uint32_t iend = min(i0 + (uint32_t)T, hi);
+    const uint64_t span0 = (fb + offs[i0]) & ~15ull;
+    const uint64_t span_end = fb + offs[iend];
+    const uint32_t staged = (uint32_t)min<uint64_t>((span_end - span0 + 15) & ~15ull, (uint64_t)SPAN);
+    {
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(data + span0);
+        for (uint32_t i = tid; i < staged / 16; i += T) s_span[i] = g[i];
+    }
+    __syncthreads();
+    const uint32_t bi = i0 + tid;
+    if (bi >= hi) return;
+    const uint64_t h0 = fb + offs[bi], h1 = fb + offs[bi + 1];
+    constexpr uint32_t HDR = CODEC == 1 ? 3u : 4u;
+    int e = 0;
+    if (h1 < h0 + HDR) e = 1;
+    const uint32_t regen = (uint32_t)min<uint64_t>((uint64_t)TILE_BM, nb - (uint64_t)bi * TILE_BM);
+    Sink<true> o;
+    o.init(out + out_base[f] + (uint64_t)bi * TILE_BM);
+    const bool in_lds = h0 >= span0 && h1 - span0 <= staged;
+    auto run = [&](const uint8_t *h) -> uint32_t {   // h: the block's header (LDS or global: one instantiation each)
+        ZdBlock b;
+        b.src = h0 + HDR; b.csize = (uint32_t)(h1 - h0) - HDR; b.dst = 0; b.regen = regen; b.frame = f; b.flex = 0;
+        b.tree_skip = (uint8_t)skips; b.seq_skip = (uint8_t)(skips >> 8); b.seq_tables = 2;
+        const uint8_t *c = h + HDR;
+        if (CODEC == 1) {
+            const uint32_t hd = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16);
+            const uint32_t type = (hd >> 1) & 3u, bs = hd >> 3;
+            if (type == 2) {
+                if (bs != b.csize) { e = 1; return 0; }
+                return zstd_block_decode<true>(c, b.csize, b, s_t.huf, s_t.huf_log, s_t.ll, s_t.ll_log, s_t.ml, s_t.ml_log, s_llx, s_mlx, o, regen, &e,
+                                               s_pll, s_pml);
+            }
+            if (bs != regen || b.csize != (type == 1 ? 1u : bs)) { e = 1; return 0; }
+            if (type == 1) { o.fill(c[0], regen); return regen; }
+            for (uint32_t k = 0; k < regen; ++k) o.put(c[k]);
+            return regen;
+        } else {
+            const uint32_t wd = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)h[3] << 24);
+            if ((wd & 0x7FFFFFFFu) != b.csize) { e = 1; return 0; }
+            if (wd >> 31) {
+                if (b.csize != regen) { e = 1; return 0; }
+                for (uint32_t k = 0; k < regen; ++k) o.put(c[k]);
+                return regen;
+            }
+            return lz4_block_decode(c, b.csize, o, regen, &e);
+        }
+    };
+    uint32_t produced = 0;
+    if (!e) produced = in_lds ? run(reinterpret_cast<const uint8_t *>(s_span) + (uint32_t)(h0 - span0)) : run(data + h0);
+    if (produced != regen) e = 1;
+    if (e) *err = 1;
+}
+
 // Raw / RLE blocks (and stored LZ4 blocks) of any size: one wavefront per 4 KiB piece
 __global__ __launch_bounds__(WG) void k_block_copy(const uint8_t *__restrict__ data, const ZdFrameList *__restrict__ lists, uint32_t nlists,
                                                      uint8_t *__restrict__ out, const uint64_t *__restrict__ out_base, uint32_t pieces_per_block)
@@ -359,6 +459,21 @@ void launch_block_decode(int codec, int row, const uint8_t *data, const void *fr
         hipLaunchKernelGGL((k_block_decode<1, false, 64, 55296>), grid(64), dim3(64), 0, s, data, l, t, p, out, out_base, err, produced_out);
     else
         hipLaunchKernelGGL((k_block_decode<2, true, 128, 32768>), grid(128), dim3(128), 0, s, data, l, t, p, out, out_base, err, produced_out);
+}
+// compact lists (k_bitmap_decode_c): codec 1 zstd, 2 LZ4; nb = bytes of one binary map
+void launch_bitmap_decode_compact(int codec, const uint8_t *data, const void *frame_lists, const uint64_t *src_base, uint32_t nframes,
+                                  uint32_t max_blocks_per_frame, const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base,
+                                  uint64_t nb, int *err, hipStream_t s)
+{
+    if (!max_blocks_per_frame) return;
+    const ZdFrameList *l = reinterpret_cast<const ZdFrameList *>(frame_lists);
+    const ZdTables *t = reinterpret_cast<const ZdTables *>(tables), *p = reinterpret_cast<const ZdTables *>(predef);
+    if (codec == 1)
+        hipLaunchKernelGGL((k_bitmap_decode_c<1, 256, 20480>), dim3((max_blocks_per_frame + 255) / 256, nframes), dim3(256), 0, s, data, l, src_base, t, p, out,
+                           out_base, nb, err);
+    else
+        hipLaunchKernelGGL((k_bitmap_decode_c<2, 128, 32768>), dim3((max_blocks_per_frame + 127) / 128, nframes), dim3(128), 0, s, data, l, src_base, t, p, out,
+                           out_base, nb, err);
 }
 // lists: nlists block lists with nblocks entries in all
 void launch_block_copy(const uint8_t *data, const void *lists, uint32_t nlists, uint32_t nblocks, uint32_t max_regen, uint8_t *out,

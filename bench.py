@@ -153,7 +153,7 @@ def cpu_baseline(frames_h, thr_h, depth, scheme):
     }
 
 
-def ingest_inclusive(stack, dark, a, nframes=128):
+def ingest_inclusive(stack, dark, a, nframes=128, validation_frame_gap=-1):
     """Extra, NOT `value`: ReCoDeWriter.run on frames that start in host memory, records appended to a part file on tmpfs
     (the reference's whole writer loop, recode_writer.py:292-428): staging copy + link + kernels + records back + file append."""
     import shutil
@@ -176,7 +176,7 @@ def ingest_inclusive(stack, dark, a, nframes=128):
         best = None
         for _ in range(2):   # first pass warms the staging buffers and the model
             w = ReCoDeWriter("bench_stack.bin", dark_data=dark_h, output_directory=out_dir, input_params=ip, mode="batch", node_id=0,
-                             batch_size=min(32, a.batch))
+                             batch_size=min(32, a.batch), validation_frame_gap=validation_frame_gap)
             w.start()
             t0 = time.perf_counter()
             w.run(data)
@@ -528,6 +528,8 @@ def run_rank(a):
         if world == 1 and not a.no_ingest and a.level in (1, 3):
             try:
                 result["ingest_inclusive"] = ingest_inclusive(stack, dark, a)
+                v = ingest_inclusive(stack, dark, a, validation_frame_gap=10)   # validation frames ride the same stream (recode_writer.py:402-415)
+                result["ingest_inclusive"]["with_validation_frame_gap_10"] = {"frames_per_s": v["frames_per_s"], "gb_per_s_in": v["gb_per_s_in"]}
             except Exception as e:   # an extra: never lets the contract line fail
                 result["ingest_inclusive"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)

@@ -149,7 +149,13 @@ int rc_ctx_wait_results(rc_ctx *ctx, void *hip_stream);
  *                       synchronous inside the HIP runtime
  *   rc_pipe_result      wait for the batch; rec_offsets[n+1], md[n][3], *total = bytes of the n records.  Returns the batch's
  *                       status (RC_ERR_RECORD_TOO_LARGE, ...)
- *   rc_pipe_fetch       start copying the records (bytes <= *total) into dst_host; rc_pipe_fetch_wait waits for it */
+ *   rc_pipe_fetch       start copying the records (bytes <= *total) into dst_host; rc_pipe_fetch_wait waits for it
+ *   rc_ctx_set_validation  validation frames on this path (pyrecode/recode_writer.py:402-415): for every frame of a submitted batch
+ *                       whose absolute id is a multiple of `gap`, the 8-connected components of the binary map inside the region
+ *                       [x0, x0 + w) x [y0, y0 + h) (<= 128 x 128: the reference's central ROI) are counted on the device, from the
+ *                       frame the reduce kernel has just read.  gap 0 switches it off.
+ *   rc_pipe_validation  counts[n] of the slot's batch (between rc_pipe_submit and rc_pipe_fetch_wait); 0xFFFFFFFF = not a
+ *                       validation frame.  dose rate = count / (w * h), as in the reference */
 #define RC_PIPE_SLOTS 3
 void *rc_host_alloc(uint64_t bytes);
 int rc_host_free(void *p);
@@ -160,6 +166,8 @@ int rc_pipe_input_done(rc_ctx *ctx, uint32_t slot);
 int rc_pipe_result(rc_ctx *ctx, uint32_t slot, uint64_t *rec_offsets, uint32_t *md, uint64_t *total);
 int rc_pipe_fetch(rc_ctx *ctx, uint32_t slot, uint8_t *dst_host, uint64_t bytes);
 int rc_pipe_fetch_wait(rc_ctx *ctx, uint32_t slot);
+int rc_ctx_set_validation(rc_ctx *ctx, uint32_t gap, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
+int rc_pipe_validation(rc_ctx *ctx, uint32_t slot, uint32_t *counts);
 
 /* zstd, modelled encoder (compression_level >= 1): the ctx fits its entropy tables to a sample of the FIRST batch it sees and
  * keeps them (every frame carries the tables it was coded with, so any model is valid for any data - only the ratio suffers when

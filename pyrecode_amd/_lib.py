@@ -57,6 +57,8 @@ SIGNATURES = {
     "rc_pipe_result": (C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u32p, C.POINTER(C.c_uint64)]),
     "rc_pipe_fetch": (C.c_int, [C.c_void_p, C.c_uint32, _u8p, C.c_uint64]),
     "rc_pipe_fetch_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rc_ctx_set_validation": (C.c_int, [C.c_void_p] + [C.c_uint32] * 5),
+    "rc_pipe_validation": (C.c_int, [C.c_void_p, C.c_uint32, _u32p]),
     "rc_compress": (C.c_int, [C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rc_decompress": (C.c_int, [C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rc_compress_bound": (C.c_uint64, [C.c_uint32, C.c_uint64]),
@@ -246,6 +248,16 @@ class ReduceContext:
 
     def pipe_fetch_wait(self, slot):
         check(lib().rc_pipe_fetch_wait(self._h, slot), "rc_pipe_fetch_wait")
+
+    def set_validation(self, gap, x0=0, y0=0, w=0, h=0):
+        """Validation frames on the streaming path: count the ROI's connected components on the device (include/recode_hip.h)."""
+        check(lib().rc_ctx_set_validation(self._h, int(gap), int(x0), int(y0), int(w), int(h)), "rc_ctx_set_validation")
+
+    def pipe_validation(self, slot, n):
+        """uint32[n]: component count of the ROI per frame of the slot's batch, 0xFFFFFFFF where the frame is no validation frame."""
+        counts = np.zeros(n, np.uint32)
+        check(lib().rc_pipe_validation(self._h, slot, ptr(counts)), "rc_pipe_validation")
+        return counts
 
     def refit_model(self):
         """zstd, modelled encoder: fit the entropy tables again to the next batch (include/recode_hip.h)."""

@@ -143,12 +143,15 @@ struct rc_ctx {
         uint64_t *d_rec = nullptr, *h_rec = nullptr;
         uint32_t *d_md = nullptr, *h_md = nullptr;
         rc::BatchStatus *h_stat = nullptr;
-        hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_fetch = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_fetch = nullptr, ev_val = nullptr;
+        uint32_t *d_val = nullptr, *h_val = nullptr;   // validation frames: component counts of the ROI (0xFFFFFFFF: not a validation frame)
+        bool has_val = false;
         uint32_t n = 0;
         bool zero_copy = false;
         int state = 0;   // 0 free, 1 submitted, 2 result taken, 3 fetching
     } pipe[RC_PIPE_SLOTS];
     hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
+    uint32_t val_gap = 0, val_x0 = 0, val_y0 = 0, val_w = 0, val_h = 0;   // rc_ctx_set_validation
     std::vector<hipEvent_t> prof_ev;   // 5 events per enqueued batch, in enqueue order
     size_t prof_used = 0;              // events consumed since the last rc_ctx_sync
     double prof_sum_ms[5] = {};
@@ -393,11 +396,11 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
             if (b) (void)hipFree(b);
     }
     for (auto &p : c->pipe) {
-        void *dev[] = {p.d_in, p.d_out, p.d_rec, p.d_md};
+        void *dev[] = {p.d_in, p.d_out, p.d_rec, p.d_md, p.d_val};
         for (void *b : dev) if (b) (void)hipFree(b);
-        void *host[] = {p.h_rec, p.h_md, p.h_stat};
+        void *host[] = {p.h_rec, p.h_md, p.h_stat, p.h_val};
         for (void *b : host) if (b) (void)hipHostFree(b);
-        hipEvent_t evs[] = {p.ev_h2d, p.ev_done, p.ev_fetch};
+        hipEvent_t evs[] = {p.ev_h2d, p.ev_done, p.ev_fetch, p.ev_val};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
@@ -763,6 +766,29 @@ static int pipe_slot_init(rc_ctx *c, rc_ctx::PipeSlot &p)
     HIP_TRY(hipEventCreateWithFlags(&p.ev_h2d, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p.ev_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p.ev_fetch, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_val, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&p.d_val, B * 4 + 64));
+    HIP_TRY(hipHostMalloc((void **)&p.h_val, B * 4 + 64, hipHostMallocDefault));
+    return RC_OK;
+}
+
+RC_EXPORT int rc_ctx_set_validation(rc_ctx *c, uint32_t gap, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    if (gap && (w == 0 || h == 0 || w > 128 || h > 128 || (uint64_t)x0 + w > c->nx || (uint64_t)y0 + h > c->ny))
+        return fail(RC_ERR_BAD_ARG, "rc_ctx_set_validation: the region must lie inside the frame and hold at most 128 x 128 pixels");
+    c->val_gap = gap; c->val_x0 = x0; c->val_y0 = y0; c->val_w = w; c->val_h = h;
+    return RC_OK;
+}
+
+RC_EXPORT int rc_pipe_validation(rc_ctx *c, uint32_t slot, uint32_t *counts)
+{
+    if (!c || slot >= RC_PIPE_SLOTS || !counts) return fail(RC_ERR_BAD_ARG, "NULL argument / slot out of range");
+    rc_ctx::PipeSlot &p = c->pipe[slot];
+    if (p.state != 1 && p.state != 2) return fail(RC_ERR_BAD_ARG, "nothing submitted on this slot");
+    if (!p.has_val) { for (uint32_t i = 0; i < p.n; ++i) counts[i] = 0xFFFFFFFFu; return RC_OK; }
+    HIP_TRY(hipEventSynchronize(p.ev_val));
+    memcpy(counts, p.h_val, (uint64_t)p.n * 4);
     return RC_OK;
 }
 
@@ -803,7 +829,14 @@ RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const uint16_t *frames_ho
     }
     int r = enqueue_batch(c, fdev, n, first_frame_id, p.d_out, rc_out_capacity(c, c->max_batch), p.d_rec, p.d_md, false);
     if (r != RC_OK) return r;
-    if (p.zero_copy) HIP_TRY(hipEventRecord(p.ev_h2d, c->stream));   // "input consumed" = the reduce kernel has run
+    p.has_val = c->val_gap != 0;
+    if (p.has_val) {   // validation frames of this batch: the dose-rate count, from the frames the reduce kernel has just read
+        rc::launch_roi_components(fdev, c->sc.thr, c->sc.N, c->nx, n, first_frame_id, c->val_gap, c->val_x0, c->val_y0, c->val_w, c->val_h, p.d_val, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(p.h_val, p.d_val, (uint64_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(p.ev_val, c->stream));
+    }
+    if (p.zero_copy) HIP_TRY(hipEventRecord(p.ev_h2d, c->stream));   // "input consumed" = the reduce kernel (and the count) have run
     hipStream_t ps = c->pstream;   // carries the batch's assembly: the metadata follows it
     HIP_TRY(hipMemcpyAsync(p.h_rec, p.d_rec, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, ps));
     HIP_TRY(hipMemcpyAsync(p.h_md, p.d_md, (uint64_t)n * 12, hipMemcpyDeviceToHost, ps));
@@ -1014,6 +1047,7 @@ struct ReadRes {
     PinnedVec<uint32_t> rd_off[RC_READ_THREADS];           // compact lists of uniform binary-map streams: one header offset per block (k_bitmap_decode_c)
     uint8_t *rd_head = nullptr; uint64_t rd_head_cap = 0;  // page-locked: decoding tables + per-frame index arrays
     uint64_t *h_res = nullptr; uint64_t h_res_cap = 0;     // page-locked: nnz prefix (n + 1) and the error word, as the device left them
+    uint8_t *h_blob = nullptr; uint64_t h_blob_cap = 0;    // page-locked: host copy of a DEVICE-resident input, for the header walk
     // a submitted batch waiting for its rc_expand_frames_wait
     bool pending = false;
     uint32_t n = 0, level = 0, bit_depth = 0;
@@ -1270,6 +1304,20 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     uint32_t *d_blk_cnt = reinterpret_cast<uint32_t *>(u.x[5]), *d_blk_off = d_blk_cnt + (uint64_t)n * nblk;
     uint64_t *d_fnnz = reinterpret_cast<uint64_t *>(d_blk_off + (uint64_t)n * nblk), *d_fbase = d_fnnz + n;
     int *d_err = reinterpret_cast<int *>(d_fbase + n + 1);
+    // The header walk below runs on the host.  Bytes that lie in device memory are fetched once into page-locked memory for it (the
+    // host CAN read device memory through the PCIe aperture, a few hundred MB/s: 187 ms for 34 MB); the decoders read them where they are.
+    const uint8_t *walk = data;
+    if (is_device_ptr(data)) {
+        if (u.h_blob_cap < total_in + 64) {
+            if (u.h_blob) HIP_TRY(hipHostFree(u.h_blob));
+            u.h_blob = nullptr; u.h_blob_cap = 0;
+            HIP_TRY(hipHostMalloc((void **)&u.h_blob, total_in + 64 + total_in / 4, hipHostMallocDefault));
+            u.h_blob_cap = total_in + 64 + total_in / 4;
+        }
+        HIP_TRY(hipMemcpyAsync(u.h_blob, data, total_in, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        walk = u.h_blob;
+    }
     if (copy_in) HIP_TRY(hipMemcpyAsync(u.x[0], data, total_in, hipMemcpyDefault, s));
     HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, s));   // bitmap padding and value-stream tails read as zero
     HIP_TRY(hipMemsetAsync(d_err, 0, 4, s));
@@ -1336,12 +1384,12 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
                 if (npk) { b.src = o + cb; b.csize = b.regen = (uint32_t)npk; b.frame = n + f; RAW.push_back(b); }
             } else if (codec == 2) {
                 all.clear();
-                rr = lz4_index_frame(data, o, cb, f, TILE_BM, nb, all, all, &got);
+                rr = lz4_index_frame(walk, o, cb, f, TILE_BM, nb, all, all, &got);
                 if (rr == ZD_OK && got != nb) rr = ZD_CORRUPT;
                 if (rr == ZD_OK) route_bitmap(F, o, cb, 4, true);
                 if (rr == ZD_OK && level == 1) {
                     all.clear();   // (a value stream holds stored chunks only: a compressed block there is outside the subset)
-                    rr = lz4_index_frame(data, o + cb, cp, n + f, 0, npk, all, RAW, &got);
+                    rr = lz4_index_frame(walk, o + cb, cp, n + f, 0, npk, all, RAW, &got);
                     if (rr == ZD_OK && got != npk) rr = ZD_CORRUPT;
                 }
             } else {
@@ -1361,11 +1409,11 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
                 };
                 Route rp{PV, RAW, true, f};
                 all.clear();
-                rr = zd_index_frame(data, o, cb, f, TILE_BM, nb, all, bm_tab[f], &got);
+                rr = zd_index_frame(walk, o, cb, f, TILE_BM, nb, all, bm_tab[f], &got);
                 if (rr == ZD_OK && got != nb) rr = ZD_CORRUPT;
                 if (rr == ZD_OK) route_bitmap(F, o, cb, 3, !(bm_tab[f].has & 4u));
                 if (rr == ZD_OK && level == 1) {
-                    rr = zd_index_frame(data, o + cb, cp, n + f, 0, npk, rp, pv_tab[f], &got);
+                    rr = zd_index_frame(walk, o + cb, cp, n + f, 0, npk, rp, pv_tab[f], &got);
                     if (rr == ZD_OK && got != npk) rr = ZD_CORRUPT;
                     if (rr == ZD_OK && rp.too_long) rr = ZD_FOREIGN;
                 }

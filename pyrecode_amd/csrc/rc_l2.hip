@@ -203,4 +203,71 @@ void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint
     hipLaunchKernelGGL(k_l2_emit, dim3(B), dim3(L2_T), 0, s, sc, w);
 }
 
+// ---- validation frames (reference recode_writer.py:402-415): the dose-rate count on the streaming path ---------------------
+// Every validation_frame_gap-th frame the reference counts the 8-connected components of the binary map inside the central
+// ROI (at most 128 x 128 pixels) with scipy.ndimage.label.  Here one workgroup per selected frame of the batch binarises the
+// ROI straight from the frame (frame > thr, the pixels the reduce kernel has just read), labels it in LDS by minimum
+// propagation over the 8 neighbours (plus one pointer jump per sweep) until nothing changes (a component's label converges to its smallest pixel index + 1:
+// monotone, so unsynchronised in-place updates reach the same fixed point), and counts the pixels that kept their own
+// label.  counts[i] = 0xFFFFFFFF for frames that are not validation frames.
+constexpr int ROI_MAX = 128, ROI_T = 256;
+__global__ __launch_bounds__(ROI_T) void k_roi_components(const uint16_t *__restrict__ frames, const uint16_t *__restrict__ thr, uint64_t N,
+                                                           uint32_t nx, uint32_t first_frame_id, uint32_t gap, uint32_t x0, uint32_t y0,
+                                                           uint32_t w, uint32_t h, uint32_t *__restrict__ counts)
+{
+    __shared__ uint16_t lab[(ROI_MAX + 2) * (ROI_MAX + 2)];   // one cell of zero border all round
+    __shared__ uint32_t s_cnt;
+    const uint32_t i = blockIdx.x;
+    if ((first_frame_id + i) % gap != 0) { if (threadIdx.x == 0) counts[i] = 0xFFFFFFFFu; return; }
+    const uint16_t *fr = frames + (uint64_t)i * N;
+    const uint32_t W = w + 2;
+    for (uint32_t k = threadIdx.x; k < (h + 2) * W; k += ROI_T) lab[k] = 0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < w * h; k += ROI_T) {
+        const uint32_t yy = k / w, xx = k - yy * w;
+        const uint64_t p = (uint64_t)(y0 + yy) * nx + (x0 + xx);
+        if (fr[p] > thr[p]) lab[(yy + 1) * W + xx + 1] = (uint16_t)(k + 1);
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < (uint32_t)ROI_MAX * ROI_MAX; ++it) {   // (a component's diameter bounds the sweeps)
+        int changed = 0;
+        for (uint32_t k = threadIdx.x; k < w * h; k += ROI_T) {
+            const uint32_t yy = k / w, xx = k - yy * w;
+            const uint32_t c = (yy + 1) * W + xx + 1;
+            const uint32_t own = lab[c];
+            if (!own) continue;
+            uint32_t m = own;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const uint32_t v = lab[(int)c + dy * (int)W + dx];
+                    if (v && v < m) m = v;
+                }
+            {   // pointer jumping: a label names a pixel; that pixel's own label is at least as good (long thin components
+                // then converge in about log(length) sweeps instead of length)
+                const uint32_t q = m - 1, qy = q / w, qx = q - qy * w;
+                const uint32_t v = lab[(qy + 1) * W + qx + 1];
+                if (v && v < m) m = v;
+            }
+            if (m < own) { lab[c] = (uint16_t)m; changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    uint32_t roots = 0;
+    for (uint32_t k = threadIdx.x; k < w * h; k += ROI_T) {
+        const uint32_t yy = k / w, xx = k - yy * w;
+        roots += lab[(yy + 1) * W + xx + 1] == k + 1 ? 1u : 0u;
+    }
+    atomicAdd(&s_cnt, roots);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[i] = s_cnt;
+}
+void launch_roi_components(const uint16_t *frames, const uint16_t *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
+                           uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t *counts, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_roi_components, dim3(n), dim3(ROI_T), 0, s, frames, thr, N, nx, first_frame_id, gap, x0, y0, w, h, counts);
+}
+
 }  // namespace rc

@@ -110,4 +110,6 @@ void launch_zstd_gather(const Scratch &sc, uint8_t *out, hipStream_t s);
 size_t zstd_tables_bytes();
 void zstd_tables_host(void *dst);  // rc_reduce.hip: FLG | BD << 8 | HC << 16
 
+void launch_roi_components(const uint16_t *frames, const uint16_t *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
+                           uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t *counts, hipStream_t s);
 }  // namespace rc

@@ -156,8 +156,8 @@ class ReCoDeWriter:
         self._ctx.set_dark(np.ascontiguousarray(self._calibration_frame), ip.calibration_threshold_epsilon)
         if ip.reduction_level == 2:
             self._ctx.set_l2_statistics(ip.L2_statistics)  # 0/1 max, 2 sum (reference :358-365)
-        # raw binary maps are only consumed for validation frames (reference :402-415); skip the extra HBM write otherwise
-        self._keep_maps = init.validation_frame_gap > 0
+        # raw binary maps are only written for the per-frame seam (_reduce_compress returns one); validation frames no longer need them
+        self._keep_maps = False
         self._ctx.keep_binary_maps(self._keep_maps)
         self._host_compress = ip.rc_operation_mode == 1 and not self._ctx.on_device_codec
         self._out = np.empty(self._ctx.out_capacity(self._batch_size), np.uint8)
@@ -172,8 +172,10 @@ class ReCoDeWriter:
         self._vc_roi['x_start'] = math.floor((nx - self._vc_roi['nx']) / 2.0)
         self._vc_roi['y_start'] = math.floor((ny - self._vc_roi['ny']) / 2.0)
         self._vc_n_pixels = self._vc_roi['nx'] * self._vc_roi['ny']
-        if init.validation_frame_gap <= 0:
-            self._alloc_staging()
+        if init.validation_frame_gap > 0:
+            self._ctx.set_validation(init.validation_frame_gap, self._vc_roi['x_start'], self._vc_roi['y_start'],
+                                     self._vc_roi['nx'], self._vc_roi['ny'])
+        self._alloc_staging()
 
     def _do_sanity_checks(self, is_first_chunk, data=None):
         ip = self._input_params
@@ -247,27 +249,11 @@ class ReCoDeWriter:
         run_metrics['run_data_read_time'] = datetime.now() - stt
 
         run_start = datetime.now()
-        gap = init.validation_frame_gap
-        if gap > 0:
-            # validation frames need every batch's binary maps on the host: the synchronous path
-            for lo in range(0, available_frames, self._batch_size):
-                batch = np.ascontiguousarray(data[lo:lo + self._batch_size])
-                first_id = self._chunk_offset + frame_offset + lo
-                records, metrics = self._reduce_compress_batch(batch, first_id)
-                for rec in records:
-                    if self._buffer_sz - len(self._rct_buffer) < len(rec):
-                        self._offload_buffer()
-                    self._note_host_record(self._intermediate_file.tell() + len(self._rct_buffer), rec)
-                    self._rct_buffer += rec
-                for i in range(batch.shape[0]):
-                    if (first_id + i) % gap == 0:
-                        self._validation_file.write(batch[i].tobytes())
-                        run_metrics.setdefault('run_dose_rates', []).append(self._count_validation_frame(i))
-                for key, value in metrics.items():
-                    run_metrics[key] = run_metrics[key] + value if key in run_metrics else value
-        else:
-            for key, value in self._run_streamed(data, available_frames, self._chunk_offset + frame_offset).items():
-                run_metrics[key] = value
+        # One path for every run: batches stream through the device (rc_pipe_*).  Validation frames (reference :402-415) ride
+        # along: the raw frame goes to the validation file from the source array, the dose-rate count of its ROI comes from
+        # the device with the batch's sizes (rc_ctx_set_validation / rc_pipe_validation).
+        for key, value in self._run_streamed(data, available_frames, self._chunk_offset + frame_offset).items():
+            run_metrics[key] = value
         self._chunk_offset += n_frames_in_chunk
         self._num_frames_in_part += available_frames
         run_metrics['run_time'] = datetime.now() - run_start
@@ -333,9 +319,17 @@ class ReCoDeWriter:
                                range(0, n, step)))
             return view
 
+        gap = self._init_params.validation_frame_gap
+        dose_rates = []
+
         def append(i):  # (writer thread) batch i's records: page-locked buffer -> part file
             ctx.pipe_fetch_wait(i % slots)
-            n, rec, md, total = info[i]
+            n, rec, md, total, counts = info[i]
+            if counts is not None:   # validation frames of this batch, in frame order (reference :402-415)
+                for k in np.nonzero(counts != 0xFFFFFFFF)[0]:
+                    self._validation_file.write(np.ascontiguousarray(data[i * B + int(k)]).tobytes())
+                    self._vc_dose_rate = int(counts[k]) / self._vc_n_pixels
+                    dose_rates.append(self._vc_dose_rate)
             buf = self._pin_out[i % slots].array
             pos = self._intermediate_file.tell()
             if self._host_compress:
@@ -359,13 +353,13 @@ class ReCoDeWriter:
                     frames = staged[i].result()
                     n = frames.shape[0]
                     ctx.pipe_submit(i % slots, frames, n, first_id + i * B)
-                    info[i] = [n, None, None, 0]
+                    info[i] = [n, None, None, 0, None]
                     if i + n_in - 1 < nbatch:
                         staged[i + n_in - 1] = stager.submit(stage, i + n_in - 1)
                 if 0 <= i - 1 < nbatch:   # batch i-1 has been computed: sizes known, start copying its records out
                     j = i - 1
                     rec, md, total = ctx.pipe_result(j % slots, info[j][0])
-                    info[j][1:] = [rec, md, total]
+                    info[j][1:] = [rec, md, total, ctx.pipe_validation(j % slots, info[j][0]) if gap > 0 else None]
                     buf = self._pin_out[j % slots]
                     if total > buf.nbytes:
                         buf.close()
@@ -383,18 +377,9 @@ class ReCoDeWriter:
         self._intermediate_file.flush()
         metrics['frame_time'] = datetime.now() - t_run
         metrics['frame_thresholding_and_counting_time'] = metrics['frame_time']   # one fused, overlapped stream: not separable
+        if dose_rates:
+            metrics['run_dose_rates'] = dose_rates
         return metrics
-
-    def _count_validation_frame(self, i):
-        """Dose-rate estimate on the central ROI of frame i's binary map (reference :402-415)."""
-        import scipy.ndimage as nd
-        nx, ny = int(self._header['nx']), int(self._header['ny'])
-        bits = np.unpackbits(self._ctx.binary_map(i), bitorder='little')[:nx * ny].reshape(ny, nx)
-        r = self._vc_roi
-        roi = bits[r['y_start']:r['y_start'] + r['ny'], r['x_start']:r['x_start'] + r['nx']]
-        _, num_features = nd.label(roi, structure=nd.generate_binary_structure(2, 2))
-        self._vc_dose_rate = num_features / self._vc_n_pixels
-        return self._vc_dose_rate
 
     def _reduce_compress_batch(self, frames, first_frame_id):
         """n frames -> list of n record byte strings + metrics summed over the batch (device stage times)."""

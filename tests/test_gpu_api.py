@@ -496,3 +496,55 @@ def test_reference_minimal_read_write_test_at_its_own_size(tmp_path, orc):
     for node, ids in ((0, [0, 2]), (1, [4]), (2, [6, 8])):
         v = np.fromfile(tmp_path / ("test_data_part%03d_validation_frames.bin" % node), np.uint16).reshape(-1, 512, 512)
         assert v.shape[0] == len(ids) and all(np.array_equal(v[k], data[z]) for k, z in enumerate(ids))
+
+
+def test_validation_frames_ride_the_streaming_path(tmp_path, orc):
+    """validation_frame_gap > 0 (reference recode_writer.py:402-415) no longer leaves the streaming writer: raw frames go to the
+    validation file, the ROI's component count comes from the device (rc_pipe_validation) - compared with scipy.ndimage.label
+    on clustered frames, a frame whose ROI holds ONE long spiral (many propagation sweeps), an empty and a full ROI, with
+    batches that start at ids which are not multiples of the gap; the records are the ones written without validation."""
+    import scipy.ndimage as nd
+    from pyrecode_amd import synth
+    from pyrecode_amd.params import InputParams
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    ny, nx, nz, gap = 200, 300, 11, 3
+    dark = synth.dark_frame(5, ny * nx).reshape(ny, nx)
+    data = synth.frames_clustered(5, 0, nz, nx, ny, 30000, dark).reshape(nz, ny, nx)
+    y0, x0 = (ny - 128) // 2, (nx - 128) // 2
+    roi = np.zeros((128, 128), bool)                        # frame 3: ONE serpentine component, ~8000 pixels end to end
+    roi[0::2, :] = True
+    for r in range(1, 127, 2):
+        roi[r, 127 if (r // 2) % 2 == 0 else 0] = True
+    data[3] = dark // 2
+    data[3, y0:y0 + 128, x0:x0 + 128][roi] = dark[y0:y0 + 128, x0:x0 + 128][roi] + 9
+    data[6] = dark // 2                                      # empty ROI
+    data[9] = (dark + 1).astype(np.uint16)                   # every pixel set: one component
+    ip = InputParams()
+    ip._param_map.update(dict(reduction_level=1, rc_operation_mode=1, calibration_threshold_epsilon=0, target_bit_depth=12,
+                              source_bit_depth=12, num_cols=nx, num_rows=ny, num_frames=nz, frame_offset=0, num_calibration_frames=1,
+                              calibration_frame_offset=0, keep_part_files=1, num_threads=1, l2_statistics=0, l4_centroiding=0,
+                              compression_scheme=2, compression_level=1, source_file_type=0, source_header_length=0,
+                              keep_calibration_data=0, calibration_file_type=0, source_data_type=0, target_data_type=0))
+    parts = {}
+    for tag, g in (("with", gap), ("without", -1)):
+        out = tmp_path / tag
+        out.mkdir()
+        w = ReCoDeWriter("stack.bin", dark_data=dark, output_directory=str(out), input_params=ip, mode="batch", validation_frame_gap=g,
+                         node_id=0, batch_size=4)
+        w.start()
+        m = w.run(data)
+        w.close()
+        parts[tag] = (out / "stack.rc1_part000").read_bytes()
+        if g > 0:
+            ids = [z for z in range(nz) if z % gap == 0]
+            want = []
+            for z in ids:
+                r = data[z, y0:y0 + 128, x0:x0 + 128] > dark[y0:y0 + 128, x0:x0 + 128]
+                want.append(nd.label(r, structure=nd.generate_binary_structure(2, 2))[1] / (128 * 128))
+            assert list(m["run_dose_rates"]) == want
+            assert want[1] == 1 / (128 * 128) and want[2] == 0 and want[3] == 1 / (128 * 128)
+            v = np.fromfile(out / "stack_part000_validation_frames.bin", np.uint16).reshape(-1, ny, nx)
+            assert v.shape[0] == len(ids) and all(np.array_equal(v[k], data[z]) for k, z in enumerate(ids))
+        else:
+            assert "run_dose_rates" not in m
+    assert parts["with"] == parts["without"]

@@ -76,6 +76,60 @@ def _zstd_host_decompress(data, decompressor_context=None):
     return bytes(out)
 
 
+def _lz4_host_decompress(data):
+    """LZ4 frame -> bytes with the stock decoder: the `lz4` package when installed (the reference's dependency,
+    recode_compressors.py:49), else liblz4's LZ4F streaming API through ctypes.  None: neither is available."""
+    if _optional('lz4') is not None:
+        import lz4.frame
+        return lz4.frame.decompress(bytes(data))
+    import ctypes.util
+    name = ctypes.util.find_library('lz4')
+    if not name:
+        return None
+    L = C.CDLL(name)
+    L.LZ4F_createDecompressionContext.restype = C.c_size_t
+    L.LZ4F_createDecompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    L.LZ4F_freeDecompressionContext.argtypes = [C.c_void_p]
+    L.LZ4F_decompress.restype = C.c_size_t
+    L.LZ4F_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
+    L.LZ4F_isError.argtypes = [C.c_size_t]
+    ctx = C.c_void_p()
+    if L.LZ4F_isError(L.LZ4F_createDecompressionContext(C.byref(ctx), 100)):
+        return None
+    src = np.frombuffer(memoryview(data), np.uint8)
+    out, chunk, pos = bytearray(), C.create_string_buffer(1 << 20), 0
+    try:
+        while pos < src.size:
+            dn, sn = C.c_size_t(len(chunk)), C.c_size_t(src.size - pos)
+            r = L.LZ4F_decompress(ctx, chunk, C.byref(dn), src.ctypes.data + pos, C.byref(sn), None)
+            if L.LZ4F_isError(r):
+                raise ValueError("liblz4 rejected the stream")
+            out += chunk.raw[:dn.value]
+            pos += sn.value
+            if r == 0:
+                break
+            if sn.value == 0 and dn.value == 0:
+                raise ValueError("truncated LZ4 frame")
+    finally:
+        L.LZ4F_freeDecompressionContext(ctx)
+    return bytes(out)
+
+
+def host_stream_decoder(scheme):
+    """bytes-like -> bytes through the STOCK library for a scheme whose foreign streams the device decoders refuse (1 zstd, 2 LZ4);
+    None when no stock decoder can be had.  Thread-safe: every call builds its own decoding context."""
+    import ctypes.util
+    if scheme == 1:
+        if _optional('zstandard') is None and not ctypes.util.find_library('zstd'):
+            return None
+        return lambda b: _zstd_host_decompress(b)
+    if scheme == 2:
+        if _optional('lz4') is None and not ctypes.util.find_library('lz4'):
+            return None
+        return lambda b: _lz4_host_decompress(b)
+    return None
+
+
 def _as_u8(data):
     return np.frombuffer(memoryview(data), dtype=np.uint8)
 

@@ -267,6 +267,12 @@ class ReCoDeReader:
             # the file is really damaged.
             if st not in (_lib.RC_ERR_UNSUPPORTED, _lib.RC_ERR_CORRUPT):
                 _lib.check(st, 'rc_expand_frames')
+            if mode == 1:
+                res = self._foreign_batch_triplets(z0, n, blob, sizes)
+                if res is not None:
+                    self._current_frame_index = z0 + n
+                    self.last_batch_path = 'host-decode + device-expand'
+                    return res
         # per-frame path
         self.last_batch_path = 'per-frame'  
         parts, prefix = [], np.zeros(n + 1, np.uint64)
@@ -278,6 +284,56 @@ class ReCoDeReader:
             parts.append(t)
             prefix[i + 1] = prefix[i] + t.shape[0]
         return prefix, np.concatenate(parts) if parts else np.zeros((0, 3), np.uint64)
+
+    def _foreign_batch_triplets(self, z0, n, blob, sizes):
+        """Streams a FOREIGN encoder wrote (the reference's own files: lz4.frame with linked 64 KiB blocks, libzstd with 4-stream
+        literals and real offsets) are serial chains of some 10^5 dependent steps per frame - the stock decoder on a CPU core
+        walks one in about a millisecond, a GPU lane needs ~1 us per step ("Foreign streams").  So they are decoded
+        by the SAME library calls the reference makes (recode_compressors.py:46-49), all 2 n streams of the batch at once on a
+        thread pool (the libraries release the GIL), into the stored-pieces layout of a mode-0 file, and ONE device call expands
+        them (rc_expand_frames, op_mode 0).  None: a stock decoder is not available or rejected a stream (the per-frame path
+        then reports it)."""
+        from concurrent.futures import ThreadPoolExecutor
+        h = self._header
+        level, scheme = int(h['reduction_level']), int(h['compression_scheme'])
+        nb = self._structures.binary_image_sz_bytes
+        dec = compressors.host_stream_decoder(scheme)
+        if dec is None:
+            return None
+        spans, off = [], 0
+        for i in range(n):
+            spans.append((off, int(sizes[i, 0])))
+            off += int(sizes[i, 0])
+            if level == 1:
+                spans.append((off, int(sizes[i, 1])))
+                off += int(sizes[i, 1])
+        view = memoryview(blob)
+        try:
+            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+                parts = list(pool.map(lambda sp: dec(view[sp[0]:sp[0] + sp[1]]), spans))
+        except Exception:
+            return None
+        per = 2 if level == 1 else 1
+        sizes0 = np.zeros((n, 3), np.uint32)
+        for i in range(n):
+            if len(parts[per * i]) != nb or (level == 1 and len(parts[2 * i + 1]) != int(sizes[i, 2])):
+                return None
+            sizes0[i, 0] = nb
+            if level == 1:
+                sizes0[i, 1] = sizes0[i, 2] = int(sizes[i, 2])
+        pieces = np.frombuffer(b''.join(parts), np.uint8)
+        L = _lib.lib()
+        prefix = np.zeros(n + 1, np.uint64)
+        args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, 0, scheme, _lib.ptr(pieces), _lib.ptr(sizes0), n)
+        if level == 1:
+            d = int(h['target_bit_depth'])
+            cap = max(int((sizes0[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
+        else:
+            _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
+            cap = max(int(prefix[n]), 1)
+        trip = np.empty((cap, 3), np.uint64)
+        _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), cap), 'rc_expand_frames')
+        return prefix, trip[:int(prefix[n])]
 
     def iter_frames_triplets(self, z0=0, n=None, batch=64):
         """Streams frames z0 .. z0+n-1 of a merged file through the batched device reader, two batches in flight
@@ -339,14 +395,15 @@ class ReCoDeReader:
         def finish(job):
             a, k, slot, cap = job
             if cap is None:
-                return (a,) + self.get_frames_triplets(a, k)
+                return (a,) + self.get_frames_triplets(a, k)       # (sets last_batch_path itself)
             prefix = np.zeros(k + 1, np.uint64)
             st = L.rc_expand_frames_wait(slot, _lib.ptr(prefix))
-            if st == _lib.RC_ERR_CORRUPT:                     # the stock decoder is the judge (per-frame path)
+            if st == _lib.RC_ERR_CORRUPT:                     # the stock decoder is the judge
                 return (a,) + self.get_frames_triplets(a, k)
             _lib.check(st, 'rc_expand_frames_wait')
             total = int(prefix[k])
             trip = bufs[2 + slot].array[:total * 24].view(np.uint64).reshape(total, 3)
+            self.last_batch_path = 'device'
             return a, prefix, trip
         queued = None        # a batch submitted and not yet waited for
         try:
@@ -355,7 +412,6 @@ class ReCoDeReader:
                 job = queued
                 queued = submit(i + 1) if i + 1 < len(starts) else None
                 res = finish(job)
-                self.last_batch_path = 'device' if job[3] is not None else 'per-frame'
                 self._current_frame_index = job[0] + job[1]
                 yield res
         finally:

@@ -4,6 +4,7 @@ import ctypes as C
 import ctypes.util
 import os
 import shutil
+import struct
 
 import numpy as np
 import pytest
@@ -548,3 +549,80 @@ def test_validation_frames_ride_the_streaming_path(tmp_path, orc):
         else:
             assert "run_dose_rates" not in m
     assert parts["with"] == parts["without"]
+
+
+def _stock_encoders():
+    """{scheme: bytes -> stock-encoded frame} through the system libraries (ctypes), as the reference's packages would write them:
+    libzstd level 1 (4-stream literals, real offsets, 128 KiB blocks), liblz4 frames with default preferences (linked 64 KiB blocks)."""
+    enc = {}
+    name = ctypes.util.find_library("zstd")
+    if name:
+        z = C.CDLL(name)
+        z.ZSTD_compress.restype = C.c_size_t
+        z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        z.ZSTD_compressBound.restype = C.c_size_t
+        z.ZSTD_compressBound.argtypes = [C.c_size_t]
+
+        def zenc(b):
+            dst = C.create_string_buffer(z.ZSTD_compressBound(len(b)) + 64)
+            n = z.ZSTD_compress(dst, len(dst), b, len(b), 1)     # (before dst.raw is taken: that is a copy)
+            return dst.raw[:n]
+        enc[1] = zenc
+    name = ctypes.util.find_library("lz4")
+    if name:
+        lz = C.CDLL(name)
+        lz.LZ4F_compressFrameBound.restype = C.c_size_t
+        lz.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+        lz.LZ4F_compressFrame.restype = C.c_size_t
+        lz.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+
+        def lenc(b):
+            dst = C.create_string_buffer(lz.LZ4F_compressFrameBound(len(b), None) + 64)
+            n = lz.LZ4F_compressFrame(dst, len(dst), b, len(b), None)
+            return dst.raw[:n]
+        enc[2] = lenc
+    return enc
+
+
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_files_a_stock_encoder_wrote_take_the_batched_path(scheme, tmp_path, orc):
+    """A merged file whose streams the STOCK libraries encoded (what the reference's writer produces with zstandard / lz4.frame):
+    the device decoders refuse them, and the batch is decoded by the stock library on a thread pool and expanded by ONE device
+    call - not frame by frame.  Sequential batches, the streaming iterator and single frames all give the oracle's triplets."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    enc = _stock_encoders().get(scheme)
+    if enc is None:
+        pytest.skip("no system library for scheme %d" % scheme)
+    ny, nx, d, nz = 600, 1100, 12, 7        # the binary map (82 500 bytes) spans two of liblz4's linked 64 KiB blocks
+    dark, frames = synth_frames(31, nz, ny, nx, 0.02, d)
+    g = load_npz("g3_l1z12.npz")
+    _write_parts(tmp_path, "own", dark, frames, 1, g, batch_size=4, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=1,
+                 compression_scheme=scheme, calibration_threshold_epsilon=0)
+    merge_parts(str(tmp_path), "own.rc1", 1)
+    own = (tmp_path / "own.rc1").read_bytes()
+    thr = orc.threshold(dark, 0)
+    md, blobs = [], []
+    for z in range(nz):
+        bitmap, packed, nnz = orc.reduce_frame_l1(frames[z].ravel(), thr.ravel(), d)
+        cb, cp = enc(bitmap.tobytes()), enc(packed.tobytes())
+        md.append(struct.pack("<III", len(cb), len(cp), packed.size))
+        blobs.append(cb + cp)
+    foreign = tmp_path / "foreign.rc1"
+    foreign.write_bytes(own[:512] + b"".join(md) + b"".join(blobs))
+    want = [orc.unpack_frame_sparse(nx, ny, d, *orc.reduce_frame_l1(frames[z].ravel(), thr.ravel(), d)[:2], 1) for z in range(nz)]
+    rd = ReCoDeReader(str(foreign), is_intermediate=False)
+    rd.open(print_header=False)
+    prefix, trip = rd.get_frames_triplets(0, nz)
+    assert rd.last_batch_path == "host-decode + device-expand"
+    for z in range(nz):
+        assert np.array_equal(trip[int(prefix[z]):int(prefix[z + 1])], want[z]), "frame %d" % z
+    seen = 0
+    for a, pre, tr in rd.iter_frames_triplets(0, nz, batch=3):
+        assert rd.last_batch_path == "host-decode + device-expand"
+        for i in range(len(pre) - 1):
+            assert np.array_equal(tr[int(pre[i]):int(pre[i + 1])], want[a + i])
+            seen += 1
+    assert seen == nz
+    f = rd.get_frame(5)[5]["data"]                                   # the reference's frame-at-a-time API on the same file
+    assert np.array_equal(np.asarray(f.todense()), np.where(frames[5] > thr, frames[5] - thr, 0))
+    rd.close()

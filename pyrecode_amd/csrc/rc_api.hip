@@ -204,6 +204,7 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
     HIP_TRY(hipMalloc((void **)&sc.tile_next, B * T * 4));
     HIP_TRY(hipMalloc((void **)&sc.frame_nnz, B * 4));
     HIP_TRY(hipMalloc((void **)&sc.frame_cbytes, B * 4));
+    HIP_TRY(hipMalloc((void **)&sc.scan_part, B * ((T + 4095) / 4096) * 32));
     HIP_TRY(hipMalloc((void **)&sc.status, sizeof(BatchStatus)));
     if (c->level != 3) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2 + 64));
     if (c->emit != 0) {
@@ -390,7 +391,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (rc::Scratch &sc : c->sets) {
         void *per_set[] = {sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
-                           sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.status, sc.pixraw, sc.pix_chunks, sc.chunk_size,
+                           sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.scan_part, sc.status, sc.pixraw, sc.pix_chunks, sc.chunk_size,
                            sc.chunk_off, sc.frame_pbytes};
         for (void *b : per_set)
             if (b) (void)hipFree(b);

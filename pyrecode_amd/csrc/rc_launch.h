@@ -25,6 +25,7 @@ struct Scratch {
     uint32_t *blk_off = nullptr;       // [B][ntiles]               exclusive prefix of blk_size inside the frame
     uint32_t *frame_nnz = nullptr;     // [B]
     uint32_t *frame_cbytes = nullptr;  // [B]                       sum of blk_size
+    uint32_t *scan_part = nullptr;     // [B][nseg][8]              partial results of the segmented scans (frames with > 4096 tiles)
     BatchStatus *status = nullptr;     // [1] of this batch
     BatchStatus *first_err = nullptr;  // [1] shared by both scratch sets: first failed batch since the last rc_ctx_sync
                                        //     (code, frame, total = number of the batch among those enqueued since then)

@@ -691,6 +691,32 @@ __device__ __forceinline__ void scan_row(uint32_t *__restrict__ row, uint32_t *_
     if (threadIdx.x == 0) *total = carry;
 }
 
+// The frame's definitions go into block t_tree (tree behind the literals header) and block t_seq (table descriptions behind the
+// modes byte) - usually the same block: the workgroup copies the block's slot into LDS and rewrites it byte by byte through
+// zm_defs_byte (the block encoders left room).  which: bit 0 = do t_tree's block, bit 1 = do t_seq's (when it is another block).
+__device__ __forceinline__ void zstd_rewrite_defs(const uint32_t *__restrict__ row, uint8_t *__restrict__ slots, uint32_t stride,
+                                                  const uint8_t *__restrict__ tree, uint32_t tl, const uint8_t *__restrict__ sdesc, uint32_t sl,
+                                                  uint32_t t_tree, uint32_t t_seq, uint32_t which, uint8_t *s_img, uint32_t *s_pos)
+{
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t t = pass == 0 ? t_tree : t_seq;
+        if (t == 0xFFFFFFFFu || (pass == 1 && t == t_tree) || !((which >> pass) & 1u)) continue;   // (uniform: shared values)
+        const uint32_t a_tl = pass == 0 ? tl : 0u, a_sl = (pass == 1 || t_seq == t_tree) ? sl : 0u;
+        uint8_t *slot = slots + (uint64_t)t * stride;
+        const uint32_t size = row[t] & 0xFFFFu;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (size + 3) / 4; i += blockDim.x)
+            reinterpret_cast<uint32_t *>(s_img)[i] = reinterpret_cast<const uint32_t *>(slot)[i];
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t q; (void)zm_block_needs(s_img, &q); *s_pos = q; }
+        __syncthreads();
+        const uint32_t pos = *s_pos;
+        for (uint32_t i = threadIdx.x; i < size + a_tl + a_sl; i += blockDim.x)
+            slot[i] = zm_defs_byte(s_img, pos, tree, a_tl, sdesc, a_sl, i);
+    }
+    __syncthreads();
+}
+
 // Modelled zstd: every block of a frame was encoded as if the decoder already had the frame's Huffman tree and sequence
 // tables (rc_zstd_wave.h, rc_pix_huff.hip).  The first block that uses the tree (ZW_TREE in its size word) and the first whose
 // sequences use the tables (ZW_SEQ) - usually the same one, the frame's first - get the descriptions inserted here: the
@@ -723,23 +749,7 @@ __device__ __forceinline__ void zstd_place_defs(const uint32_t *__restrict__ row
     const uint32_t t_tree = s_first[0], t_seq = s_first[1];
     const uint32_t tl = t_tree != 0xFFFFFFFFu ? tree_len : 0u, sl = t_seq != 0xFFFFFFFFu ? sdesc_len : 0u;
     if (threadIdx.x == 0) { adj[0] = t_tree; adj[1] = tl; adj[2] = t_seq; adj[3] = sl; }
-    for (int pass = 0; pass < 2; ++pass) {
-        const uint32_t t = pass == 0 ? t_tree : t_seq;
-        if (t == 0xFFFFFFFFu || (pass == 1 && t == t_tree)) continue;   // (uniform: shared values)
-        const uint32_t a_tl = pass == 0 ? tl : 0u, a_sl = (pass == 1 || t_seq == t_tree) ? sl : 0u;
-        uint8_t *slot = slots + (uint64_t)t * stride;
-        const uint32_t size = row[t] & 0xFFFFu;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < (size + 3) / 4; i += SCAN_T)
-            reinterpret_cast<uint32_t *>(s_img)[i] = reinterpret_cast<const uint32_t *>(slot)[i];
-        __syncthreads();
-        if (threadIdx.x == 0) { uint32_t q; (void)zm_block_needs(s_img, &q); s_pos = q; }
-        __syncthreads();
-        const uint32_t pos = s_pos;
-        for (uint32_t i = threadIdx.x; i < size + a_tl + a_sl; i += SCAN_T)
-            slot[i] = zm_defs_byte(s_img, pos, tree, a_tl, sdesc, a_sl, i);
-    }
-    __syncthreads();
+    zstd_rewrite_defs(row, slots, stride, tree, tl, sdesc, sl, t_tree, t_seq, 3u, s_img, &s_pos);
 }
 
 __host__ __device__ inline uint32_t packed_bytes(uint32_t nnz, uint32_t depth);
@@ -829,9 +839,159 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_cou
     }
 }
 
+// ---- the same scans for frames with many tiles (11520 x 8184: 23 018), cut into segments of SEG tiles ------------------------
+// One workgroup per frame walks such a row in dependent rounds (three arrays, a global round trip and two barriers per round:
+// 228 us for 32 frames).  Here a workgroup takes ONE segment: k_scan_seg leaves segment-local prefixes, next-non-empty links that
+// end at the segment's border, and per segment {block bytes, set pixels, first non-empty tile, first block that needs the tree,
+// first that needs the sequence tables}; k_scan_fix reads the frame's handful of partials, places the frame's zstd definitions
+// (the workgroup whose segment holds the block), adds the bases and closes the links across the borders.  Same results as
+// k_scan_frames, entry for entry.
+constexpr int SEG_I = 16, SEG = SCAN_T * SEG_I;   // 4096 tiles per segment
+struct ScanPart { uint32_t blk_sum, cnt_sum, first_nonempty, first_tree, first_seq, pad[3]; };
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_seg(Scratch sc, int with_counts, int with_blocks)
+{
+    __shared__ uint32_t sm[SCAN_W];
+    __shared__ uint32_t s_min[3];
+    const uint32_t seg = blockIdx.x, f = blockIdx.y, n = sc.ntiles, nseg = gridDim.x;
+    const uint64_t fr = (uint64_t)f * n;
+    const uint32_t t = seg * SEG + threadIdx.x * SEG_I;
+    ScanPart *part = reinterpret_cast<ScanPart *>(sc.scan_part) + (uint64_t)f * nseg + seg;
+    if (threadIdx.x < 3) s_min[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t blk_sum = 0, cnt_sum = 0;
+    if (with_blocks) {
+        uint32_t *row = sc.blk_size + fr, *orow = sc.blk_off + fr;
+        const bool zm = sc.zm_model != nullptr;
+        uint32_t v[SEG_I], sum = 0, mt = 0xFFFFFFFFu, mq = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < SEG_I; ++k) {
+            const uint32_t w = t + k < n ? row[t + k] : 0;
+            if (zm) {
+                if ((w & ZW_TREE) && mt == 0xFFFFFFFFu) mt = t + k;
+                if ((w & ZW_SEQ) && mq == 0xFFFFFFFFu) mq = t + k;
+                v[k] = w & 0xFFFFu;
+                if (t + k < n) row[t + k] = v[k];        // the clean size (k_scan_fix adds the definitions' bytes to two of them)
+            } else v[k] = w;
+            sum += v[k];
+        }
+        if (mt != 0xFFFFFFFFu) atomicMin(&s_min[1], mt);
+        if (mq != 0xFFFFFFFFu) atomicMin(&s_min[2], mq);
+        uint32_t ex = scan_block_excl(sum, sm, &blk_sum);
+#pragma unroll
+        for (int k = 0; k < SEG_I; ++k) {
+            if (t + k < n) orow[t + k] = ex;
+            ex += v[k];
+        }
+    }
+    if (with_counts) {
+        const uint32_t *row = sc.tile_cnt + fr;
+        uint32_t *orow = sc.tile_off + fr, *nrow = sc.tile_next + fr;
+        uint32_t v[SEG_I], sum = 0, first = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = SEG_I - 1; k >= 0; --k) {
+            v[k] = t + k < n ? row[t + k] : 0;
+            if (v[k]) first = t + k;
+            sum += v[k];
+        }
+        uint32_t ex = scan_block_excl(sum, sm, &cnt_sum);
+#pragma unroll
+        for (int k = 0; k < SEG_I; ++k) {
+            if (t + k < n) orow[t + k] = ex;
+            ex += v[k];
+        }
+        // next non-empty tile inside the segment: suffix minimum of the threads' first non-empty index
+        uint32_t m = first;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_down(m, d);
+            if (lane_id() + d < 64) m = min(m, y);
+        }
+        const int w = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane_id() == 0) sm[w] = m;
+        __syncthreads();
+        uint32_t right = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = SCAN_W - 1; i >= 0; --i)
+            if (i > w) right = min(right, sm[i]);
+        uint32_t excl = __shfl_down(m, 1);
+        if (lane_id() == 63) excl = 0xFFFFFFFFu;
+        uint32_t nxt = min(excl, right);   // 0xFFFFFFFF: nothing behind this thread's chunk inside the segment (k_scan_fix closes it)
+#pragma unroll
+        for (int k = SEG_I - 1; k >= 0; --k) {
+            if (t + k < n) nrow[t + k] = nxt;
+            if (v[k]) nxt = t + k;
+        }
+        if (first != 0xFFFFFFFFu) atomicMin(&s_min[0], first);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { part->blk_sum = blk_sum; part->cnt_sum = cnt_sum; part->first_nonempty = s_min[0]; part->first_tree = s_min[1]; part->first_seq = s_min[2]; }
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_fix(Scratch sc, int with_counts, int with_blocks)
+{
+    __shared__ uint32_t s_v[8];   // blk base, cnt base, next non-empty behind the segment, t_tree, t_seq, blk total, cnt total
+    __shared__ uint32_t s_pos;
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[PIX_SLOT + 16];
+    const uint32_t seg = blockIdx.x, f = blockIdx.y, n = sc.ntiles, nseg = gridDim.x;
+    const uint64_t fr = (uint64_t)f * n;
+    const ScanPart *parts = reinterpret_cast<const ScanPart *>(sc.scan_part) + (uint64_t)f * nseg;
+    if (threadIdx.x == 0) {
+        uint32_t bb = 0, cb = 0, bt = 0, ct = 0, nx = n, tt = 0xFFFFFFFFu, tq = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < nseg; ++i) {
+            const ScanPart p = parts[i];
+            if (i < seg) { bb += p.blk_sum; cb += p.cnt_sum; }
+            bt += p.blk_sum; ct += p.cnt_sum;
+            if (i > seg && p.first_nonempty < nx) nx = p.first_nonempty;
+            tt = min(tt, p.first_tree); tq = min(tq, p.first_seq);
+        }
+        s_v[0] = bb; s_v[1] = cb; s_v[2] = nx; s_v[3] = tt; s_v[4] = tq; s_v[5] = bt; s_v[6] = ct;
+    }
+    __syncthreads();
+    const uint32_t lo = seg * SEG, hi = min(lo + (uint32_t)SEG, n);
+    if (with_blocks) {
+        uint32_t tl = 0, sl = 0;
+        const uint32_t t_tree = s_v[3], t_seq = s_v[4];
+        if (sc.zm_model) {
+            const ZstdModel *M = reinterpret_cast<const ZstdModel *>(sc.zm_model);
+            tl = t_tree != 0xFFFFFFFFu ? M->lit_desc_len : 0u;
+            sl = t_seq != 0xFFFFFFFFu ? M->seq_desc_len : 0u;
+            const uint32_t mine = (t_tree >= lo && t_tree < hi ? 1u : 0u) | (t_seq >= lo && t_seq < hi ? 2u : 0u);
+            if (mine) {
+                zstd_rewrite_defs(sc.blk_size + fr, sc.blk_slots + fr * BLK_SLOT, BLK_SLOT, M->lit_desc, tl, M->seq_desc, sl, t_tree, t_seq, mine, s_img, &s_pos);
+                if (threadIdx.x == 0) {   // (behind the rewrite, which reads the blocks' clean sizes)
+                    if (mine & 1u) sc.blk_size[fr + t_tree] += tl;
+                    if (mine & 2u) sc.blk_size[fr + t_seq] += sl;
+                }
+            }
+        }
+        uint32_t *orow = sc.blk_off + fr;
+        const uint32_t base = s_v[0];
+        for (uint32_t t = lo + threadIdx.x; t < hi; t += SCAN_T)
+            orow[t] += base + (t > t_tree ? tl : 0u) + (t > t_seq ? sl : 0u);   // (t_tree, t_seq == 0xFFFFFFFF: never)
+        if (seg == 0 && threadIdx.x == 0) sc.frame_cbytes[f] = s_v[5] + tl + sl;
+    }
+    if (with_counts) {
+        uint32_t *orow = sc.tile_off + fr, *nrow = sc.tile_next + fr;
+        const uint32_t base = s_v[1], nx = s_v[2];
+        for (uint32_t t = lo + threadIdx.x; t < hi; t += SCAN_T) {
+            orow[t] += base;
+            if (nrow[t] == 0xFFFFFFFFu) nrow[t] = nx;
+        }
+        if (seg == 0 && threadIdx.x == 0) sc.frame_nnz[f] = s_v[6];
+    }
+}
+
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s)
 {
     if (!with_counts && !with_blocks) return;
+    if (sc.ntiles > (uint32_t)SEG && sc.scan_part) {   // (a ctx's scratch; the stateless seams scan their one row with the kernel below)
+        const dim3 grid((sc.ntiles + SEG - 1) / SEG, B);
+        hipLaunchKernelGGL(k_scan_seg, grid, dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
+        hipLaunchKernelGGL(k_scan_fix, grid, dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
+        return;
+    }
     if (sc.ntiles > 8192) hipLaunchKernelGGL(k_scan_frames<32>, dim3(B), dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
     else hipLaunchKernelGGL(k_scan_frames<16>, dim3(B), dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
 }

@@ -265,3 +265,49 @@ def test_4096_detector_like_clusters_full_oracle_compare(env, scheme):
     assert int(prefix[B]) == capt
     for z in range(B):
         assert np.array_equal(trip[int(prefix[z]):int(prefix[z + 1])], want_trip[z]), "frame %d" % z
+
+
+@pytest.mark.parametrize("scheme,depth", [(1, 12), (2, 16), (0, 12)])
+def test_frames_with_more_than_4096_tiles_take_the_segmented_scans(env, scheme, depth):
+    """ntiles = 4200 (two scan segments, k_scan_seg / k_scan_fix): an ordinary frame, a frame whose first 4150 tiles are EMPTY
+    (the first block that needs the zstd tree and tables lies in the second segment; every next-non-empty link of the first
+    segment crosses the border), an empty frame, and a frame with events only in tile 0 and the last tile - all against the oracle."""
+    torch, hip, synth, orc = env
+    ny, nx = 4200, 4096
+    N, B = ny * nx, 4
+    L = hip.lib()
+    dark_d = torch.empty(N, dtype=torch.int16, device="cuda")
+    frames_d = torch.empty((B, N), dtype=torch.int16, device="cuda")
+    hip.check(L.rc_synth_dark(0, 41, N, dark_d.data_ptr()))
+    hip.check(L.rc_synth_frames(0, 41, 0, B, N, 10000, dark_d.data_ptr(), frames_d.data_ptr()))
+    thr = dark_d.cpu().numpy().view(np.uint16)
+    frames = frames_d.cpu().numpy().view(np.uint16).copy()
+    frames[1, :4150 * 4096] = thr[:4150 * 4096] // 2
+    frames[2] = thr // 2
+    frames[3] = thr // 2
+    frames[3, 5] = thr[5] + 77
+    frames[3, N - 3] = thr[N - 3] + 1234
+    frames_d.copy_(torch.from_numpy(frames.view(np.int16)))
+    mode = 0 if scheme == 0 else 1
+    ctx = hip.ReduceContext(nx, ny, depth, 1, mode, scheme, 1, 0, max_batch=B)
+    ctx.set_dark(dark_d.data_ptr(), 0)
+    cap = B * N
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    rec = torch.empty(B + 1, dtype=torch.int64, device="cuda")
+    md = torch.empty((B, 3), dtype=torch.int32, device="cuda")
+    for _ in range(2):   # (zstd: the first batch fits the model; the second runs with it in place)
+        ctx.enqueue(frames_d.data_ptr(), B, 0, out.data_ptr(), cap, rec.data_ptr(), md.data_ptr())
+        ctx.sync()
+        rec_h = rec.cpu().numpy()
+        out_h = out[:int(rec_h[-1])].cpu().numpy()
+        for z in range(B):
+            r = out_h[int(rec_h[z]):int(rec_h[z + 1])].tobytes()
+            bitmap, packed, nnz = orc.reduce_frame_l1(frames[z], thr, depth)
+            if mode == 0:
+                assert struct.unpack_from("<II", r, 0) == (z, packed.size) and r[8:] == bitmap.tobytes() + packed.tobytes(), "frame %d" % z
+                continue
+            fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+            assert fid == z and npk == packed.size and len(r) == 16 + cb + cp
+            assert _decode(orc, scheme, r[16:16 + cb], bitmap.size + 8) == bitmap.tobytes(), "frame %d" % z
+            assert _decode(orc, scheme, r[16 + cb:], packed.size + 8) == packed.tobytes(), "frame %d" % z
+    ctx.close()

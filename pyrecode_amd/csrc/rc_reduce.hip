@@ -483,7 +483,9 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 #endif
 constexpr int RWAVES = RC_REDUCE_WAVES, RWG = 64 * RWAVES;
 template <int BZ, bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
-__global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(3))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
+// (three waves per SIMD = 168 VGPRs where the aligned instantiations fit; the scalar-load ones - N % 8 != 0, or a frame pointer that is
+// not 16-byte aligned - need more registers for their predicated loads and spilled 83-110 of them at that limit: two waves for those)
+__global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(ALIGNED ? 3 : 1))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t tile0, uint32_t tile_end,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,

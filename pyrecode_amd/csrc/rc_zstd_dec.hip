@@ -339,7 +339,7 @@ __global__ __launch_bounds__(T) void k_block_decode(const uint8_t *__restrict__ 
 }
 
 // The binary-map streams of frames THIS library's shape of encoder wrote ("uniform": every block regenerates TILE_BM bytes, the
-// last one the rest; rc_api.hip checks that on the host) need no 32-byte entry per block: the host walk leaves ONE dword per block,
+// last one the rest; rc_reader.hip checks that on the host) need no 32-byte entry per block: the host walk leaves ONE dword per block,
 // the offset of its header inside the frame's stream (n + 1 of them: the last is the stream's end), and the lane reads type, size and
 // table modes from the block itself.  The lists are read over the link (page-locked host memory, once): 1 MB instead of 8 MB per 64
 // frames of 4096 x 4096 - with full entries the link, not the decoder, set this kernel's time (315 us; entries in device memory: 159).

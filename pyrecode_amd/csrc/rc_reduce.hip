@@ -18,6 +18,19 @@ namespace rc {
 // Profiling builds only (tools/build_ablate.sh): -DRC_ABLATE=<bits> drops one kind of global store of the reduce kernel while
 // keeping every computation alive (a value is "stored" only if it equals a magic number).
 //   1: residual lines   2: encoded block lines   4: the 4-byte count / size stores
+// -DRC_PHASE_TIMING (tools/build_def.sh): lane 0 of every wavefront adds the s_memtime cycles of each phase of reduce_one_frame to
+// g_phase[] (rc_debug_phases reads and clears them).  s_memtime waits for the wave's outstanding LDS / scalar traffic, so the phases do
+// not overlap as they do in the product build: the SHARES are what the numbers are good for.
+#ifdef RC_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+// (sampled: one workgroup in 64 records, each wave's sums leave in one burst at the end of reduce_one_frame's last phase)
+#define RC_PHASE_BEGIN unsigned long long ph_t_ = __builtin_amdgcn_s_memtime(); unsigned long long ph_a_[8] = {};
+#define RC_PHASE(i) do { const unsigned long long ph_n_ = __builtin_amdgcn_s_memtime(); ph_a_[i] = ph_n_ - ph_t_; ph_t_ = ph_n_; \
+        if ((i) == 6 && lane_id() == 0 && (blockIdx.x & 63u) == 0) { for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_phase[q_], ph_a_[q_]); atomicAdd(&g_phase[7], 1ull); } } while (0)
+#else
+#define RC_PHASE_BEGIN
+#define RC_PHASE(i) do { } while (0)
+#endif
 #ifndef RC_ABLATE
 #define RC_ABLATE 0
 #endif
@@ -300,8 +313,10 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                                                  Pending &pend, uint32_t &stores_behind, const ZmParams &zp)
 {
     const int lane = lane_id();
+    RC_PHASE_BEGIN
     // x was fetched by vm_issue_loads during the previous frame: wait for those loads, not for the stores issued since
     if (ASMLOAD) vm_wait_loads(stores_behind, x);
+    RC_PHASE(0);
     // residuals (saturating subtract, in place) and the 8-bit mask of this lane's 8 pixels, per group
     uint32_t m8[R];
 #pragma unroll
@@ -318,6 +333,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                                        __builtin_bit_cast(u16x2, (uint32_t)((1u << (2 * k)) | (2u << (2 * k + 16)))), M, false);
         m8[r] = M;
     }
+    RC_PHASE(1);
     // this frame's data has arrived (the subtract above consumed it): start the NEXT frame's loads now, into the other
     // register set, so that they fly during the whole compaction + encoding of this frame ...
     if (have_next) {
@@ -332,6 +348,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
             for (int r = 0; r < R; ++r) xn[r] = load8<ALIGNED, true>(next, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
         }
     }
+    RC_PHASE(2);
     pend.valid = true;
     pend.ft = ft;
     pend.f = f;
@@ -359,6 +376,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
         __builtin_amdgcn_wave_barrier();
         pend.own = *reinterpret_cast<const u32x2 *>(&bm[lane * 8]);
     }
+    RC_PHASE(3);
     if (LEVEL1) {
         // After the transpose a lane owns 64 CONSECUTIVE pixels (its 8 bitmap bytes): row-major order is lane order, so one
         // prefix sum of the per-lane popcounts places everything, and each lane moves its own set pixels from `val` to
@@ -431,6 +449,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
         pend.cnt = wave_total;
         if (pend.depth < 16 && wave_total) pack_stage(pend.buf, wave_total, pend.depth);
     }
+    RC_PHASE(4);
     if (CODEC == 2) {
         const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
         pend.csize = lz4_encode_block<false>(bytes, n_blk, *s_lz);
@@ -452,8 +471,10 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
         pend.cown = bitshuffle_block(bytes, n_blk, *s_lz);
         pend.csize = lz4_encode_block(pend.cown, n_blk, *s_lz);
     }
+    RC_PHASE(5);
     stores_behind = flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st);
     pend.valid = false;
+    RC_PHASE(6);
 }
 
 // Workgroup id -> (tile block, frame group).  A tile block is WAVES consecutive tiles (one per wavefront); a frame group
@@ -616,6 +637,16 @@ static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t 
     else if (level == 1) launch_reduce_c<BZ, AL, true, false>(sc, frames, B, codec, keep, depth, s, s_tail);
     else launch_reduce_c<BZ, AL, false, false>(sc, frames, B, codec, keep, depth, s, s_tail);
 }
+#ifdef RC_PHASE_TIMING
+extern "C" __attribute__((visibility("default"))) int rc_debug_phases(unsigned long long *out16)
+{
+    unsigned long long z[16] = {};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof z) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 // s_tail (optional): the stream for the small launch over a frame's partial last tile; it must already be ordered behind
 // whatever produced the frames
 void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,

@@ -6,7 +6,7 @@ name=$1; shift
 cd "$(dirname "$0")/../pyrecode_amd/csrc"
 mkdir -p ../../ab_build
 d=$(mktemp -d)
-for f in rc_api rc_reduce rc_lz4 rc_zstd rc_pix_huff rc_zstd_dec rc_blosc rc_l2 rc_expand; do
+for f in rc_api rc_reader rc_codec_api rc_reduce rc_lz4 rc_zstd rc_pix_huff rc_zstd_dec rc_blosc rc_l2 rc_expand; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -w "$@" -c $f.hip -o $d/$f.o &
 done
 wait

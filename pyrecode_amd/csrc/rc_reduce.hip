@@ -140,6 +140,17 @@ __device__ __forceinline__ void vm_issue_loads(u32x4 (&x)[R], const uint16_t *la
                  "global_load_dwordx4 %3, %4, off offset:3072 nt"
                  : "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]) : "v"(p1) : "memory");
 }
+// one of the eight (group r): the rolling form re-arms a group's registers as soon as the group has been consumed
+__device__ __forceinline__ void vm_issue_load1(u32x4 &xr, const uint16_t *lane_ptr, int r)
+{
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(lane_ptr) + (r >= 4 ? 4096 : 0);
+    switch (r & 3) {
+    case 0: asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    case 1: asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    case 2: asm volatile("global_load_dwordx4 %0, %1, off offset:2048 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    default: asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    }
+}
 // Wait until at most `later` vector-memory instructions are outstanding, `later` (wave-uniform) being the number issued
 // BEHIND the loads of x; an over-estimate would let the loads through unfinished, so anything unusual waits for everything.
 // The empty statement at the end names the registers as operands: no use of them can be scheduled in front of the wait.
@@ -160,10 +171,10 @@ __device__ __forceinline__ void vm_wait_loads(uint32_t later, u32x4 (&x)[R])
 }
 
 // Wave-private LDS stage of the residual path.  `val` receives the tile's 4096 values in pixel order (8 x ds_write_b128 per
-// lane); sparse tiles are compacted from there into `out`, tiles with more than STAGE_CAP set pixels are compacted straight
-// from the registers into `val` (the older group-by-group path, which needs no second buffer).  3 workgroups x 4 waves x
-// (this + Lz4Lds) = 158.7 KB of the CU's 160 KB.
-constexpr int STAGE_CAP = 1536;
+// lane); sparse tiles are compacted from there into `out`, tiles with more than STAGE_CAP set pixels are compacted inside `val`,
+// 256 pixels at a time through `out` (compact_dense_in_place).  STAGE_CAP = 256 (6.25 % of a tile) is what lets FIVE workgroups of
+// three waves share a CU's 160 KB: 3 x (this + Lz4Lds) = 31.9 KB.
+constexpr int STAGE_CAP = 256;
 struct __attribute__((aligned(16))) WaveStage {
     uint16_t val[TILE_PX];
     uint16_t out[STAGE_CAP];
@@ -301,10 +312,42 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)nst);
 }
 
-// One frame of one tile: x holds the 8 loaded groups of this lane (destroyed), xn receives the prefetch of `next`.
+// A tile with more set pixels than `out` holds: `val` has the tile's values in pixel order, a lane owns the mask of 64 consecutive
+// pixels (own), inc / cnt are the inclusive scan and the counts of the lanes' set pixels.  The values are compacted INSIDE `val`:
+// four lanes' pixels (256, what `out` holds even if all are set) at a time go through `out` and from there to their final place,
+// which lies at or in front of the chunk's own pixels - nothing unread is overwritten.  Sixteen uniform rounds; needs no register of
+// the frame (the frame registers already carry the next frame's loads).
+__device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const u32x2 &own, uint32_t inc, uint32_t cnt)
+{
+    const int lane = lane_id();
+    const uint32_t excl = inc - cnt;
+    for (int c = 0; c < 16; ++c) {
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)excl, 4 * c);
+        const uint32_t n_c = (uint32_t)__builtin_amdgcn_readlane((int)inc, 4 * c + 3) - base;
+        if ((lane >> 2) == c) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint16_t *mine = st->val + 64 * lane + 32 * h;
+                uint32_t qh = own[h];
+                uint32_t o = excl - base + (h ? (uint32_t)__builtin_popcount(own[0]) : 0u);
+                while (qh) {
+                    const uint32_t i0 = (uint32_t)__builtin_ctz(qh);
+                    qh &= qh - 1;
+                    st->out[o++] = mine[i0];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = lane; j < n_c; j += 64) st->val[base + j] = st->out[j];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// One frame of one tile.  x holds the 8 loaded groups of this lane; each group's registers are re-armed with the NEXT frame's load as
+// soon as the group has been consumed (ASMLOAD), so the loads stay one frame ahead with ONE register set.
 // t: the wave's threshold tile, in registers for all BZ frames (keeping it in LDS or re-reading it from L2 was no faster).
 template <bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
-__device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], const uint16_t *__restrict__ next, bool have_next,
+__device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *__restrict__ cur, const uint16_t *__restrict__ next, bool have_next,
                                                  const u32x4 (&t)[R], uint64_t lane_px0, uint64_t N, bool full,
                                                  uint32_t f, uint32_t tile, uint64_t ft, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
@@ -316,6 +359,14 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
     RC_PHASE_BEGIN
     // x was fetched by vm_issue_loads during the previous frame: wait for those loads, not for the stores issued since
     if (ASMLOAD) vm_wait_loads(stores_behind, x);
+    else if (ALIGNED && full) {   // (the partial last tile of a frame / unaligned frames: plain loads, no prefetch)
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(cur + lane_px0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = __builtin_nontemporal_load(p + r * (GROUP_PX / 8));
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = load8<ALIGNED, true>(cur, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
+    }
     RC_PHASE(0);
     // residuals (saturating subtract, in place) and the 8-bit mask of this lane's 8 pixels, per group
     uint32_t m8[R];
@@ -332,22 +383,20 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
             M = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pk_min_u16(x[r][k], one)),
                                        __builtin_bit_cast(u16x2, (uint32_t)((1u << (2 * k)) | (2u << (2 * k + 16)))), M, false);
         m8[r] = M;
+        if (LEVEL1) {
+            // the group's values in pixel order -> LDS (level 2 keeps the raw frame value: residual + threshold)
+            u32x4 v = x[r];
+            if (RAWVAL) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = pk_add_u16(v[k], tt[k]);
+            }
+            (reinterpret_cast<u32x4 *>(st->val) + lane)[r * 64] = v;
+        }
+        // the group is consumed: its registers take the NEXT frame's load, which then flies during the whole compaction + encoding
+        // of this frame (the whole tile lies inside the frame in this instantiation: no predication)
+        if (ASMLOAD && have_next) vm_issue_load1(x[r], next + lane_px0, r);
     }
     RC_PHASE(1);
-    // this frame's data has arrived (the subtract above consumed it): start the NEXT frame's loads now, into the other
-    // register set, so that they fly during the whole compaction + encoding of this frame ...
-    if (have_next) {
-        if (ASMLOAD) {  // the whole tile lies inside the frame (all tiles but possibly a frame's last): no predication
-            vm_issue_loads(xn, next + lane_px0);
-        } else if (ALIGNED && full) {
-            const u32x4 *p = reinterpret_cast<const u32x4 *>(next + lane_px0);
-#pragma unroll
-            for (int r = 0; r < R; ++r) xn[r] = __builtin_nontemporal_load(p + r * (GROUP_PX / 8));
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) xn[r] = load8<ALIGNED, true>(next, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
-        }
-    }
     RC_PHASE(2);
     pend.valid = true;
     pend.ft = ft;
@@ -355,19 +404,6 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
     pend.cnt = 0;
     pend.csize = 0;
     pend.buf = st->out;
-    if (LEVEL1) {
-        // the tile's values in pixel order -> LDS (level 2 keeps the raw frame value: residual + threshold)
-        u32x4 *dst = reinterpret_cast<u32x4 *>(st->val) + lane;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            u32x4 v = x[r];
-            if (RAWVAL) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = pk_add_u16(v[k], t[r][k]);
-            }
-            dst[r * 64] = v;
-        }
-    }
     if (LEVEL1 || KEEP_BITMAP || CODEC) {
         // transpose through wave-private LDS: byte (r, lane) -> position r*64 + lane; 8 contiguous bytes per lane out
         uint8_t *bm = CODEC ? s_lz->raw : s_bm;
@@ -405,45 +441,9 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
                 }
             }
         } else {
-            // dense tile: exclusive prefix of the per-lane popcounts in (group, lane) order, three groups per packed scan
-            // (each field <= 512 needs 10 bits); values go from the registers into `val` (its staged copy is not needed)
             pend.buf = st->val;
             __builtin_amdgcn_wave_barrier();
-            uint32_t total = 0;
-#pragma unroll
-            for (int r0 = 0; r0 < R; r0 += 3) {
-                uint32_t pk = 0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (r0 + k < R) pk |= (uint32_t)__builtin_popcount(m8[r0 + k]) << (10 * k);
-                const uint32_t pinc = wave_incl_scan(pk);
-                const uint32_t tot = wave_last(pinc);
-                const uint32_t exc = pinc - pk;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (r0 + k < R) {
-                        const int r = r0 + k;
-                        uint32_t m = m8[r];
-                        uint32_t o = total + ((exc >> (10 * k)) & 0x3FFu);
-                        while (m) {
-                            const uint32_t i = (uint32_t)__builtin_ctz(m);
-                            m &= m - 1;
-                            // pixel i = halfword i of the lane's 16 bytes: v_perm_b32 picks halfword (i & 3) of a register
-                            // pair (selector bytes 2j, 2j+1, then two constant-zero bytes), one select between the pairs
-                            const uint32_t sel = 0x0c0c0100u + (i & 3u) * 0x0202u;
-                            const uint32_t p01 = __builtin_amdgcn_perm(x[r][1], x[r][0], sel);
-                            const uint32_t p23 = __builtin_amdgcn_perm(x[r][3], x[r][2], sel);
-                            uint32_t d = (i & 4u) ? p23 : p01;
-                            if (RAWVAL) {
-                                const uint32_t q01 = __builtin_amdgcn_perm(t[r][1], t[r][0], sel);
-                                const uint32_t q23 = __builtin_amdgcn_perm(t[r][3], t[r][2], sel);
-                                d += (i & 4u) ? q23 : q01;
-                            }
-                            st->val[o++] = (uint16_t)d;
-                        }
-                        total += (tot >> (10 * k)) & 0x3FFu;
-                    }
-            }
+            compact_dense_in_place(st, pend.own, inc, cnt);
         }
         __builtin_amdgcn_wave_barrier();
         pend.cnt = wave_total;
@@ -500,13 +500,13 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], u32x4 (&xn)[R], 
 // Workgroup = RWAVES wavefronts.  The wavefronts of this kernel never talk to each other, so the workgroup size is free
 // (measurements in launch_reduce_t).
 #ifndef RC_REDUCE_WAVES
-#define RC_REDUCE_WAVES 4
+#define RC_REDUCE_WAVES 3
 #endif
 constexpr int RWAVES = RC_REDUCE_WAVES, RWG = 64 * RWAVES;
 template <int BZ, bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
-// (three waves per SIMD = 168 VGPRs where the aligned instantiations fit; the scalar-load ones - N % 8 != 0, or a frame pointer that is
-// not 16-byte aligned - need more registers for their predicated loads and spilled 83-110 of them at that limit: two waves for those)
-__global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(ALIGNED ? 3 : 1))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
+// (four waves per SIMD = 128 VGPRs, which the steady-state instantiation fits with its one frame register set; the plain-load ones -
+// a frame's partial last tile, N % 8 != 0, a frame pointer that is not 16-byte aligned - take what they need)
+__global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu((ALIGNED && ASMLOAD) ? 4 : 1))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t tile0, uint32_t tile_end,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
@@ -539,15 +539,8 @@ __global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(ALIGNED ? 3
     if (f0 >= B) return;
     const bool full = (uint64_t)(tile + 1) * TILE_PX <= N;  // wave-uniform (always true in the ASMLOAD instantiation)
 
-    u32x4 xa[R], xb[R];
-    {
-        const uint16_t *fr = frames + (uint64_t)f0 * N;
-        if (ASMLOAD) vm_issue_loads(xa, fr + lane_px0);
-        else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) xa[r] = load8<ALIGNED, true>(fr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
-        }
-    }
+    u32x4 xa[R];
+    if (ASMLOAD) vm_issue_loads(xa, frames + (uint64_t)f0 * N + lane_px0);
     u32x4 t[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) t[r] = load8<ALIGNED, false>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
@@ -566,18 +559,11 @@ __global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu(ALIGNED ? 3
     // compiler has had its way with them, so the first wait is for everything)
     uint32_t stores_behind = 0;
 #pragma unroll 1
-    for (int z = 0; z < BZ; z += 2) {
-        uint32_t f = f0 + z;
+    for (int z = 0; z < BZ; ++z) {
+        const uint32_t f = f0 + z;
         if (f >= B) break;
-        bool nxt = z + 1 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xa, xb, frames + (uint64_t)(f + 1) * N, nxt, t,
-                                                                             lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
-                                                                             bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
-                                                                             blk_size, lz, bm, st, pend, stores_behind, zm);
-        if (!nxt) break;
-        ++f;
-        nxt = z + 2 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xb, xa, frames + (uint64_t)(f + 1) * N, nxt, t,
+        const bool nxt = z + 1 < BZ && f + 1 < B;
+        reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xa, frames + (uint64_t)f * N, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
                                                                              blk_size, lz, bm, st, pend, stores_behind, zm);

@@ -169,7 +169,12 @@ static int ctx_alloc(rc_ctx *c)
     RC_ON_DEVICE(c->device);
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     // (a high-priority second-stage stream was measured: no gain with LZ4 or zstd, 2 % slower at 11520x8184 - tools/ab_bench.sh)
-    HIP_TRY(hipStreamCreateWithFlags(&c->pstream_all, hipStreamNonBlocking));
+    if (getenv("RC_PSTREAM_PRIO")) {   // experiment knob: the second stage on a high-priority stream
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->pstream_all, hipStreamNonBlocking, hi));
+    } else
+        HIP_TRY(hipStreamCreateWithFlags(&c->pstream_all, hipStreamNonBlocking));
     {
         // Experiment knob, off by default.  In pipelined mode the second stage runs next to the following batch's reduce
         // kernel; its waves (80 VGPRs, latency bound) settle on every SIMD and push out one of the three reduce waves

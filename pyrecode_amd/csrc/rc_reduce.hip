@@ -8,6 +8,7 @@
 //   A5 LSB-first d-bit pack                     pyrecode/recode_writer.py:637-652
 //   A7 record assembly                          pyrecode/recode_writer.py:485-494,518-525,546-550,559-574
 #include <cstdlib>
+#include <type_traits>
 
 #include "rc_launch.h"
 #include "rc_lz4_block.h"
@@ -172,7 +173,7 @@ __device__ __forceinline__ void vm_wait_loads(uint32_t later, u32x4 (&x)[R])
 
 // Wave-private LDS stage of the residual path.  `val` receives the tile's 4096 values in pixel order (8 x ds_write_b128 per
 // lane); sparse tiles are compacted from there into `out`, tiles with more than STAGE_CAP set pixels are compacted inside `val`,
-// 256 pixels at a time through `out` (compact_dense_in_place).  STAGE_CAP = 256 (6.25 % of a tile) is what lets FIVE workgroups of
+// STAGE_CAP values at a time through `out` (compact_dense_in_place).  STAGE_CAP = 256 (6.25 % of a tile) is what lets FIVE workgroups of
 // three waves share a CU's 160 KB: 3 x (this + Lz4Lds) = 31.9 KB.
 constexpr int STAGE_CAP = 256;
 struct __attribute__((aligned(16))) WaveStage {
@@ -313,32 +314,30 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
 }
 
 // A tile with more set pixels than `out` holds: `val` has the tile's values in pixel order, a lane owns the mask of 64 consecutive
-// pixels (own), inc / cnt are the inclusive scan and the counts of the lanes' set pixels.  The values are compacted INSIDE `val`:
-// four lanes' pixels (256, what `out` holds even if all are set) at a time go through `out` and from there to their final place,
-// which lies at or in front of the chunk's own pixels - nothing unread is overwritten.  Sixteen uniform rounds; needs no register of
-// the frame (the frame registers already carry the next frame's loads).
-__device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const u32x2 &own, uint32_t inc, uint32_t cnt)
+// pixels (own), inc / cnt are the inclusive scan and the counts of the lanes' set pixels, total their sum.  The values are compacted
+// INSIDE `val`, STAGE_CAP of them per round: every lane moves those of its values whose compact index falls into the round's window
+// into `out`, then the window goes to its final place val[round * STAGE_CAP ...).  A value's pixel index is never below its compact
+// index, so what a round overwrites has been read in this round or an earlier one.  ceil(total / STAGE_CAP) rounds; needs no register
+// of the frame (the frame registers already carry the next frame's loads).
+__device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const u32x2 &own, uint32_t inc, uint32_t cnt, uint32_t total)
 {
     const int lane = lane_id();
-    const uint32_t excl = inc - cnt;
-    for (int c = 0; c < 16; ++c) {
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)excl, 4 * c);
-        const uint32_t n_c = (uint32_t)__builtin_amdgcn_readlane((int)inc, 4 * c + 3) - base;
-        if ((lane >> 2) == c) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint16_t *mine = st->val + 64 * lane + 32 * h;
-                uint32_t qh = own[h];
-                uint32_t o = excl - base + (h ? (uint32_t)__builtin_popcount(own[0]) : 0u);
-                while (qh) {
-                    const uint32_t i0 = (uint32_t)__builtin_ctz(qh);
-                    qh &= qh - 1;
-                    st->out[o++] = mine[i0];
-                }
-            }
+    const uint16_t *mine = st->val + 64 * lane;
+    uint32_t q0 = own[0], q1 = own[1];   // this lane's set pixels still to move (low half first)
+    uint32_t e = inc - cnt;              // compact index of the next one
+    const uint32_t rounds = (total + STAGE_CAP - 1) / STAGE_CAP;
+    for (uint32_t c = 0; c < rounds; ++c) {
+        const uint32_t lim = (c + 1) * STAGE_CAP;
+        while (e < lim && (q0 | q1)) {
+            uint32_t i;
+            if (q0) { i = (uint32_t)__builtin_ctz(q0); q0 &= q0 - 1; }
+            else { i = 32u + (uint32_t)__builtin_ctz(q1); q1 &= q1 - 1; }
+            st->out[e - c * STAGE_CAP] = mine[i];
+            ++e;
         }
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t j = lane; j < n_c; j += 64) st->val[base + j] = st->out[j];
+        const uint32_t n_c = min((uint32_t)STAGE_CAP, total - c * STAGE_CAP);
+        for (uint32_t j = lane; j < n_c; j += 64) st->val[c * STAGE_CAP + j] = st->out[j];
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -443,7 +442,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *
         } else {
             pend.buf = st->val;
             __builtin_amdgcn_wave_barrier();
-            compact_dense_in_place(st, pend.own, inc, cnt);
+            compact_dense_in_place(st, pend.own, inc, cnt, wave_total);
         }
         __builtin_amdgcn_wave_barrier();
         pend.cnt = wave_total;
@@ -499,14 +498,11 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *
 // leaves loads and waits to the compiler.  tile0: first tile of this launch.
 // Workgroup = RWAVES wavefronts.  The wavefronts of this kernel never talk to each other, so the workgroup size is free
 // (measurements in launch_reduce_t).
-#ifndef RC_REDUCE_WAVES
-#define RC_REDUCE_WAVES 3
-#endif
-constexpr int RWAVES = RC_REDUCE_WAVES, RWG = 64 * RWAVES;
-template <int BZ, bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
+// RWAVES = 3 where the kernel's LDS then lets five workgroups (15 waves) share a CU and the step gains from it, 4 elsewhere (launch_reduce_t)
+template <int RWAVES, int BZ, bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
 // (four waves per SIMD = 128 VGPRs, which the steady-state instantiation fits with its one frame register set; the plain-load ones -
 // a frame's partial last tile, N % 8 != 0, a frame pointer that is not 16-byte aligned - take what they need)
-__global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu((ALIGNED && ASMLOAD) ? 4 : 1))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
+__global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((ALIGNED && ASMLOAD) ? ((RWAVES == 4 && LEVEL1) ? 3 : 4) : 1))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t tile0, uint32_t tile_end,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
@@ -519,13 +515,14 @@ __global__ __launch_bounds__(RWG) __attribute__((amdgpu_waves_per_eu((ALIGNED &&
     if (blockIdx.x == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
     __shared__ uint16_t s_code[CODEC == 3 ? 256 : 2];                                           // modelled zstd: Huffman code table
     if (CODEC == 3) {   // (the only barrier of the kernel, in front of every early exit)
-        for (uint32_t i = threadIdx.x; i < 128; i += RWG) reinterpret_cast<uint32_t *>(s_code)[i] = reinterpret_cast<const uint32_t *>(zm.lit_code)[i];
+        for (uint32_t i = threadIdx.x; i < 128; i += 64 * RWAVES) reinterpret_cast<uint32_t *>(s_code)[i] = reinterpret_cast<const uint32_t *>(zm.lit_code)[i];
         __syncthreads();
         zm.lit_code = s_code;
     }
     __shared__ Lz4Lds s_lz[CODEC ? RWAVES : 1];                                                  // codec working set
     __shared__ __attribute__((aligned(16))) uint8_t s_bm[CODEC ? 1 : RWAVES][CODEC ? 16 : TILE_BM];  // transpose only
-    __shared__ WaveStage s_stage[LEVEL1 ? RWAVES : 1];                                           // compacted residuals
+    __shared__ WaveStage s_stage[LEVEL1 ? RWAVES : 1];
+                                          // compacted residuals
 
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t grp = j % ngroups;
@@ -583,19 +580,31 @@ static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t 
     // drained: the step gets LONGER (0.97 ms vs 0.83; LZ4 0.483 vs 0.478).  Shrinking the second stage's workgroups to one
     // wavefront as well brings the interference back in full (0.465 ms, step 0.478).  Two wavefronts: in between.  The work is
     // conserved; four wavefronts per workgroup overlaps it best.
-    auto grid_for = [&](uint32_t nt) { return (((nt + RWAVES - 1) / RWAVES + 7) / 8) * 8 * ngroups; };
     // aligned frames: the tiles that lie wholly inside the frame go through the explicit-wait instantiation; a partial last
     // tile (N not a multiple of TILE_PX) gets a second, tiny launch of the plain one
     const uint32_t nfull = AL ? (uint32_t)(sc.N / TILE_PX) : 0u;
     const ZmParams zm{reinterpret_cast<const uint16_t *>(sc.zm_lit_code), sc.zm_valid, sc.zm_budget, sc.zm_seq_bits};
-    if (nfull)
-        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, AL, L1, CODEC, KEEP, RAW>), dim3(grid_for(nfull)), dim3(RWG), 0, s, frames, sc.thr, sc.N,
-                           sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
-                           sc.blk_size, depth, sc.status, zm);
-    if (nfull < sc.ntiles)   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
-        hipLaunchKernelGGL((k_reduce_tiles<BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(RWG), 0, nfull ? s_tail : s, frames,
-                           sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
-                           sc.blk_slots, sc.blk_size, depth, sc.status, zm);
+    // Workgroups of THREE waves let five of them (15 waves) share a CU's LDS where four-wave workgroups fit three (12 waves).  Same-box
+    // A/B against the two-register-set kernel of round 2 (tools/ab_configs.sh): LZ4 level 1 +1.3..3.5 %, d = 12 +4.5 %, 11520 x 8184
+    // zstd +4.5 %; level 3 / mode 0 (nothing to gain from LDS, three-wave workgroups cost 2-4 %) and the configurations whose second
+    // stage is long next to the following batch's reduce kernel (zstd at 4096^2, level 2, blosc: the STEP got 1-6 % longer although the
+    // kernel got 5 % shorter) keep four-wave workgroups.
+    static const char *rw_env = getenv("RC_REDUCE_WG_WAVES");   // (experiments: 3 or 4)
+    const bool three = rw_env ? atoi(rw_env) == 3 : (L1 && !RAW && (CODEC == 2 || CODEC == 4 || sc.ntiles > 8192));
+    auto go = [&](auto rw) {
+        constexpr int RW = decltype(rw)::value;
+        auto grid_for = [&](uint32_t nt) { return (((nt + RW - 1) / RW + 7) / 8) * 8 * ngroups; };
+        if (nfull)
+            hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, AL, L1, CODEC, KEEP, RAW>), dim3(grid_for(nfull)), dim3(64 * RW), 0, s, frames, sc.thr, sc.N,
+                               sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
+                               sc.blk_size, depth, sc.status, zm);
+        if (nfull < sc.ntiles)   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
+            hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
+                               sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
+                               sc.blk_slots, sc.blk_size, depth, sc.status, zm);
+    };
+    if (three) go(std::integral_constant<int, 3>{});
+    else go(std::integral_constant<int, 4>{});
 }
 template <int BZ, bool AL, bool L1, bool RAW>
 static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s, hipStream_t s_tail)

@@ -35,98 +35,132 @@ _DEVICE_DECODERS = (2, 8)  # LZ4 frames and blosc1-LZ4 chunks are always DEcoded
 # device decoder's subset (everything this library writes; rc_decompress says RC_ERR_UNSUPPORTED otherwise), else by the stock library
 
 
-def _zstd_host_decompress(data, decompressor_context=None):
+_HOST_LIBS = {}
+
+
+def _host_lib(name):
+    """The system's libzstd / liblz4 through ctypes, loaded ONCE (ctypes.util.find_library runs ldconfig: tens of milliseconds a call)."""
+    if name not in _HOST_LIBS:
+        import ctypes.util
+        path = ctypes.util.find_library(name)
+        L = C.CDLL(path) if path else None
+        if L is not None and name == 'zstd':
+            L.ZSTD_createDStream.restype = C.c_void_p
+            L.ZSTD_freeDStream.argtypes = [C.c_void_p]
+            L.ZSTD_decompressStream.restype = C.c_size_t
+            L.ZSTD_decompressStream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            L.ZSTD_isError.argtypes = [C.c_size_t]
+        if L is not None and name == 'lz4':
+            L.LZ4F_createDecompressionContext.restype = C.c_size_t
+            L.LZ4F_createDecompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+            L.LZ4F_freeDecompressionContext.argtypes = [C.c_void_p]
+            L.LZ4F_decompress.restype = C.c_size_t
+            L.LZ4F_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
+            L.LZ4F_isError.argtypes = [C.c_size_t]
+        _HOST_LIBS[name] = L
+    return _HOST_LIBS[name]
+
+
+class _ZBuf(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('size', C.c_size_t), ('pos', C.c_size_t)]
+
+
+def _zstd_host_decompress(data, decompressor_context=None, size_hint=0, into=None):
     """Stream-decode a zstd frame without a content-size field (what both the reference and this library write,
     recode_writer.py:177-178) with the stock decoder: the `zstandard` package when installed (the reference's own
-    dependency), else libzstd through ctypes.  Host library call, like reference recode_compressors.py:46."""
+    dependency), else libzstd through ctypes.  Host library call, like reference recode_compressors.py:46.
+    size_hint: the decoded size when the caller knows it (one output buffer, no growing).  into: uint8 array that receives
+    the bytes (exactly: a stream that decodes to another length raises); the return value is then the length."""
     zs = _optional('zstandard')
-    if zs is not None:
+    if zs is not None and into is None:
         ctx = decompressor_context if hasattr(decompressor_context, 'decompressobj') else zs.ZstdDecompressor()
         return ctx.decompressobj().decompress(bytes(data))
-    import ctypes.util
-    name = ctypes.util.find_library('zstd')
-    if not name:
+    L = _host_lib('zstd')
+    if L is None:
         raise ImportError("For compression code 1 package zstandard (or libzstd) is required.")
-    L = C.CDLL(name)
-
-    class Buf(C.Structure):
-        _fields_ = [('p', C.c_void_p), ('size', C.c_size_t), ('pos', C.c_size_t)]
-    L.ZSTD_createDStream.restype = C.c_void_p
-    L.ZSTD_freeDStream.argtypes = [C.c_void_p]
-    L.ZSTD_decompressStream.restype = C.c_size_t
-    L.ZSTD_decompressStream.argtypes = [C.c_void_p, C.POINTER(Buf), C.POINTER(Buf)]
-    L.ZSTD_isError.argtypes = [C.c_size_t]
-    src = (C.c_char * len(data)).from_buffer_copy(bytes(data)) if len(data) else (C.c_char * 1)()
+    src = np.frombuffer(memoryview(data), np.uint8) if len(data) else np.zeros(1, np.uint8)
+    out = into if into is not None else np.empty(max(int(size_hint), 1 << 16) + 64, np.uint8)
     zds = L.ZSTD_createDStream()
-    out, chunk = bytearray(), C.create_string_buffer(1 << 20)
-    ib = Buf(C.addressof(src), len(data), 0)
+    ib, got = _ZBuf(src.ctypes.data, len(data), 0), 0
     try:
         while True:
-            ob = Buf(C.addressof(chunk), len(chunk), 0)
+            ob = _ZBuf(out.ctypes.data + got, out.size - got, 0)
             r = L.ZSTD_decompressStream(zds, C.byref(ob), C.byref(ib))
             if L.ZSTD_isError(r):
                 raise ValueError("libzstd rejected the stream")
-            out += chunk.raw[:ob.pos]
+            got += ob.pos
             if r == 0 and ib.pos == ib.size:
                 break
             if ib.pos == ib.size and ob.pos < ob.size:
                 raise ValueError("truncated zstd frame")
+            if got == out.size:
+                if into is not None:
+                    raise ValueError("stream decodes to more bytes than expected")
+                out = np.concatenate([out, np.empty(out.size, np.uint8)])
     finally:
         L.ZSTD_freeDStream(zds)
-    return bytes(out)
+    if into is not None:
+        if got != into.size:
+            raise ValueError("stream decodes to fewer bytes than expected")
+        return got
+    return out[:got].tobytes()
 
 
-def _lz4_host_decompress(data):
+def _lz4_host_decompress(data, size_hint=0, into=None):
     """LZ4 frame -> bytes with the stock decoder: the `lz4` package when installed (the reference's dependency,
     recode_compressors.py:49), else liblz4's LZ4F streaming API through ctypes.  None: neither is available."""
-    if _optional('lz4') is not None:
+    if _optional('lz4') is not None and into is None:
         import lz4.frame
         return lz4.frame.decompress(bytes(data))
-    import ctypes.util
-    name = ctypes.util.find_library('lz4')
-    if not name:
+    L = _host_lib('lz4')
+    if L is None:
         return None
-    L = C.CDLL(name)
-    L.LZ4F_createDecompressionContext.restype = C.c_size_t
-    L.LZ4F_createDecompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
-    L.LZ4F_freeDecompressionContext.argtypes = [C.c_void_p]
-    L.LZ4F_decompress.restype = C.c_size_t
-    L.LZ4F_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
-    L.LZ4F_isError.argtypes = [C.c_size_t]
     ctx = C.c_void_p()
     if L.LZ4F_isError(L.LZ4F_createDecompressionContext(C.byref(ctx), 100)):
         return None
     src = np.frombuffer(memoryview(data), np.uint8)
-    out, chunk, pos = bytearray(), C.create_string_buffer(1 << 20), 0
+    out, got, pos = (into if into is not None else np.empty(max(int(size_hint), 1 << 16) + 64, np.uint8)), 0, 0
     try:
         while pos < src.size:
-            dn, sn = C.c_size_t(len(chunk)), C.c_size_t(src.size - pos)
-            r = L.LZ4F_decompress(ctx, chunk, C.byref(dn), src.ctypes.data + pos, C.byref(sn), None)
+            dn, sn = C.c_size_t(out.size - got), C.c_size_t(src.size - pos)
+            r = L.LZ4F_decompress(ctx, out.ctypes.data + got, C.byref(dn), src.ctypes.data + pos, C.byref(sn), None)
             if L.LZ4F_isError(r):
                 raise ValueError("liblz4 rejected the stream")
-            out += chunk.raw[:dn.value]
+            got += dn.value
             pos += sn.value
             if r == 0:
                 break
             if sn.value == 0 and dn.value == 0:
                 raise ValueError("truncated LZ4 frame")
+            if got == out.size and pos < src.size:
+                if into is not None:
+                    # (an exactly filled buffer: the frame's end mark and checksum may still be unread)
+                    dn, sn = C.c_size_t(0), C.c_size_t(src.size - pos)
+                    r = L.LZ4F_decompress(ctx, out.ctypes.data, C.byref(dn), src.ctypes.data + pos, C.byref(sn), None)
+                    if L.LZ4F_isError(r) or r != 0:
+                        raise ValueError("stream decodes to more bytes than expected")
+                    break
+                out = np.concatenate([out, np.empty(out.size, np.uint8)])
     finally:
         L.LZ4F_freeDecompressionContext(ctx)
-    return bytes(out)
+    if into is not None:
+        if got != into.size:
+            raise ValueError("stream decodes to fewer bytes than expected")
+        return got
+    return out[:got].tobytes()
 
 
 def host_stream_decoder(scheme):
-    """bytes-like -> bytes through the STOCK library for a scheme whose foreign streams the device decoders refuse (1 zstd, 2 LZ4);
-    None when no stock decoder can be had.  Thread-safe: every call builds its own decoding context."""
-    import ctypes.util
+    """(bytes-like, decoded size or 0, into=None or the uint8 array to fill) -> bytes (or the length) through the STOCK library for a scheme whose foreign streams the device decoders refuse
+    (1 zstd, 2 LZ4); None when no stock decoder can be had.  Thread-safe: every call builds its own decoding context."""
     if scheme == 1:
-        if _optional('zstandard') is None and not ctypes.util.find_library('zstd'):
+        if _optional('zstandard') is None and _host_lib('zstd') is None:
             return None
-        return lambda b: _zstd_host_decompress(b)
+        return lambda b, n=0, into=None: _zstd_host_decompress(b, None, n, into)
     if scheme == 2:
-        if _optional('lz4') is None and not ctypes.util.find_library('lz4'):
+        if _optional('lz4') is None and _host_lib('lz4') is None:
             return None
-        return lambda b: _lz4_host_decompress(b)
+        return lambda b, n=0, into=None: _lz4_host_decompress(b, n, into)
     return None
 
 
@@ -219,7 +253,7 @@ def import_checks(header):
         return True
     if s == 1:
         import ctypes.util
-        if _optional('zstandard') is None and not ctypes.util.find_library('zstd'):
+        if _optional('zstandard') is None and _host_lib('zstd') is None:
             print("For compression code 1 package zstandard is required.")
             raise ImportError()
         return True

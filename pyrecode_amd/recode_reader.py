@@ -142,6 +142,12 @@ class ReCoDeReader:
         if getattr(self, '_read_pool', None) is not None:
             self._read_pool.shutdown(wait=True)
             self._read_pool = None
+        if getattr(self, '_decode_pool', None) is not None:
+            self._decode_pool.shutdown(wait=True)
+            self._decode_pool = None
+        if getattr(self, '_pin_pieces', None) is not None:
+            self._pin_pieces.close()
+            self._pin_pieces = None
 
     def _read_into(self, view, pos):
         """file bytes [pos, pos + len(view)) -> view (page-locked memory), in a few pieces on worker threads: a read from the page
@@ -300,28 +306,38 @@ class ReCoDeReader:
         dec = compressors.host_stream_decoder(scheme)
         if dec is None:
             return None
-        spans, off = [], 0
-        for i in range(n):
-            spans.append((off, int(sizes[i, 0])))
-            off += int(sizes[i, 0])
-            if level == 1:
-                spans.append((off, int(sizes[i, 1])))
-                off += int(sizes[i, 1])
-        view = memoryview(blob)
-        try:
-            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
-                parts = list(pool.map(lambda sp: dec(view[sp[0]:sp[0] + sp[1]]), spans))
-        except Exception:
-            return None
-        per = 2 if level == 1 else 1
+        # every stream decodes straight into its place of the stored-pieces image, in page-locked memory (sizes are known: the
+        # binary map's nb bytes, the value stream's bytes_in_packed_pixvals)
+        spans, off, dst = [], 0, 0
         sizes0 = np.zeros((n, 3), np.uint32)
         for i in range(n):
-            if len(parts[per * i]) != nb or (level == 1 and len(parts[2 * i + 1]) != int(sizes[i, 2])):
-                return None
+            spans.append((off, int(sizes[i, 0]), dst, nb))
+            off += int(sizes[i, 0])
+            dst += nb
             sizes0[i, 0] = nb
             if level == 1:
-                sizes0[i, 1] = sizes0[i, 2] = int(sizes[i, 2])
-        pieces = np.frombuffer(b''.join(parts), np.uint8)
+                npk = int(sizes[i, 2])
+                spans.append((off, int(sizes[i, 1]), dst, npk))
+                off += int(sizes[i, 1])
+                dst += npk
+                sizes0[i, 1] = sizes0[i, 2] = npk
+        if getattr(self, '_pin_pieces', None) is None or self._pin_pieces.nbytes < dst + 64:
+            if getattr(self, '_pin_pieces', None) is not None:
+                self._pin_pieces.close()
+            self._pin_pieces = _lib.PinnedBuffer(int(dst * 1.25) + (1 << 20))
+        pieces = self._pin_pieces.array[:dst]
+        view = memoryview(blob)
+
+        def one(sp):
+            src_off, src_n, at, want = sp
+            if want:
+                dec(view[src_off:src_off + src_n], want, pieces[at:at + want])
+        try:
+            if getattr(self, '_decode_pool', None) is None:
+                self._decode_pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1))
+            list(self._decode_pool.map(one, spans))
+        except Exception:
+            return None
         L = _lib.lib()
         prefix = np.zeros(n + 1, np.uint64)
         args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, 0, scheme, _lib.ptr(pieces), _lib.ptr(sizes0), n)

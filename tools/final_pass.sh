@@ -5,26 +5,36 @@
 T=$1
 OUT=gpurun_out/final_$T
 mkdir -p $OUT
-line() { name=$1; shift; python3 bench.py "$@" > $OUT/$name.json 2> $OUT/$name.err; tail -c 600 $OUT/$name.json | head -c 400; echo; }
+line() { name=$1; shift; python3 bench.py "$@" > $OUT/$name.json 2> $OUT/$name.err; tail -c 700 $OUT/$name.json | head -c 300; echo; }
+Q="--no-cpu-baseline --no-ingest --min-seconds 1"
 line headline
-line cfg3_zstd --scheme 1 --no-cpu-baseline
-line zstd_fast --scheme 1 --clevel 0 --no-cpu-baseline --no-ingest
-line cfg4 --scheme 8 --level 2 --sparsity-ppm 1000 --no-cpu-baseline --no-ingest
-line cfg5_b16 --ny 8184 --nx 11520 --batch 16 --stack 32 --sparsity-ppm 50000 --scheme 1 --depth 12 --no-cpu-baseline --no-ingest
-line cfg5_b32 --ny 8184 --nx 11520 --batch 32 --stack 64 --sparsity-ppm 50000 --scheme 1 --depth 12 --no-cpu-baseline --no-ingest
-line l3_lz4 --level 3 --no-cpu-baseline --no-ingest
-line mode0 --scheme 0 --no-cpu-baseline --no-ingest
-line lz4_d12 --depth 12 --no-cpu-baseline --no-ingest
-line zstd_d12 --scheme 1 --depth 12 --no-cpu-baseline --no-ingest
-line read_zstd --read --scheme 1
-line read_lz4 --read --scheme 2
-line read_zstd_fast --read --scheme 1 --clevel 0
-line read_cfg5 --read --scheme 1 --ny 8184 --nx 11520 --batch 16 --sparsity-ppm 50000 --depth 12
+line cfg1 --config 1 $Q
+line cfg3_zstd --config 3 --no-cpu-baseline
+line zstd_fast --scheme 1 --clevel 0 $Q
+line lz4_level0 --clevel 0 $Q
+line cfg4 --config 4 $Q
+line cfg5_b16 --config 5 --batch 16 --stack 32 $Q
+line cfg5_b32 --config 5 $Q
+line l3_lz4 --level 3 $Q
+line mode0 --scheme 0 $Q
+line lz4_d12 --depth 12 $Q
+line zstd_d12 --scheme 1 --depth 12 $Q
+line detector_like_lz4 --clustered --sparsity-ppm 11000 --depth 12 $Q
+line detector_like_zstd --clustered --sparsity-ppm 11000 --depth 12 --scheme 1 $Q
+line rehearsal_2ranks_gloo_shared_gpu --gpus 2 --shared-gpu --dist-backend gloo --stack 128 --min-seconds 1
+line read_zstd --read --scheme 1 --steps 30 --warmup 5 --min-seconds 1
+line read_lz4 --read --scheme 2 --steps 30 --warmup 5 --min-seconds 1
+line read_zstd_fast --read --scheme 1 --clevel 0 --steps 30 --warmup 5 --min-seconds 1
+line read_zstd_blob_on_device --read --scheme 1 --blob-on-device --steps 30 --warmup 5 --min-seconds 1
+line read_cfg5 --read --scheme 1 --ny 8184 --nx 11520 --batch 16 --sparsity-ppm 50000 --depth 12 --steps 10 --warmup 2 --min-seconds 1
+python3 tools/foreign_read_rate.py 1 64 32 > $OUT/foreign_zstd.log 2>&1; tail -2 $OUT/foreign_zstd.log
+python3 tools/foreign_read_rate.py 2 64 32 > $OUT/foreign_lz4.log 2>&1; tail -2 $OUT/foreign_lz4.log
 echo "== profiles"
 tools/prof_round.sh ${T}_lz4 > $OUT/prof_lz4.log 2>&1
 tools/prof_round.sh ${T}_zstd --scheme 1 > $OUT/prof_zstd.log 2>&1
-tools/prof_round.sh ${T}_zstd_fast --scheme 1 --clevel 0 > $OUT/prof_zstd_fast.log 2>&1
-tools/prof_round.sh ${T}_cfg5_b16 --ny 8184 --nx 11520 --batch 16 --stack 32 --sparsity-ppm 50000 --scheme 1 --depth 12 > $OUT/prof_cfg5_b16.log 2>&1
-tools/prof_round.sh ${T}_cfg4 --scheme 8 --level 2 --sparsity-ppm 1000 > $OUT/prof_cfg4.log 2>&1
+tools/prof_round.sh ${T}_cfg5 --config 5 > $OUT/prof_cfg5.log 2>&1
+tools/prof_round.sh ${T}_cfg5_b16 --config 5 --batch 16 --stack 32 > $OUT/prof_cfg5_b16.log 2>&1
+tools/prof_round.sh ${T}_cfg4 --config 4 > $OUT/prof_cfg4.log 2>&1
 tools/prof_round.sh ${T}_d12 --depth 12 > $OUT/prof_d12.log 2>&1
+for s in 1 2; do tools/prof_bench.sh ${T}_read_s$s --read --scheme $s --steps 30 --warmup 5 --min-seconds 0.5 > $OUT/prof_read_s$s.log 2>&1; done
 echo done

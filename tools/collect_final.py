@@ -4,7 +4,7 @@ usage: python tools/collect_final.py <tag> <round>      e.g.  r02c r02"""
 import glob, json, os, shutil, sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
-ARGS = {"lz4": "", "zstd": "--scheme 1", "zstd_fast": "--scheme 1 --clevel 0",
+ARGS = {"lz4": "", "zstd": "--scheme 1", "zstd_fast": "--scheme 1 --clevel 0", "read_s1": "--read --scheme 1", "read_s2": "--read --scheme 2",
         "cfg5": "--ny 8184 --nx 11520 --batch 32 --stack 64 --sparsity-ppm 50000 --scheme 1 --depth 12",
         "cfg5_b16": "--ny 8184 --nx 11520 --batch 16 --stack 32 --sparsity-ppm 50000 --scheme 1 --depth 12",
         "cfg4": "--scheme 8 --level 2 --sparsity-ppm 1000", "d12": "--depth 12"}

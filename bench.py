@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the per-frame reduce -> bit-pack -> compress hot path on N MI355X GPUs.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).  With no RANK in the environment and
+N > 1 this process starts its own N ranks - a CHILD `python -m torch.distributed.run --nproc-per-node N bench.py ...`, before it has
+touched the GPU - relays rank 0's line and exits non-zero if any rank fails; launched by torch.distributed.run itself it is a rank
+(one rank per GPU, RCCL).
 
   step      one pass of the hot path over one batch of B synthetic frames per GPU, inputs resident in HBM:
             rc_reduce_compress_batch_async = reduce kernel (LZ4 bitmap encoder fused in) -> scans -> record layout ->
             assembly (zstd: its block encoder runs as a kernel of its own after the reduce kernel),
             records + offsets + metadata left in HBM; for N > 1 each step also issues the path's one exchange step, the
-            RCCL all-gather of the per-frame metadata (12 B / frame, SURVEY.md §8e), on a side stream so that it overlaps
-            the next step (metadata rows double-buffered; all of them are complete inside the timed region).
-  workload  BASELINE.json configs[1]: 4096x4096 uint16, 1 % sparsity, L1 + LZ4 (d = 16 primary; --depth 12 secondary).
+            RCCL all-gather of the per-frame metadata (12 B / frame, SURVEY.md 8e), on a side stream so that it overlaps
+            the next step (metadata rows double-buffered; all of them are complete inside the timed region):
+            pyrecode_amd/parallel.py::ShardedStepLoop.
+  workload  BASELINE.json configs[1]: 4096x4096 uint16, 1 % sparsity, L1 + LZ4 (d = 16 primary; --depth 12 secondary);
+            --config 1..5 = the other BASELINE configurations, --clustered = detector-like events.
   value     frames/s, whole job (all ranks' frames / max-over-ranks time); gb_per_s_in = value * 2*nx*ny.
+  verified  every rank decodes one record of its last batch with the stock library / the oracle's decoders and compares it with the
+            oracle's reduce of that frame (level 2: scipy.ndimage.label); gather_verified: every rank's block of the metadata table
+            the last step gathered, on every rank.
   roofline  dominant kernel = the reduce kernel (k_reduce_tiles): algorithmic bytes per launch = B * 2*nx*ny
-            (one read of the uint16 frames, SURVEY §8d) / its mean duration, measured with HIP events on the ctx's
+            (one read of the uint16 frames, SURVEY 8d) / its mean duration, measured with HIP events on the ctx's
             stream inside the timed region; peak = 8000 GB/s (MI355X_MICROARCH.md).
   cpu_baseline  the oracle's C restatement (+ stock liblz4 for the LZ4 stage) on the box's host cores, bounded sample.
 """

@@ -157,6 +157,12 @@ __global__ __launch_bounds__(WG) void k_expand_bases(const uint64_t *__restrict_
         if (err && base > cap) atomicOr(err, 2);
     }
 }
+// A workgroup's triplets are ONE contiguous range of the output (frame base + block offset, in row-major order), so they are
+// assembled in LDS and leave as consecutive 8-byte stores - a lane writing its three words itself spreads every store instruction
+// over a dozen partially written lines (181 us for 64 frames of 4096 x 4096 at 1 %; this form: see DESIGN.md).  Blocks with more set
+// pixels than the stage holds write directly.  Row / column of a word's first pixel come from ONE division (frames have fewer than
+// 2^32 pixels: nx, ny <= 65 535), the pixels behind it step the column.
+constexpr uint32_t EMIT_STAGE = 1024;   // triplets
 __global__ __launch_bounds__(WG) void k_expand_emit_b(const uint8_t *__restrict__ bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx,
                                                         uint32_t nblk, const uint32_t *__restrict__ blk_off, const uint64_t *__restrict__ frame_base,
                                                         const uint8_t *__restrict__ pv, uint64_t pv_stride, const uint32_t *__restrict__ pv_bytes,
@@ -164,25 +170,43 @@ __global__ __launch_bounds__(WG) void k_expand_emit_b(const uint8_t *__restrict_
                                                         const int *__restrict__ err)
 {
     __shared__ uint32_t sm[WAVES + 1];
+    __shared__ uint64_t s_trip[3 * EMIT_STAGE];
     if (err && *err) return;   // (workgroup-uniform: k_expand_bases, a decoder or nobody has set it before this kernel started)
     const uint32_t f = blockIdx.y;
     const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t bits = expand_word(bm + f * bm_stride, nb8, N, i);
     const uint64_t k0 = i * 64;
     uint32_t tot;
-    uint64_t rank = blk_off[(uint64_t)f * nblk + blockIdx.x] + block_excl_scan((uint32_t)__builtin_popcountll(bits), sm, &tot);
+    const uint32_t local = block_excl_scan((uint32_t)__builtin_popcountll(bits), sm, &tot);
+    if (tot == 0) return;
+    const uint64_t wg_rank = blk_off[(uint64_t)f * nblk + blockIdx.x];      // rank of the workgroup's first set pixel inside the frame
     const uint64_t base = frame_base[f];
     const uint8_t *pix = pv + f * pv_stride;
     const uint64_t pix_bytes = level == 1 ? pv_bytes[f] : 0;
-    for (; bits; bits &= bits - 1, ++rank) {
-        if (base + rank >= cap) break;
-        const uint64_t k = k0 + (uint64_t)__builtin_ctzll(bits);
-        const uint32_t row = (uint32_t)(k / nx), col = (uint32_t)(k - (uint64_t)row * nx);
-        uint64_t *o = out + 3 * (base + rank);
-        o[0] = row;
-        o[1] = col;
-        o[2] = level == 1 ? read_field(pix, pix_bytes, rank, d) : 1ull;
+    const bool staged = tot <= EMIT_STAGE && base + wg_rank + tot <= cap;    // (uniform; a range that would cross cap keeps the per-entry check)
+    if (bits) {
+        uint32_t row = (uint32_t)((uint32_t)k0 / nx), col = (uint32_t)k0 - row * nx, prev = 0;
+        uint32_t r = local;
+        for (; bits; bits &= bits - 1, ++r) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(bits);
+            col += b - prev;
+            prev = b;
+            while (col >= nx) { col -= nx; ++row; }
+            const uint64_t rank = wg_rank + r;
+            const uint64_t val = level != 1 ? 1ull : ((d == 16 && 2 * rank + 2 <= pix_bytes) ? (uint64_t)reinterpret_cast<const uint16_t *>(pix)[rank]   // (value streams are 16-byte aligned)
+                                                                                                : read_field(pix, pix_bytes, rank, d));
+            if (staged) { s_trip[3 * r] = row; s_trip[3 * r + 1] = col; s_trip[3 * r + 2] = val; }
+            else {
+                if (base + rank >= cap) break;
+                uint64_t *o = out + 3 * (base + rank);
+                o[0] = row; o[1] = col; o[2] = val;
+            }
+        }
     }
+    if (!staged) return;
+    __syncthreads();
+    uint64_t *o = out + 3 * (base + wg_rank);
+    for (uint32_t j = threadIdx.x; j < 3 * tot; j += WG) o[j] = s_trip[j];
 }
 void launch_expand_batch_count(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t n, uint32_t *blk_cnt, uint32_t *blk_off,
                                uint64_t *frame_nnz, uint64_t *frame_base, hipStream_t s, const uint32_t *pv_bytes, uint32_t d, uint32_t level,

@@ -197,7 +197,7 @@ def ingest_inclusive(stack, dark, a, nframes=128, validation_frame_gap=-1):
         shutil.rmtree(out_dir, ignore_errors=True)
 
 
-def bench_read(a):
+def bench_read(a, emit=True):
     """Reader line: a step = one batch of B stored frames through the batched reader (host blobs in, triplets left in device memory),
     streamed with two batches in flight (rc_expand_frames_submit / _wait); the synchronous one-call form is reported next to it.
     Roofline of the path: the decoded streams are read once by the expand kernels and 24 bytes are written per set pixel
@@ -273,7 +273,7 @@ def bench_read(a):
     fps_call, fps = B * a.steps / dt, B * a.steps / pdt
     dt_call, dt = dt, pdt
     alg = (N // 8) * B + int(sizes[:, 2].sum()) + 24 * nnz
-    print(json.dumps({
+    line = {
         "metric": "reader: frames/sec, stored frames -> decode both streams -> (row, col, value) triplets in device memory",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
         "one_call_at_a_time": {"frames_per_s": round(fps_call, 1), "ms_per_call": round(dt_call / a.steps * 1e3, 4),
@@ -284,7 +284,10 @@ def bench_read(a):
         "roofline": {"bound": "hbm", "achieved": round(alg * a.steps / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg * a.steps / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_call": alg, "note": "whole call incl. host-side block indexing and the copy-in of the compressed blobs over the link (%.0f B/frame: the link alone allows about %.0f k frames/s); the decoders are serial chains per block (latency bound), not bandwidth bound" % (blob.size / B, 57e9 / (blob.size / B) / 1e3)},
-        "nnz_per_frame": round(nnz / B, 1)}), flush=True)
+        "nnz_per_frame": round(nnz / B, 1)}
+    if emit:
+        print(json.dumps(line), flush=True)
+    return line
 
 
 def launch_children(a, argv):
@@ -539,6 +542,21 @@ def run_rank(a):
                 result["ingest_inclusive"]["with_validation_frame_gap_10"] = {"frames_per_s": v["frames_per_s"], "gb_per_s_in": v["gb_per_s_in"]}
             except Exception as e:   # an extra: never lets the contract line fail
                 result["ingest_inclusive"] = {"error": repr(e)}
+        if world == 1 and not a.no_ingest and a.level in (1, 3) and a.scheme in (1, 2):
+            # extra, not `value`: the READER's batched path on the same configuration (stored frames in host memory -> device decode of both
+            # streams -> triplets in device memory; bench.py --read prints this as a line of its own)
+            try:
+                import copy
+                ra = copy.copy(a)
+                ra.steps, ra.warmup, ra.min_seconds = 20, 3, 0.5
+                ctx.close()
+                del stack
+                torch.cuda.empty_cache()
+                rl = bench_read(ra, emit=False)
+                result["reader"] = {"frames_per_s_streaming": rl["value"], "frames_per_s_one_call_at_a_time": rl["one_call_at_a_time"]["frames_per_s"],
+                                    "verified": rl["verified"], "what": rl["metric"]}
+            except Exception as e:
+                result["reader"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
     ok = (gather_verified is not False)
     if use_dist:

@@ -32,6 +32,9 @@ __device__ unsigned long long g_phase[16];
 #define RC_PHASE_BEGIN
 #define RC_PHASE(i) do { } while (0)
 #endif
+#ifndef RC_BZ
+#define RC_BZ 4   // frames a wavefront keeps its tile (and the threshold registers) for
+#endif
 #ifndef RC_ABLATE
 #define RC_ABLATE 0
 #endif
@@ -650,8 +653,8 @@ void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32
     if (depth == 0 || depth > 16) depth = 16;
     if (!s_tail) s_tail = s;
     const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
-    if (aligned) launch_reduce_a<4, true>(sc, frames, B, level, codec, keep_bitmap, depth, s, s_tail);
-    else launch_reduce_a<4, false>(sc, frames, B, level, codec, keep_bitmap, depth, s, s_tail);
+    if (aligned) launch_reduce_a<RC_BZ, true>(sc, frames, B, level, codec, keep_bitmap, depth, s, s_tail);
+    else launch_reduce_a<RC_BZ, false>(sc, frames, B, level, codec, keep_bitmap, depth, s, s_tail);
 }
 
 // ---- per-frame scans over tiles ---------------------------------------------------------------------------

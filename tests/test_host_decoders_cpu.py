@@ -1,0 +1,75 @@
+"""CPU: the stock-library decoders the reader falls back to for streams a FOREIGN encoder wrote (pyrecode_amd/recode_compressors.py:
+host_stream_decoder - the same library calls the reference makes, recode_compressors.py:46-49): frames of the system's libzstd / liblz4
+decode through the ctypes bindings, into a caller's buffer of the known size as well, and damaged or mis-sized streams raise."""
+import ctypes as C
+import ctypes.util
+
+import numpy as np
+import pytest
+
+from pyrecode_amd import recode_compressors as rcomp
+
+
+def _stock_encoders():
+    enc = {}
+    name = ctypes.util.find_library("zstd")
+    if name:
+        z = C.CDLL(name)
+        z.ZSTD_compress.restype = C.c_size_t
+        z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+
+        def zenc(b, level=1):
+            dst = C.create_string_buffer(len(b) + len(b) // 8 + 1024)
+            n = z.ZSTD_compress(dst, len(dst), b, len(b), level)
+            return dst.raw[:n]
+        enc[1] = zenc
+    name = ctypes.util.find_library("lz4")
+    if name:
+        lz = C.CDLL(name)
+        lz.LZ4F_compressFrameBound.restype = C.c_size_t
+        lz.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+        lz.LZ4F_compressFrame.restype = C.c_size_t
+        lz.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+
+        def lenc(b, level=1):
+            dst = C.create_string_buffer(lz.LZ4F_compressFrameBound(len(b), None) + 64)
+            n = lz.LZ4F_compressFrame(dst, len(dst), b, len(b), None)
+            return dst.raw[:n]
+        enc[2] = lenc
+    return enc
+
+
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_stock_frames_decode_through_the_ctypes_bindings(scheme):
+    enc = _stock_encoders().get(scheme)
+    if enc is None:
+        pytest.skip("no system library for scheme %d" % scheme)
+    dec = rcomp.host_stream_decoder(scheme)
+    assert dec is not None
+    rng = np.random.default_rng(scheme)
+    payloads = [b"", b"\x07", bytes(70000),                                                         # empty, one byte, a long zero run
+                np.packbits(rng.random(300000 * 8) < 0.01).tobytes(),                               # a sparse binary map (several 64 KiB blocks)
+                rng.integers(0, 2048, 50000).astype("<u2").tobytes(),                               # residuals: incompressible low bytes
+                rng.integers(0, 256, 200000).astype(np.uint8).tobytes()]                            # noise: stored blocks
+    for data in payloads:
+        comp = enc(data)
+        assert dec(comp) == data
+        assert dec(comp, len(data)) == data
+        if data:
+            out = np.full(len(data), 0xAA, np.uint8)
+            assert dec(comp, len(data), out) == len(data) and out.tobytes() == data
+            with pytest.raises(ValueError):                                                          # the caller's size is a contract
+                dec(comp, len(data) - 1, np.empty(len(data) - 1, np.uint8))
+            with pytest.raises(ValueError):
+                dec(comp, len(data) + 1, np.empty(len(data) + 1, np.uint8))
+            with pytest.raises(ValueError):                                                          # truncated stream
+                dec(comp[:len(comp) // 2], len(data), np.empty(len(data), np.uint8))
+    threads = 8                                                                                      # every call builds its own context
+    from concurrent.futures import ThreadPoolExecutor
+    comp = enc(payloads[3])
+    with ThreadPoolExecutor(threads) as pool:
+        assert all(r == payloads[3] for r in pool.map(lambda _: dec(comp, len(payloads[3])), range(32)))
+
+
+def test_unknown_scheme_has_no_host_stream_decoder():
+    assert rcomp.host_stream_decoder(0) is None and rcomp.host_stream_decoder(8) is None

@@ -151,8 +151,8 @@ def _lz4_host_decompress(data, size_hint=0, into=None):
 
 
 def host_stream_decoder(scheme):
-    """(bytes-like, decoded size or 0, into=None or the uint8 array to fill) -> bytes (or the length) through the STOCK library for a scheme whose foreign streams the device decoders refuse
-    (1 zstd, 2 LZ4); None when no stock decoder can be had.  Thread-safe: every call builds its own decoding context."""
+    """(bytes-like, decoded size or 0, into=None or the uint8 array to fill) -> bytes (or the length) through the STOCK library: for schemes whose foreign streams the device decoders refuse
+    (1 zstd, 2 LZ4) and for the host-only ones of the standard library (0 zlib, 4 bz2, 5 lzma); None when no stock decoder can be had.  Thread-safe: every call builds its own decoding context."""
     if scheme == 1:
         if _optional('zstandard') is None and _host_lib('zstd') is None:
             return None
@@ -161,6 +161,18 @@ def host_stream_decoder(scheme):
         if _optional('lz4') is None and _host_lib('lz4') is None:
             return None
         return lambda b, n=0, into=None: _lz4_host_decompress(b, n, into)
+    if scheme in (0, 4, 5):   # host-only schemes of the standard library (zlib is the reference's own test configuration)
+        fn = {0: zlib.decompress, 4: bz2.decompress, 5: lzma.decompress}[scheme]
+
+        def dec(b, n=0, into=None):
+            out = fn(bytes(b))
+            if into is None:
+                return out
+            if len(out) != into.size:
+                raise ValueError("stream decodes to %d bytes, %d expected" % (len(out), into.size))
+            into[:] = np.frombuffer(out, np.uint8)
+            return len(out)
+        return dec
     return None
 
 

@@ -232,7 +232,8 @@ class ReCoDeReader:
             raise ValueError('Requested frame index is greater than number of frames in dataset')
         level, mode, scheme = int(h['reduction_level']), int(h['rc_operation_mode']), int(h['compression_scheme'])
         fast = level in (1, 3) and (mode == 0 or scheme in (1, 2))
-        if fast:
+        host_only = level in (1, 3) and mode == 1 and scheme in (0, 4, 5)   # zlib / bz2 / lzma: stock decoder on the thread pool, ONE device expand
+        if fast or host_only:
             sizes = np.zeros((n, 3), np.uint32)
             for i in range(n):
                 md = self._frame_metadata[z0 + i]
@@ -253,7 +254,9 @@ class ReCoDeReader:
             prefix = np.zeros(n + 1, np.uint64)
             L = _lib.lib()
             args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, mode, scheme, _lib.ptr(blob), _lib.ptr(sizes), n)
-            if level == 1:
+            if host_only:
+                st = _lib.RC_ERR_UNSUPPORTED
+            elif level == 1:
                 # a frame's packed stream holds one depth-bit field per set pixel: its size bounds the count, one call does it all
                 d = int(h['target_bit_depth'])
                 cap = max(int((sizes[:, 2].astype(np.uint64) * 8 // d).sum()), 1)

@@ -399,7 +399,7 @@ def test_batched_reader_equals_per_frame_reader(tmp_path, scheme, clevel, mode, 
     rd.open(print_header=False)
     prefix, trip = rd.get_frames_triplets(1, nz - 1)
     assert prefix[0] == 0 and prefix[-1] == trip.shape[0]
-    assert rd.last_batch_path == ("per-frame" if (mode == 1 and scheme == 0) else "device")   # zlib: host library, like the reference
+    assert rd.last_batch_path == ("host-decode + device-expand" if (mode == 1 and scheme == 0) else "device")   # zlib: the host library on the pool
     want = np.where(frames > dark, frames - dark if level == 1 else 1, 0)
     for i, z in enumerate(range(1, nz)):
         t = trip[int(prefix[i]):int(prefix[i + 1])]
@@ -625,4 +625,32 @@ def test_files_a_stock_encoder_wrote_take_the_batched_path(scheme, tmp_path, orc
     assert seen == nz
     f = rd.get_frame(5)[5]["data"]                                   # the reference's frame-at-a-time API on the same file
     assert np.array_equal(np.asarray(f.todense()), np.where(frames[5] > thr, frames[5] - thr, 0))
+    rd.close()
+
+
+@pytest.mark.parametrize("tag", ["l1z12", "l1z16"])
+def test_reference_zlib_files_take_the_batched_path(tag):
+    """Files the REFERENCE wrote with its default codec (zlib, host-only) are read in batches too: the stock decoder on the thread pool,
+    one device expand - against what the reference's own reader returned for them (fixture G3)."""
+    from pyrecode_amd.recode_reader import ReCoDeReader
+    g = load_npz("g3_%s.npz" % tag)
+    frames, dark = g["frames"], g["dark"]
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    thr = (dark + np.uint16(cfg["calibration_threshold_epsilon"])).astype(np.uint16)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16)
+    rd = ReCoDeReader(os.path.join(FILES, "g3_%s.rc1" % tag), is_intermediate=False)
+    rd.open(print_header=False)
+    nz, (ny, nx) = frames.shape[0], frames.shape[1:]
+    prefix, trip = rd.get_frames_triplets(0, nz)
+    assert rd.last_batch_path == "host-decode + device-expand"
+    seen = 0
+    for a, pre, tr in rd.iter_frames_triplets(0, nz, batch=2):
+        assert np.array_equal(tr, trip[int(prefix[a]):int(prefix[a + len(pre) - 1])])
+        seen += len(pre) - 1
+    assert seen == nz
+    for z in range(nz):
+        t = trip[int(prefix[z]):int(prefix[z + 1])]
+        dense = np.zeros((ny, nx), np.uint16)
+        dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16)
+        assert np.array_equal(dense, want[z]), "frame %d" % z
     rd.close()

@@ -71,5 +71,13 @@ def test_stock_frames_decode_through_the_ctypes_bindings(scheme):
         assert all(r == payloads[3] for r in pool.map(lambda _: dec(comp, len(payloads[3])), range(32)))
 
 
-def test_unknown_scheme_has_no_host_stream_decoder():
-    assert rcomp.host_stream_decoder(0) is None and rcomp.host_stream_decoder(8) is None
+def test_standard_library_schemes_and_unknown_ones():
+    import bz2, lzma, zlib
+    data = np.packbits(np.random.default_rng(5).random(40000 * 8) < 0.02).tobytes()
+    for scheme, enc in ((0, lambda b: zlib.compress(b, 1)), (4, bz2.compress), (5, lzma.compress)):
+        dec = rcomp.host_stream_decoder(scheme)
+        out = np.zeros(len(data), np.uint8)
+        assert dec(enc(data)) == data and dec(enc(data), len(data), out) == len(data) and out.tobytes() == data
+        with pytest.raises(ValueError):
+            dec(enc(data), len(data) + 3, np.zeros(len(data) + 3, np.uint8))
+    assert rcomp.host_stream_decoder(8) is None and rcomp.host_stream_decoder(3) is None

@@ -261,6 +261,17 @@ int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t redu
 int rc_expand_frames_submit(uint32_t slot, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t reduction_level, uint32_t op_mode,
                             uint32_t scheme, const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *triplets_dev, uint64_t cap);
 int rc_expand_frames_wait(uint32_t slot, uint64_t *nnz_prefix);
+/* The host half of a batch whose streams only a STOCK decoder takes - files the reference's writer produced with zstandard /
+ * lz4.frame / zlib (recode_compressors.py:82-120): linked 64 KiB LZ4 blocks, 4-stream Huffman literals and real offsets in zstd,
+ * deflate.  Each is one serial chain, which the reference walks with one library call per stream (recode_compressors.py:40-79:
+ * zlib.decompress :43, zstd :46, lz4.frame.decompress :49).  rc_host_decode_streams makes the SAME library's call (libzstd.so.1 /
+ * liblz4.so.1 / libz.so.1, bound at run time) for n streams at once on worker threads: stream i is src[spans[4i] .. + spans[4i+1])
+ * and must decode to exactly spans[4i+3] bytes at dst + spans[4i+2] (host pointers; dst is typically the page-locked stored-pieces
+ * image that rc_expand_frames / _submit then takes with op_mode 0).  threads 0 = min(16, cores).  Schemes 1 (zstd), 2 (LZ4), 0 (zlib).
+ * RC_ERR_UNSUPPORTED: no such library on this host (rc_host_decoder_available says so beforehand);
+ * RC_ERR_CORRUPT: the stock decoder rejected a stream or it decodes to another size.  No GPU is touched. */
+int rc_host_decoder_available(uint32_t scheme);     /* 1 / 0 */
+int rc_host_decode_streams(uint32_t scheme, const uint8_t *src, uint8_t *dst, const uint64_t *spans, uint32_t n, uint32_t threads);
 /* bit_pack_pixel_intensities -> _bit_pack_pixel_intensities (reader.h:105-140) with the intended semantics of
  * the numba _bit_pack (recode_writer.py:637-652): zero, then LSB-first d-bit fields.  out_n = ceil(n*d/8). */
 int rc_bit_pack(const uint16_t *pixvals, uint64_t n, uint32_t bit_depth, uint8_t *out, uint64_t out_n);

@@ -8,6 +8,7 @@ ReCoDeWriter the device codecs never come through here: the batched operator emi
 import bz2
 import ctypes as C
 import lzma
+import threading
 import zlib
 
 import numpy as np
@@ -50,6 +51,10 @@ def _host_lib(name):
             L.ZSTD_decompressStream.restype = C.c_size_t
             L.ZSTD_decompressStream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
             L.ZSTD_isError.argtypes = [C.c_size_t]
+            L.ZSTD_initDStream.restype = C.c_size_t
+            L.ZSTD_initDStream.argtypes = [C.c_void_p]
+            L.ZSTD_decompressDCtx.restype = C.c_size_t
+            L.ZSTD_decompressDCtx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         if L is not None and name == 'lz4':
             L.LZ4F_createDecompressionContext.restype = C.c_size_t
             L.LZ4F_createDecompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
@@ -57,8 +62,37 @@ def _host_lib(name):
             L.LZ4F_decompress.restype = C.c_size_t
             L.LZ4F_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
             L.LZ4F_isError.argtypes = [C.c_size_t]
+            L.LZ4F_resetDecompressionContext.restype = None
+            L.LZ4F_resetDecompressionContext.argtypes = [C.c_void_p]
         _HOST_LIBS[name] = L
     return _HOST_LIBS[name]
+
+
+class _ThreadCtx:
+    """One decoding context of a stock library per THREAD, kept for the thread's life.  A fresh context per stream costs more than
+    its allocation: its 100 KB - 2 MB buffers come from mmap and go back with munmap, and with 16 decoding threads in one process
+    those calls (address-space lock, TLB shootdowns) serialise the pool - measured: 8 threads no faster than one."""
+    _tls = threading.local()
+
+    def __init__(self, handle, free):
+        self.handle, self._free = handle, free
+
+    def __del__(self):
+        try:
+            self._free(self.handle)
+        except Exception:
+            pass
+
+    @classmethod
+    def get(cls, key, make, free):
+        c = getattr(cls._tls, key, None)
+        if c is None:
+            h = make()
+            if not h:
+                return None
+            c = cls(h, free)
+            setattr(cls._tls, key, c)
+        return c.handle
 
 
 class _ZBuf(C.Structure):
@@ -79,30 +113,34 @@ def _zstd_host_decompress(data, decompressor_context=None, size_hint=0, into=Non
     if L is None:
         raise ImportError("For compression code 1 package zstandard (or libzstd) is required.")
     src = np.frombuffer(memoryview(data), np.uint8) if len(data) else np.zeros(1, np.uint8)
-    out = into if into is not None else np.empty(max(int(size_hint), 1 << 16) + 64, np.uint8)
-    zds = L.ZSTD_createDStream()
-    ib, got = _ZBuf(src.ctypes.data, len(data), 0), 0
-    try:
-        while True:
-            ob = _ZBuf(out.ctypes.data + got, out.size - got, 0)
-            r = L.ZSTD_decompressStream(zds, C.byref(ob), C.byref(ib))
-            if L.ZSTD_isError(r):
-                raise ValueError("libzstd rejected the stream")
-            got += ob.pos
-            if r == 0 and ib.pos == ib.size:
-                break
-            if ib.pos == ib.size and ob.pos < ob.size:
-                raise ValueError("truncated zstd frame")
-            if got == out.size:
-                if into is not None:
-                    raise ValueError("stream decodes to more bytes than expected")
-                out = np.concatenate([out, np.empty(out.size, np.uint8)])
-    finally:
-        L.ZSTD_freeDStream(zds)
+    zds = _ThreadCtx.get('zstd', L.ZSTD_createDStream, L.ZSTD_freeDStream)
+    if zds is None:
+        raise MemoryError("ZSTD_createDStream")
     if into is not None:
-        if got != into.size:
+        # the decoded size is known and the buffer is the caller's: one call, straight into it, no window buffer in between
+        r = L.ZSTD_decompressDCtx(zds, into.ctypes.data, into.size, src.ctypes.data, len(data))
+        if L.ZSTD_isError(r):
+            raise ValueError("libzstd rejected the stream (or it decodes to more bytes than expected)")
+        if r != into.size:
             raise ValueError("stream decodes to fewer bytes than expected")
-        return got
+        return int(r)
+    out = np.empty(max(int(size_hint), 1 << 16) + 64, np.uint8)
+    L.ZSTD_initDStream(zds)
+    ib, got = _ZBuf(src.ctypes.data, len(data), 0), 0
+    while True:
+        ob = _ZBuf(out.ctypes.data + got, out.size - got, 0)
+        r = L.ZSTD_decompressStream(zds, C.byref(ob), C.byref(ib))
+        if L.ZSTD_isError(r):
+            raise ValueError("libzstd rejected the stream")
+        got += ob.pos
+        if r == 0 and ib.pos == ib.size:
+            break
+        if ib.pos == ib.size and ob.pos < ob.size:
+            raise ValueError("truncated zstd frame")
+        if got == out.size:
+            if into is not None:
+                raise ValueError("stream decodes to more bytes than expected")
+            out = np.concatenate([out, np.empty(out.size, np.uint8)])
     return out[:got].tobytes()
 
 
@@ -115,9 +153,13 @@ def _lz4_host_decompress(data, size_hint=0, into=None):
     L = _host_lib('lz4')
     if L is None:
         return None
-    ctx = C.c_void_p()
-    if L.LZ4F_isError(L.LZ4F_createDecompressionContext(C.byref(ctx), 100)):
+    def make():
+        c = C.c_void_p()
+        return None if L.LZ4F_isError(L.LZ4F_createDecompressionContext(C.byref(c), 100)) else c.value
+    ctx = _ThreadCtx.get('lz4f', make, L.LZ4F_freeDecompressionContext)
+    if ctx is None:
         return None
+    L.LZ4F_resetDecompressionContext(ctx)
     src = np.frombuffer(memoryview(data), np.uint8)
     out, got, pos = (into if into is not None else np.empty(max(int(size_hint), 1 << 16) + 64, np.uint8)), 0, 0
     try:
@@ -142,7 +184,7 @@ def _lz4_host_decompress(data, size_hint=0, into=None):
                     break
                 out = np.concatenate([out, np.empty(out.size, np.uint8)])
     finally:
-        L.LZ4F_freeDecompressionContext(ctx)
+        L.LZ4F_resetDecompressionContext(ctx)       # (an error leaves the context mid-frame)
     if into is not None:
         if got != into.size:
             raise ValueError("stream decodes to fewer bytes than expected")

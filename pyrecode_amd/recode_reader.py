@@ -145,16 +145,22 @@ class ReCoDeReader:
         if getattr(self, '_decode_pool', None) is not None:
             self._decode_pool.shutdown(wait=True)
             self._decode_pool = None
-        if getattr(self, '_pin_pieces', None) is not None:
-            self._pin_pieces.close()
-            self._pin_pieces = None
+        if getattr(self, '_decode_coord', None) is not None:
+            self._decode_coord.shutdown(wait=True)
+            self._decode_coord = None
+        for b in getattr(self, '_pin_pieces', None) or []:
+            if b is not None:
+                b.close()
+        self._pin_pieces = None
+        self._host_blobs = None
 
-    def _read_into(self, view, pos):
+    def _read_into(self, view, pos, move_fp=True):
         """file bytes [pos, pos + len(view)) -> view (page-locked memory), in a few pieces on worker threads: a read from the page
-        cache is a memcpy, and one thread moves 5-7 GB/s where the batched device reader takes 35 GB/s of compressed frames."""
+        cache is a memcpy, and one thread moves 5-7 GB/s where the batched device reader takes 35 GB/s of compressed frames.
+        move_fp=False: positional reads only - the form a helper thread uses while the caller's thread owns the file position."""
         total = view.nbytes
         nthr = 4 if total >= (8 << 20) else 1
-        if nthr == 1:
+        if nthr == 1 and move_fp:
             self._fp.seek(pos, 0)
             if self._fp.readinto(memoryview(view)) != total:
                 raise ValueError('file shorter than its seek table says')
@@ -174,7 +180,8 @@ class ReCoDeReader:
                     raise ValueError('file shorter than its seek table says')
                 got += k
         list(self._read_pool.map(piece, range(nthr)))
-        self._fp.seek(pos + total, 0)      # (where a plain read would have left the file)
+        if move_fp:
+            self._fp.seek(pos + total, 0)      # (where a plain read would have left the file)
 
     def seek_to_frame_data(self):
         self._frame_data_start_position = self._rc_header.get_frame_data_offset(self._is_intermediate,
@@ -254,8 +261,8 @@ class ReCoDeReader:
             prefix = np.zeros(n + 1, np.uint64)
             L = _lib.lib()
             args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, mode, scheme, _lib.ptr(blob), _lib.ptr(sizes), n)
-            if host_only:
-                st = _lib.RC_ERR_UNSUPPORTED
+            if host_only or (mode == 1 and getattr(self, '_foreign_file', False)):
+                st = _lib.RC_ERR_UNSUPPORTED            # (a file whose streams the device decoders refused once is not offered again)
             elif level == 1:
                 # a frame's packed stream holds one depth-bit field per set pixel: its size bounds the count, one call does it all
                 d = int(h['target_bit_depth'])
@@ -281,6 +288,7 @@ class ReCoDeReader:
                 if res is not None:
                     self._current_frame_index = z0 + n
                     self.last_batch_path = 'host-decode + device-expand'
+                    self._foreign_file = not host_only
                     return res
         # per-frame path
         self.last_batch_path = 'per-frame'  
@@ -302,6 +310,31 @@ class ReCoDeReader:
         thread pool (the libraries release the GIL), into the stored-pieces layout of a mode-0 file, and ONE device call expands
         them (rc_expand_frames, op_mode 0).  None: a stock decoder is not available or rejected a stream (the per-frame path
         then reports it)."""
+        h = self._header
+        level, scheme = int(h['reduction_level']), int(h['compression_scheme'])
+        got = self._host_decode_batch(blob, sizes, n, 0)
+        if got is None:
+            return None
+        pieces, sizes0 = got
+        L = _lib.lib()
+        prefix = np.zeros(n + 1, np.uint64)
+        args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, 0, scheme, _lib.ptr(pieces), _lib.ptr(sizes0), n)
+        if level == 1:
+            d = int(h['target_bit_depth'])
+            cap = max(int((sizes0[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
+        else:
+            _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
+            cap = max(int(prefix[n]), 1)
+        trip = np.empty((cap, 3), np.uint64)
+        _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), cap), 'rc_expand_frames')
+        return prefix, trip[:int(prefix[n])]
+
+    def _host_decode_batch(self, blob, sizes, n, slot):
+        """The 2 n streams of a batch (file bytes in `blob`, stream sizes in `sizes`) through the stock decoder of the file's scheme on the
+        thread pool, each straight into its place of a stored-pieces image in page-locked memory (sizes are known beforehand: the
+        binary map's nb bytes, the value stream's bytes_in_packed_pixvals).  Returns (pieces, sizes of a mode-0 batch), or None when
+        there is no stock decoder for the scheme or it rejected a stream.  `slot` picks one of two images, so that a batch can be
+        decoded while the device still copies the previous one in."""
         from concurrent.futures import ThreadPoolExecutor
         h = self._header
         level, scheme = int(h['reduction_level']), int(h['compression_scheme'])
@@ -309,8 +342,6 @@ class ReCoDeReader:
         dec = compressors.host_stream_decoder(scheme)
         if dec is None:
             return None
-        # every stream decodes straight into its place of the stored-pieces image, in page-locked memory (sizes are known: the
-        # binary map's nb bytes, the value stream's bytes_in_packed_pixvals)
         spans, off, dst = [], 0, 0
         sizes0 = np.zeros((n, 3), np.uint32)
         for i in range(n):
@@ -324,11 +355,25 @@ class ReCoDeReader:
                 off += int(sizes[i, 1])
                 dst += npk
                 sizes0[i, 1] = sizes0[i, 2] = npk
-        if getattr(self, '_pin_pieces', None) is None or self._pin_pieces.nbytes < dst + 64:
-            if getattr(self, '_pin_pieces', None) is not None:
-                self._pin_pieces.close()
-            self._pin_pieces = _lib.PinnedBuffer(int(dst * 1.25) + (1 << 20))
-        pieces = self._pin_pieces.array[:dst]
+        if getattr(self, '_pin_pieces', None) is None:
+            self._pin_pieces = [None, None]
+        buf = self._pin_pieces[slot]
+        if buf is None or buf.nbytes < dst + 64:
+            if buf is not None:
+                buf.close()
+            buf = self._pin_pieces[slot] = _lib.PinnedBuffer(int(dst * 1.25) + (1 << 20))
+        pieces = buf.array[:dst]
+        # zstd / LZ4 / zlib: the library's own worker threads make the stock library's calls (rc_host_decode_streams) - no
+        # interpreter in the loop; the other schemes, or a host without those shared libraries: the Python-level decoders on a pool
+        L = _lib.lib()
+        if scheme in (0, 1, 2) and L.rc_host_decoder_available(scheme):
+            table = np.array([(a, b, c, e) for a, b, c, e in spans], np.uint64).reshape(-1, 4)
+            src = np.frombuffer(memoryview(blob), np.uint8)
+            st = L.rc_host_decode_streams(scheme, _lib.ptr(src), _lib.ptr(pieces), _lib.ptr(table), table.shape[0], 0)
+            if st == _lib.RC_OK:
+                return pieces, sizes0
+            if st != _lib.RC_ERR_UNSUPPORTED:
+                return None                              # a stream the stock decoder rejects: the per-frame path names it
         view = memoryview(blob)
 
         def one(sp):
@@ -338,21 +383,94 @@ class ReCoDeReader:
         try:
             if getattr(self, '_decode_pool', None) is None:
                 self._decode_pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1))
+            spans.sort(key=lambda sp: -sp[1])            # longest streams first: the pool's tail is then a short one
             list(self._decode_pool.map(one, spans))
         except Exception:
             return None
+        return pieces, sizes0
+
+    def _iter_host_decoded(self, z0, n, batch):
+        """iter_frames_triplets for files whose streams only a stock decoder takes (foreign encoders, zlib / bz2 / lzma): batch i + 1 is
+        read and decoded on the host's thread pool while the device expands batch i (rc_expand_frames_submit / _wait, op_mode 0, on the
+        page-locked stored-pieces image) and the consumer works on its triplets."""
+        from concurrent.futures import ThreadPoolExecutor
+        h = self._header
+        level, scheme, d = int(h['reduction_level']), int(h['compression_scheme']), int(h['target_bit_depth'])
         L = _lib.lib()
-        prefix = np.zeros(n + 1, np.uint64)
-        args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, 0, scheme, _lib.ptr(pieces), _lib.ptr(sizes0), n)
-        if level == 1:
-            d = int(h['target_bit_depth'])
-            cap = max(int((sizes0[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
-        else:
-            _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
-            cap = max(int(prefix[n]), 1)
-        trip = np.empty((cap, 3), np.uint64)
-        _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), cap), 'rc_expand_frames')
-        return prefix, trip[:int(prefix[n])]
+        geom0 = (int(h['nx']), int(h['ny']), d, level, 0, scheme)
+        starts = list(range(z0, z0 + n, batch))
+        if getattr(self, '_stream_bufs', None) is None:
+            self._stream_bufs = [None, None, None, None]
+        if getattr(self, '_host_blobs', None) is None:
+            self._host_blobs = [None, None]
+        if getattr(self, '_decode_coord', None) is None:
+            self._decode_coord = ThreadPoolExecutor(max_workers=1)
+        bufs = self._stream_bufs
+
+        def prepare(i):
+            a = starts[i]
+            k = min(batch, z0 + n - a)
+            slot = i & 1
+            sizes = np.zeros((k, 3), np.uint32)
+            for j in range(k):
+                md = self._frame_metadata[a + j]
+                sz_map, sz_val = self._stream_sizes(md)
+                sizes[j, 0] = sz_map
+                if level == 1:
+                    sizes[j, 1], sizes[j, 2] = sz_val, int(md['bytes_in_packed_pixvals'])
+            total = int(self._seek_table[a:a + k, 0].sum())
+            if self._host_blobs[slot] is None or self._host_blobs[slot].size < total:
+                self._host_blobs[slot] = np.empty(int(total * 1.25) + 64, np.uint8)
+            blob = self._host_blobs[slot][:total]
+            self._read_into(blob, self._frame_data_start_position + int(self._seek_table[a, 1]), move_fp=False)
+            return a, k, slot, self._host_decode_batch(blob, sizes, k, slot)
+
+        fut = self._decode_coord.submit(prepare, 0) if starts else None
+        submitted = None
+        try:
+            for i in range(len(starts)):
+                a, k, slot, got = fut.result()
+                fut = self._decode_coord.submit(prepare, i + 1) if i + 1 < len(starts) else None
+                if got is None or level != 1:
+                    # (level 3 needs a counting call to size its output: the synchronous form does both)
+                    if got is None:
+                        res = (a,) + self.get_frames_triplets(a, k)
+                    else:
+                        pieces, sizes0 = got
+                        prefix = np.zeros(k + 1, np.uint64)
+                        args = geom0 + (_lib.ptr(pieces), _lib.ptr(sizes0), k)
+                        _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
+                        trip = np.empty((max(int(prefix[k]), 1), 3), np.uint64)
+                        _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0]), 'rc_expand_frames')
+                        self.last_batch_path = 'host-decode + device-expand'
+                        res = (a, prefix, trip[:int(prefix[k])])
+                else:
+                    pieces, sizes0 = got
+                    cap = max(int((sizes0[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
+                    if bufs[2 + slot] is None or bufs[2 + slot].nbytes < cap * 24:
+                        if bufs[2 + slot] is not None:
+                            bufs[2 + slot].close()
+                        bufs[2 + slot] = _lib.PinnedBuffer(max(int(cap * 24 * 1.25), 1 << 20))
+                    _lib.check(L.rc_expand_frames_submit(slot, *geom0, _lib.ptr(pieces), _lib.ptr(sizes0), k, bufs[2 + slot]._p, cap),
+                               'rc_expand_frames_submit')
+                    submitted = (slot, k)
+                    prefix = np.zeros(k + 1, np.uint64)
+                    st = L.rc_expand_frames_wait(slot, _lib.ptr(prefix))
+                    submitted = None
+                    _lib.check(st, 'rc_expand_frames_wait')
+                    total = int(prefix[k])
+                    self.last_batch_path = 'host-decode + device-expand'
+                    res = (a, prefix, bufs[2 + slot].array[:total * 24].view(np.uint64).reshape(total, 3))
+                self._current_frame_index = a + k
+                yield res
+        finally:
+            if fut is not None:
+                try:
+                    fut.result()          # the decode that runs ahead writes into buffers close() frees
+                except Exception:
+                    pass
+            if submitted is not None:
+                L.rc_expand_frames_wait(submitted[0], _lib.ptr(np.zeros(submitted[1] + 1, np.uint64)))
 
     def iter_frames_triplets(self, z0=0, n=None, batch=64):
         """Streams frames z0 .. z0+n-1 of a merged file through the batched device reader, two batches in flight
@@ -371,6 +489,9 @@ class ReCoDeReader:
         level, mode, scheme = int(h['reduction_level']), int(h['rc_operation_mode']), int(h['compression_scheme'])
         d = int(h['target_bit_depth'])
         starts = list(range(z0, z0 + n, batch))
+        if level in (1, 3) and mode == 1 and (scheme in (0, 4, 5) or (scheme in (1, 2) and getattr(self, '_foreign_file', False))):
+            yield from self._iter_host_decoded(z0, n, batch)       # stock decoders on the pool, one batch ahead of the device
+            return
         if not (level == 1 and (mode == 0 or scheme in (1, 2))):
             for a in starts:
                 k = min(batch, z0 + n - a)
@@ -429,6 +550,13 @@ class ReCoDeReader:
             queued = submit(0) if starts else None
             for i in range(len(starts)):
                 job = queued
+                if getattr(self, '_foreign_file', False):
+                    # the previous batch turned out to be a foreign encoder's: the rest of the file goes through the host-decoded pipeline
+                    if job[3] is not None:
+                        L.rc_expand_frames_wait(job[2], _lib.ptr(np.zeros(job[1] + 1, np.uint64)))
+                    queued = None
+                    yield from self._iter_host_decoded(job[0], z0 + n - job[0], batch)
+                    return
                 queued = submit(i + 1) if i + 1 < len(starts) else None
                 res = finish(job)
                 self._current_frame_index = job[0] + job[1]

@@ -626,6 +626,26 @@ def test_files_a_stock_encoder_wrote_take_the_batched_path(scheme, tmp_path, orc
     f = rd.get_frame(5)[5]["data"]                                   # the reference's frame-at-a-time API on the same file
     assert np.array_equal(np.asarray(f.todense()), np.where(frames[5] > thr, frames[5] - thr, 0))
     rd.close()
+    # a fresh reader finds out INSIDE the streaming iterator (its first two batches are refused by the device decoders) and moves the
+    # rest of the file to the host-decoded pipeline, which decodes one batch ahead of the device
+    rd = ReCoDeReader(str(foreign), is_intermediate=False)
+    rd.open(print_header=False)
+    seen, paths = 0, []
+    for a, pre, tr in rd.iter_frames_triplets(0, nz, batch=2):
+        paths.append(rd.last_batch_path)
+        assert a == seen
+        for i in range(len(pre) - 1):
+            assert np.array_equal(tr[int(pre[i]):int(pre[i + 1])], want[a + i])
+            seen += 1
+    assert seen == nz and set(paths) == {"host-decode + device-expand"}
+    it = rd.iter_frames_triplets(1, nz - 1, batch=2)                 # a consumer that stops early, with a decode running ahead
+    a, pre, tr = next(it)
+    assert a == 1 and np.array_equal(tr[:int(pre[1])], want[1])
+    it.close()
+    prefix, trip = rd.get_frames_triplets(2, 3)
+    for i in range(3):
+        assert np.array_equal(trip[int(prefix[i]):int(prefix[i + 1])], want[2 + i])
+    rd.close()
 
 
 @pytest.mark.parametrize("tag", ["l1z12", "l1z16"])

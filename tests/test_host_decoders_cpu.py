@@ -81,3 +81,50 @@ def test_standard_library_schemes_and_unknown_ones():
         with pytest.raises(ValueError):
             dec(enc(data), len(data) + 3, np.zeros(len(data) + 3, np.uint8))
     assert rcomp.host_stream_decoder(8) is None and rcomp.host_stream_decoder(3) is None
+
+
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_native_batch_decoder_makes_the_stock_librarys_calls(scheme):
+    """rc_host_decode_streams (include/recode_hip.h): n streams of a stock encoder at once on the library's worker threads, each to its
+    exact place and size; a damaged stream, a stream of another length and trailing bytes are RC_ERR_CORRUPT.  No GPU involved."""
+    import zlib
+    from pyrecode_amd import _lib
+    L = _lib.lib()
+    enc = (lambda b: zlib.compress(b, 1)) if scheme == 0 else _stock_encoders().get(scheme)
+    if enc is None or not L.rc_host_decoder_available(scheme):
+        pytest.skip("no system library for scheme %d" % scheme)
+    rng = np.random.default_rng(40 + scheme)
+    payloads = [np.packbits(rng.random(n * 8) < p).tobytes() for n, p in ((300000, 0.01), (70000, 0.002), (513, 0.3), (1, 0.5), (150000, 0.05))]
+    payloads += [rng.integers(1, 2048, 40000).astype("<u2").tobytes(), bytes(100000), b""]
+    payloads = payloads * 5                                            # 40 streams: more than the worker threads
+    comp = [enc(p) for p in payloads]
+    src = np.frombuffer(b"".join(comp), np.uint8)
+    spans, so, do = [], 0, 7                                           # (an unaligned destination)
+    for c, p in zip(comp, payloads):
+        spans.append((so, len(c), do, len(p)))
+        so += len(c)
+        do += len(p) + 3                                               # 3 guard bytes behind every stream
+    table = np.array(spans, np.uint64)
+    for threads in (0, 1, 3):
+        dst = np.full(do, 0xA5, np.uint8)
+        assert L.rc_host_decode_streams(scheme, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(table), len(spans), threads) == _lib.RC_OK
+        for (a, n, at, want), p in zip(spans, payloads):
+            assert dst[at:at + want].tobytes() == p
+            assert (dst[at + want:at + want + 3] == 0xA5).all()
+    assert L.rc_host_decode_streams(scheme, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(table), 0, 0) == _lib.RC_OK
+    # refusals
+    dst = np.zeros(do, np.uint8)
+    bad = table.copy(); bad[0, 3] -= 1                                 # decodes to MORE than expected
+    assert L.rc_host_decode_streams(scheme, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(bad), len(spans), 0) == _lib.RC_ERR_CORRUPT
+    assert "stream 0" in _lib.last_error()
+    bad = table.copy(); bad[4, 3] += 1                                 # ... to fewer
+    assert L.rc_host_decode_streams(scheme, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(bad), len(spans), 0) == _lib.RC_ERR_CORRUPT
+    bad = table.copy(); bad[1, 1] -= 5                                 # truncated
+    assert L.rc_host_decode_streams(scheme, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(bad), len(spans), 0) == _lib.RC_ERR_CORRUPT
+    if scheme != 0:                                                    # (zlib.decompress itself ignores nothing either, but uncompress() stops at the end mark)
+        bad = table.copy(); bad[2, 1] += 4                             # bytes behind the frame
+        assert L.rc_host_decode_streams(scheme, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(bad), len(spans), 0) == _lib.RC_ERR_CORRUPT
+    flipped = src.copy(); flipped[int(table[0, 0]) + int(table[0, 1]) // 2] ^= 0x10
+    st = L.rc_host_decode_streams(scheme, _lib.ptr(flipped), _lib.ptr(dst), _lib.ptr(table), len(spans), 0)
+    assert st in (_lib.RC_OK, _lib.RC_ERR_CORRUPT)                     # (a flipped literal still decodes; it must not crash or overrun)
+    assert L.rc_host_decode_streams(7, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(table), len(spans), 0) == _lib.RC_ERR_UNSUPPORTED

@@ -70,6 +70,19 @@ for a in range(0, nz, batch):
     rd.get_frames_triplets(a, min(batch, nz - a))
 dt = time.perf_counter() - t0
 print("[foreign] scheme %d, %d frames 4096x4096 1 %%, batches of %d: %.0f frames/s (%s)" % (scheme, nz, batch, nz / dt, rd.last_batch_path))
+import pyrecode_amd.recode_reader as RR
+acc = dict(decode=0.0)
+_orig = rd._host_decode_batch
+def timed(*a, **k):
+    t = time.perf_counter(); r = _orig(*a, **k); acc["decode"] += time.perf_counter() - t; return r
+rd._host_decode_batch = timed
+t0 = time.perf_counter()
+nseen = 0
+for a, pre, tr in rd.iter_frames_triplets(0, nz, batch=batch):
+    nseen += len(pre) - 1
+dt = time.perf_counter() - t0
+print("[foreign] streaming iterator (decode one batch ahead of the device): %.0f frames/s; host decode alone %.0f frames/s (%s)"
+      % (nseen / dt, nseen / max(acc["decode"], 1e-9), rd.last_batch_path))
 t0 = time.perf_counter()
 for zf in range(min(nz, 8)):
     rd.get_frame(zf)

@@ -153,6 +153,12 @@ class ReCoDeReader:
                 b.close()
         self._pin_pieces = None
         self._host_blobs = None
+        if getattr(self, '_file_map', None) is not None:
+            try:
+                self._file_map.close()
+            except BufferError:                # (a caller still holds a view of a batch: the map goes with it)
+                pass
+            self._file_map = None
 
     def _read_into(self, view, pos, move_fp=True):
         """file bytes [pos, pos + len(view)) -> view (page-locked memory), in a few pieces on worker threads: a read from the page
@@ -405,6 +411,12 @@ class ReCoDeReader:
             self._host_blobs = [None, None]
         if getattr(self, '_decode_coord', None) is None:
             self._decode_coord = ThreadPoolExecutor(max_workers=1)
+        if getattr(self, '_file_map', None) is None:
+            import mmap
+            try:
+                self._file_map = mmap.mmap(self._fp.fileno(), 0, access=mmap.ACCESS_READ)
+            except (OSError, ValueError):
+                self._file_map = None                                          # (not mappable: positional reads into a buffer instead)
         bufs = self._stream_bufs
 
         def prepare(i):
@@ -419,10 +431,14 @@ class ReCoDeReader:
                 if level == 1:
                     sizes[j, 1], sizes[j, 2] = sz_val, int(md['bytes_in_packed_pixvals'])
             total = int(self._seek_table[a:a + k, 0].sum())
-            if self._host_blobs[slot] is None or self._host_blobs[slot].size < total:
-                self._host_blobs[slot] = np.empty(int(total * 1.25) + 64, np.uint8)
-            blob = self._host_blobs[slot][:total]
-            self._read_into(blob, self._frame_data_start_position + int(self._seek_table[a, 1]), move_fp=False)
+            lo = self._frame_data_start_position + int(self._seek_table[a, 1])
+            if self._file_map is not None:
+                blob = np.frombuffer(self._file_map, np.uint8, total, lo)      # the decoders read the page cache itself
+            else:
+                if self._host_blobs[slot] is None or self._host_blobs[slot].size < total:
+                    self._host_blobs[slot] = np.empty(int(total * 1.25) + 64, np.uint8)
+                blob = self._host_blobs[slot][:total]
+                self._read_into(blob, lo, move_fp=False)
             return a, k, slot, self._host_decode_batch(blob, sizes, k, slot)
 
         fut = self._decode_coord.submit(prepare, 0) if starts else None

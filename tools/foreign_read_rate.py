@@ -76,13 +76,22 @@ _orig = rd._host_decode_batch
 def timed(*a, **k):
     t = time.perf_counter(); r = _orig(*a, **k); acc["decode"] += time.perf_counter() - t; return r
 rd._host_decode_batch = timed
+from pyrecode_amd import _lib as _L
+LL = _L.lib()
+_sub, _wait = LL.rc_expand_frames_submit, LL.rc_expand_frames_wait
+def t_sub(*a):
+    acc["t_sub"] = time.perf_counter(); return _sub(*a)
+def t_wait(*a):
+    r = _wait(*a); acc["device"] = acc.get("device", 0.0) + time.perf_counter() - acc["t_sub"]; return r
+LL.rc_expand_frames_submit, LL.rc_expand_frames_wait = t_sub, t_wait
 t0 = time.perf_counter()
 nseen = 0
 for a, pre, tr in rd.iter_frames_triplets(0, nz, batch=batch):
     nseen += len(pre) - 1
 dt = time.perf_counter() - t0
-print("[foreign] streaming iterator (decode one batch ahead of the device): %.0f frames/s; host decode alone %.0f frames/s (%s)"
-      % (nseen / dt, nseen / max(acc["decode"], 1e-9), rd.last_batch_path))
+print("[foreign] streaming iterator (decode one batch ahead of the device): %.0f frames/s; host decode alone %.0f frames/s, device copy-in + expand + copy-out alone %.0f frames/s (%s)"
+      % (nseen / dt, nseen / max(acc["decode"], 1e-9), nseen / max(acc.get("device", 0), 1e-9), rd.last_batch_path))
+LL.rc_expand_frames_submit, LL.rc_expand_frames_wait = _sub, _wait
 t0 = time.perf_counter()
 for zf in range(min(nz, 8)):
     rd.get_frame(zf)

@@ -107,6 +107,66 @@ class ReCoDeReader:
         if len(sizes) > 1:
             self._seek_table[1:, 1] = np.cumsum(sizes[:-1])
 
+    def _load_part_index(self):
+        """Intermediate (part) files carry no metadata table: every record is `u32 frame_id | metadata row | data` (reference
+        recode_writer.py:559-574).  One walk over the record headers gives the batched readers what the seek table gives them for a
+        merged file: per record the metadata row, the data's size and position - and the frame id, in `part_frame_ids`.  A record cut
+        short at the end of the file (a writer that was interrupted) ends the index."""
+        h = self._header
+        level, mode = h['reduction_level'], h['rc_operation_mode']
+        fields = self._md_fields()
+        hdr = 4 + self._sz_frame_metadata
+        std = sum(int(f['bytes']) for f in fields)
+        fd = self._fp.fileno()
+        pos, ids, mds, sizes, offs = self._frame_data_start_position, [], [], [], []
+        while pos + hdr <= self._file_size:
+            raw = os.pread(fd, hdr, pos)
+            if len(raw) < hdr:
+                break
+            d, at = {}, 4
+            for f in fields:
+                d[f['name']] = np.frombuffer(raw, dtype=f['dtype'], count=1, offset=at)[0]
+                at += int(f['bytes'])
+            size = int(self._structures.get_frame_data_size(level, mode, d))
+            if pos + hdr + size > self._file_size:
+                break
+            ids.append(int(np.frombuffer(raw, np.uint32, 1)[0]))
+            mds.append(d)
+            sizes.append(size)
+            offs.append(pos + hdr - self._frame_data_start_position)
+            pos += hdr + size
+        assert std <= self._sz_frame_metadata
+        self._frame_metadata = mds
+        self.part_frame_ids = np.array(ids, np.uint32)
+        self._seek_table = np.zeros((len(ids), 2), np.uint64)
+        self._seek_table[:, 0] = sizes
+        self._seek_table[:, 1] = offs            # (relative to the first record, like a merged file's - but NOT contiguous)
+
+    def _batch_frames(self):
+        """number of frames the batched readers can address: nz of a merged file, the records of a part file (indexed on first use)"""
+        if self._is_intermediate:
+            if self._frame_metadata is None:
+                self._load_part_index()
+            return len(self._frame_metadata)
+        return int(self._header['nz'])
+
+    def _read_batch_into(self, blob, z0, n, move_fp=True):
+        """the data of frames z0 .. z0+n-1 -> blob, back to back (what rc_expand_frames takes): one contiguous range of a merged file;
+        a part file's records have their headers in between, so frame by frame"""
+        lo = self._frame_data_start_position + int(self._seek_table[z0, 1])
+        if not self._is_intermediate:
+            return self._read_into(blob, lo, move_fp)
+        fd, at = self._fp.fileno(), 0
+        for z in range(z0, z0 + n):
+            size, pos = int(self._seek_table[z, 0]), self._frame_data_start_position + int(self._seek_table[z, 1])
+            got = 0
+            while got < size:
+                k = os.preadv(fd, [memoryview(blob[at + got:at + size])], pos + got)
+                if k <= 0:
+                    raise ValueError('file shorter than its records say')
+                got += k
+            at += size
+
     # ---- accessors -----------------------------------------------------------------------------------------
     def get_header(self):
         return self._rc_header
@@ -232,15 +292,14 @@ class ReCoDeReader:
 
     # ---- batched access (device-resident decode + expand; no counterpart in the reference, which reads frame by frame) ------
     def get_frames_triplets(self, z0, n):
-        """Frames z0 .. z0+n-1 of a merged file in ONE device call (rc_expand_frames): both streams of every frame are
+        """Frames z0 .. z0+n-1 of a merged file - or records z0 .. z0+n-1 of a part file, whose frame ids are part_frame_ids[z] - in ONE
+        device call (rc_expand_frames): both streams of every frame are
         decompressed and expanded on the GPU without a host round trip in between.  Returns (nnz_prefix uint64[n+1],
         triplets uint64[total, 3]) - frame i's (row, col, value) rows are triplets[nnz_prefix[i]:nnz_prefix[i+1]], in the
         reference's row-major order (pyrecode.cpp:95-119).  Falls back to the per-frame path (stock decoder on the host) for
         streams outside the device decoders' subset, for level 2 and for host-only schemes."""
-        if self._is_intermediate:
-            raise ValueError("Random acceess is not available for intermediate files")
         h = self._header
-        nz = int(h['nz'])
+        nz = self._batch_frames()
         if z0 < 0 or n <= 0 or z0 + n > nz:
             raise ValueError('Requested frame index is greater than number of frames in dataset')
         level, mode, scheme = int(h['reduction_level']), int(h['rc_operation_mode']), int(h['compression_scheme'])
@@ -257,13 +316,12 @@ class ReCoDeReader:
                     sizes[i, 2] = int(md['bytes_in_packed_pixvals'])
             lo = self._frame_data_start_position + int(self._seek_table[z0, 1])
             total = int(self._seek_table[z0:z0 + n, 0].sum())
-            self._fp.seek(lo, 0)
             if getattr(self, '_pin_blob', None) is None or self._pin_blob.nbytes < total:   # file -> page-locked memory, no copy in between
                 if getattr(self, '_pin_blob', None) is not None:
                     self._pin_blob.close()
                 self._pin_blob = _lib.PinnedBuffer(max(int(total * 1.25), 1 << 20))
             blob = self._pin_blob.array[:total]
-            self._read_into(blob, lo)
+            self._read_batch_into(blob, z0, n)
             prefix = np.zeros(n + 1, np.uint64)
             L = _lib.lib()
             args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, mode, scheme, _lib.ptr(blob), _lib.ptr(sizes), n)
@@ -281,7 +339,7 @@ class ReCoDeReader:
                     trip = np.empty((max(int(prefix[n]), 1), 3), np.uint64)
                     st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0])
             if st == _lib.RC_OK:
-                self._current_frame_index = z0 + n
+                self._note_batch_end(z0 + n)
                 self.last_batch_path = 'device'
                 return prefix, trip[:int(prefix[n])]
             # Outside the device decoders' subset - or a stream they could not make sense of (a foreign encoder's independent 64 KiB
@@ -292,21 +350,31 @@ class ReCoDeReader:
             if mode == 1:
                 res = self._foreign_batch_triplets(z0, n, blob, sizes)
                 if res is not None:
-                    self._current_frame_index = z0 + n
+                    self._note_batch_end(z0 + n)
                     self.last_batch_path = 'host-decode + device-expand'
                     self._foreign_file = not host_only
                     return res
         # per-frame path
         self.last_batch_path = 'per-frame'  
         parts, prefix = [], np.zeros(n + 1, np.uint64)
+        keep = self._fp.tell()
         for i in range(n):
-            coo = self.get_frame(z0 + i)[z0 + i]['data']
+            self._fp.seek(self._frame_data_start_position + int(self._seek_table[z0 + i, 1]), 0)
+            coo = self._get_frame_sparse(self._frame_metadata[z0 + i])
             coo = coo[0] if isinstance(coo, tuple) else coo
             t = np.stack([coo.row.astype(np.uint64), coo.col.astype(np.uint64), coo.data.astype(np.uint64)], axis=1) if coo is not None and coo.nnz \
                 else np.zeros((0, 3), np.uint64)
             parts.append(t)
             prefix[i + 1] = prefix[i] + t.shape[0]
+        if self._is_intermediate:
+            self._fp.seek(keep, 0)           # (get_next_frame's cursor)
+        else:
+            self._note_batch_end(z0 + n)
         return prefix, np.concatenate(parts) if parts else np.zeros((0, 3), np.uint64)
+
+    def _note_batch_end(self, z):
+        if not self._is_intermediate:        # (a part file's sequential cursor is its file position, which the batched readers leave alone)
+            self._current_frame_index = z
 
     def _foreign_batch_triplets(self, z0, n, blob, sizes):
         """Streams a FOREIGN encoder wrote (the reference's own files: lz4.frame with linked 64 KiB blocks, libzstd with 4-stream
@@ -432,13 +500,13 @@ class ReCoDeReader:
                     sizes[j, 1], sizes[j, 2] = sz_val, int(md['bytes_in_packed_pixvals'])
             total = int(self._seek_table[a:a + k, 0].sum())
             lo = self._frame_data_start_position + int(self._seek_table[a, 1])
-            if self._file_map is not None:
+            if self._file_map is not None and not self._is_intermediate:
                 blob = np.frombuffer(self._file_map, np.uint8, total, lo)      # the decoders read the page cache itself
             else:
                 if self._host_blobs[slot] is None or self._host_blobs[slot].size < total:
                     self._host_blobs[slot] = np.empty(int(total * 1.25) + 64, np.uint8)
                 blob = self._host_blobs[slot][:total]
-                self._read_into(blob, lo, move_fp=False)
+                self._read_batch_into(blob, a, k, move_fp=False)
             return a, k, slot, self._host_decode_batch(blob, sizes, k, slot)
 
         fut = self._decode_coord.submit(prepare, 0) if starts else None
@@ -477,7 +545,7 @@ class ReCoDeReader:
                     total = int(prefix[k])
                     self.last_batch_path = 'host-decode + device-expand'
                     res = (a, prefix, bufs[2 + slot].array[:total * 24].view(np.uint64).reshape(total, 3))
-                self._current_frame_index = a + k
+                self._note_batch_end(a + k)
                 yield res
         finally:
             if fut is not None:
@@ -489,16 +557,15 @@ class ReCoDeReader:
                 L.rc_expand_frames_wait(submitted[0], _lib.ptr(np.zeros(submitted[1] + 1, np.uint64)))
 
     def iter_frames_triplets(self, z0=0, n=None, batch=64):
-        """Streams frames z0 .. z0+n-1 of a merged file through the batched device reader, two batches in flight
+        """Streams frames z0 .. z0+n-1 of a merged file (records z0 .. of a part file: the reference's own read test sums a part file's
+        frames one get_next_frame at a time, tests/recode_v1_read_test.py:9-21) through the batched device reader, two batches in flight
         (rc_expand_frames_submit / _wait): while the device decodes one batch, the next one is read from the file, its block headers
         are walked and its bytes copied in.  Yields (first frame index, nnz_prefix uint64[k+1], triplets uint64[total, 3]) per batch
         of k <= `batch` frames; `triplets` is a VIEW of page-locked memory the device wrote directly - valid until the generator is
         advanced (copy it to keep it).  Files the device path does not take (level 2, host-only schemes, foreign streams) go through
         get_frames_triplets batch by batch."""
-        if self._is_intermediate:
-            raise ValueError("Random acceess is not available for intermediate files")
         h = self._header
-        nz = int(h['nz'])
+        nz = self._batch_frames()
         n = nz - z0 if n is None else n
         if z0 < 0 or n < 0 or z0 + n > nz or batch <= 0:
             raise ValueError('Requested frame index is greater than number of frames in dataset')
@@ -539,7 +606,7 @@ class ReCoDeReader:
             total = int(self._seek_table[a:a + k, 0].sum())
             bufs[slot] = pinned(bufs[slot], total + 64)
             blob = bufs[slot].array[:total]
-            self._read_into(blob, self._frame_data_start_position + int(self._seek_table[a, 1]))
+            self._read_batch_into(blob, a, k)
             cap = max(int((sizes[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
             bufs[2 + slot] = pinned(bufs[2 + slot], cap * 24)
             st = L.rc_expand_frames_submit(slot, *geom, _lib.ptr(blob), _lib.ptr(sizes), k, bufs[2 + slot]._p, cap)
@@ -575,7 +642,7 @@ class ReCoDeReader:
                     return
                 queued = submit(i + 1) if i + 1 < len(starts) else None
                 res = finish(job)
-                self._current_frame_index = job[0] + job[1]
+                self._note_batch_end(job[0] + job[1])
                 yield res
         finally:
             # a consumer that stops early leaves a batch queued: wait for it before its buffers go away
@@ -589,7 +656,8 @@ class ReCoDeReader:
         for i in range(n):
             d = trip[int(prefix[i]):int(prefix[i + 1])]
             coo = coo_matrix((d[:, 2], (d[:, 0], d[:, 1])), shape=(int(self._header['ny']), int(self._header['nx'])), dtype=self._numpy_dtype)
-            out[z0 + i] = {'metadata': self._frame_metadata[z0 + i], 'data': coo}
+            key = int(self.part_frame_ids[z0 + i]) if self._is_intermediate else z0 + i      # (what get_next_frame keys a part file's frames by)
+            out[key] = {'metadata': self._frame_metadata[z0 + i], 'data': coo}
         return out
 
     def _next_header(self):

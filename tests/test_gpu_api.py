@@ -674,3 +674,48 @@ def test_reference_zlib_files_take_the_batched_path(tag):
         dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16)
         assert np.array_equal(dense, want[z]), "frame %d" % z
     rd.close()
+
+
+@pytest.mark.parametrize("tag,level,nodes", [("l1z12", 1, 3), ("l1ro16", 1, 2), ("l3z", 3, 2)])
+def test_part_files_the_reference_wrote_stream_through_the_batched_reader(tag, level, nodes):
+    """The reference's second test sums the frames of a PART file one get_next_frame at a time (tests/recode_v1_read_test.py:9-21).
+    Part files have no metadata table; the batched readers index their records once and then take them like a merged file's frames:
+    every part file of fixture G3 (zlib = host decode + device expand, reduce-only and level 3 = device) against the frames the
+    reference's own reader returned, the sum the reference test computes, and the sequential reader on the same file afterwards."""
+    from pyrecode_amd.recode_reader import ReCoDeReader
+    g = load_npz("g3_%s.npz" % tag)
+    frames, dark = g["frames"], g["dark"]
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    thr = (dark + np.uint16(cfg["calibration_threshold_epsilon"])).astype(np.uint16)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16) if level == 1 else (frames > thr).astype(np.uint16)
+    nz, (ny, nx) = frames.shape[0], frames.shape[1:]
+    seen = []
+    for node in range(nodes):
+        rd = ReCoDeReader(os.path.join(FILES, "g3_%s.rc%d_part%03d" % (tag, level, node)), is_intermediate=True)
+        rd.open(print_header=False)
+        first = rd.get_next_frame()                                  # the sequential cursor sits behind the first record ...
+        summed = np.zeros((ny, nx), np.int64)
+        for a, pre, tr in rd.iter_frames_triplets(batch=2):
+            for i in range(len(pre) - 1):
+                fid = int(rd.part_frame_ids[a + i])
+                t = tr[int(pre[i]):int(pre[i + 1])]
+                dense = np.zeros((ny, nx), np.uint16)
+                dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16) if level == 1 else 1
+                assert np.array_equal(dense, want[fid]), "part %d, frame id %d" % (node, fid)
+                summed += dense
+                seen.append(fid)
+        ids = rd.part_frame_ids.tolist()
+        assert np.array_equal(summed, want[ids].astype(np.int64).sum(axis=0))
+        got = rd.get_frames(0, len(ids))                             # keyed by frame id, like get_next_frame
+        assert sorted(got) == ids
+        for fid in ids:
+            assert np.array_equal(np.asarray(got[fid]["data"].todense()) != 0, want[fid] != 0)
+        prefix, trip = rd.get_frames_triplets(len(ids) - 1, 1)       # positional access to the last record
+        assert int(prefix[1]) == int((want[ids[-1]] != 0).sum())
+        second = rd.get_next_frame()                                 # ... and is still there
+        if len(ids) > 1:
+            assert list(first) == [ids[0]] and list(second) == [ids[1]]
+        with pytest.raises(ValueError):
+            rd.get_frame(0)                                          # (the reference's rule for its frame-at-a-time call stays)
+        rd.close()
+    assert sorted(seen) == list(range(nz))

@@ -162,6 +162,43 @@ def test_reader_raw_access_and_seek_table(tag, level, nodes):
     with pytest.raises(ValueError):
         part.get_frame(0)
     part.close()
+    # the batched readers' index of a part file (one walk over the record headers): same ids, metadata rows and data positions as the
+    # sequential walk; a file cut in the middle of its last record indexes the whole records only; the sequential cursor is left alone
+    for node in range(nodes):
+        path = base + "_part%03d" % node
+        part = ReCoDeReader(path, is_intermediate=True)
+        part.open(print_header=False)
+        seq = []
+        while True:
+            f = part.get_next_frame_raw(read_data=False)
+            if f is None:
+                break
+            (fid, body), = f.items()
+            seq.append((int(fid), {k: int(v) for k, v in body["metadata"].items()}, part.get_file_position()))
+        part.close()
+        part = ReCoDeReader(path, is_intermediate=True)
+        part.open(print_header=False)
+        first = part.get_next_frame_raw(read_data=False)
+        here = part.get_file_position()
+        assert part._batch_frames() == len(seq) and part.get_file_position() == here
+        assert part.part_frame_ids.tolist() == [q[0] for q in seq]
+        for z, (fid, md, end) in enumerate(seq):
+            assert {k: int(v) for k, v in part._frame_metadata[z].items()} == md
+            assert part._frame_data_start_position + int(part._seek_table[z, 1]) + int(part._seek_table[z, 0]) == end
+        part.close()
+    whole = open(base + "_part000", "rb").read()
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        cut = os.path.join(tmp, "cut.rc%d_part000" % level)
+        with open(cut, "wb") as f:
+            f.write(whole[:-3])
+        part = ReCoDeReader(cut, is_intermediate=True)
+        part.open(print_header=False)
+        full = ReCoDeReader(base + "_part000", is_intermediate=True)
+        full.open(print_header=False)
+        assert part._batch_frames() == full._batch_frames() - 1
+        part.close()
+        full.close()
 
 
 def test_writer_constructor_validation(tmp_path):

@@ -789,6 +789,66 @@ def test_expand_frames_rejects_damaged_and_foreign_streams(hip, orc):
         assert st in (hip.RC_ERR_UNSUPPORTED, hip.RC_ERR_CORRUPT)
 
 
+@pytest.mark.parametrize("scheme,clevel", [(1, 1), (1, 0), (2, 1), (2, 0)])
+def test_expand_frames_survives_mutated_streams(hip, orc, scheme, clevel):
+    """The batched reader on damaged files: some hundred mutations of a valid batch per codec (bit flips anywhere - block headers,
+    literal / sequence sections, table descriptions, LZ4 tokens and offsets -, sizes that lie, truncations).  Every call answers with a
+    status (never hangs or faults), leaves the rows behind the output's capacity alone, and the valid batch still decodes afterwards."""
+    import torch
+    ny, nx, d, n = 64, 512, 12, 3
+    dark, frames = synth_frames(17, n, ny, nx, 0.03, d)
+    frames[1, 10:14, :] = 4000                     # a few solid tiles: RLE / long-match blocks among the sparse ones
+    thr = orc.threshold(dark, 0)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, scheme, clevel, 0, max_batch=n)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, 0)
+    ctx.close()
+    L = hip.lib()
+    blob = np.ascontiguousarray(np.concatenate([out[int(rec[z]) + 16:int(rec[z + 1])] for z in range(n)]))
+    sizes = np.ascontiguousarray(md[:, :3], dtype=np.uint32)
+    nnz = int((frames > thr).sum())
+    cap = int((sizes[:, 2].astype(np.uint64) * 8 // d).sum())
+    want_prefix, want = np.zeros(n + 1, np.uint64), np.zeros((cap, 3), np.uint64)
+    hip.check(L.rc_expand_frames(nx, ny, d, 1, 1, scheme, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(want_prefix), hip.ptr(want), cap))
+    assert int(want_prefix[n]) == nnz
+    guard = 64
+    dev = torch.full((cap + guard, 3), -7, dtype=torch.int64, device="cuda")
+    prefix = np.zeros(n + 1, np.uint64)
+    rng = np.random.default_rng(1000 * scheme + clevel + int(os.environ.get("RC_FUZZ_SEED", "0")))
+    allowed = {hip.RC_OK, hip.RC_ERR_CORRUPT, hip.RC_ERR_UNSUPPORTED, hip.RC_ERR_OUT_TOO_SMALL}
+    seen = {}
+    bounds = np.concatenate([[0], np.cumsum(sizes[:, :2].astype(np.int64).ravel())])      # stream boundaries inside the blob
+    room = np.zeros(blob.size + 4096, np.uint8)      # (sizes that claim more than the blob holds must still describe readable memory: the API's contract)
+    for it in range(int(os.environ.get("RC_MUTATE_ITERS", "600"))):          # (longer runs by hand)
+        room[:blob.size] = blob
+        b, sz = room[:blob.size], sizes.copy()
+        kind = it % 6
+        if kind < 3:                                # 1..3 bit flips anywhere
+            for _ in range(kind + 1):
+                b[int(rng.integers(0, b.size))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 3:                             # flips in the first 24 bytes of a stream: frame header, first block header, tree / table descriptions
+            at = int(bounds[int(rng.integers(0, bounds.size - 1))])
+            for _ in range(2):
+                b[min(at + int(rng.integers(0, 24)), b.size - 1)] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 4:                             # a size that lies (the streams behind it then start in the wrong place, too)
+            i, j = int(rng.integers(0, n)), int(rng.integers(0, 3))
+            sz[i, j] = max(0, int(sz[i, j]) + int(rng.integers(-40, 41)))
+        else:                                       # the blob ends early (sizes unchanged: the last stream is short of bytes)
+            cut = int(rng.integers(1, 200))
+            room[blob.size - cut:blob.size] = 0
+            sz[n - 1, 1] = max(0, int(sz[n - 1, 1]) - cut)
+        st = L.rc_expand_frames(nx, ny, d, 1, 1, scheme, hip.ptr(b), hip.ptr(sz), n, hip.ptr(prefix), dev.data_ptr(), cap)
+        assert st in allowed, (it, kind, st, hip.last_error())
+        seen[st] = seen.get(st, 0) + 1
+        if it % 50 == 49:
+            assert bool((dev[cap:] == -7).all()), "rows behind the capacity were written (mutation %d)" % it
+    assert bool((dev[cap:] == -7).all())
+    assert seen.get(hip.RC_ERR_CORRUPT, 0) > 50, seen          # (most damage is noticed; a flipped literal bit is a valid other stream)
+    got = torch.zeros((cap, 3), dtype=torch.int64, device="cuda")
+    hip.check(L.rc_expand_frames(nx, ny, d, 1, 1, scheme, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(prefix), got.data_ptr(), cap))
+    assert np.array_equal(prefix, want_prefix) and np.array_equal(got.cpu().numpy().view(np.uint64)[:nnz], want[:nnz])
+
+
 # ---- reduction level 2 (SURVEY N1): specification by intent, checked against scipy.ndimage.label + numpy -----------------
 def _l2_expected(frame, thr, stat, d=16):
     import scipy.ndimage as nd

@@ -849,6 +849,60 @@ def test_expand_frames_survives_mutated_streams(hip, orc, scheme, clevel):
     assert np.array_equal(prefix, want_prefix) and np.array_equal(got.cpu().numpy().view(np.uint64)[:nnz], want[:nnz])
 
 
+@pytest.mark.parametrize("scheme", [1, 2, 8])
+def test_decompress_survives_mutated_streams(hip, scheme):
+    """Seam 2 (rc_decompress = de_compress of recode_compressors.py:40-79 for the device codecs) on damaged input: bit flips, cut and
+    padded streams of this library's own frames and - LZ4 - of a stock liblz4 frame with linked blocks and real matches.  Every call
+    returns a status; the bytes behind the output's capacity stay as they were; the intact stream still decodes afterwards."""
+    import ctypes as C
+    import ctypes.util
+    from pyrecode_amd import recode_compressors as rcomp
+    L = hip.lib()
+    rng = np.random.default_rng(77 + scheme + int(os.environ.get("RC_FUZZ_SEED", "0")))
+    payloads = [np.packbits(rng.random(40000 * 8) < 0.02, bitorder="little").tobytes(),                  # a sparse binary map, many blocks
+                rng.integers(1, 2048, 6000).astype("<u2").tobytes(), bytes(3000) + b"\x07" * 900]        # residuals; runs
+    streams = [(rcomp.compress(scheme, 1, p, None), p) for p in payloads]
+    name = ctypes.util.find_library("lz4")
+    if scheme == 2 and name:
+        lz = C.CDLL(name)
+        lz.LZ4F_compressFrameBound.restype = C.c_size_t
+        lz.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+        lz.LZ4F_compressFrame.restype = C.c_size_t
+        lz.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        text = (bytes(rng.integers(97, 101, 5000, dtype=np.uint8)) * 30)[:140000]                         # three linked 64 KiB blocks, real offsets
+        dst = C.create_string_buffer(lz.LZ4F_compressFrameBound(len(text), None) + 64)
+        k = lz.LZ4F_compressFrame(dst, len(dst), text, len(text), None)
+        streams.append((dst.raw[:k], text))
+    allowed = {hip.RC_OK, hip.RC_ERR_CORRUPT, hip.RC_ERR_UNSUPPORTED, hip.RC_ERR_OUT_TOO_SMALL, hip.RC_ERR_BAD_ARG}
+    iters = int(os.environ.get("RC_MUTATE_ITERS", "250"))
+    for comp, plain in streams:
+        src0 = np.frombuffer(comp, np.uint8)
+        cap, guard = len(plain) + 64, 256
+        out = np.empty(cap + guard, np.uint8)
+        n = C.c_uint64(0)
+        assert L.rc_decompress(scheme, hip.ptr(src0), src0.size, hip.ptr(out), cap, C.byref(n)) == hip.RC_OK and out[:n.value].tobytes() == plain
+        seen = {}
+        for it in range(iters):
+            b = src0.copy()
+            kind = it % 4
+            if kind < 2:
+                for _ in range(1 + kind * 2):
+                    b[int(rng.integers(0, b.size))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 2:                         # the frame header / first block
+                b[int(rng.integers(0, min(24, b.size)))] ^= 1 << int(rng.integers(0, 8))
+            else:                                   # cut short
+                b = np.ascontiguousarray(b[:int(rng.integers(0, b.size))])
+            if b.size == 0:
+                continue
+            out[:] = 0xA5
+            st = L.rc_decompress(scheme, hip.ptr(b), b.size, hip.ptr(out), cap, C.byref(n))
+            assert st in allowed, (scheme, it, st, hip.last_error())
+            assert (out[cap:] == 0xA5).all(), "bytes behind the capacity were written (mutation %d)" % it
+            seen[st] = seen.get(st, 0) + 1
+        assert seen.get(hip.RC_ERR_CORRUPT, 0) + seen.get(hip.RC_ERR_UNSUPPORTED, 0) > iters // 10, seen
+        assert L.rc_decompress(scheme, hip.ptr(src0), src0.size, hip.ptr(out), cap, C.byref(n)) == hip.RC_OK and out[:n.value].tobytes() == plain
+
+
 # ---- reduction level 2 (SURVEY N1): specification by intent, checked against scipy.ndimage.label + numpy -----------------
 def _l2_expected(frame, thr, stat, d=16):
     import scipy.ndimage as nd

@@ -18,6 +18,7 @@ Fixture groups:
   G1  thr / binary map / L1 residuals          (recode_writer.py:126-137, 437, 440)
   G2  _pack_binary_frame / _bit_pack outputs   (recode_writer.py:622-634, 637-652)
   G3  whole part files + merged file           (recode_writer.py:184-607, recode_reader.py:495-595)
+  G7  mode='stream': part files of a writer fed chunk by chunk (recode_writer.py:311-322,422-423)
   G4  512-byte header bytes                    (recode_header.py:58-94, 257-275)
   G5  get_frame_sparse triplets                (pyrecode.cpp:95-119, reader.h:10-68)
   G6  321-byte v0.1 header                     (recode_header.py:27-56, 98-127, 257-275)
@@ -241,11 +242,57 @@ def g6():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# --------------------------------------------------------------------------------------------
+# G7: mode='stream' - the writer is handed one chunk after the other (recode_writer.py:311-322,422-423): every chunk is split
+# over the nodes by the same contiguous-block rule, frame ids run on from chunk to chunk (_chunk_offset), so a part file's ids
+# are increasing but NOT contiguous.  Part files only: the reference's own merge misorders such parts.
+# --------------------------------------------------------------------------------------------
+def g7():
+    chunks, ny, nx, nodes = (5, 4, 1, 6), 24, 40, 2
+    dark, frames = synth_stack(2700, sum(chunks), ny, nx, 0.10, 12)
+    tmp = tempfile.mkdtemp()
+    try:
+        base = "g7_stream"
+        for node in range(nodes):
+            ip, cfg = make_params(tmp, num_frames=1, num_rows=ny, num_cols=nx, num_threads=nodes)   # (<= every chunk: recode_writer.py:283-286)
+            w = quiet(ref_writer.ReCoDeWriter, base, dark_data=dark, output_directory=tmp, input_params=ip,
+                      mode="stream", validation_frame_gap=-1, node_id=node, run_name=base)      # (stream mode names its files after run_name, :193-194)
+            quiet(w.start)
+            at = 0
+            for c in chunks:
+                quiet(w.run, frames[at:at + c])
+                at += c
+            quiet(w.close)
+        ids = []
+        for node in range(nodes):
+            fn = "%s.rc1_part%03d" % (base, node)
+            shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+            rd = ref_reader.ReCoDeReader(os.path.join(tmp, fn), is_intermediate=True)
+            quiet(rd.open, print_header=False)
+            mine = []
+            while True:
+                f = quiet(rd.get_next_frame_raw, read_data=False)
+                if not f:
+                    break
+                mine.append(int(list(f.keys())[0]))
+            rd.close()
+            ids.append(mine)
+        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, chunks=np.array(chunks),
+                            cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array(list(cfg.values())), n_nodes=nodes,
+                            ids_part0=np.array(ids[0]), ids_part1=np.array(ids[1]))
+        print("g7:", ids)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g6":
         g6()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g7":
+        g7()
     else:
         g1_g2()
         g3_g4()
         g5()
         g6()
+        g7()

@@ -719,3 +719,60 @@ def test_part_files_the_reference_wrote_stream_through_the_batched_reader(tag, l
             rd.get_frame(0)                                          # (the reference's rule for its frame-at-a-time call stays)
         rd.close()
     assert sorted(seen) == list(range(nz))
+
+
+@pytest.mark.parametrize("batch_size", [None, 2])
+def test_stream_mode_writer_reproduces_the_references_part_files(tmp_path, batch_size):
+    """mode='stream' (reference recode_writer.py:193-194,311-322,422-423): the writer is handed chunk after chunk, every chunk is split
+    over the nodes by the contiguous-block rule and the frame ids run on from chunk to chunk - a part file's ids are increasing but not
+    contiguous.  Fixture G7: the reference's own writer fed chunks of 5, 4, 1 and 6 frames on 2 nodes (a node that gets NOTHING of the
+    one-frame chunk included).  The part files are the reference's byte for byte; merge_parts then interleaves them by frame id (the
+    reference's own merge misorders such parts) and both readers return every frame in its place."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    g = load_npz("g7_stream.npz")
+    dark, frames, chunks, nodes = g["dark"], g["frames"], g["chunks"].tolist(), int(g["n_nodes"])
+    base = "g7_stream"
+    for node in range(nodes):
+        ip, cfg = _params(tmp_path, g)
+        w = ReCoDeWriter(base, dark_data=dark, output_directory=str(tmp_path), input_params=ip, mode="stream", validation_frame_gap=-1,
+                         node_id=node, run_name=base, batch_size=batch_size)
+        w.start()
+        at, took = 0, 0
+        for c in chunks:
+            took += w.run(frames[at:at + c])["run_frames"]
+            at += c
+        w.close()
+        fn = "%s.rc1_part%03d" % (base, node)
+        assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
+        assert took == len(g["ids_part%d" % node])
+    thr = (dark + np.uint16(cfg["calibration_threshold_epsilon"])).astype(np.uint16)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16)
+    nz = frames.shape[0]
+    # the batched reader on a part file with gaps in its ids
+    part = ReCoDeReader(str(tmp_path / (base + ".rc1_part000")), is_intermediate=True)
+    part.open(print_header=False)
+    got_ids = []
+    for a, pre, tr in part.iter_frames_triplets(batch=4):
+        for i in range(len(pre) - 1):
+            fid = int(part.part_frame_ids[a + i])
+            t = tr[int(pre[i]):int(pre[i + 1])]
+            dense = np.zeros(want.shape[1:], np.uint16)
+            dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16)
+            assert np.array_equal(dense, want[fid])
+            got_ids.append(fid)
+    assert got_ids == g["ids_part0"].tolist()
+    part.close()
+    merge_parts(str(tmp_path), base + ".rc1", nodes)
+    rd = ReCoDeReader(str(tmp_path / (base + ".rc1")), is_intermediate=False)
+    rd.open(print_header=False)
+    assert rd.get_shape()[0] == nz
+    for z in (0, 3, 5, 9, 12, 13, nz - 1):
+        assert np.array_equal(np.asarray(rd.get_frame(z)[z]["data"].todense()).astype(np.uint16), want[z]), "frame %d" % z
+    prefix, trip = rd.get_frames_triplets(0, nz)
+    for z in range(nz):
+        t = trip[int(prefix[z]):int(prefix[z + 1])]
+        dense = np.zeros(want.shape[1:], np.uint16)
+        dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16)
+        assert np.array_equal(dense, want[z]), "frame %d" % z
+    rd.close()

@@ -239,3 +239,38 @@ def test_compressor_seam_host_schemes_and_errors():
     with pytest.raises(NotImplementedError):
         rcmp.de_compress(99, data, None)
     assert rcmp.import_checks({"compression_scheme": 0}) and rcmp.import_checks({"compression_scheme": 2})
+
+
+def test_merge_interleaves_stream_mode_parts_by_frame_id(tmp_path):
+    """Fixture G7: part files the reference's writer produced in mode='stream' (chunks of 5, 4, 1, 6 frames on 2 nodes: ids
+    [0,1,2,5,6,9,10,11,12] and [3,4,7,8,13,14,15]).  merge_parts is a real k-way merge by frame id - the reference's own keeps the POPPED
+    id as a part's next key and would emit 0,1,2,5,...: frame z of the merged file is the record with id z."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    g = load_npz("g7_stream.npz")
+    by_id = {}
+    for node in range(2):
+        fn = "g7_stream.rc1_part%03d" % node
+        shutil.copy(os.path.join(FILES, fn), tmp_path / fn)
+        part = ReCoDeReader(str(tmp_path / fn), is_intermediate=True)
+        part.open(print_header=False)
+        ids = []
+        while True:
+            f = part.get_next_frame_raw()
+            if f is None:
+                break
+            (fid, body), = f.items()
+            ids.append(int(fid))
+            by_id[int(fid)] = ({k: int(v) for k, v in body["metadata"].items()}, b"".join(body["data"].values()))
+        assert ids == g["ids_part%d" % node].tolist()
+        part.close()
+    merge_parts(str(tmp_path), "g7_stream.rc1", 2)
+    rd = ReCoDeReader(str(tmp_path / "g7_stream.rc1"), is_intermediate=False)
+    rd.open(print_header=False)
+    nz = g["frames"].shape[0]
+    assert rd.get_shape()[0] == nz == len(by_id)
+    for z in range(nz):
+        (fid, body), = rd.get_next_frame_raw().items()
+        assert fid == z
+        assert {k: int(v) for k, v in body["metadata"].items()} == by_id[z][0]
+        assert b"".join(body["data"].values()) == by_id[z][1], "frame %d" % z
+    rd.close()

@@ -19,6 +19,7 @@ Fixture groups:
   G2  _pack_binary_frame / _bit_pack outputs   (recode_writer.py:622-634, 637-652)
   G3  whole part files + merged file           (recode_writer.py:184-607, recode_reader.py:495-595)
   G7  mode='stream': part files of a writer fed chunk by chunk (recode_writer.py:311-322,422-423)
+  G8  validation frames: side file + dose rates      (recode_writer.py:207-211,400-415)
   G4  512-byte header bytes                    (recode_header.py:58-94, 257-275)
   G5  get_frame_sparse triplets                (pyrecode.cpp:95-119, reader.h:10-68)
   G6  321-byte v0.1 header                     (recode_header.py:27-56, 98-127, 257-275)
@@ -285,8 +286,51 @@ def g7():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# --------------------------------------------------------------------------------------------
+# G8: validation frames (recode_writer.py:207-211,400-415): every validation_frame_gap-th frame (by absolute frame id) goes raw into
+# <base>_partNNN_validation_frames.bin and its dose rate - 8-connected components of the binary map inside the central 128 x 128
+# pixels / ROI pixels - into run_metrics['run_dose_rates'].  Clustered events, so that components are not single pixels.
+# --------------------------------------------------------------------------------------------
+def g8():
+    nz, ny, nx, nodes, gap = 10, 150, 170, 2, 3
+    rng = np.random.default_rng(2800)
+    dark = rng.integers(3, 21, (ny, nx)).astype(np.uint16)
+    frames = np.empty((nz, ny, nx), np.uint16)
+    for z in range(nz):
+        f = np.floor(rng.random((ny, nx)) * (dark + 1)).astype(np.uint16)
+        for _ in range(int(rng.integers(40, 160))):                # blobs of 1..9 pixels, some touching only diagonally
+            y, x = int(rng.integers(0, ny - 3)), int(rng.integers(0, nx - 3))
+            shape = rng.random((3, 3)) < 0.45
+            shape[1, 1] = True
+            f[y:y + 3, x:x + 3] = np.where(shape, dark[y:y + 3, x:x + 3] + rng.integers(1, 3000, (3, 3)).astype(np.uint16), f[y:y + 3, x:x + 3])
+        frames[z] = f
+    tmp = tempfile.mkdtemp()
+    try:
+        base = "g8_valid"
+        rates, vbytes = [], []
+        for node in range(nodes):
+            ip, cfg = make_params(tmp, num_frames=nz, num_rows=ny, num_cols=nx, num_threads=nodes)
+            w = quiet(ref_writer.ReCoDeWriter, base, dark_data=dark, output_directory=tmp, input_params=ip,
+                      mode="batch", validation_frame_gap=gap, node_id=node)
+            quiet(w.start)
+            m = quiet(w.run, frames)
+            quiet(w.close)
+            rates.append(np.array(m.get("run_dose_rates", []), np.float64))
+            fn = "%s.rc1_part%03d" % (base, node)
+            shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+            vbytes.append(np.frombuffer(open(os.path.join(tmp, "%s_part%03d_validation_frames.bin" % (base, node)), "rb").read(), np.uint8))
+        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, gap=gap,
+                            cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array(list(cfg.values())), n_nodes=nodes,
+                            rates_part0=rates[0], rates_part1=rates[1], validation_part0=vbytes[0], validation_part1=vbytes[1])
+        print("g8:", [r.tolist() for r in rates], [v.size for v in vbytes])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g6":
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g6":
         g6()
     elif len(sys.argv) > 1 and sys.argv[1] == "g7":
         g7()
@@ -296,3 +340,4 @@ if __name__ == "__main__":
         g5()
         g6()
         g7()
+        g8()

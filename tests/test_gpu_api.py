@@ -776,3 +776,26 @@ def test_stream_mode_writer_reproduces_the_references_part_files(tmp_path, batch
         dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16)
         assert np.array_equal(dense, want[z]), "frame %d" % z
     rd.close()
+
+
+@pytest.mark.parametrize("batch_size", [None, 3])
+def test_validation_frames_and_dose_rates_equal_the_references(tmp_path, batch_size):
+    """Fixture G8: the reference's writer with validation_frame_gap = 3 on 10 frames of clustered events (150 x 170: the 128 x 128 ROI
+    is a true sub-window), 2 nodes.  Here the ROI's components are counted on the device (k_roi_components) while the batch streams
+    through: part files, validation side files and every dose rate equal the reference's own (recode_writer.py:400-415)."""
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    g = load_npz("g8_valid.npz")
+    dark, frames, nodes, gap = g["dark"], g["frames"], int(g["n_nodes"]), int(g["gap"])
+    base = "g8_valid"
+    for node in range(nodes):
+        ip, cfg = _params(tmp_path, g)
+        w = ReCoDeWriter(base, dark_data=dark, output_directory=str(tmp_path), input_params=ip, mode="batch", validation_frame_gap=gap,
+                         node_id=node, batch_size=batch_size)
+        w.start()
+        m = w.run(frames)
+        w.close()
+        fn = "%s.rc1_part%03d" % (base, node)
+        assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
+        side = (tmp_path / ("%s_part%03d_validation_frames.bin" % (base, node))).read_bytes()
+        assert side == g["validation_part%d" % node].tobytes()
+        assert list(m["run_dose_rates"]) == g["rates_part%d" % node].tolist()

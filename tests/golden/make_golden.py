@@ -20,6 +20,7 @@ Fixture groups:
   G3  whole part files + merged file           (recode_writer.py:184-607, recode_reader.py:495-595)
   G7  mode='stream': part files of a writer fed chunk by chunk (recode_writer.py:311-322,422-423)
   G8  validation frames: side file + dose rates      (recode_writer.py:207-211,400-415)
+  G9  bz2 / lzma / zlib level 9 / level 3 reduce-only: whole files (recode_compressors.py:82-101)
   G4  512-byte header bytes                    (recode_header.py:58-94, 257-275)
   G5  get_frame_sparse triplets                (pyrecode.cpp:95-119, reader.h:10-68)
   G6  321-byte v0.1 header                     (recode_header.py:27-56, 98-127, 257-275)
@@ -327,8 +328,45 @@ def g8():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# --------------------------------------------------------------------------------------------
+# G9: the other host-only schemes of the standard library (recode_compressors.py:97-101: 4 = bz2, 5 = lzma) and a second zlib level:
+# whole part files + merged file, as G3.
+# --------------------------------------------------------------------------------------------
+def g9():
+    for tag, over in (("l1bz2", dict(compression_scheme=4, compression_level=3)), ("l1lzma", dict(compression_scheme=5, compression_level=2)),
+                      ("l1z12_lvl9", dict(compression_scheme=0, compression_level=9)), ("l3ro", dict(reduction_level=3, rc_operation_mode=0))):
+        nz, ny, nx, nodes = 5, 24, 40, 2
+        tmp = tempfile.mkdtemp()
+        dark, frames = synth_stack(2900 + len(tag), nz, ny, nx, 0.10, 12)
+        base = "g9_" + tag
+        cfg = write_parts(tmp, base, dark, frames, nodes, **over)
+        level = cfg["reduction_level"]
+        for node in range(nodes):
+            fn = "%s.rc%d_part%03d" % (base, level, node)
+            shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+        fn = "%s.rc%d" % (base, level)
+        dec = np.zeros(0)
+        readable = cfg["compression_scheme"] not in (4, 5)     # the reference's READER cannot open bz2 / lzma files: import_checks has no
+        if readable:                                            # entry for them (recode_compressors.py:122-124, KeyError) - part files only
+            quiet(ref_reader.merge_parts, tmp, fn, nodes)
+            shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+        if level == 1 and readable:
+            rd = ref_reader.ReCoDeReader(os.path.join(tmp, fn), is_intermediate=False)
+            quiet(rd.open, print_header=False)
+            dec = np.zeros_like(frames)
+            for z in range(nz):
+                dec[z] = np.asarray(quiet(rd.get_frame, z)[z]["data"].todense()).astype(np.uint16)
+            rd.close()
+        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
+                            cfg_vals=np.array(list(cfg.values())), n_nodes=nodes, decoded=dec)
+        shutil.rmtree(tmp)
+        print("g9:", tag)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        g9()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8()
     elif len(sys.argv) > 1 and sys.argv[1] == "g6":
         g6()
@@ -341,3 +379,4 @@ if __name__ == "__main__":
         g6()
         g7()
         g8()
+        g9()

@@ -799,3 +799,35 @@ def test_validation_frames_and_dose_rates_equal_the_references(tmp_path, batch_s
         side = (tmp_path / ("%s_part%03d_validation_frames.bin" % (base, node))).read_bytes()
         assert side == g["validation_part%d" % node].tobytes()
         assert list(m["run_dose_rates"]) == g["rates_part%d" % node].tolist()
+
+
+@pytest.mark.parametrize("tag,level,has_merged", [("l1bz2", 1, False), ("l1lzma", 1, False), ("l1z12_lvl9", 1, True), ("l3ro", 3, True)])
+def test_other_host_schemes_reproduce_the_references_files(tag, level, has_merged, tmp_path):
+    """Fixture G9: bz2 and lzma (recode_compressors.py:97-101), zlib at level 9, level 3 without compression - the reference's part files
+    byte for byte (and its merged file where its own reader can open the parts: it has no import entry for bz2 / lzma, so those stop at
+    the part files).  Every merged file then reads back to the expected frames through the batched reader."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    g = load_npz("g9_%s.npz" % tag)
+    nodes, base = int(g["n_nodes"]), "g9_" + tag
+    dark, frames = g["dark"], g["frames"]
+    cfg, _ = _write_parts(tmp_path, base, dark, frames, nodes, g, batch_size=2)
+    for node in range(nodes):
+        fn = "%s.rc%d_part%03d" % (base, level, node)
+        assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
+    merged = "%s.rc%d" % (base, level)
+    merge_parts(str(tmp_path), merged, nodes)
+    if has_merged:
+        assert (tmp_path / merged).read_bytes() == open(os.path.join(FILES, merged), "rb").read()
+    thr = (dark + np.uint16(cfg["calibration_threshold_epsilon"])).astype(np.uint16)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16) if level == 1 else (frames > thr).astype(np.uint16)
+    if level == 1 and has_merged:
+        assert np.array_equal(g["decoded"], want)                      # (what the reference's own reader returned)
+    rd = ReCoDeReader(str(tmp_path / merged), is_intermediate=False)
+    rd.open(print_header=False)
+    prefix, trip = rd.get_frames_triplets(0, frames.shape[0])
+    for z in range(frames.shape[0]):
+        t = trip[int(prefix[z]):int(prefix[z + 1])]
+        dense = np.zeros(want.shape[1:], np.uint16)
+        dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16) if level == 1 else 1
+        assert np.array_equal(dense, want[z]), "frame %d" % z
+    rd.close()

@@ -118,6 +118,48 @@ def test_g3_records_byte_exact(tag, level):
         assert np.array_equal(g["decoded"], np.where(frames > thr, frames - thr, 0).astype(np.uint16))
 
 
+def test_g7_stream_mode_records_and_ids():
+    """G7: the reference's writer fed chunk after chunk (mode='stream'): every chunk is split by the contiguous-block rule and the ids run
+    on from chunk to chunk (recode_writer.py:311-322,383,422) - the oracle's records with those ids are the part files' bytes."""
+    g = load_npz("g7_stream.npz")
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    dark, frames, nodes, chunks = g["dark"], g["frames"], int(g["n_nodes"]), g["chunks"].tolist()
+    thr = orc.threshold(dark, cfg["calibration_threshold_epsilon"])
+    for node in range(nodes):
+        ids, at = [], 0
+        for c in chunks:
+            lo, cnt = orc.node_frames(c, nodes, node)
+            ids += [at + lo + i for i in range(cnt)]
+            at += c
+        assert ids == g["ids_part%d" % node].tolist()
+        recs = _parse_part(os.path.join(GOLDEN, "files", "g7_stream.rc1_part%03d" % node), 1, 1)
+        assert len(recs) == len(ids)
+        for fid, ref_rec in zip(ids, recs):
+            assert orc.l1_record(frames[fid], thr, cfg["source_bit_depth"], fid, 1)[0] == ref_rec
+
+
+@pytest.mark.parametrize("tag,level", [("l1bz2", 1), ("l1lzma", 1), ("l1z12_lvl9", 1), ("l3ro", 3)])
+def test_g9_other_host_schemes_records_byte_exact(tag, level):
+    """G9: the reference's part files for bz2, lzma, zlib level 9 and level 3 without compression = the oracle's pieces through the same
+    standard-library call (recode_compressors.py:82-101)."""
+    import bz2
+    import lzma
+    import zlib
+    g = load_npz("g9_%s.npz" % tag)
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    dark, frames, nodes = g["dark"], g["frames"], int(g["n_nodes"])
+    thr = orc.threshold(dark, cfg["calibration_threshold_epsilon"])
+    mode, d, lvl = cfg["rc_operation_mode"], cfg["source_bit_depth"], cfg["compression_level"]
+    comp = {0: lambda b: zlib.compress(b, lvl), 4: lambda b: bz2.compress(b, compresslevel=lvl), 5: lambda b: lzma.compress(b, preset=lvl)}[cfg["compression_scheme"]]
+    for node in range(nodes):
+        recs = _parse_part(os.path.join(GOLDEN, "files", "g9_%s.rc%d_part%03d" % (tag, level, node)), level, mode)
+        lo, cnt = orc.node_frames(frames.shape[0], nodes, node)
+        assert len(recs) == cnt
+        for i, ref_rec in enumerate(recs):
+            rec = orc.l1_record(frames[lo + i], thr, d, lo + i, mode, comp)[0] if level == 1 else orc.l3_record(frames[lo + i], thr, lo + i, mode, comp)[0]
+            assert rec == ref_rec
+
+
 def test_against_reference_c_loops_when_built():
     """oracle/_ref/libreader_ref.so = the reference's own reader.h compiled in place (build_ref.sh)."""
     import ctypes as C

@@ -386,7 +386,7 @@ class ReCoDeReader:
         then reports it)."""
         h = self._header
         level, scheme = int(h['reduction_level']), int(h['compression_scheme'])
-        got = self._host_decode_batch(blob, sizes, n, 0)
+        got = self._host_decode_batch(blob, sizes, n, 2)        # (an image of its own: the iterator's two may be in use between its steps)
         if got is None:
             return None
         pieces, sizes0 = got
@@ -407,8 +407,8 @@ class ReCoDeReader:
         """The 2 n streams of a batch (file bytes in `blob`, stream sizes in `sizes`) through the stock decoder of the file's scheme on the
         thread pool, each straight into its place of a stored-pieces image in page-locked memory (sizes are known beforehand: the
         binary map's nb bytes, the value stream's bytes_in_packed_pixvals).  Returns (pieces, sizes of a mode-0 batch), or None when
-        there is no stock decoder for the scheme or it rejected a stream.  `slot` picks one of two images, so that a batch can be
-        decoded while the device still copies the previous one in."""
+        there is no stock decoder for the scheme or it rejected a stream.  `slot` picks one of three images: two for the streaming
+        iterator (a batch is decoded while the device still copies the previous one in), one for the synchronous call."""
         from concurrent.futures import ThreadPoolExecutor
         h = self._header
         level, scheme = int(h['reduction_level']), int(h['compression_scheme'])
@@ -430,7 +430,7 @@ class ReCoDeReader:
                 dst += npk
                 sizes0[i, 1] = sizes0[i, 2] = npk
         if getattr(self, '_pin_pieces', None) is None:
-            self._pin_pieces = [None, None]
+            self._pin_pieces = [None, None, None]
         buf = self._pin_pieces[slot]
         if buf is None or buf.nbytes < dst + 64:
             if buf is not None:
@@ -514,20 +514,24 @@ class ReCoDeReader:
         try:
             for i in range(len(starts)):
                 a, k, slot, got = fut.result()
+                fut = None
+                if got is None:
+                    # the stock decoder rejected a stream: the synchronous call goes frame by frame and names it (nothing decodes ahead
+                    # meanwhile: that call reads the same file and may use the same pools)
+                    res = (a,) + self.get_frames_triplets(a, k)
                 fut = self._decode_coord.submit(prepare, i + 1) if i + 1 < len(starts) else None
-                if got is None or level != 1:
+                if got is None:
+                    pass
+                elif level != 1:
                     # (level 3 needs a counting call to size its output: the synchronous form does both)
-                    if got is None:
-                        res = (a,) + self.get_frames_triplets(a, k)
-                    else:
-                        pieces, sizes0 = got
-                        prefix = np.zeros(k + 1, np.uint64)
-                        args = geom0 + (_lib.ptr(pieces), _lib.ptr(sizes0), k)
-                        _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
-                        trip = np.empty((max(int(prefix[k]), 1), 3), np.uint64)
-                        _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0]), 'rc_expand_frames')
-                        self.last_batch_path = 'host-decode + device-expand'
-                        res = (a, prefix, trip[:int(prefix[k])])
+                    pieces, sizes0 = got
+                    prefix = np.zeros(k + 1, np.uint64)
+                    args = geom0 + (_lib.ptr(pieces), _lib.ptr(sizes0), k)
+                    _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
+                    trip = np.empty((max(int(prefix[k]), 1), 3), np.uint64)
+                    _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0]), 'rc_expand_frames')
+                    self.last_batch_path = 'host-decode + device-expand'
+                    res = (a, prefix, trip[:int(prefix[k])])
                 else:
                     pieces, sizes0 = got
                     cap = max(int((sizes0[:, 2].astype(np.uint64) * 8 // d).sum()), 1)

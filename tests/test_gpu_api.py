@@ -641,10 +641,37 @@ def test_files_a_stock_encoder_wrote_take_the_batched_path(scheme, tmp_path, orc
     it = rd.iter_frames_triplets(1, nz - 1, batch=2)                 # a consumer that stops early, with a decode running ahead
     a, pre, tr = next(it)
     assert a == 1 and np.array_equal(tr[:int(pre[1])], want[1])
+    p2, t2 = rd.get_frames_triplets(0, nz)                           # a synchronous call BETWEEN the iterator's steps has buffers of its own
+    for z in range(nz):
+        assert np.array_equal(t2[int(p2[z]):int(p2[z + 1])], want[z])
+    a, pre, tr = next(it)
+    assert a == 3 and np.array_equal(tr[:int(pre[1])], want[3]) and np.array_equal(tr[int(pre[1]):int(pre[2])], want[4])
     it.close()
     prefix, trip = rd.get_frames_triplets(2, 3)
     for i in range(3):
         assert np.array_equal(trip[int(prefix[i]):int(prefix[i + 1])], want[2 + i])
+    rd.close()
+    # a damaged stream in such a file: the batches in front of it arrive, its own batch raises (the stock decoder is the judge), and the
+    # reader still serves the intact frames afterwards
+    raw = bytearray(foreign.read_bytes())
+    data0 = 512 + nz * 12
+    at = data0 + sum(len(b) for b in blobs[:4]) + len(blobs[4]) // 4        # inside frame 4's binary-map stream
+    for j in range(8):
+        raw[at + j] ^= 0xFF
+    damaged = tmp_path / "damaged.rc1"
+    damaged.write_bytes(bytes(raw))
+    rd = ReCoDeReader(str(damaged), is_intermediate=False)
+    rd.open(print_header=False)
+    got = []
+    with pytest.raises(Exception):
+        for a, pre, tr in rd.iter_frames_triplets(0, nz, batch=2):
+            got.append(a)
+            for i in range(len(pre) - 1):
+                assert np.array_equal(tr[int(pre[i]):int(pre[i + 1])], want[a + i])
+    assert got == [0, 2]
+    prefix, trip = rd.get_frames_triplets(5, 2)
+    for i in range(2):
+        assert np.array_equal(trip[int(prefix[i]):int(prefix[i + 1])], want[5 + i])
     rd.close()
 
 

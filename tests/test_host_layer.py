@@ -36,6 +36,21 @@ def test_no_gpu_means_loud_failure_not_fallback():
     vals = np.arange(4, dtype=np.uint16)
     with pytest.raises(_lib.RecodeHipError):
         _lib.check(_lib.lib().rc_bit_pack(vals.ctypes.data, 4, 12, out.ctypes.data, 6))
+    # every other stateless compute entry point: RC_ERR_DEVICE, nothing computed on the host
+    import ctypes as C
+    L = _lib.lib()
+    n = C.c_uint64(0)
+    src = np.zeros(64, np.uint8)
+    big = np.zeros(4096, np.uint8)
+    u64 = np.zeros(64, np.uint64)
+    sizes = np.array([[8, 8, 8]], np.uint32)
+    for scheme in (1, 2, 8):
+        assert L.rc_compress(scheme, 1, src.ctypes.data, src.size, big.ctypes.data, big.size, C.byref(n)) == _lib.RC_ERR_DEVICE
+        assert L.rc_decompress(scheme, src.ctypes.data, src.size, big.ctypes.data, big.size, C.byref(n)) == _lib.RC_ERR_DEVICE
+    assert L.rc_bit_unpack(src.ctypes.data, 6, 4, 12, u64.ctypes.data) == _lib.RC_ERR_DEVICE
+    assert L.rc_unpack_frame_sparse(8, 8, 12, src.ctypes.data, src.ctypes.data, 6, u64.ctypes.data, 16, 1) == _lib.RC_ERR_DEVICE
+    assert L.rc_expand_frames(8, 8, 12, 1, 0, 0, src.ctypes.data, sizes.ctypes.data, 1, u64.ctypes.data, u64.ctypes.data + 64, 4) == _lib.RC_ERR_DEVICE
+    assert L.rc_expand_frames_submit(0, 8, 8, 12, 1, 0, 0, src.ctypes.data, sizes.ctypes.data, 1, u64.ctypes.data, 4) == _lib.RC_ERR_DEVICE
 
 
 def test_product_never_imports_the_oracle():

@@ -161,16 +161,21 @@ struct PinnedVec {
     void clear() { n = 0; ok = true; }
     size_t size() const { return n; }
     const T *data() const { return p; }
+    bool grow(size_t nc)
+    {
+        T *q = nullptr;
+        if (hipHostMalloc((void **)&q, nc * sizeof(T), hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); ok = false; return false; }
+        if (n) memcpy(q, p, n * sizeof(T));
+        if (p) (void)hipHostFree(p);
+        p = q; cap = nc;
+        return true;
+    }
+    // room for `want` entries up front: every doubling is a page-locked allocation (about a millisecond), and a reader's first
+    // batches otherwise pay five or six of them per indexing thread
+    void reserve(size_t want) { if (want > cap) (void)grow(want); }
     void push_back(const T &v)
     {
-        if (n == cap) {
-            const size_t nc = cap ? cap * 2 : 8192;
-            T *q = nullptr;
-            if (hipHostMalloc((void **)&q, nc * sizeof(T), hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
-            if (n) memcpy(q, p, n * sizeof(T));
-            if (p) (void)hipHostFree(p);
-            p = q; cap = nc;
-        }
+        if (n == cap && !grow(cap ? cap * 2 : 8192)) return;
         p[n++] = v;
     }
 };

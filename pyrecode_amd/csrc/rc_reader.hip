@@ -175,10 +175,19 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     // frames are claimed one at a time: the calling thread starts at once, the pool's workers join in as they wake up (their
     // wake-up, not the walk - 30 us per frame - is what a static split waited for)
     std::atomic<uint32_t> next_frame{0};
+    uint64_t max_npk = 0;
+    if (level == 1) for (uint32_t f = 0; f < n; ++f) max_npk = std::max<uint64_t>(max_npk, sizes[3 * f + 2]);
     auto index_range = [&](uint32_t t) {
         if (t) (void)hipSetDevice(dev_now);   // (a worker thread: page-locked memory it allocates belongs to this device's context)
         auto &BM = u.rd_bm[t]; auto &PV = u.rd_pv[t]; auto &RAW = u.rd_raw[t]; auto &all = u.rd_tmp[t]; auto &OFF = u.rd_off[t];
         BM.clear(); PV.clear(); RAW.clear(); OFF.clear();
+        if (codec) {
+            // what this thread is likely to collect (frames are claimed one at a time: up to three times its even share), reserved
+            // in one allocation each; anything beyond still grows by doubling
+            const uint64_t share = std::min<uint64_t>(n, 3ull * ((n + nthr - 1) / nthr));
+            OFF.reserve(share * ((nb + TILE_BM - 1) / TILE_BM + 1));
+            if (level == 1 && codec == 1) PV.reserve(share * (max_npk / 1000 + 2));   // (value-stream chunks: PIX_CHUNK = 1008 bytes each)
+        }
         // A binary-map stream whose blocks all regenerate TILE_BM bytes (the last one the rest), lie back to back and keep to one
         // set of sequence tables - what this library's encoders write - leaves one dword per block (k_bitmap_decode_c); any other
         // stream inside the decoders' subset leaves full entries, Compressed blocks and stored ones apart, as before.

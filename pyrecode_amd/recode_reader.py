@@ -156,16 +156,27 @@ class ReCoDeReader:
         lo = self._frame_data_start_position + int(self._seek_table[z0, 1])
         if not self._is_intermediate:
             return self._read_into(blob, lo, move_fp)
-        fd, at = self._fp.fileno(), 0
-        for z in range(z0, z0 + n):
-            size, pos = int(self._seek_table[z, 0]), self._frame_data_start_position + int(self._seek_table[z, 1])
-            got = 0
-            while got < size:
-                k = os.preadv(fd, [memoryview(blob[at + got:at + size])], pos + got)
-                if k <= 0:
-                    raise ValueError('file shorter than its records say')
-                got += k
-            at += size
+        fd = self._fp.fileno()
+        sizes = self._seek_table[z0:z0 + n, 0].astype(np.int64)
+        ats = np.concatenate([[0], np.cumsum(sizes)])
+
+        def some(lo, hi):
+            for i in range(lo, hi):
+                size, at = int(sizes[i]), int(ats[i])
+                pos, got = self._frame_data_start_position + int(self._seek_table[z0 + i, 1]), 0
+                while got < size:
+                    k = os.preadv(fd, [memoryview(blob[at + got:at + size])], pos + got)
+                    if k <= 0:
+                        raise ValueError('file shorter than its records say')
+                    got += k
+        nthr = 4 if int(ats[-1]) >= (8 << 20) and n >= 4 else 1      # (as _read_into: a read from the page cache is a memcpy)
+        if nthr == 1:
+            return some(0, n)
+        if getattr(self, '_read_pool', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._read_pool = ThreadPoolExecutor(max_workers=4)
+        cuts = [n * t // nthr for t in range(nthr + 1)]
+        list(self._read_pool.map(lambda t: some(cuts[t], cuts[t + 1]), range(nthr)))
 
     # ---- accessors -----------------------------------------------------------------------------------------
     def get_header(self):

@@ -272,6 +272,10 @@ int rc_expand_frames_wait(uint32_t slot, uint64_t *nnz_prefix);
  * RC_ERR_CORRUPT: the stock decoder rejected a stream or it decodes to another size.  No GPU is touched. */
 int rc_host_decoder_available(uint32_t scheme);     /* 1 / 0 */
 int rc_host_decode_streams(uint32_t scheme, const uint8_t *src, uint8_t *dst, const uint64_t *spans, uint32_t n, uint32_t threads);
+/* The last step of the reference's get_frame (recode_reader.py:466-469: coo_matrix((data, (row, col)))) for a frame's triplets: its
+ * uint64 (row, col, value) rows -> int32 rows, int32 columns and values as unsigned integers of val_bytes (1 / 2 / 4 / 8) bytes, in ONE
+ * pass.  Host pointers; no GPU is touched. */
+int rc_split_triplets(const uint64_t *triplets, uint64_t n, int32_t *row, int32_t *col, void *val, uint32_t val_bytes);
 /* bit_pack_pixel_intensities -> _bit_pack_pixel_intensities (reader.h:105-140) with the intended semantics of
  * the numba _bit_pack (recode_writer.py:637-652): zero, then LSB-first d-bit fields.  out_n = ceil(n*d/8). */
 int rc_bit_pack(const uint16_t *pixvals, uint64_t n, uint32_t bit_depth, uint8_t *out, uint64_t out_n);

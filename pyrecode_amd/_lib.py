@@ -68,6 +68,7 @@ SIGNATURES = {
     "rc_expand_frames_wait": (C.c_int, [C.c_uint32, _u64p]),
     "rc_host_decoder_available": (C.c_int, [C.c_uint32]),
     "rc_host_decode_streams": (C.c_int, [C.c_uint32, _u8p, _u8p, _u64p, C.c_uint32, C.c_uint32]),
+    "rc_split_triplets": (C.c_int, [_u64p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "rc_bit_pack": (C.c_int, [_u16p, C.c_uint64, C.c_uint32, _u8p, C.c_uint64]),
     "rc_bit_unpack": (C.c_int, [_u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
     "rc_synth_dark": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, _u16p]),

@@ -5,6 +5,7 @@
 // library) on worker threads, each stream straight into its place of a stored-pieces image that rc_expand_frames (op_mode 0) then
 // expands on the device.  No HIP call in this file.
 #include <dlfcn.h>
+#include <type_traits>
 
 #include "rc_host.h"
 
@@ -157,6 +158,28 @@ RC_EXPORT int rc_host_decode_streams(uint32_t scheme, const uint8_t *src, uint8_
         snprintf(msg, sizeof msg, "rc_host_decode_streams: the stock decoder rejected stream %lld (or it does not decode to the expected size)",
                  (long long)bad.load());
         return fail(RC_ERR_CORRUPT, msg);
+    }
+    return RC_OK;
+}
+
+// (row, col, value) rows -> the three arrays of a COO matrix, one pass over the rows (three strided numpy conversions read them three times).
+RC_EXPORT int rc_split_triplets(const uint64_t *triplets, uint64_t n, int32_t *row, int32_t *col, void *val, uint32_t val_bytes)
+{
+    if (n && (!triplets || !row || !col || !val)) return fail(RC_ERR_BAD_ARG, "rc_split_triplets: null argument");
+    auto run = [&](auto *v) {
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t *t = triplets + 3 * i;
+            row[i] = (int32_t)t[0];
+            col[i] = (int32_t)t[1];
+            v[i] = (typename std::remove_pointer<decltype(v)>::type)t[2];
+        }
+    };
+    switch (val_bytes) {
+    case 1: run(static_cast<uint8_t *>(val)); break;
+    case 2: run(static_cast<uint16_t *>(val)); break;
+    case 4: run(static_cast<uint32_t *>(val)); break;
+    case 8: run(static_cast<uint64_t *>(val)); break;
+    default: return fail(RC_ERR_BAD_ARG, "rc_split_triplets: val_bytes must be 1, 2, 4 or 8");
     }
     return RC_OK;
 }

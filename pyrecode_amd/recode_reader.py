@@ -202,6 +202,7 @@ class ReCoDeReader:
         return self._sz_frame_metadata
 
     def close(self):
+        self._drop_readahead()
         self._fp.close()
         if getattr(self, '_pin_blob', None) is not None:
             self._pin_blob.close()
@@ -288,11 +289,77 @@ class ReCoDeReader:
             d['summary_stats'] = stats
         return {key: d}
 
+    _RA_FRAMES = 32          # frames fetched ahead once the calls turn out to be sequential
+    _RA_BYTES = 512 << 20    # ... as long as their triplets fit into this much page-locked memory
+
+    def _readahead_frame(self, z):
+        """The frame-at-a-time calls of the reference (get_frame in a loop, get_next_frame) served out of the batched reader: after
+        three calls in sequence the frames from z on are fetched a batch at a time (get_frames_triplets into a page-locked buffer
+        of this reader's), and the following calls only wrap their rows as COO.  Returns the COO matrix, or None for "take the
+        frame-at-a-time path" (not sequential, level 2, an empty frame - whose conventions that path knows -, or a batch the batched
+        reader could not deliver: the per-frame path then names the frame that is to blame).  Nothing stays queued on the device
+        between calls: any number of readers in a process may do this side by side."""
+        if getattr(self, '_ra_off', False) or int(self._header['reduction_level']) not in (1, 3):
+            return None
+        ra = getattr(self, '_ra', None)
+        fetch = False
+        if ra is not None and not (ra[0] <= z < ra[0] + ra[1]):
+            fetch = z == ra[0] + ra[1]                   # the batch behind the one just used up
+            ra = self._ra = None
+        if ra is None and not fetch:
+            last = getattr(self, '_ra_last', None)
+            self._ra_streak = getattr(self, '_ra_streak', 0) + 1 if last is not None and z == last + 1 else 0
+            fetch = self._ra_streak >= 2
+        self._ra_last = z
+        if ra is None:
+            if not fetch:
+                return None
+            nz = self._batch_frames()
+            if nz - z < 2:
+                return None
+            k, d, level = self._RA_FRAMES, int(self._header['target_bit_depth']), int(self._header['reduction_level'])
+            if level == 1:                               # batches sized by what they expand to (24 bytes per set pixel)
+                per = max(int(self._frame_metadata[z]['bytes_in_packed_pixvals']) * 8 // d * 24, 1)
+                k = max(2, min(k, self._RA_BYTES // per))
+            k = min(k, nz - z)
+            if getattr(self, '_ra_buf', None) is None:
+                self._ra_buf = [None]
+            keep = (self._current_frame_index, self._fp.tell())
+            try:
+                prefix, trip = self.get_frames_triplets(z, k, out=self._ra_buf)
+            except Exception:
+                self._ra_off = True
+                return None
+            finally:
+                self._current_frame_index = keep[0]
+                self._fp.seek(keep[1], 0)
+            if self.last_batch_path == 'per-frame':      # nothing batched about this file: frame by frame it is
+                self._ra_off = True
+                return None
+            ra = self._ra = (z, k, prefix, trip)
+        a, _, prefix, trip = ra
+        lo, hi = int(prefix[z - a]), int(prefix[z - a + 1])
+        if hi == lo:
+            return None
+        self.readahead_frames_served = getattr(self, 'readahead_frames_served', 0) + 1
+        return self._make_coo_frame(hi - lo, trip[lo:hi])
+
+    def _drop_readahead(self):
+        self._ra = None
+        buf = getattr(self, '_ra_buf', None)
+        if buf is not None and buf[0] is not None:
+            buf[0].close()
+        self._ra_buf = None
+
     def get_frame(self, z):
         if self._is_intermediate:
             raise ValueError("Random acceess is not available for intermediate files")
         if z >= self._header['nz']:
             raise ValueError('Requested frame index is greater than number of frames in dataset')
+        coo = self._readahead_frame(int(z))
+        if coo is not None:
+            self._current_frame_index = z + 1
+            return self._pack(z, self._frame_metadata[z], coo)
         self._fp.seek(self._frame_data_start_position + int(self._seek_table[z, 1]), 0)
         if self._file_size - self._fp.tell() == 0:
             return self._pack(z, None, None)
@@ -302,13 +369,16 @@ class ReCoDeReader:
         return out
 
     # ---- batched access (device-resident decode + expand; no counterpart in the reference, which reads frame by frame) ------
-    def get_frames_triplets(self, z0, n):
+    def get_frames_triplets(self, z0, n, out=None):
         """Frames z0 .. z0+n-1 of a merged file - or records z0 .. z0+n-1 of a part file, whose frame ids are part_frame_ids[z] - in ONE
         device call (rc_expand_frames): both streams of every frame are
         decompressed and expanded on the GPU without a host round trip in between.  Returns (nnz_prefix uint64[n+1],
         triplets uint64[total, 3]) - frame i's (row, col, value) rows are triplets[nnz_prefix[i]:nnz_prefix[i+1]], in the
         reference's row-major order (pyrecode.cpp:95-119).  Falls back to the per-frame path (stock decoder on the host) for
-        streams outside the device decoders' subset, for level 2 and for host-only schemes."""
+        streams outside the device decoders' subset, for level 2 and for host-only schemes.
+        out: None (the triplets come in an array of their own), or a one-element list holding a _lib.PinnedBuffer or None - the
+        triplets are then written into that page-locked buffer (grown when too small) and the returned array is a view of it,
+        valid until the next call with the same holder."""
         h = self._header
         nz = self._batch_frames()
         if z0 < 0 or n <= 0 or z0 + n > nz:
@@ -342,12 +412,12 @@ class ReCoDeReader:
                 # a frame's packed stream holds one depth-bit field per set pixel: its size bounds the count, one call does it all
                 d = int(h['target_bit_depth'])
                 cap = max(int((sizes[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
-                trip = np.empty((cap, 3), np.uint64)
+                trip = self._trip_buffer(cap, out)
                 st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), cap)
             else:
                 st = L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0)        # level 3: a counting call sizes the output
                 if st == _lib.RC_OK:
-                    trip = np.empty((max(int(prefix[n]), 1), 3), np.uint64)
+                    trip = self._trip_buffer(max(int(prefix[n]), 1), out)
                     st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0])
             if st == _lib.RC_OK:
                 self._note_batch_end(z0 + n)
@@ -359,7 +429,7 @@ class ReCoDeReader:
             if st not in (_lib.RC_ERR_UNSUPPORTED, _lib.RC_ERR_CORRUPT):
                 _lib.check(st, 'rc_expand_frames')
             if mode == 1:
-                res = self._foreign_batch_triplets(z0, n, blob, sizes)
+                res = self._foreign_batch_triplets(z0, n, blob, sizes, out)
                 if res is not None:
                     self._note_batch_end(z0 + n)
                     self.last_batch_path = 'host-decode + device-expand'
@@ -387,7 +457,7 @@ class ReCoDeReader:
         if not self._is_intermediate:        # (a part file's sequential cursor is its file position, which the batched readers leave alone)
             self._current_frame_index = z
 
-    def _foreign_batch_triplets(self, z0, n, blob, sizes):
+    def _foreign_batch_triplets(self, z0, n, blob, sizes, out=None):
         """Streams a FOREIGN encoder wrote (the reference's own files: lz4.frame with linked 64 KiB blocks, libzstd with 4-stream
         literals and real offsets) are serial chains of some 10^5 dependent steps per frame - the stock decoder on a CPU core
         walks one in about a millisecond, a GPU lane needs ~1 us per step ("Foreign streams").  So they are decoded
@@ -410,9 +480,20 @@ class ReCoDeReader:
         else:
             _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
             cap = max(int(prefix[n]), 1)
-        trip = np.empty((cap, 3), np.uint64)
+        trip = self._trip_buffer(cap, out)
         _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), cap), 'rc_expand_frames')
         return prefix, trip[:int(prefix[n])]
+
+    @staticmethod
+    def _trip_buffer(cap, out):
+        """room for cap triplets: an array of its own, or a view of the caller's page-locked buffer (get_frames_triplets' `out`)"""
+        if out is None:
+            return np.empty((cap, 3), np.uint64)
+        if out[0] is None or out[0].nbytes < cap * 24:
+            if out[0] is not None:
+                out[0].close()
+            out[0] = _lib.PinnedBuffer(max(int(cap * 24 * 1.25), 1 << 20))
+        return out[0].array[:cap * 24].view(np.uint64).reshape(cap, 3)
 
     def _host_decode_batch(self, blob, sizes, n, slot):
         """The 2 n streams of a batch (file bytes in `blob`, stream sizes in `sizes`) through the stock decoder of the file's scheme on the
@@ -689,6 +770,15 @@ class ReCoDeReader:
         return frame_id, self._read_metadata_row()
 
     def get_next_frame(self):
+        z = self._current_frame_index
+        # sequential by definition: from the third call on the frames come out of the batched reader (part files included, whose
+        # records it indexes then) and this call only wraps its rows
+        coo = self._readahead_frame(z)                    # (leaves the frame counter and the file position as they were)
+        if coo is not None:
+            # the file position goes where the frame-at-a-time path would have left it
+            self._fp.seek(self._frame_data_start_position + int(self._seek_table[z, 1]) + int(self._seek_table[z, 0]), 0)
+            self._current_frame_index = z + 1
+            return self._pack(int(self.part_frame_ids[z]) if self._is_intermediate else z, self._frame_metadata[z], coo)
         nxt = self._next_header()
         if nxt is None:
             return None
@@ -802,9 +892,25 @@ class ReCoDeReader:
         return coo, stats[:n_stats].astype(self._numpy_dtype)
 
     def _make_coo_frame(self, n, buf):
+        """(row, col, value) uint64 triplets -> the COO matrix the reference returns (recode_reader.py:466-469).  The arrays are handed to
+        an empty matrix instead of going through the constructor, whose index checks (min / max over both index arrays, dtype
+        negotiation, copies) cost more than the device call that produced the triplets; rows and columns come from the expand kernel,
+        inside the frame by construction."""
         d = buf[:n]
-        return coo_matrix((d[:, 2], (d[:, 0], d[:, 1])), shape=(int(self._header['ny']), int(self._header['nx'])),
-                          dtype=self._numpy_dtype)
+        m = coo_matrix((int(self._header['ny']), int(self._header['nx'])), dtype=self._numpy_dtype)
+        dt = np.dtype(self._numpy_dtype)
+        if dt.kind in 'ui' and d.flags['C_CONTIGUOUS']:
+            # one pass over the rows (rc_split_triplets) instead of three strided conversions
+            data, row, col = np.empty(n, dt), np.empty(n, np.int32), np.empty(n, np.int32)
+            _lib.check(_lib.lib().rc_split_triplets(_lib.ptr(d), n, _lib.ptr(row), _lib.ptr(col), _lib.ptr(data), dt.itemsize), 'rc_split_triplets')
+        else:
+            data, row, col = d[:, 2].astype(dt), d[:, 0].astype(np.int32), d[:, 1].astype(np.int32)
+        if hasattr(m, 'coords'):
+            m.data, m.coords = data, (row, col)
+        else:
+            m.data, m.row, m.col = data, row, col
+        m.has_canonical_format = False          # (what the constructor leaves; the triplets are in fact sorted and unique)
+        return m
 
 
 def merge_parts(folder_path, base_filename, num_parts):

@@ -858,3 +858,86 @@ def test_other_host_schemes_reproduce_the_references_files(tag, level, has_merge
         dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16) if level == 1 else 1
         assert np.array_equal(dense, want[z]), "frame %d" % z
     rd.close()
+
+
+def _coo_equal(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.row, b.row) and np.array_equal(a.col, b.col) and np.array_equal(a.data, b.data)
+
+
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_frame_at_a_time_calls_read_ahead_and_return_the_same_frames(scheme, tmp_path, orc):
+    """The reference's calls - get_frame(z) in a loop, get_next_frame() - are served out of the batched reader once they turn out to
+    be sequential (ReCoDeReader._readahead_frame).  Same dictionaries, same COO arrays, same file positions as a reader that goes
+    frame by frame (_ra_off), on a merged file with an EMPTY frame in the middle (whose conventions stay with the frame-at-a-time
+    path), on its part files, with jumps, repeats and a switch between the two calls."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, d, nz = 96, 200, 12, 23
+    dark, frames = synth_frames(77, nz, ny, nx, 0.03, d)
+    frames[9] = 0                                                        # an empty frame
+    g = load_npz("g3_l1z12.npz")
+    _write_parts(tmp_path, "ra", dark, frames, 2, g, batch_size=5, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=2,
+                 compression_scheme=scheme, calibration_threshold_epsilon=0)
+    merge_parts(str(tmp_path), "ra.rc1", 2)
+    thr = orc.threshold(dark, 0)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16)
+
+    def readers(name, inter):
+        out = []
+        for off in (False, True):
+            rd = ReCoDeReader(str(tmp_path / name), is_intermediate=inter)
+            rd.open(print_header=False)
+            rd._RA_FRAMES = 4                                            # several batches in this short file
+            rd._ra_off = off
+            out.append(rd)
+        return out
+    # get_frame in a loop, then jumps / repeats / backwards
+    a, b = readers("ra.rc1", False)
+    order = list(range(nz)) + [3, 4, 5, 6, 7, 8, 9, 10, 11, 2, 2, 20, 21, 22, 0, 1, 2, 3]
+    for z in order:
+        fa, fb = a.get_frame(z), b.get_frame(z)
+        assert list(fa) == list(fb) == [z]
+        if frames[z].any():
+            assert fa[z]["metadata"] == fb[z]["metadata"] and _coo_equal(fa[z]["data"], fb[z]["data"]), "frame %d" % z
+            assert np.array_equal(np.asarray(fa[z]["data"].todense()), want[z])
+        else:
+            assert fa[z]["data"] is None or fa[z]["data"].nnz == 0
+            assert (fa[z]["data"] is None) == (fb[z]["data"] is None)
+    assert a.readahead_frames_served >= nz - 3 and not hasattr(b, "readahead_frames_served")
+    # get_next_frame from the start to the end of the file, with a get_frame in between
+    a2, b2 = readers("ra.rc1", False)
+    for z in range(nz):
+        if z == 12:
+            assert _coo_equal(a2.get_frame(5)[5]["data"], b2.get_frame(5)[5]["data"])
+            a2._current_frame_index = b2._current_frame_index = 12
+            a2._fp.seek(a2._frame_data_start_position + int(a2._seek_table[12, 1]), 0)
+            b2._fp.seek(b2._frame_data_start_position + int(b2._seek_table[12, 1]), 0)
+        fa, fb = a2.get_next_frame(), b2.get_next_frame()
+        if fa is None or fb is None:                                     # (the empty frame of a reduce-only file; not in these schemes)
+            assert fa is None and fb is None
+            break
+        assert list(fa) == list(fb) == [z]
+        if frames[z].any():
+            assert _coo_equal(fa[z]["data"], fb[z]["data"])
+        assert a2.get_file_position() == b2.get_file_position(), "after frame %d" % z
+    assert a2.get_next_frame() is None and b2.get_next_frame() is None      # (end of file: None, as in the reference :224-226)
+    assert a2.readahead_frames_served >= nz - 8
+    # the part files, sequentially (the reference's own read test): ids as keys, None at the end
+    for node in range(2):
+        pa, pb = readers("ra.rc1_part%03d" % node, True)
+        seen = 0
+        while True:
+            fa, fb = pa.get_next_frame(), pb.get_next_frame()
+            if fb is None:
+                assert fa is None
+                break
+            assert list(fa) == list(fb)
+            (fid, body), = fa.items()
+            if frames[fid].any():
+                assert _coo_equal(body["data"], fb[fid]["data"]) and np.array_equal(np.asarray(body["data"].todense()), want[fid])
+            assert pa.get_file_position() == pb.get_file_position()
+            seen += 1
+        assert seen == len(pa.part_frame_ids) and pa.readahead_frames_served >= seen - 4 and not hasattr(pb, "readahead_frames_served")
+        for r in (pa, pb):
+            r.close()
+    for r in (a, b, a2, b2):
+        r.close()

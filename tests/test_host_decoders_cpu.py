@@ -128,3 +128,20 @@ def test_native_batch_decoder_makes_the_stock_librarys_calls(scheme):
     st = L.rc_host_decode_streams(scheme, _lib.ptr(flipped), _lib.ptr(dst), _lib.ptr(table), len(spans), 0)
     assert st in (_lib.RC_OK, _lib.RC_ERR_CORRUPT)                     # (a flipped literal still decodes; it must not crash or overrun)
     assert L.rc_host_decode_streams(7, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(table), len(spans), 0) == _lib.RC_ERR_UNSUPPORTED
+
+
+def test_split_triplets_equals_the_three_numpy_conversions():
+    """rc_split_triplets: (row, col, value) uint64 rows -> int32 rows, int32 columns, values of 1 / 2 / 4 / 8 bytes, one pass (what
+    ReCoDeReader._make_coo_frame hands to the COO matrix, reference recode_reader.py:466-469); n = 0 and a bad width."""
+    from pyrecode_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 1000, 70001):
+        trip = np.empty((n, 3), np.uint64)
+        trip[:, 0], trip[:, 1], trip[:, 2] = rng.integers(0, 8184, n), rng.integers(0, 11520, n), rng.integers(0, 1 << 16, n)
+        for width, dt in ((1, np.uint8), (2, np.uint16), (4, np.uint32), (8, np.uint64), (2, np.int16), (4, np.int32)):
+            row, col, val = np.full(n + 1, -5, np.int32), np.full(n + 1, -5, np.int32), np.full(n + 1, 77, dt)
+            assert L.rc_split_triplets(_lib.ptr(trip) if n else None, n, _lib.ptr(row), _lib.ptr(col), _lib.ptr(val), width) == _lib.RC_OK
+            assert np.array_equal(row[:n], trip[:, 0].astype(np.int32)) and np.array_equal(col[:n], trip[:, 1].astype(np.int32))
+            assert np.array_equal(val[:n], trip[:, 2].astype(dt)) and row[n] == -5 and col[n] == -5 and val[n] == 77
+    assert L.rc_split_triplets(_lib.ptr(trip), n, _lib.ptr(row), _lib.ptr(col), _lib.ptr(val), 3) == _lib.RC_ERR_BAD_ARG

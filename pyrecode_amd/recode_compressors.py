@@ -194,7 +194,7 @@ def _lz4_host_decompress(data, size_hint=0, into=None):
 
 def host_stream_decoder(scheme):
     """(bytes-like, decoded size or 0, into=None or the uint8 array to fill) -> bytes (or the length) through the STOCK library: for schemes whose foreign streams the device decoders refuse
-    (1 zstd, 2 LZ4) and for the host-only ones of the standard library (0 zlib, 4 bz2, 5 lzma); None when no stock decoder can be had.  Thread-safe: every call builds its own decoding context."""
+    (1 zstd, 2 LZ4) and for the host-only ones of the standard library (0 zlib, 4 bz2, 5 lzma); None when no stock decoder can be had.  Thread-safe: one decoding context per thread (_ThreadCtx)."""
     if scheme == 1:
         if _optional('zstandard') is None and _host_lib('zstd') is None:
             return None

@@ -867,9 +867,19 @@ class ReCoDeReader:
         values = self._fp.read(sz_val) if sz_val is not None else None
         if mode == 1:
             scheme = h['compression_scheme']
-            binary_map = compressors.de_compress(scheme, binary_map, self._decompressor_context)
-            if values is not None:
-                values = compressors.de_compress(scheme, values, self._decompressor_context)
+            # zstd / LZ4 streams that arrive here were refused by the fused call: a stock encoder's serial chains (DESIGN.md "Foreign
+            # streams").  The stock library on the host walks one in a millisecond or two; the device's seam-2 LZ4 decoder would take
+            # linked 64 KiB blocks too, but with ONE thread per frame (0.3 s per 4096 x 4096 binary map) - it stays what
+            # recode_compressors.de_compress offers, not what the reader uses.
+            host = compressors.host_stream_decoder(scheme) if scheme in (1, 2) and level in (1, 3) else None
+            if host is not None:
+                binary_map = host(binary_map, self._structures.binary_image_sz_bytes)
+                if values is not None:
+                    values = host(values, int(frame_metadata['bytes_in_packed_pixvals']) if level == 1 else 0)
+            else:
+                binary_map = compressors.de_compress(scheme, binary_map, self._decompressor_context)
+                if values is not None:
+                    values = compressors.de_compress(scheme, values, self._decompressor_context)
         # size the triplet buffer from the value stream (L1) or ask the library to count (bitmap-only levels)
         d = int(h['target_bit_depth'])
         if level == 1:

@@ -93,9 +93,16 @@ print("[foreign] streaming iterator (decode one batch ahead of the device): %.0f
       % (nseen / dt, nseen / max(acc["decode"], 1e-9), nseen / max(acc.get("device", 0), 1e-9), rd.last_batch_path))
 LL.rc_expand_frames_submit, LL.rc_expand_frames_wait = _sub, _wait
 t0 = time.perf_counter()
+for zf in range(nz):
+    rd.get_frame(zf)
+dt = time.perf_counter() - t0
+print("[foreign] frame-at-a-time get_frame over the whole file (reads ahead once sequential): %.0f frames/s" % (nz / dt))
+rd._ra_off = True
+rd._drop_readahead()
+t0 = time.perf_counter()
 for zf in range(min(nz, 8)):
     rd.get_frame(zf)
 dt = time.perf_counter() - t0
-print("[foreign] frame-at-a-time get_frame: %.0f frames/s" % (min(nz, 8) / dt))
+print("[foreign] frame-at-a-time get_frame, one frame per call: %.0f frames/s" % (min(nz, 8) / dt))
 rd.close()
 import shutil; shutil.rmtree(tmp, ignore_errors=True)

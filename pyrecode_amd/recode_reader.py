@@ -843,7 +843,10 @@ class ReCoDeReader:
         if cap == 0:
             return NotImplemented      # (an empty frame: the plain path knows the reference's conventions for it)
         buf = np.empty((cap, 3), dtype=np.uint64)
-        if L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(buf), cap) != _lib.RC_OK:
+        st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(buf), cap)
+        if st != _lib.RC_OK:
+            if st == _lib.RC_ERR_UNSUPPORTED and int(h['rc_operation_mode']) == 1:
+                self._foreign_file = True      # a stock encoder's streams: this file is not offered to the device decoders again
             return NotImplemented      # foreign or damaged: the stock decoder is the judge
         n = int(prefix[1])
         if n == 0:
@@ -855,7 +858,8 @@ class ReCoDeReader:
         h = self._header
         level, mode = h['reduction_level'], h['rc_operation_mode']
         sz_map, sz_val = self._stream_sizes(frame_metadata)
-        if level in (1, 3) and (mode == 0 or h['compression_scheme'] in (1, 2)) and not getattr(self, '_no_fused_frame', False):
+        if level in (1, 3) and (mode == 0 or h['compression_scheme'] in (1, 2)) and not getattr(self, '_no_fused_frame', False) \
+                and not (mode == 1 and getattr(self, '_foreign_file', False)):
             # one device call for the whole frame (rc_expand_frames, n = 1): compressed streams in, triplets out - the decoded binary
             # map and value stream never visit the host (the reference's three steps below remain for everything it does not take)
             pos = self._fp.tell()

@@ -631,13 +631,18 @@ class ReCoDeReader:
                         if bufs[2 + slot] is not None:
                             bufs[2 + slot].close()
                         bufs[2 + slot] = _lib.PinnedBuffer(max(int(cap * 24 * 1.25), 1 << 20))
-                    _lib.check(L.rc_expand_frames_submit(slot, *geom0, _lib.ptr(pieces), _lib.ptr(sizes0), k, bufs[2 + slot]._p, cap),
-                               'rc_expand_frames_submit')
-                    submitted = (slot, k)
                     prefix = np.zeros(k + 1, np.uint64)
-                    st = L.rc_expand_frames_wait(slot, _lib.ptr(prefix))
-                    submitted = None
-                    _lib.check(st, 'rc_expand_frames_wait')
+                    st = L.rc_expand_frames_submit(slot, *geom0, _lib.ptr(pieces), _lib.ptr(sizes0), k, bufs[2 + slot]._p, cap)
+                    if st == _lib.RC_ERR_BAD_ARG and 'submitted batch' in _lib.last_error():
+                        # another iterator of this process holds the slot: the synchronous call has resources of its own
+                        _lib.check(L.rc_expand_frames(*geom0, _lib.ptr(pieces), _lib.ptr(sizes0), k, _lib.ptr(prefix), bufs[2 + slot]._p, cap),
+                                   'rc_expand_frames')
+                    else:
+                        _lib.check(st, 'rc_expand_frames_submit')
+                        submitted = (slot, k)
+                        st = L.rc_expand_frames_wait(slot, _lib.ptr(prefix))
+                        submitted = None
+                        _lib.check(st, 'rc_expand_frames_wait')
                     total = int(prefix[k])
                     self.last_batch_path = 'host-decode + device-expand'
                     res = (a, prefix, bufs[2 + slot].array[:total * 24].view(np.uint64).reshape(total, 3))
@@ -708,6 +713,10 @@ class ReCoDeReader:
             st = L.rc_expand_frames_submit(slot, *geom, _lib.ptr(blob), _lib.ptr(sizes), k, bufs[2 + slot]._p, cap)
             if st in (_lib.RC_ERR_UNSUPPORTED, _lib.RC_ERR_CORRUPT):
                 return (a, k, slot, None)
+            if st == _lib.RC_ERR_BAD_ARG and 'submitted batch' in _lib.last_error():
+                # the library's two streaming slots are per process and device: ANOTHER iterator (another reader) holds this one.
+                # This batch goes through the synchronous call, which has resources of its own.
+                return (a, k, slot, None)
             _lib.check(st, 'rc_expand_frames_submit')
             return (a, k, slot, cap)
 
@@ -751,7 +760,7 @@ class ReCoDeReader:
         out = {}
         for i in range(n):
             d = trip[int(prefix[i]):int(prefix[i + 1])]
-            coo = coo_matrix((d[:, 2], (d[:, 0], d[:, 1])), shape=(int(self._header['ny']), int(self._header['nx'])), dtype=self._numpy_dtype)
+            coo = self._make_coo_frame(d.shape[0], d)
             key = int(self.part_frame_ids[z0 + i]) if self._is_intermediate else z0 + i      # (what get_next_frame keys a part file's frames by)
             out[key] = {'metadata': self._frame_metadata[z0 + i], 'data': coo}
         return out

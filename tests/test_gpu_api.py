@@ -941,3 +941,46 @@ def test_frame_at_a_time_calls_read_ahead_and_return_the_same_frames(scheme, tmp
             r.close()
     for r in (a, b, a2, b2):
         r.close()
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_two_streaming_iterators_side_by_side(scheme, tmp_path, orc):
+    """The library's two streaming slots belong to the process, not to a reader: two iterators advanced in turn (two readers of two
+    files, as a program comparing datasets would) both deliver every frame - the one that finds a slot taken sends that batch through
+    the synchronous call."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, d, nz = 64, 256, 12, 13
+    g = load_npz("g3_l1z12.npz")
+    sets = []
+    for tag, seed in (("one", 5), ("two", 6)):
+        dark, frames = synth_frames(seed, nz, ny, nx, 0.04, d)
+        sub = tmp_path / tag
+        sub.mkdir()
+        _write_parts(sub, tag, dark, frames, 1, g, batch_size=4, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=1,
+                     compression_scheme=scheme, calibration_threshold_epsilon=0)
+        merge_parts(str(sub), tag + ".rc1", 1)
+        thr = orc.threshold(dark, 0)
+        rd = ReCoDeReader(str(sub / (tag + ".rc1")), is_intermediate=False)
+        rd.open(print_header=False)
+        sets.append((rd, np.where(frames > thr, frames - thr, 0).astype(np.uint16)))
+    its = [rd.iter_frames_triplets(batch=3) for rd, _ in sets]
+    seen = [0, 0]
+    alive = [True, True]
+    while any(alive):
+        for j in (0, 1):
+            if not alive[j]:
+                continue
+            try:
+                a, pre, tr = next(its[j])
+            except StopIteration:
+                alive[j] = False
+                continue
+            for i in range(len(pre) - 1):
+                t = tr[int(pre[i]):int(pre[i + 1])]
+                dense = np.zeros((ny, nx), np.uint16)
+                dense[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16)
+                assert np.array_equal(dense, sets[j][1][a + i]), "reader %d frame %d" % (j, a + i)
+                seen[j] += 1
+    assert seen == [nz, nz]
+    for rd, _ in sets:
+        rd.close()

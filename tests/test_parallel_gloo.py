@@ -146,7 +146,7 @@ LOOP_WORKER = textwrap.dedent("""
     ctx = StubCtx()
     out, rec = torch.zeros(64, dtype=torch.uint8), torch.zeros(B + 1, dtype=torch.int64)
     loop = ShardedStepLoop(ctx, B, lambda i: (7 * i + rank, rank * 1000 + i * B), out, rec, torch.device("cpu"))
-    assert loop.world == 2 and loop.rank == rank
+    assert loop.world == world and loop.rank == rank
     nsteps = 7
     loop.fence()
     for i in range(nsteps):
@@ -157,26 +157,29 @@ LOOP_WORKER = textwrap.dedent("""
         want = np.concatenate([rows(r, i) for r in range(world)])
         assert np.array_equal(loop.md_all2[i & 1].numpy(), want), (rank, i)
     assert loop.verify_gather() is True
-    if rank == 1:                            # one rank's table damaged: EVERY rank must learn it
+    if rank == world - 1:                    # one rank's table damaged: EVERY rank must learn it
         loop.md_all2[(nsteps - 1) & 1][0, 0] += 1
     assert loop.verify_gather() is False
     dist.destroy_process_group()
 """)
 
 
-def _run_two_ranks(script_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() * 7 + 3) % 2000), WORLD_SIZE="2")
+def _run_ranks(script_path, world=2):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() * 7 + 3 + world) % 2000), WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, str(script_path)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r])
 
 
-def test_step_loop_two_ranks_over_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_step_loop_over_gloo(tmp_path, world):
+    """the bench's step loop with 2 ranks, and with the 8 the scaling run uses (one process per GPU of a node)"""
     script = tmp_path / "loop_worker.py"
     script.write_text(LOOP_WORKER % dict(repo=REPO))
-    _run_two_ranks(script)
+    _run_ranks(script, world)
 
 
 def test_bench_starts_its_own_ranks_and_reports_their_failure():

@@ -41,6 +41,26 @@ class ReCoDeReader:
         self._structures = None
         self._numpy_dtype = None
         self._decompressor_context = None
+        # batched access (rc_expand_frames & co.): buffers, pools and bookkeeping, created on first use and released by close()
+        self._pin_blob = None            # page-locked image of a batch's file bytes (get_frames_triplets)
+        self._stream_bufs = None         # [blob 0, blob 1, triplets 0, triplets 1] of the streaming iterator
+        self._read_pool = None           # a few threads for page-cache reads
+        self._decode_pool = None         # stock decoders of the Python level (bz2, lzma; zstd / LZ4 without the shared libraries)
+        self._decode_coord = None        # the thread that decodes one batch ahead (_iter_host_decoded)
+        self._pin_pieces = None          # stored-pieces images of host-decoded batches: two for the iterator, one for the synchronous call
+        self._host_blobs = None
+        self._file_map = None            # the file, mapped, for the host decoders
+        self._foreign_file = False       # the device decoders refused this file's streams once: a stock encoder wrote them
+        self._no_fused_frame = False
+        self.part_frame_ids = None       # part files: frame id of every record (index built on first batched access)
+        self.last_batch_path = None      # 'device' | 'host-decode + device-expand' | 'per-frame'
+        # read-ahead of the frame-at-a-time calls (_readahead_frame)
+        self._ra = None                  # (first frame, frames, nnz prefix, triplets) of the batch fetched ahead
+        self._ra_buf = None              # its page-locked triplet buffer
+        self._ra_last = None             # the frame asked for last
+        self._ra_streak = 0              # calls in sequence so far
+        self._ra_off = False             # this file gains nothing from it (or a batch failed: the per-frame path reports)
+        self.readahead_frames_served = 0
 
     # ---- opening -------------------------------------------------------------------------------------------
     def open(self, print_header=True):
@@ -172,7 +192,7 @@ class ReCoDeReader:
         nthr = 4 if int(ats[-1]) >= (8 << 20) and n >= 4 else 1      # (as _read_into: a read from the page cache is a memcpy)
         if nthr == 1:
             return some(0, n)
-        if getattr(self, '_read_pool', None) is None:
+        if self._read_pool is None:
             from concurrent.futures import ThreadPoolExecutor
             self._read_pool = ThreadPoolExecutor(max_workers=4)
         cuts = [n * t // nthr for t in range(nthr + 1)]
@@ -204,28 +224,28 @@ class ReCoDeReader:
     def close(self):
         self._drop_readahead()
         self._fp.close()
-        if getattr(self, '_pin_blob', None) is not None:
+        if self._pin_blob is not None:
             self._pin_blob.close()
             self._pin_blob = None
-        for b in getattr(self, '_stream_bufs', None) or []:
+        for b in self._stream_bufs or []:
             if b is not None:
                 b.close()
         self._stream_bufs = None
-        if getattr(self, '_read_pool', None) is not None:
+        if self._read_pool is not None:
             self._read_pool.shutdown(wait=True)
             self._read_pool = None
-        if getattr(self, '_decode_pool', None) is not None:
+        if self._decode_pool is not None:
             self._decode_pool.shutdown(wait=True)
             self._decode_pool = None
-        if getattr(self, '_decode_coord', None) is not None:
+        if self._decode_coord is not None:
             self._decode_coord.shutdown(wait=True)
             self._decode_coord = None
-        for b in getattr(self, '_pin_pieces', None) or []:
+        for b in self._pin_pieces or []:
             if b is not None:
                 b.close()
         self._pin_pieces = None
         self._host_blobs = None
-        if getattr(self, '_file_map', None) is not None:
+        if self._file_map is not None:
             try:
                 self._file_map.close()
             except BufferError:                # (a caller still holds a view of a batch: the map goes with it)
@@ -243,7 +263,7 @@ class ReCoDeReader:
             if self._fp.readinto(memoryview(view)) != total:
                 raise ValueError('file shorter than its seek table says')
             return
-        if getattr(self, '_read_pool', None) is None:
+        if self._read_pool is None:
             from concurrent.futures import ThreadPoolExecutor
             self._read_pool = ThreadPoolExecutor(max_workers=4)
         fd = self._fp.fileno()
@@ -299,16 +319,16 @@ class ReCoDeReader:
         frame-at-a-time path" (not sequential, level 2, an empty frame - whose conventions that path knows -, or a batch the batched
         reader could not deliver: the per-frame path then names the frame that is to blame).  Nothing stays queued on the device
         between calls: any number of readers in a process may do this side by side."""
-        if getattr(self, '_ra_off', False) or int(self._header['reduction_level']) not in (1, 3):
+        if self._ra_off or int(self._header['reduction_level']) not in (1, 3):
             return None
-        ra = getattr(self, '_ra', None)
+        ra = self._ra
         fetch = False
         if ra is not None and not (ra[0] <= z < ra[0] + ra[1]):
             fetch = z == ra[0] + ra[1]                   # the batch behind the one just used up
             ra = self._ra = None
         if ra is None and not fetch:
-            last = getattr(self, '_ra_last', None)
-            self._ra_streak = getattr(self, '_ra_streak', 0) + 1 if last is not None and z == last + 1 else 0
+            last = self._ra_last
+            self._ra_streak = self._ra_streak + 1 if last is not None and z == last + 1 else 0
             fetch = self._ra_streak >= 2
         self._ra_last = z
         if ra is None:
@@ -322,7 +342,7 @@ class ReCoDeReader:
                 per = max(int(self._frame_metadata[z]['bytes_in_packed_pixvals']) * 8 // d * 24, 1)
                 k = max(2, min(k, self._RA_BYTES // per))
             k = min(k, nz - z)
-            if getattr(self, '_ra_buf', None) is None:
+            if self._ra_buf is None:
                 self._ra_buf = [None]
             keep = (self._current_frame_index, self._fp.tell())
             try:
@@ -341,12 +361,12 @@ class ReCoDeReader:
         lo, hi = int(prefix[z - a]), int(prefix[z - a + 1])
         if hi == lo:
             return None
-        self.readahead_frames_served = getattr(self, 'readahead_frames_served', 0) + 1
+        self.readahead_frames_served = self.readahead_frames_served + 1
         return self._make_coo_frame(hi - lo, trip[lo:hi])
 
     def _drop_readahead(self):
         self._ra = None
-        buf = getattr(self, '_ra_buf', None)
+        buf = self._ra_buf
         if buf is not None and buf[0] is not None:
             buf[0].close()
         self._ra_buf = None
@@ -397,8 +417,8 @@ class ReCoDeReader:
                     sizes[i, 2] = int(md['bytes_in_packed_pixvals'])
             lo = self._frame_data_start_position + int(self._seek_table[z0, 1])
             total = int(self._seek_table[z0:z0 + n, 0].sum())
-            if getattr(self, '_pin_blob', None) is None or self._pin_blob.nbytes < total:   # file -> page-locked memory, no copy in between
-                if getattr(self, '_pin_blob', None) is not None:
+            if self._pin_blob is None or self._pin_blob.nbytes < total:   # file -> page-locked memory, no copy in between
+                if self._pin_blob is not None:
                     self._pin_blob.close()
                 self._pin_blob = _lib.PinnedBuffer(max(int(total * 1.25), 1 << 20))
             blob = self._pin_blob.array[:total]
@@ -406,7 +426,7 @@ class ReCoDeReader:
             prefix = np.zeros(n + 1, np.uint64)
             L = _lib.lib()
             args = (int(h['nx']), int(h['ny']), int(h['target_bit_depth']), level, mode, scheme, _lib.ptr(blob), _lib.ptr(sizes), n)
-            if host_only or (mode == 1 and getattr(self, '_foreign_file', False)):
+            if host_only or (mode == 1 and self._foreign_file):
                 st = _lib.RC_ERR_UNSUPPORTED            # (a file whose streams the device decoders refused once is not offered again)
             elif level == 1:
                 # a frame's packed stream holds one depth-bit field per set pixel: its size bounds the count, one call does it all
@@ -521,7 +541,7 @@ class ReCoDeReader:
                 off += int(sizes[i, 1])
                 dst += npk
                 sizes0[i, 1] = sizes0[i, 2] = npk
-        if getattr(self, '_pin_pieces', None) is None:
+        if self._pin_pieces is None:
             self._pin_pieces = [None, None, None]
         buf = self._pin_pieces[slot]
         if buf is None or buf.nbytes < dst + 64:
@@ -547,7 +567,7 @@ class ReCoDeReader:
             if want:
                 dec(view[src_off:src_off + src_n], want, pieces[at:at + want])
         try:
-            if getattr(self, '_decode_pool', None) is None:
+            if self._decode_pool is None:
                 self._decode_pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1))
             spans.sort(key=lambda sp: -sp[1])            # longest streams first: the pool's tail is then a short one
             list(self._decode_pool.map(one, spans))
@@ -565,13 +585,13 @@ class ReCoDeReader:
         L = _lib.lib()
         geom0 = (int(h['nx']), int(h['ny']), d, level, 0, scheme)
         starts = list(range(z0, z0 + n, batch))
-        if getattr(self, '_stream_bufs', None) is None:
+        if self._stream_bufs is None:
             self._stream_bufs = [None, None, None, None]
-        if getattr(self, '_host_blobs', None) is None:
+        if self._host_blobs is None:
             self._host_blobs = [None, None]
-        if getattr(self, '_decode_coord', None) is None:
+        if self._decode_coord is None:
             self._decode_coord = ThreadPoolExecutor(max_workers=1)
-        if getattr(self, '_file_map', None) is None:
+        if self._file_map is None:
             import mmap
             try:
                 self._file_map = mmap.mmap(self._fp.fileno(), 0, access=mmap.ACCESS_READ)
@@ -673,7 +693,7 @@ class ReCoDeReader:
         level, mode, scheme = int(h['reduction_level']), int(h['rc_operation_mode']), int(h['compression_scheme'])
         d = int(h['target_bit_depth'])
         starts = list(range(z0, z0 + n, batch))
-        if level in (1, 3) and mode == 1 and (scheme in (0, 4, 5) or (scheme in (1, 2) and getattr(self, '_foreign_file', False))):
+        if level in (1, 3) and mode == 1 and (scheme in (0, 4, 5) or (scheme in (1, 2) and self._foreign_file)):
             yield from self._iter_host_decoded(z0, n, batch)       # stock decoders on the pool, one batch ahead of the device
             return
         if not (level == 1 and (mode == 0 or scheme in (1, 2))):
@@ -683,7 +703,7 @@ class ReCoDeReader:
             return
         L = _lib.lib()
         geom = (int(h['nx']), int(h['ny']), d, level, mode, scheme)
-        if getattr(self, '_stream_bufs', None) is None:
+        if self._stream_bufs is None:
             self._stream_bufs = [None, None, None, None]       # page-locked: two input blobs, two outputs; kept until close()
         bufs = self._stream_bufs
 
@@ -738,7 +758,7 @@ class ReCoDeReader:
             queued = submit(0) if starts else None
             for i in range(len(starts)):
                 job = queued
-                if getattr(self, '_foreign_file', False):
+                if self._foreign_file:
                     # the previous batch turned out to be a foreign encoder's: the rest of the file goes through the host-decoded pipeline
                     if job[3] is not None:
                         L.rc_expand_frames_wait(job[2], _lib.ptr(np.zeros(job[1] + 1, np.uint64)))
@@ -867,8 +887,8 @@ class ReCoDeReader:
         h = self._header
         level, mode = h['reduction_level'], h['rc_operation_mode']
         sz_map, sz_val = self._stream_sizes(frame_metadata)
-        if level in (1, 3) and (mode == 0 or h['compression_scheme'] in (1, 2)) and not getattr(self, '_no_fused_frame', False) \
-                and not (mode == 1 and getattr(self, '_foreign_file', False)):
+        if level in (1, 3) and (mode == 0 or h['compression_scheme'] in (1, 2)) and not self._no_fused_frame \
+                and not (mode == 1 and self._foreign_file):
             # one device call for the whole frame (rc_expand_frames, n = 1): compressed streams in, triplets out - the decoded binary
             # map and value stream never visit the host (the reference's three steps below remain for everything it does not take)
             pos = self._fp.tell()

@@ -190,11 +190,50 @@ def ingest_inclusive(stack, dark, a, nframes=128, validation_frame_gap=-1):
             dt = time.perf_counter() - t0
             w.close()
             best = dt if best is None else min(best, dt)
-        size = os.path.getsize(os.path.join(out_dir, "bench_stack.rc%d_part000" % a.level))
-        return {"frames_per_s": round(n / best, 1), "gb_per_s_in": round(n * a.ny * a.nx * 2 / best / 1e9, 2), "frames": n,
-                "part_file_bytes": size, "what": "ReCoDeWriter.run: host frames -> page-locked staging -> GPU -> records -> part file on %s" % (base or "tmp")}
+        part = os.path.join(out_dir, "bench_stack.rc%d_part000" % a.level)
+        size = os.path.getsize(part)
+        res = {"frames_per_s": round(n / best, 1), "gb_per_s_in": round(n * a.ny * a.nx * 2 / best / 1e9, 2), "frames": n,
+               "part_file_bytes": size, "what": "ReCoDeWriter.run: host frames -> page-locked staging -> GPU -> records -> part file on %s" % (base or "tmp")}
+        if validation_frame_gap <= 0 and a.level in (1, 3):
+            res["read_back"] = read_back(part, n, int((data > dark_h[None]).sum()))
+        return res
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def read_back(part_file, n, nnz_expected):
+    """Extra, NOT `value`: the part file just written, read back through ReCoDeReader with the triplets delivered to the HOST - the batched
+    iterator (24-byte (row, col, value) rows: bound by the link) and the reference's frame-at-a-time call (get_next_frame, which reads
+    ahead through the batched reader once sequential and wraps every frame as a scipy COO matrix, reference recode_reader.py:188-221)."""
+    from pyrecode_amd.recode_reader import ReCoDeReader
+    out = {}
+    rd = ReCoDeReader(part_file, is_intermediate=True)
+    rd.open(print_header=False)
+    try:
+        for _ in range(2):
+            t0 = time.perf_counter()
+            got = 0
+            for _, prefix, _ in rd.iter_frames_triplets(batch=32):
+                got += int(prefix[-1])
+            dt = time.perf_counter() - t0
+        out["iter_frames_triplets_frames_per_s"] = round(n / dt, 1)
+        out["verified"] = bool(got == nnz_expected)
+        t0 = time.perf_counter()
+        k = nnz = 0
+        while True:
+            f = rd.get_next_frame()
+            if f is None:
+                break
+            (_, body), = f.items()
+            nnz += body["data"].nnz
+            k += 1
+        dt = time.perf_counter() - t0
+        out["get_next_frame_frames_per_s"] = round(k / dt, 1)
+        out["verified"] = bool(out["verified"] and k == n and nnz == nnz_expected)
+        out["path"] = rd.last_batch_path
+    finally:
+        rd.close()
+    return out
 
 
 def bench_read(a, emit=True):

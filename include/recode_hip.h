@@ -261,6 +261,15 @@ int rc_expand_frames(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t redu
 int rc_expand_frames_submit(uint32_t slot, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t reduction_level, uint32_t op_mode,
                             uint32_t scheme, const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *triplets_dev, uint64_t cap);
 int rc_expand_frames_wait(uint32_t slot, uint64_t *nnz_prefix);
+/* The same two calls with the output laid out as what the reference's reader makes of the triplets - the three arrays of a scipy COO
+ * matrix (recode_reader.py:466-469): `coo` = int32 rows[cap] | int32 columns[cap] | uint16 values[cap] (10 * cap bytes; entry i of the
+ * batch at index i of each array, frame f's entries at nnz_prefix[f] .. nnz_prefix[f+1]).  10 instead of 24 bytes per set pixel cross
+ * the link, and the host has nothing to split.  bit_depth <= 16.  rc_expand_frames_coo_submit is waited for with
+ * rc_expand_frames_wait like a triplet batch. */
+int rc_expand_frames_coo(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t reduction_level, uint32_t op_mode, uint32_t scheme,
+                         const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, void *coo, uint64_t cap);
+int rc_expand_frames_coo_submit(uint32_t slot, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t reduction_level, uint32_t op_mode,
+                                uint32_t scheme, const uint8_t *data, const uint32_t *sizes, uint32_t n, void *coo_dev, uint64_t cap);
 /* The host half of a batch whose streams only a STOCK decoder takes - files the reference's writer produced with zstandard /
  * lz4.frame / zlib (recode_compressors.py:82-120): linked 64 KiB LZ4 blocks, 4-stream Huffman literals and real offsets in zstd,
  * deflate.  Each is one serial chain, which the reference walks with one library call per stream (recode_compressors.py:40-79:

@@ -66,6 +66,8 @@ SIGNATURES = {
     "rc_expand_frames": (C.c_int, [C.c_uint32] * 6 + [_u8p, _u32p, C.c_uint32, _u64p, _u64p, C.c_uint64]),
     "rc_expand_frames_submit": (C.c_int, [C.c_uint32] * 7 + [_u8p, _u32p, C.c_uint32, _u64p, C.c_uint64]),
     "rc_expand_frames_wait": (C.c_int, [C.c_uint32, _u64p]),
+    "rc_expand_frames_coo": (C.c_int, [C.c_uint32] * 6 + [_u8p, _u32p, C.c_uint32, _u64p, C.c_void_p, C.c_uint64]),
+    "rc_expand_frames_coo_submit": (C.c_int, [C.c_uint32] * 7 + [_u8p, _u32p, C.c_uint32, C.c_void_p, C.c_uint64]),
     "rc_host_decoder_available": (C.c_int, [C.c_uint32]),
     "rc_host_decode_streams": (C.c_int, [C.c_uint32, _u8p, _u8p, _u64p, C.c_uint32, C.c_uint32]),
     "rc_split_triplets": (C.c_int, [_u64p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),

@@ -13,7 +13,7 @@ void launch_expand_batch_count(const uint8_t *bm, uint64_t bm_stride, uint64_t n
                                uint32_t level = 0, uint64_t cap = 0, int *err = nullptr);
 void launch_expand_batch_emit(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx, uint32_t n, const uint32_t *blk_off,
                               const uint64_t *frame_base, const uint8_t *pv, uint64_t pv_stride, const uint32_t *pv_bytes, uint32_t d,
-                              uint32_t level, uint64_t cap, uint64_t *out, hipStream_t s, const int *err = nullptr);
+                              uint32_t level, uint64_t cap, void *out, hipStream_t s, const int *err = nullptr, bool coo = false);
 // rc_zstd_dec.hip: block decoders of the batched reader
 void launch_block_decode(int codec, int row, const uint8_t *data, const void *frame_lists, uint32_t nframes, uint32_t max_blocks_per_frame,
                          const void *tables, const void *predef, uint8_t *out, const uint64_t *out_base, int *err, hipStream_t s,

@@ -163,15 +163,24 @@ __global__ __launch_bounds__(WG) void k_expand_bases(const uint64_t *__restrict_
 // pixels than the stage holds write directly.  Row / column of a word's first pixel come from ONE division (frames have fewer than
 // 2^32 pixels: nx, ny <= 65 535), the pixels behind it step the column.
 constexpr uint32_t EMIT_STAGE = 1024;   // triplets
+// COO = false: out = uint64_t[cap][3], the reference's (row, col, value) rows (pyrecode.cpp:95-119).
+// COO = true: out = int32 rows[cap] | int32 columns[cap] | uint16 values[cap] - the three arrays of the scipy COO matrix the reference's
+// reader wraps the rows into (recode_reader.py:466-469), 10 instead of 24 bytes per set pixel on the link and no split on the host.
+template <bool COO>
 __global__ __launch_bounds__(WG) void k_expand_emit_b(const uint8_t *__restrict__ bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx,
                                                         uint32_t nblk, const uint32_t *__restrict__ blk_off, const uint64_t *__restrict__ frame_base,
                                                         const uint8_t *__restrict__ pv, uint64_t pv_stride, const uint32_t *__restrict__ pv_bytes,
-                                                        uint32_t d, uint32_t level, uint64_t cap, uint64_t *__restrict__ out,
+                                                        uint32_t d, uint32_t level, uint64_t cap, void *__restrict__ out_any,
                                                         const int *__restrict__ err)
 {
     __shared__ uint32_t sm[WAVES + 1];
-    __shared__ uint64_t s_trip[3 * EMIT_STAGE];
+    __shared__ uint64_t s_trip[COO ? 1 : 3 * EMIT_STAGE];
+    __shared__ uint32_t s_row[COO ? EMIT_STAGE : 1], s_col[COO ? EMIT_STAGE : 1];
+    __shared__ uint16_t s_val[COO ? EMIT_STAGE : 1];
     if (err && *err) return;   // (workgroup-uniform: k_expand_bases, a decoder or nobody has set it before this kernel started)
+    uint64_t *out = static_cast<uint64_t *>(out_any);
+    int32_t *o_row = static_cast<int32_t *>(out_any), *o_col = o_row + cap;
+    uint16_t *o_val = reinterpret_cast<uint16_t *>(o_col + cap);
     const uint32_t f = blockIdx.y;
     const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t bits = expand_word(bm + f * bm_stride, nb8, N, i);
@@ -195,18 +204,28 @@ __global__ __launch_bounds__(WG) void k_expand_emit_b(const uint8_t *__restrict_
             const uint64_t rank = wg_rank + r;
             const uint64_t val = level != 1 ? 1ull : ((d == 16 && 2 * rank + 2 <= pix_bytes) ? (uint64_t)reinterpret_cast<const uint16_t *>(pix)[rank]   // (value streams are 16-byte aligned)
                                                                                                 : read_field(pix, pix_bytes, rank, d));
-            if (staged) { s_trip[3 * r] = row; s_trip[3 * r + 1] = col; s_trip[3 * r + 2] = val; }
-            else {
+            if (staged) {
+                if (COO) { s_row[r] = row; s_col[r] = col; s_val[r] = (uint16_t)val; }
+                else { s_trip[3 * r] = row; s_trip[3 * r + 1] = col; s_trip[3 * r + 2] = val; }
+            } else {
                 if (base + rank >= cap) break;
-                uint64_t *o = out + 3 * (base + rank);
-                o[0] = row; o[1] = col; o[2] = val;
+                if (COO) { o_row[base + rank] = (int32_t)row; o_col[base + rank] = (int32_t)col; o_val[base + rank] = (uint16_t)val; }
+                else {
+                    uint64_t *o = out + 3 * (base + rank);
+                    o[0] = row; o[1] = col; o[2] = val;
+                }
             }
         }
     }
     if (!staged) return;
     __syncthreads();
-    uint64_t *o = out + 3 * (base + wg_rank);
-    for (uint32_t j = threadIdx.x; j < 3 * tot; j += WG) o[j] = s_trip[j];
+    if (COO) {
+        const uint64_t at = base + wg_rank;
+        for (uint32_t j = threadIdx.x; j < tot; j += WG) { o_row[at + j] = (int32_t)s_row[j]; o_col[at + j] = (int32_t)s_col[j]; o_val[at + j] = s_val[j]; }
+    } else {
+        uint64_t *o = out + 3 * (base + wg_rank);
+        for (uint32_t j = threadIdx.x; j < 3 * tot; j += WG) o[j] = s_trip[j];
+    }
 }
 void launch_expand_batch_count(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t n, uint32_t *blk_cnt, uint32_t *blk_off,
                                uint64_t *frame_nnz, uint64_t *frame_base, hipStream_t s, const uint32_t *pv_bytes, uint32_t d, uint32_t level,
@@ -219,11 +238,15 @@ void launch_expand_batch_count(const uint8_t *bm, uint64_t bm_stride, uint64_t n
 }
 void launch_expand_batch_emit(const uint8_t *bm, uint64_t bm_stride, uint64_t nb8, uint64_t N, uint32_t nx, uint32_t n, const uint32_t *blk_off,
                               const uint64_t *frame_base, const uint8_t *pv, uint64_t pv_stride, const uint32_t *pv_bytes, uint32_t d,
-                              uint32_t level, uint64_t cap, uint64_t *out, hipStream_t s, const int *err)
+                              uint32_t level, uint64_t cap, void *out, hipStream_t s, const int *err, bool coo)
 {
     const uint32_t nblk = (uint32_t)((nb8 + WG - 1) / WG);
-    hipLaunchKernelGGL(k_expand_emit_b, dim3(nblk, n), dim3(WG), 0, s, bm, bm_stride, nb8, N, nx, nblk, blk_off, frame_base, pv, pv_stride,
-                       pv_bytes, d, level, cap, out, err);
+    if (coo)
+        hipLaunchKernelGGL(k_expand_emit_b<true>, dim3(nblk, n), dim3(WG), 0, s, bm, bm_stride, nb8, N, nx, nblk, blk_off, frame_base, pv, pv_stride,
+                           pv_bytes, d, level, cap, out, err);
+    else
+        hipLaunchKernelGGL(k_expand_emit_b<false>, dim3(nblk, n), dim3(WG), 0, s, bm, bm_stride, nb8, N, nx, nblk, blk_off, frame_base, pv, pv_stride,
+                           pv_bytes, d, level, cap, out, err);
 }
 
 // ---- stand-alone pack / unpack ------------------------------------------------------------------------------

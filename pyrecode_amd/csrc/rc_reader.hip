@@ -54,9 +54,12 @@ int lz4_index_frame(const uint8_t *base, uint64_t off, uint64_t n, uint32_t fram
 }  // namespace
 
 // slot, submit_only: rc_expand_frames = (RC_READ_SLOTS - its own resources -, false); rc_expand_frames_submit = (slot, true): returns once everything is queued.
+// coo: the output is not uint64 triplets but the three arrays of a COO matrix - int32 rows[cap] | int32 columns[cap] | uint16 values[cap]
+// (k_expand_emit_b<true>): 10 bytes per set pixel and capacity instead of 24.
 static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode, uint32_t scheme,
-                      const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap)
+                      const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, uint64_t *triplets, uint64_t cap, bool coo = false)
 {
+    const uint64_t esz = coo ? 10 : 24;      // bytes per entry of the output
     using namespace rc;
     if (!data || !sizes || (!nnz_prefix && !submit_only) || n == 0 || nx == 0 || ny == 0 || (!triplets && cap)) return fail(RC_ERR_BAD_ARG, "NULL / zero argument");
     if (level != 1 && level != 3) return fail(RC_ERR_UNSUPPORTED, "rc_expand_frames: reduction level 1 or 3");
@@ -329,7 +332,7 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     if (submit_only && !dev_out) {
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, triplets) == hipSuccess && a.type == hipMemoryTypeHost) {
-            if ((r = need(6, cap * 24 + 64)) != RC_OK) { (void)hipStreamSynchronize(s); return r; }
+            if ((r = need(6, cap * esz + 64)) != RC_OK) { (void)hipStreamSynchronize(s); return r; }
             host_async = triplets;
             triplets = reinterpret_cast<uint64_t *>(u.x[6]);
             dev_out = true;
@@ -338,13 +341,13 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
     if (submit_only && !dev_out) return bail(RC_ERR_BAD_ARG, "rc_expand_frames_submit: triplets must be device or page-locked host memory");
     if (dev_out) {
         launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s, d_pv_bytes, bit_depth, level, cap, d_err);
-        launch_expand_batch_emit(d_bm, bm_stride, nb8, N, nx, n, d_blk_off, d_fbase, d_pv, pv_stride, d_pv_bytes, bit_depth, level, cap, triplets, s, d_err);
+        launch_expand_batch_emit(d_bm, bm_stride, nb8, N, nx, n, d_blk_off, d_fbase, d_pv, pv_stride, d_pv_bytes, bit_depth, level, cap, triplets, s, d_err, coo);
     } else
         launch_expand_batch_count(d_bm, bm_stride, nb8, N, n, d_blk_cnt, d_blk_off, d_fnnz, d_fbase, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(u.h_res, d_fbase, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(u.h_res + n + 1, d_err, 4, hipMemcpyDeviceToHost, s));
-    if (host_async && cap) HIP_TRY(hipMemcpyAsync(host_async, triplets, cap * 24, hipMemcpyDeviceToHost, s));
+    if (host_async && cap) HIP_TRY(hipMemcpyAsync(host_async, triplets, cap * esz, hipMemcpyDeviceToHost, s));
     if (submit_only) {   // (dev_out is a precondition, checked above)
         HIP_TRY(hipEventRecord(u.done, s));
         u.pending = true;
@@ -371,6 +374,18 @@ static int expand_run(uint32_t slot, bool submit_only, uint32_t nx, uint32_t ny,
         return RC_OK;
     }
     if (total == 0) return RC_OK;
+    if (coo) {
+        // the three arrays keep the caller's stride (cap) on the device as in the caller's buffer: three copies of `total` entries
+        if ((r = need(6, cap * esz + 64)) != RC_OK) return r;
+        launch_expand_batch_emit(d_bm, bm_stride, nb8, N, nx, n, d_blk_off, d_fbase, d_pv, pv_stride, d_pv_bytes, bit_depth, level, cap, u.x[6], s, nullptr, true);
+        HIP_TRY(hipGetLastError());
+        uint8_t *h = reinterpret_cast<uint8_t *>(triplets);
+        HIP_TRY(hipMemcpyAsync(h, u.x[6], total * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h + cap * 4, u.x[6] + cap * 4, total * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h + cap * 8, u.x[6] + cap * 8, total * 2, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return RC_OK;
+    }
     if ((r = need(6, total * 24)) != RC_OK) return r;
     uint64_t *d_trip = reinterpret_cast<uint64_t *>(u.x[6]);
     launch_expand_batch_emit(d_bm, bm_stride, nb8, N, nx, n, d_blk_off, d_fbase, d_pv, pv_stride, d_pv_bytes, bit_depth, level, total, d_trip, s);
@@ -395,6 +410,22 @@ RC_EXPORT int rc_expand_frames_submit(uint32_t slot, uint32_t nx, uint32_t ny, u
     if (slot >= RC_READ_SLOTS) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_submit: slot 0 or 1");
     if (!triplets_dev) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_submit: triplets must be device or page-locked host memory");
     return expand_run(slot, true, nx, ny, bit_depth, level, op_mode, scheme, data, sizes, n, nullptr, triplets_dev, cap);
+}
+
+RC_EXPORT int rc_expand_frames_coo(uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode, uint32_t scheme,
+                                   const uint8_t *data, const uint32_t *sizes, uint32_t n, uint64_t *nnz_prefix, void *coo, uint64_t cap)
+{
+    if (level == 1 && bit_depth > 16) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_coo: values are uint16 (bit_depth <= 16)");
+    return expand_run(RC_READ_SLOTS, false, nx, ny, bit_depth, level, op_mode, scheme, data, sizes, n, nnz_prefix, static_cast<uint64_t *>(coo), cap, true);
+}
+
+RC_EXPORT int rc_expand_frames_coo_submit(uint32_t slot, uint32_t nx, uint32_t ny, uint32_t bit_depth, uint32_t level, uint32_t op_mode,
+                                          uint32_t scheme, const uint8_t *data, const uint32_t *sizes, uint32_t n, void *coo_dev, uint64_t cap)
+{
+    if (slot >= RC_READ_SLOTS) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_coo_submit: slot 0 or 1");
+    if (!coo_dev) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_coo_submit: the output must be device or page-locked host memory");
+    if (level == 1 && bit_depth > 16) return fail(RC_ERR_BAD_ARG, "rc_expand_frames_coo: values are uint16 (bit_depth <= 16)");
+    return expand_run(slot, true, nx, ny, bit_depth, level, op_mode, scheme, data, sizes, n, nullptr, static_cast<uint64_t *>(coo_dev), cap, true);
 }
 
 RC_EXPORT int rc_expand_frames_wait(uint32_t slot, uint64_t *nnz_prefix)

@@ -22,6 +22,54 @@ from .recode_header import ReCoDeHeader
 from .structures import ReCoDeStructures
 
 
+class _BatchOut:
+    """Where a batch's expanded entries go and how they are laid out: the reference's uint64 (row, col, value) rows (24 bytes a set
+    pixel; rc_expand_frames), or the three arrays of the COO matrix its reader wraps them into - int32 rows | int32 columns | uint16
+    values, each `cap` entries long (10 bytes; rc_expand_frames_coo).  holder: None (an array of its own per call) or a one-element
+    list with a _lib.PinnedBuffer / None (page-locked, reused, grown when too small: results are views, valid until its next use)."""
+
+    def __init__(self, coo=False, holder=None):
+        self.coo, self.holder, self.esz = bool(coo), holder, 10 if coo else 24
+        self.buf, self.cap = None, 0
+
+    def room(self, cap):
+        nbytes = cap * self.esz
+        if self.holder is None:
+            self.buf = np.empty(nbytes, np.uint8)
+        else:
+            if self.holder[0] is None or self.holder[0].nbytes < nbytes:
+                if self.holder[0] is not None:
+                    self.holder[0].close()
+                self.holder[0] = _lib.PinnedBuffer(max(int(nbytes * 1.25), 1 << 20))
+            self.buf = self.holder[0].array[:nbytes]
+        self.cap = cap
+        return self
+
+    def ptr(self):
+        return _lib.ptr(self.buf)
+
+    def fn(self, L, submit=False):
+        if submit:
+            return L.rc_expand_frames_coo_submit if self.coo else L.rc_expand_frames_submit
+        return L.rc_expand_frames_coo if self.coo else L.rc_expand_frames
+
+    def result(self, total):
+        return self.views(self.buf, self.cap, total, self.coo)
+
+    @staticmethod
+    def views(buf, cap, total, coo):
+        if not coo:
+            return buf[:total * 24].view(np.uint64).reshape(total, 3)
+        return (buf[:4 * cap].view(np.int32)[:total], buf[4 * cap:8 * cap].view(np.int32)[:total], buf[8 * cap:10 * cap].view(np.uint16)[:total])
+
+    @staticmethod
+    def from_triplets(trip, coo):
+        """the frame-at-a-time path's triplets in the layout asked for"""
+        if not coo:
+            return trip
+        return (trip[:, 0].astype(np.int32), trip[:, 1].astype(np.int32), trip[:, 2].astype(np.uint16))
+
+
 class ReCoDeReader:
 
     def __init__(self, file, is_intermediate=False):
@@ -346,7 +394,7 @@ class ReCoDeReader:
                 self._ra_buf = [None]
             keep = (self._current_frame_index, self._fp.tell())
             try:
-                prefix, trip = self.get_frames_triplets(z, k, out=self._ra_buf)
+                prefix, arrays = self.get_frames_triplets(z, k, out=self._ra_buf, coo=True)
             except Exception:
                 self._ra_off = True
                 return None
@@ -356,13 +404,14 @@ class ReCoDeReader:
             if self.last_batch_path == 'per-frame':      # nothing batched about this file: frame by frame it is
                 self._ra_off = True
                 return None
-            ra = self._ra = (z, k, prefix, trip)
-        a, _, prefix, trip = ra
+            ra = self._ra = (z, k, prefix, arrays)
+        a, _, prefix, (rows, cols, vals) = ra
         lo, hi = int(prefix[z - a]), int(prefix[z - a + 1])
         if hi == lo:
             return None
         self.readahead_frames_served = self.readahead_frames_served + 1
-        return self._make_coo_frame(hi - lo, trip[lo:hi])
+        # the batch came as the COO arrays themselves (rc_expand_frames_coo): the frame's matrix takes its own copies of its slices
+        return self._coo_from_arrays(vals[lo:hi].astype(self._numpy_dtype), rows[lo:hi].copy(), cols[lo:hi].copy())
 
     def _drop_readahead(self):
         self._ra = None
@@ -389,7 +438,7 @@ class ReCoDeReader:
         return out
 
     # ---- batched access (device-resident decode + expand; no counterpart in the reference, which reads frame by frame) ------
-    def get_frames_triplets(self, z0, n, out=None):
+    def get_frames_triplets(self, z0, n, out=None, coo=False):
         """Frames z0 .. z0+n-1 of a merged file - or records z0 .. z0+n-1 of a part file, whose frame ids are part_frame_ids[z] - in ONE
         device call (rc_expand_frames): both streams of every frame are
         decompressed and expanded on the GPU without a host round trip in between.  Returns (nnz_prefix uint64[n+1],
@@ -398,7 +447,10 @@ class ReCoDeReader:
         streams outside the device decoders' subset, for level 2 and for host-only schemes.
         out: None (the triplets come in an array of their own), or a one-element list holding a _lib.PinnedBuffer or None - the
         triplets are then written into that page-locked buffer (grown when too small) and the returned array is a view of it,
-        valid until the next call with the same holder."""
+        valid until the next call with the same holder.
+        coo=True: instead of the triplet rows, (rows int32[total], columns int32[total], values uint16[total]) - the arrays of the COO
+        matrices the frame-at-a-time calls return, 10 instead of 24 bytes per set pixel over the link (rc_expand_frames_coo)."""
+        dst = _BatchOut(coo, out)
         h = self._header
         nz = self._batch_frames()
         if z0 < 0 or n <= 0 or z0 + n > nz:
@@ -432,24 +484,23 @@ class ReCoDeReader:
                 # a frame's packed stream holds one depth-bit field per set pixel: its size bounds the count, one call does it all
                 d = int(h['target_bit_depth'])
                 cap = max(int((sizes[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
-                trip = self._trip_buffer(cap, out)
-                st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), cap)
+                st = dst.fn(L)(*args, _lib.ptr(prefix), dst.room(cap).ptr(), cap)
             else:
                 st = L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0)        # level 3: a counting call sizes the output
                 if st == _lib.RC_OK:
-                    trip = self._trip_buffer(max(int(prefix[n]), 1), out)
-                    st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0])
+                    cap = max(int(prefix[n]), 1)
+                    st = dst.fn(L)(*args, _lib.ptr(prefix), dst.room(cap).ptr(), cap)
             if st == _lib.RC_OK:
                 self._note_batch_end(z0 + n)
                 self.last_batch_path = 'device'
-                return prefix, trip[:int(prefix[n])]
+                return prefix, dst.result(int(prefix[n]))
             # Outside the device decoders' subset - or a stream they could not make sense of (a foreign encoder's independent 64 KiB
             # LZ4 blocks look like that): the per-frame path below decodes with the stock library, which is also the judge of whether
             # the file is really damaged.
             if st not in (_lib.RC_ERR_UNSUPPORTED, _lib.RC_ERR_CORRUPT):
                 _lib.check(st, 'rc_expand_frames')
             if mode == 1:
-                res = self._foreign_batch_triplets(z0, n, blob, sizes, out)
+                res = self._foreign_batch_triplets(z0, n, blob, sizes, dst)
                 if res is not None:
                     self._note_batch_end(z0 + n)
                     self.last_batch_path = 'host-decode + device-expand'
@@ -471,13 +522,13 @@ class ReCoDeReader:
             self._fp.seek(keep, 0)           # (get_next_frame's cursor)
         else:
             self._note_batch_end(z0 + n)
-        return prefix, np.concatenate(parts) if parts else np.zeros((0, 3), np.uint64)
+        return prefix, _BatchOut.from_triplets(np.concatenate(parts) if parts else np.zeros((0, 3), np.uint64), coo)
 
     def _note_batch_end(self, z):
         if not self._is_intermediate:        # (a part file's sequential cursor is its file position, which the batched readers leave alone)
             self._current_frame_index = z
 
-    def _foreign_batch_triplets(self, z0, n, blob, sizes, out=None):
+    def _foreign_batch_triplets(self, z0, n, blob, sizes, dst=None):
         """Streams a FOREIGN encoder wrote (the reference's own files: lz4.frame with linked 64 KiB blocks, libzstd with 4-stream
         literals and real offsets) are serial chains of some 10^5 dependent steps per frame - the stock decoder on a CPU core
         walks one in about a millisecond, a GPU lane needs ~1 us per step ("Foreign streams").  So they are decoded
@@ -500,20 +551,9 @@ class ReCoDeReader:
         else:
             _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
             cap = max(int(prefix[n]), 1)
-        trip = self._trip_buffer(cap, out)
-        _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), cap), 'rc_expand_frames')
-        return prefix, trip[:int(prefix[n])]
-
-    @staticmethod
-    def _trip_buffer(cap, out):
-        """room for cap triplets: an array of its own, or a view of the caller's page-locked buffer (get_frames_triplets' `out`)"""
-        if out is None:
-            return np.empty((cap, 3), np.uint64)
-        if out[0] is None or out[0].nbytes < cap * 24:
-            if out[0] is not None:
-                out[0].close()
-            out[0] = _lib.PinnedBuffer(max(int(cap * 24 * 1.25), 1 << 20))
-        return out[0].array[:cap * 24].view(np.uint64).reshape(cap, 3)
+        dst = dst if dst is not None else _BatchOut()
+        _lib.check(dst.fn(L)(*args, _lib.ptr(prefix), dst.room(cap).ptr(), cap), 'rc_expand_frames')
+        return prefix, dst.result(int(prefix[n]))
 
     def _host_decode_batch(self, blob, sizes, n, slot):
         """The 2 n streams of a batch (file bytes in `blob`, stream sizes in `sizes`) through the stock decoder of the file's scheme on the
@@ -575,7 +615,7 @@ class ReCoDeReader:
             return None
         return pieces, sizes0
 
-    def _iter_host_decoded(self, z0, n, batch):
+    def _iter_host_decoded(self, z0, n, batch, coo=False):
         """iter_frames_triplets for files whose streams only a stock decoder takes (foreign encoders, zlib / bz2 / lzma): batch i + 1 is
         read and decoded on the host's thread pool while the device expands batch i (rc_expand_frames_submit / _wait, op_mode 0, on the
         page-locked stored-pieces image) and the consumer works on its triplets."""
@@ -630,7 +670,7 @@ class ReCoDeReader:
                 if got is None:
                     # the stock decoder rejected a stream: the synchronous call goes frame by frame and names it (nothing decodes ahead
                     # meanwhile: that call reads the same file and may use the same pools)
-                    res = (a,) + self.get_frames_triplets(a, k)
+                    res = (a,) + self.get_frames_triplets(a, k, coo=coo)
                 fut = self._decode_coord.submit(prepare, i + 1) if i + 1 < len(starts) else None
                 if got is None:
                     pass
@@ -640,22 +680,23 @@ class ReCoDeReader:
                     prefix = np.zeros(k + 1, np.uint64)
                     args = geom0 + (_lib.ptr(pieces), _lib.ptr(sizes0), k)
                     _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), None, 0), 'rc_expand_frames')
-                    trip = np.empty((max(int(prefix[k]), 1), 3), np.uint64)
-                    _lib.check(L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(trip), trip.shape[0]), 'rc_expand_frames')
+                    dst = _BatchOut(coo).room(max(int(prefix[k]), 1))
+                    _lib.check(dst.fn(L)(*args, _lib.ptr(prefix), dst.ptr(), dst.cap), 'rc_expand_frames')
                     self.last_batch_path = 'host-decode + device-expand'
-                    res = (a, prefix, trip[:int(prefix[k])])
+                    res = (a, prefix, dst.result(int(prefix[k])))
                 else:
                     pieces, sizes0 = got
                     cap = max(int((sizes0[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
-                    if bufs[2 + slot] is None or bufs[2 + slot].nbytes < cap * 24:
+                    esz = 10 if coo else 24
+                    if bufs[2 + slot] is None or bufs[2 + slot].nbytes < cap * esz:
                         if bufs[2 + slot] is not None:
                             bufs[2 + slot].close()
-                        bufs[2 + slot] = _lib.PinnedBuffer(max(int(cap * 24 * 1.25), 1 << 20))
+                        bufs[2 + slot] = _lib.PinnedBuffer(max(int(cap * esz * 1.25), 1 << 20))
                     prefix = np.zeros(k + 1, np.uint64)
-                    st = L.rc_expand_frames_submit(slot, *geom0, _lib.ptr(pieces), _lib.ptr(sizes0), k, bufs[2 + slot]._p, cap)
+                    st = _BatchOut(coo).fn(L, submit=True)(slot, *geom0, _lib.ptr(pieces), _lib.ptr(sizes0), k, bufs[2 + slot]._p, cap)
                     if st == _lib.RC_ERR_BAD_ARG and 'submitted batch' in _lib.last_error():
                         # another iterator of this process holds the slot: the synchronous call has resources of its own
-                        _lib.check(L.rc_expand_frames(*geom0, _lib.ptr(pieces), _lib.ptr(sizes0), k, _lib.ptr(prefix), bufs[2 + slot]._p, cap),
+                        _lib.check(_BatchOut(coo).fn(L)(*geom0, _lib.ptr(pieces), _lib.ptr(sizes0), k, _lib.ptr(prefix), bufs[2 + slot]._p, cap),
                                    'rc_expand_frames')
                     else:
                         _lib.check(st, 'rc_expand_frames_submit')
@@ -665,7 +706,7 @@ class ReCoDeReader:
                         _lib.check(st, 'rc_expand_frames_wait')
                     total = int(prefix[k])
                     self.last_batch_path = 'host-decode + device-expand'
-                    res = (a, prefix, bufs[2 + slot].array[:total * 24].view(np.uint64).reshape(total, 3))
+                    res = (a, prefix, _BatchOut.views(bufs[2 + slot].array, cap, total, coo))
                 self._note_batch_end(a + k)
                 yield res
         finally:
@@ -677,14 +718,15 @@ class ReCoDeReader:
             if submitted is not None:
                 L.rc_expand_frames_wait(submitted[0], _lib.ptr(np.zeros(submitted[1] + 1, np.uint64)))
 
-    def iter_frames_triplets(self, z0=0, n=None, batch=64):
+    def iter_frames_triplets(self, z0=0, n=None, batch=64, coo=False):
         """Streams frames z0 .. z0+n-1 of a merged file (records z0 .. of a part file: the reference's own read test sums a part file's
         frames one get_next_frame at a time, tests/recode_v1_read_test.py:9-21) through the batched device reader, two batches in flight
         (rc_expand_frames_submit / _wait): while the device decodes one batch, the next one is read from the file, its block headers
         are walked and its bytes copied in.  Yields (first frame index, nnz_prefix uint64[k+1], triplets uint64[total, 3]) per batch
         of k <= `batch` frames; `triplets` is a VIEW of page-locked memory the device wrote directly - valid until the generator is
         advanced (copy it to keep it).  Files the device path does not take (level 2, host-only schemes, foreign streams) go through
-        get_frames_triplets batch by batch."""
+        get_frames_triplets batch by batch.  coo=True: the third item is (rows int32, columns int32, values uint16) instead of the
+        triplet rows - 10 instead of 24 bytes per set pixel over the link (rc_expand_frames_coo_submit)."""
         h = self._header
         nz = self._batch_frames()
         n = nz - z0 if n is None else n
@@ -694,12 +736,12 @@ class ReCoDeReader:
         d = int(h['target_bit_depth'])
         starts = list(range(z0, z0 + n, batch))
         if level in (1, 3) and mode == 1 and (scheme in (0, 4, 5) or (scheme in (1, 2) and self._foreign_file)):
-            yield from self._iter_host_decoded(z0, n, batch)       # stock decoders on the pool, one batch ahead of the device
+            yield from self._iter_host_decoded(z0, n, batch, coo)  # stock decoders on the pool, one batch ahead of the device
             return
         if not (level == 1 and (mode == 0 or scheme in (1, 2))):
             for a in starts:
                 k = min(batch, z0 + n - a)
-                yield (a,) + self.get_frames_triplets(a, k)
+                yield (a,) + self.get_frames_triplets(a, k, coo=coo)
             return
         L = _lib.lib()
         geom = (int(h['nx']), int(h['ny']), d, level, mode, scheme)
@@ -729,8 +771,8 @@ class ReCoDeReader:
             blob = bufs[slot].array[:total]
             self._read_batch_into(blob, a, k)
             cap = max(int((sizes[:, 2].astype(np.uint64) * 8 // d).sum()), 1)
-            bufs[2 + slot] = pinned(bufs[2 + slot], cap * 24)
-            st = L.rc_expand_frames_submit(slot, *geom, _lib.ptr(blob), _lib.ptr(sizes), k, bufs[2 + slot]._p, cap)
+            bufs[2 + slot] = pinned(bufs[2 + slot], cap * (10 if coo else 24))
+            st = _BatchOut(coo).fn(L, submit=True)(slot, *geom, _lib.ptr(blob), _lib.ptr(sizes), k, bufs[2 + slot]._p, cap)
             if st in (_lib.RC_ERR_UNSUPPORTED, _lib.RC_ERR_CORRUPT):
                 return (a, k, slot, None)
             if st == _lib.RC_ERR_BAD_ARG and 'submitted batch' in _lib.last_error():
@@ -743,14 +785,14 @@ class ReCoDeReader:
         def finish(job):
             a, k, slot, cap = job
             if cap is None:
-                return (a,) + self.get_frames_triplets(a, k)       # (sets last_batch_path itself)
+                return (a,) + self.get_frames_triplets(a, k, coo=coo)       # (sets last_batch_path itself)
             prefix = np.zeros(k + 1, np.uint64)
             st = L.rc_expand_frames_wait(slot, _lib.ptr(prefix))
             if st == _lib.RC_ERR_CORRUPT:                     # the stock decoder is the judge
-                return (a,) + self.get_frames_triplets(a, k)
+                return (a,) + self.get_frames_triplets(a, k, coo=coo)
             _lib.check(st, 'rc_expand_frames_wait')
             total = int(prefix[k])
-            trip = bufs[2 + slot].array[:total * 24].view(np.uint64).reshape(total, 3)
+            trip = _BatchOut.views(bufs[2 + slot].array, cap, total, coo)
             self.last_batch_path = 'device'
             return a, prefix, trip
         queued = None        # a batch submitted and not yet waited for
@@ -763,7 +805,7 @@ class ReCoDeReader:
                     if job[3] is not None:
                         L.rc_expand_frames_wait(job[2], _lib.ptr(np.zeros(job[1] + 1, np.uint64)))
                     queued = None
-                    yield from self._iter_host_decoded(job[0], z0 + n - job[0], batch)
+                    yield from self._iter_host_decoded(job[0], z0 + n - job[0], batch, coo)
                     return
                 queued = submit(i + 1) if i + 1 < len(starts) else None
                 res = finish(job)
@@ -940,7 +982,6 @@ class ReCoDeReader:
         negotiation, copies) cost more than the device call that produced the triplets; rows and columns come from the expand kernel,
         inside the frame by construction."""
         d = buf[:n]
-        m = coo_matrix((int(self._header['ny']), int(self._header['nx'])), dtype=self._numpy_dtype)
         dt = np.dtype(self._numpy_dtype)
         if dt.kind in 'ui' and d.flags['C_CONTIGUOUS']:
             # one pass over the rows (rc_split_triplets) instead of three strided conversions
@@ -948,11 +989,15 @@ class ReCoDeReader:
             _lib.check(_lib.lib().rc_split_triplets(_lib.ptr(d), n, _lib.ptr(row), _lib.ptr(col), _lib.ptr(data), dt.itemsize), 'rc_split_triplets')
         else:
             data, row, col = d[:, 2].astype(dt), d[:, 0].astype(np.int32), d[:, 1].astype(np.int32)
+        return self._coo_from_arrays(data, row, col)
+
+    def _coo_from_arrays(self, data, row, col):
+        m = coo_matrix((int(self._header['ny']), int(self._header['nx'])), dtype=self._numpy_dtype)
         if hasattr(m, 'coords'):
             m.data, m.coords = data, (row, col)
         else:
             m.data, m.row, m.col = data, row, col
-        m.has_canonical_format = False          # (what the constructor leaves; the triplets are in fact sorted and unique)
+        m.has_canonical_format = False          # (what the constructor leaves; the entries are in fact sorted and unique)
         return m
 
 

@@ -984,3 +984,34 @@ def test_two_streaming_iterators_side_by_side(scheme, tmp_path, orc):
     assert seen == [nz, nz]
     for rd, _ in sets:
         rd.close()
+
+
+@pytest.mark.parametrize("scheme,level", [(0, 1), (1, 1), (2, 1), (1, 3), (0, 3)])
+def test_batched_readers_coo_layout_equals_their_triplets(scheme, level, tmp_path, orc):
+    """get_frames_triplets / iter_frames_triplets with coo=True hand out (rows int32, columns int32, values uint16) - the arrays of the COO
+    matrices get_frame returns - instead of uint64 triplet rows: same entries, same prefixes, on the device path (zstd, LZ4), the
+    host-decoded path (zlib), level 3, a merged file and a part file."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, d, nz = 80, 144, 12, 11
+    dark, frames = synth_frames(91, nz, ny, nx, 0.05, d)
+    frames[4] = 0
+    g = load_npz("g3_l1z12.npz" if level == 1 else "g3_l3z.npz")
+    _write_parts(tmp_path, "coo", dark, frames, 2, g, batch_size=3, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=2,
+                 compression_scheme=scheme, calibration_threshold_epsilon=0, reduction_level=level)
+    merge_parts(str(tmp_path), "coo.rc%d" % level, 2)
+    for name, inter in (("coo.rc%d" % level, False), ("coo.rc%d_part001" % level, True)):
+        rd = ReCoDeReader(str(tmp_path / name), is_intermediate=inter)
+        rd.open(print_header=False)
+        n = rd._batch_frames()
+        p0, t0 = rd.get_frames_triplets(0, n)
+        p1, (rows, cols, vals) = rd.get_frames_triplets(0, n, coo=True)
+        assert np.array_equal(p0, p1) and rows.dtype == np.int32 and cols.dtype == np.int32 and vals.dtype == np.uint16
+        assert np.array_equal(rows, t0[:, 0].astype(np.int32)) and np.array_equal(cols, t0[:, 1].astype(np.int32)) and np.array_equal(vals, t0[:, 2].astype(np.uint16))
+        seen = 0
+        for a, pre, (r, c, v) in rd.iter_frames_triplets(batch=4, coo=True):
+            lo, hi = int(p0[a]), int(p0[a + len(pre) - 1])
+            assert np.array_equal(pre - pre[0], p0[a:a + len(pre)] - p0[a])
+            assert np.array_equal(r, t0[lo:hi, 0].astype(np.int32)) and np.array_equal(c, t0[lo:hi, 1].astype(np.int32)) and np.array_equal(v, t0[lo:hi, 2].astype(np.uint16))
+            seen += len(pre) - 1
+        assert seen == n
+        rd.close()

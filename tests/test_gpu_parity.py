@@ -599,6 +599,74 @@ def test_expand_frames_blob_in_device_memory(hip, orc, scheme):
     assert bool((small == -7).all())
 
 
+@pytest.mark.parametrize("scheme,mode,level,d", [(1, 1, 1, 12), (2, 1, 1, 16), (0, 0, 1, 9), (1, 1, 3, 12), (2, 1, 3, 16)])
+def test_expand_frames_coo_layout_equals_the_triplets(hip, orc, scheme, mode, level, d):
+    """rc_expand_frames_coo / _coo_submit: the same batch as int32 rows | int32 columns | uint16 values (what the reference's reader makes
+    of the triplets, recode_reader.py:466-469) - entry for entry the triplet rows of rc_expand_frames, into pageable host memory, device
+    memory and page-locked memory (the streaming form), with spare capacity, with none, and refused when one short."""
+    import torch
+    ny, nx, n = 70, 300, 5
+    dark, frames = synth_frames(41, n, ny, nx, 0.04, d)
+    frames[2] = 0                                                        # an empty frame inside the batch
+    thr = orc.threshold(dark, 0)
+    ctx = hip.ReduceContext(nx, ny, d, level, mode, scheme, 1, 0, max_batch=n)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, 0)
+    ctx.close()
+    L = hip.lib()
+    hdr = 4 + 4 * md.shape[1] if mode == 1 or level == 1 else 4
+    nb = (ny * nx + 7) // 8
+    sizes = np.zeros((n, 3), np.uint32)
+    blobs = []
+    for z in range(n):
+        r = out[int(rec[z]):int(rec[z + 1])]
+        if level == 1 and mode == 1:
+            sizes[z] = md[z, :3]
+            blobs.append(r[16:])
+        elif level == 1:
+            sizes[z] = (nb, md[z, 0], md[z, 0])
+            blobs.append(r[8:])
+        else:
+            sizes[z, 0] = md[z, 0]
+            blobs.append(r[8:])
+    blob = np.ascontiguousarray(np.concatenate(blobs))
+    nnz = int((frames > thr).sum())
+    geom = (nx, ny, d, level, mode, scheme)
+    want_prefix, want = np.zeros(n + 1, np.uint64), np.zeros((nnz, 3), np.uint64)
+    hip.check(L.rc_expand_frames(*geom, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(want_prefix), hip.ptr(want), nnz))
+    assert int(want_prefix[n]) == nnz and int(want_prefix[3]) == int(want_prefix[2])
+
+    def check(buf, cap, prefix):
+        assert np.array_equal(prefix, want_prefix)
+        rows, cols, vals = buf[:4 * cap].view(np.int32)[:nnz], buf[4 * cap:8 * cap].view(np.int32)[:nnz], buf[8 * cap:10 * cap].view(np.uint16)[:nnz]
+        assert np.array_equal(rows, want[:, 0].astype(np.int32)) and np.array_equal(cols, want[:, 1].astype(np.int32))
+        assert np.array_equal(vals, want[:, 2].astype(np.uint16))
+    for cap in (nnz, nnz + 37):
+        prefix = np.zeros(n + 1, np.uint64)
+        host = np.full(10 * cap + 16, 0xA5, np.uint8)                    # pageable host memory, guard bytes behind
+        hip.check(L.rc_expand_frames_coo(*geom, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(prefix), hip.ptr(host), cap))
+        check(host, cap, prefix)
+        assert (host[10 * cap:] == 0xA5).all()
+        dev = torch.full((10 * cap + 16,), 0x5A, dtype=torch.uint8, device="cuda")
+        prefix[:] = 0
+        hip.check(L.rc_expand_frames_coo(*geom, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(prefix), dev.data_ptr(), cap))
+        got = dev.cpu().numpy()
+        check(got, cap, prefix)
+        assert (got[10 * cap:] == 0x5A).all()
+        pin = hip.PinnedBuffer(10 * cap + 16)
+        pin.array[:] = 0x77
+        hip.check(L.rc_expand_frames_coo_submit(1, *geom, hip.ptr(blob), hip.ptr(sizes), n, pin._p, cap))
+        prefix[:] = 0
+        hip.check(L.rc_expand_frames_wait(1, hip.ptr(prefix)))
+        check(pin.array, cap, prefix)
+        assert (pin.array[10 * cap:] == 0x77).all()
+        pin.close()
+    prefix = np.zeros(n + 1, np.uint64)
+    small = np.zeros(10 * nnz, np.uint8)
+    assert L.rc_expand_frames_coo(*geom, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(prefix), hip.ptr(small), nnz - 1) == hip.RC_ERR_OUT_TOO_SMALL
+    assert int(prefix[n]) == nnz
+
+
 def test_expand_frames_decodes_stock_lz4_blocks_with_real_matches(hip, orc):
     """LZ4 frames of independent 512-byte blocks compressed by STOCK liblz4 (its hash-table matcher emits matches at arbitrary offsets,
     which this library's own encoder never does): inside the device decoder's subset, so rc_expand_frames must decode them - each lane

@@ -218,6 +218,14 @@ def read_back(part_file, n, nnz_expected):
             dt = time.perf_counter() - t0
         out["iter_frames_triplets_frames_per_s"] = round(n / dt, 1)
         out["verified"] = bool(got == nnz_expected)
+        for _ in range(2):                       # the same batches as the COO arrays (int32 rows, int32 columns, uint16 values: 10 bytes a set pixel)
+            t0 = time.perf_counter()
+            got = 0
+            for _, prefix, (rows, _, _) in rd.iter_frames_triplets(batch=32, coo=True):
+                got += rows.shape[0]
+            dt = time.perf_counter() - t0
+        out["iter_frames_coo_frames_per_s"] = round(n / dt, 1)
+        out["verified"] = bool(out["verified"] and got == nnz_expected)
         t0 = time.perf_counter()
         k = nnz = 0
         while True:

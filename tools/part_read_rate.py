@@ -53,6 +53,14 @@ for name, inter in (("own.rc1", False), ("own.rc1_part000", True), ("own.rc1", F
     print("[part-read] %-16s scheme %d, %d frames, batches of %d: %.0f frames/s to host triplets (%s; index %.1f ms)"
           % (name, scheme, nz, batch, nz / dt, rd.last_batch_path, t_index * 1e3))
     print("            of %.1f ms: %s" % (dt * 1e3, ", ".join("%s %.1f ms" % (k, v * 1e3) for k, v in acc.items())))
+    for rep in range(2):
+        t0 = time.perf_counter()
+        got = 0
+        for a, pre, (rows, cols, vals) in rd.iter_frames_triplets(batch=batch, coo=True):
+            got += rows.shape[0]
+        dtc = time.perf_counter() - t0
+    assert got == want
+    print("[part-read] %-16s the same as COO arrays (10 bytes a set pixel): %.0f frames/s" % (name, nz / dtc))
     print("            calls:", trace)
     for obj, nm, fn in saved:
         setattr(obj, nm, fn)               # (back to the library's own entry points, argtypes and all)

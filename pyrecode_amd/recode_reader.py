@@ -818,11 +818,15 @@ class ReCoDeReader:
 
     def get_frames(self, z0, n):
         """{frame index: {'metadata', 'data': COO}} for n consecutive frames, decoded in one device call."""
-        prefix, trip = self.get_frames_triplets(z0, n)
+        coo_ok = int(self._header['reduction_level']) in (1, 3) and int(self._header['target_bit_depth']) <= 16
+        prefix, got = self.get_frames_triplets(z0, n, coo=coo_ok)
         out = {}
         for i in range(n):
-            d = trip[int(prefix[i]):int(prefix[i + 1])]
-            coo = self._make_coo_frame(d.shape[0], d)
+            lo, hi = int(prefix[i]), int(prefix[i + 1])
+            if coo_ok:      # the batch came as the matrices' own arrays: a frame's matrix takes copies of its slices
+                coo = self._coo_from_arrays(got[2][lo:hi].astype(self._numpy_dtype), got[0][lo:hi].copy(), got[1][lo:hi].copy())
+            else:
+                coo = self._make_coo_frame(hi - lo, got[lo:hi])
             key = int(self.part_frame_ids[z0 + i]) if self._is_intermediate else z0 + i      # (what get_next_frame keys a part file's frames by)
             out[key] = {'metadata': self._frame_metadata[z0 + i], 'data': coo}
         return out

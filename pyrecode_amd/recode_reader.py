@@ -917,8 +917,9 @@ class ReCoDeReader:
             cap = int(prefix[1])
         if cap == 0:
             return NotImplemented      # (an empty frame: the plain path knows the reference's conventions for it)
-        buf = np.empty((cap, 3), dtype=np.uint64)
-        st = L.rc_expand_frames(*args, _lib.ptr(prefix), _lib.ptr(buf), cap)
+        coo = d <= 16                  # the matrix's own arrays straight from the device (rc_expand_frames_coo), else triplet rows
+        dst = _BatchOut(coo).room(cap)
+        st = dst.fn(L)(*args, _lib.ptr(prefix), dst.ptr(), cap)
         if st != _lib.RC_OK:
             if st == _lib.RC_ERR_UNSUPPORTED and int(h['rc_operation_mode']) == 1:
                 self._foreign_file = True      # a stock encoder's streams: this file is not offered to the device decoders again
@@ -926,7 +927,10 @@ class ReCoDeReader:
         n = int(prefix[1])
         if n == 0:
             return NotImplemented
-        return self._make_coo_frame(n, buf)
+        if not coo:
+            return self._make_coo_frame(n, dst.result(n))
+        rows, cols, vals = dst.result(n)       # (views of this call's own buffer: the matrix keeps it alive)
+        return self._coo_from_arrays(vals if vals.dtype == self._numpy_dtype else vals.astype(self._numpy_dtype), rows, cols)
 
     def _get_frame_sparse(self, frame_metadata):
         """Read one frame's streams, decompress if needed, expand on the GPU, wrap as COO (reference :379-471)."""

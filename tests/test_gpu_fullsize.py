@@ -209,6 +209,14 @@ def test_direct_electron_size_zstd_write_read_config5(env, tmp_path):
         rows, cols = np.nonzero(want)
         assert np.array_equal(t[:, 0], rows.astype(np.uint64)) and np.array_equal(t[:, 1], cols.astype(np.uint64))
         assert np.array_equal(t[:, 2], want[rows, cols].astype(np.uint64))
+    # the same batch in the COO layout (rc_expand_frames_coo; 14 million set pixels: rows | columns | values each that long), and
+    # streamed two frames at a time
+    p2, (r2, c2, v2) = rd.get_frames_triplets(0, nz, coo=True)
+    assert np.array_equal(p2, prefix)
+    assert np.array_equal(r2, trip[:, 0].astype(np.int32)) and np.array_equal(c2, trip[:, 1].astype(np.int32)) and np.array_equal(v2, trip[:, 2].astype(np.uint16))
+    for a, pre, (r3, c3, v3) in rd.iter_frames_triplets(batch=2, coo=True):
+        lo, hi = int(prefix[a]), int(prefix[a + len(pre) - 1])
+        assert np.array_equal(r3, r2[lo:hi]) and np.array_equal(c3, c2[lo:hi]) and np.array_equal(v3, v2[lo:hi])
     rd.close()
 
 

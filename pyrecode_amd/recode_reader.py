@@ -816,6 +816,14 @@ class ReCoDeReader:
             if queued is not None and queued[3] is not None:
                 L.rc_expand_frames_wait(queued[2], _lib.ptr(np.zeros(queued[1] + 1, np.uint64)))
 
+    def get_frames_coo(self, z0, n, out=None):
+        """get_frames_triplets in the COO layout: (nnz_prefix, (rows int32, columns int32, values uint16))"""
+        return self.get_frames_triplets(z0, n, out=out, coo=True)
+
+    def iter_frames_coo(self, z0=0, n=None, batch=64):
+        """iter_frames_triplets in the COO layout: yields (first frame, nnz_prefix, (rows int32, columns int32, values uint16))"""
+        return self.iter_frames_triplets(z0, n, batch, coo=True)
+
     def get_frames(self, z0, n):
         """{frame index: {'metadata', 'data': COO}} for n consecutive frames, decoded in one device call."""
         coo_ok = int(self._header['reduction_level']) in (1, 3) and int(self._header['target_bit_depth']) <= 16

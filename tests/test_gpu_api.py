@@ -1004,11 +1004,11 @@ def test_batched_readers_coo_layout_equals_their_triplets(scheme, level, tmp_pat
         rd.open(print_header=False)
         n = rd._batch_frames()
         p0, t0 = rd.get_frames_triplets(0, n)
-        p1, (rows, cols, vals) = rd.get_frames_triplets(0, n, coo=True)
+        p1, (rows, cols, vals) = rd.get_frames_coo(0, n)
         assert np.array_equal(p0, p1) and rows.dtype == np.int32 and cols.dtype == np.int32 and vals.dtype == np.uint16
         assert np.array_equal(rows, t0[:, 0].astype(np.int32)) and np.array_equal(cols, t0[:, 1].astype(np.int32)) and np.array_equal(vals, t0[:, 2].astype(np.uint16))
         seen = 0
-        for a, pre, (r, c, v) in rd.iter_frames_triplets(batch=4, coo=True):
+        for a, pre, (r, c, v) in rd.iter_frames_coo(batch=4):
             lo, hi = int(p0[a]), int(p0[a + len(pre) - 1])
             assert np.array_equal(pre - pre[0], p0[a:a + len(pre)] - p0[a])
             assert np.array_equal(r, t0[lo:hi, 0].astype(np.int32)) and np.array_equal(c, t0[lo:hi, 1].astype(np.int32)) and np.array_equal(v, t0[lo:hi, 2].astype(np.uint16))

@@ -113,7 +113,8 @@ def cpu_baseline(frames_h, thr_h, depth, scheme):
     t0 = time.perf_counter()
     one(frames_h[0], np.empty(bound, np.uint8))
     t_one = time.perf_counter() - t0
-    threads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))  # every core this process may use
+    from pyrecode_amd.misc import effective_cpus
+    threads, visible = effective_cpus()   # every core this process may REALLY use: the affinity mask capped by the cgroup's CPU quota
     nfr = frames_h.shape[0]
     budget_s = 12.0                      # wall-clock bound: every worker runs until the deadline and counts its frames
     done = [0] * threads
@@ -152,7 +153,7 @@ def cpu_baseline(frames_h, thr_h, depth, scheme):
     except OSError:
         pass
     return {
-        "value": round(total / dt, 2), "unit": "frames/s", "cores": threads, "cpu_model": model, "kind": "port",
+        "value": round(total / dt, 2), "unit": "frames/s", "cores": threads, "cores_visible": visible, "cpu_model": model, "kind": "port",
         "single_core_value": round(single, 2),
         "sample": "%d frame passes over %d distinct synthetic frames of the GPU stack (%.1f s wall), oracle C reduce+pack%s" % (
             total, nfr, dt, " + liblz4 LZ4F_compressFrame on bitmap and pixvals" if lz4 is not None else

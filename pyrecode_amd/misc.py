@@ -45,3 +45,31 @@ def get_dtype_string(dtype):
     if not 0 <= code < len(_DTYPE_NAMES):
         raise ValueError("Unknown dtype")
     return _DTYPE_NAMES[code]
+
+
+def effective_cpus():
+    """(CPUs this process may really use, CPUs it may be scheduled on): the scheduler affinity, capped by the cgroup's CPU bandwidth
+    quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  A container with 256 visible cores and a quota of 16 runs 256
+    busy threads at 16 cores' worth - and is throttled for the rest of every accounting period once the quota is spent, which stalls
+    pipelines that count on their helper threads: pools are sized by the first number."""
+    import math
+    import os
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = visible if quota is None else max(1, min(visible, int(math.ceil(quota))))
+    return usable, visible

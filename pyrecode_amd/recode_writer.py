@@ -20,7 +20,7 @@ import numpy as np
 from . import _lib
 from . import recode_compressors as compressors
 from .em_reader import emfile
-from .misc import rc_cfg as rc
+from .misc import effective_cpus, rc_cfg as rc
 from .params import InitParams, InputParams
 from .recode_header import ReCoDeHeader
 from .structures import ReCoDeStructures
@@ -331,7 +331,10 @@ class ReCoDeWriter:
         gap = self._init_params.validation_frame_gap
         dose_rates, val_jobs = [], []
         val_writer = ThreadPoolExecutor(max_workers=4) if gap > 0 else None
-        host_pool = (ThreadPoolExecutor(max_workers=max(2, min(32, (os.cpu_count() or 8) // 4)))
+        usable, visible = effective_cpus()
+        # a quota'd container is this writer's alone (one rank per GPU box: all of its share); a whole node is shared by its ranks
+        host_workers = max(2, min(32, usable if usable < visible else visible // 4))
+        host_pool = (ThreadPoolExecutor(max_workers=host_workers)
                      if self._host_compress and int(self._header['compression_scheme']) in (0, 4, 5) else None)
 
         def append(i):  # (writer thread) batch i's records: page-locked buffer -> part file

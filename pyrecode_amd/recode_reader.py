@@ -386,10 +386,13 @@ class ReCoDeReader:
             if nz - z < 2:
                 return None
             k, d, level = self._RA_FRAMES, int(self._header['target_bit_depth']), int(self._header['reduction_level'])
-            if level == 1:                               # batches sized by what they expand to (24 bytes per set pixel)
-                per = max(int(self._frame_metadata[z]['bytes_in_packed_pixvals']) * 8 // d * 24, 1)
-                k = max(2, min(k, self._RA_BYTES // per))
-            k = min(k, nz - z)
+            # batches sized by what they expand to (10 bytes per set pixel): the value stream's length says how many there are; a
+            # bitmap-only file does not - one set pixel in ten is assumed
+            if level == 1:
+                per = max(int(self._frame_metadata[z]['bytes_in_packed_pixvals']) * 8 // d * 10, 1)
+            else:
+                per = max(int(self._header['nx']) * int(self._header['ny']), 1)
+            k = min(max(2, min(k, self._RA_BYTES // per)), nz - z)
             if self._ra_buf is None:
                 self._ra_buf = [None]
             keep = (self._current_frame_index, self._fp.tell())

@@ -289,3 +289,65 @@ def test_merge_interleaves_stream_mode_parts_by_frame_id(tmp_path):
         assert {k: int(v) for k, v in body["metadata"].items()} == by_id[z][0]
         assert b"".join(body["data"].values()) == by_id[z][1], "frame %d" % z
     rd.close()
+
+
+def test_readahead_state_machine_without_a_gpu(monkeypatch):
+    """ReCoDeReader._readahead_frame (the frame-at-a-time calls served from batches fetched ahead) with the batched call stubbed at
+    get_frames_triplets: it starts with the third call in sequence, moves from batch to batch, drops its window on a jump, leaves empty
+    frames and the frame counter / file position to the frame-at-a-time path, and turns itself off when a batch fails."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, _BatchOut
+    g = load_npz("g3_l1z12.npz")
+    frames, dark = g["frames"], g["dark"]
+    want = np.where(frames > dark, frames - dark, 0).astype(np.uint16)
+    nz = frames.shape[0]
+    rd = ReCoDeReader(os.path.join(FILES, "g3_l1z12.rc1"), is_intermediate=False)
+    rd.open(print_header=False)
+    rd._RA_FRAMES = 3
+    calls = []
+
+    def fake(z0, n, out=None, coo=False):
+        assert coo and out is rd._ra_buf
+        calls.append((z0, n))
+        rows, cols, vals, prefix = [], [], [], np.zeros(n + 1, np.uint64)
+        for i in range(n):
+            r, c = np.nonzero(want[z0 + i]) if z0 + i != 5 else (np.zeros(0, np.int64), np.zeros(0, np.int64))   # frame 5 pretends to be empty
+            rows.append(r.astype(np.int32)); cols.append(c.astype(np.int32)); vals.append(want[z0 + i][r, c])
+            prefix[i + 1] = prefix[i] + r.size
+        rd.last_batch_path = "device"
+        rd._current_frame_index = 99                     # (what a batched call leaves behind: the caller must not see it)
+        rd._fp.seek(7, 0)
+        return prefix, (np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
+    monkeypatch.setattr(rd, "get_frames_triplets", fake)
+    rd._current_frame_index = 3
+    rd._fp.seek(123, 0)
+    assert rd._readahead_frame(0) is None and rd._readahead_frame(1) is None and calls == []
+    m = rd._readahead_frame(2)
+    assert calls == [(2, 3)] and np.array_equal(np.asarray(m.todense()), want[2]) and m.dtype == np.uint16
+    assert rd._current_frame_index == 3 and rd._fp.tell() == 123               # put back
+    assert np.array_equal(np.asarray(rd._readahead_frame(3).todense()), want[3]) and calls == [(2, 3)]
+    assert np.array_equal(np.asarray(rd._readahead_frame(4).todense()), want[4]) and calls == [(2, 3)]
+    assert rd._readahead_frame(5) is None and calls == [(2, 3), (5, 3)]          # the next batch; the empty frame is not served
+    assert np.array_equal(np.asarray(rd._readahead_frame(6).todense()), want[6]) and rd.readahead_frames_served == 4
+    assert rd._readahead_frame(1) is None and rd._ra is None                     # a jump back: window dropped, streak restarts
+    assert rd._readahead_frame(2) is None
+    assert np.array_equal(np.asarray(rd._readahead_frame(3).todense()), want[3]) and calls[-1] == (3, 3)
+    assert rd._readahead_frame(7) is None and rd._ra is None and calls[-1] == (3, 3)     # a jump ahead, past the window's end: dropped as well
+    assert rd._readahead_frame(6) is None                                          # (backwards again)
+
+    def failing(z0, n, out=None, coo=False):
+        raise ValueError("a damaged stream")
+    monkeypatch.setattr(rd, "get_frames_triplets", failing)
+    rd._ra, rd._ra_last, rd._ra_streak = None, 0, 1
+    assert rd._readahead_frame(1) is None and rd._ra_off is True
+    assert rd._readahead_frame(2) is None
+    rd.close()
+    # the layout helper: triplet rows / the three COO arrays inside one buffer of `cap` entries
+    buf = np.arange(10 * 7, dtype=np.uint8)
+    r, c, v = _BatchOut.views(buf, 7, 5, True)
+    assert r.dtype == np.int32 and r.size == 5 and r.ctypes.data == buf.ctypes.data
+    assert c.ctypes.data == buf.ctypes.data + 4 * 7 and v.dtype == np.uint16 and v.ctypes.data == buf.ctypes.data + 8 * 7 and v.size == 5
+    t = _BatchOut.views(np.zeros(24 * 7, np.uint8), 7, 5, False)
+    assert t.shape == (5, 3) and t.dtype == np.uint64
+    tr = np.array([[1, 2, 3], [4, 5, 70000]], np.uint64)
+    rr, cc, vv = _BatchOut.from_triplets(tr, True)
+    assert rr.tolist() == [1, 4] and cc.tolist() == [2, 5] and vv.dtype == np.uint16 and _BatchOut.from_triplets(tr, False) is tr

@@ -9,7 +9,6 @@ zstd frames are stream-decoded, merge_parts is a plain k-way merge by frame id.
 """
 import heapq
 import os
-import struct
 
 import numpy as np
 from scipy.sparse import coo_matrix

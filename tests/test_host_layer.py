@@ -351,3 +351,19 @@ def test_readahead_state_machine_without_a_gpu(monkeypatch):
     tr = np.array([[1, 2, 3], [4, 5, 70000]], np.uint64)
     rr, cc, vv = _BatchOut.from_triplets(tr, True)
     assert rr.tolist() == [1, 4] and cc.tolist() == [2, 5] and vv.dtype == np.uint16 and _BatchOut.from_triplets(tr, False) is tr
+
+
+def test_batched_access_on_an_empty_part_file(tmp_path):
+    """a part file that holds its header and nothing else (a writer whose block of the stack was empty): no frames, no batches, None"""
+    from pyrecode_amd.recode_reader import ReCoDeReader
+    src = open(os.path.join(FILES, "g3_l1z12.rc1_part000"), "rb").read()
+    p = tmp_path / "empty.rc1_part000"
+    p.write_bytes(src[:512])
+    rd = ReCoDeReader(str(p), is_intermediate=True)
+    rd.open(print_header=False)
+    assert rd._batch_frames() == 0 and rd.part_frame_ids.size == 0
+    assert list(rd.iter_frames_triplets(batch=4)) == [] and list(rd.iter_frames_coo(batch=4)) == []
+    assert rd.get_next_frame() is None
+    with pytest.raises(ValueError):
+        rd.get_frames_triplets(0, 1)
+    rd.close()

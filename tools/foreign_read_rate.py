@@ -92,6 +92,14 @@ dt = time.perf_counter() - t0
 print("[foreign] streaming iterator (decode one batch ahead of the device): %.0f frames/s; host decode alone %.0f frames/s, device copy-in + expand + copy-out alone %.0f frames/s (%s)"
       % (nseen / dt, nseen / max(acc["decode"], 1e-9), nseen / max(acc.get("device", 0), 1e-9), rd.last_batch_path))
 LL.rc_expand_frames_submit, LL.rc_expand_frames_wait = _sub, _wait
+rd._host_decode_batch = _orig
+for rep in range(2):
+    t0 = time.perf_counter()
+    nseen = 0
+    for a, pre, (rows, cols, vals) in rd.iter_frames_coo(0, nz, batch=batch):
+        nseen += len(pre) - 1
+    dt = time.perf_counter() - t0
+print("[foreign] streaming iterator, COO layout (10 bytes a set pixel to the host): %.0f frames/s" % (nseen / dt))
 t0 = time.perf_counter()
 for zf in range(nz):
     rd.get_frame(zf)

@@ -150,6 +150,8 @@ class BatchedAccess:
         if ra is not None and not (ra[0] <= z < ra[0] + ra[1]):
             fetch = z == ra[0] + ra[1]                   # the batch behind the one just used up
             ra = self._ra = None
+            if not fetch:
+                self._close_ra_iter()
         if ra is None and not fetch:
             last = self._ra_last
             self._ra_streak = self._ra_streak + 1 if last is not None and z == last + 1 else 0
@@ -172,9 +174,25 @@ class BatchedAccess:
             if self._ra_buf is None:
                 self._ra_buf = [None]
             keep = (self._current_frame_index, self._fp.tell())
+            mode, scheme = int(self._header['rc_operation_mode']), int(self._header['compression_scheme'])
             try:
-                prefix, arrays = self.get_frames_triplets(z, k, out=self._ra_buf, coo=True)
+                if mode == 1 and (scheme in (0, 4, 5) or self._foreign_file):
+                    # streams only a stock decoder takes: the host-decoded pipeline, kept alive between calls - its helper thread decodes
+                    # the batch behind this one while the caller works through this one (nothing stays queued on the DEVICE in between)
+                    if self._ra_iter is None or self._ra_iter_at != z:
+                        self._close_ra_iter()
+                        self._ra_iter = self._iter_host_decoded(z, nz - z, k, coo=True)
+                    try:
+                        a, prefix, arrays = next(self._ra_iter)
+                    except StopIteration:
+                        self._close_ra_iter()
+                        return None
+                    k = len(prefix) - 1
+                    self._ra_iter_at = z + k
+                else:
+                    prefix, arrays = self.get_frames_triplets(z, k, out=self._ra_buf, coo=True)
             except Exception:
+                self._close_ra_iter()
                 self._ra_off = True
                 return None
             finally:
@@ -192,8 +210,14 @@ class BatchedAccess:
         # the batch came as the COO arrays themselves (rc_expand_frames_coo): the frame's matrix takes its own copies of its slices
         return self._coo_from_arrays(vals[lo:hi].astype(self._numpy_dtype), rows[lo:hi].copy(), cols[lo:hi].copy())
 
+    def _close_ra_iter(self):
+        it, self._ra_iter, self._ra_iter_at = self._ra_iter, None, -1
+        if it is not None:
+            it.close()
+
     def _drop_readahead(self):
         self._ra = None
+        self._close_ra_iter()
         buf = self._ra_buf
         if buf is not None and buf[0] is not None:
             buf[0].close()

@@ -57,6 +57,8 @@ class ReCoDeReader(BatchedAccess):
         # read-ahead of the frame-at-a-time calls (_readahead_frame)
         self._ra = None                  # (first frame, frames, nnz prefix, triplets) of the batch fetched ahead
         self._ra_buf = None              # its page-locked triplet buffer
+        self._ra_iter = None             # host-decoded files: the pipeline that decodes one batch ahead, and the frame it delivers next
+        self._ra_iter_at = -1
         self._ra_last = None             # the frame asked for last
         self._ra_streak = 0              # calls in sequence so far
         self._ra_off = False             # this file gains nothing from it (or a batch failed: the per-frame path reports)

@@ -291,7 +291,8 @@ def test_merge_interleaves_stream_mode_parts_by_frame_id(tmp_path):
     rd.close()
 
 
-def test_readahead_state_machine_without_a_gpu(monkeypatch):
+@pytest.mark.parametrize("host_decoded", [False, True])
+def test_readahead_state_machine_without_a_gpu(monkeypatch, host_decoded):
     """ReCoDeReader._readahead_frame (the frame-at-a-time calls served from batches fetched ahead) with the batched call stubbed at
     get_frames_triplets: it starts with the third call in sequence, moves from batch to batch, drops its window on a jump, leaves empty
     frames and the frame counter / file position to the frame-at-a-time path, and turns itself off when a batch fails."""
@@ -317,7 +318,15 @@ def test_readahead_state_machine_without_a_gpu(monkeypatch):
         rd._current_frame_index = 99                     # (what a batched call leaves behind: the caller must not see it)
         rd._fp.seek(7, 0)
         return prefix, (np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
+    def fake_iter(z0, n, batch, coo=False):              # the host-decoded pipeline (zlib files, stock-encoder files), batch by batch
+        assert coo
+        for a in range(z0, z0 + n, batch):
+            k = min(batch, z0 + n - a)
+            yield (a,) + fake(a, k, out=rd._ra_buf, coo=True)
     monkeypatch.setattr(rd, "get_frames_triplets", fake)
+    monkeypatch.setattr(rd, "_iter_host_decoded", fake_iter)
+    if not host_decoded:
+        rd._header["compression_scheme"] = 1             # (a file of this library's own zstd streams: one synchronous batched call per window)
     rd._current_frame_index = 3
     rd._fp.seek(123, 0)
     assert rd._readahead_frame(0) is None and rd._readahead_frame(1) is None and calls == []
@@ -336,7 +345,11 @@ def test_readahead_state_machine_without_a_gpu(monkeypatch):
 
     def failing(z0, n, out=None, coo=False):
         raise ValueError("a damaged stream")
+    def failing_iter(z0, n, batch, coo=False):
+        raise ValueError("a damaged stream")
+        yield
     monkeypatch.setattr(rd, "get_frames_triplets", failing)
+    monkeypatch.setattr(rd, "_iter_host_decoded", failing_iter)
     rd._ra, rd._ra_last, rd._ra_streak = None, 0, 1
     assert rd._readahead_frame(1) is None and rd._ra_off is True
     assert rd._readahead_frame(2) is None

@@ -135,6 +135,7 @@ class BatchedAccess:
 
     _RA_FRAMES = 32          # frames fetched ahead once the calls turn out to be sequential
     _RA_BYTES = 512 << 20    # ... as long as their triplets fit into this much page-locked memory
+    _RA_PIPELINED = True     # the batch behind the current one is prepared meanwhile (False: one synchronous batched call per window)
 
     def _readahead_frame(self, z):
         """The frame-at-a-time calls of the reference (get_frame in a loop, get_next_frame) served out of the batched reader: after
@@ -176,12 +177,14 @@ class BatchedAccess:
             keep = (self._current_frame_index, self._fp.tell())
             mode, scheme = int(self._header['rc_operation_mode']), int(self._header['compression_scheme'])
             try:
-                if mode == 1 and (scheme in (0, 4, 5) or self._foreign_file):
-                    # streams only a stock decoder takes: the host-decoded pipeline, kept alive between calls - its helper thread decodes
-                    # the batch behind this one while the caller works through this one (nothing stays queued on the DEVICE in between)
+                if (mode == 1 and (scheme in (0, 4, 5) or self._foreign_file)) or self._RA_PIPELINED:
+                    # The streaming iterator, kept alive between calls: while the caller works through this batch the next one is on its
+                    # way - decoded by the helper thread (streams only a stock decoder takes), or read, walked and queued on the device
+                    # (this library's own streams; the iterator of another reader that finds the slot taken goes through the
+                    # synchronous call for that batch, so readers side by side still all get their frames).
                     if self._ra_iter is None or self._ra_iter_at != z:
                         self._close_ra_iter()
-                        self._ra_iter = self._iter_host_decoded(z, nz - z, k, coo=True)
+                        self._ra_iter = self.iter_frames_triplets(z, nz - z, batch=k, coo=True)
                     try:
                         a, prefix, arrays = next(self._ra_iter)
                     except StopIteration:

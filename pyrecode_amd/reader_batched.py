@@ -142,8 +142,9 @@ class BatchedAccess:
         three calls in sequence the frames from z on are fetched a batch at a time (get_frames_triplets into a page-locked buffer
         of this reader's), and the following calls only wrap their rows as COO.  Returns the COO matrix, or None for "take the
         frame-at-a-time path" (not sequential, level 2, an empty frame - whose conventions that path knows -, or a batch the batched
-        reader could not deliver: the per-frame path then names the frame that is to blame).  Nothing stays queued on the device
-        between calls: any number of readers in a process may do this side by side."""
+        reader could not deliver: the per-frame path then names the frame that is to blame).  The iterator stays alive between
+        calls (the batch behind the current one is prepared meanwhile); one that finds a device slot taken by another reader's sends that
+        batch through the synchronous call, so any number of readers in a process may do this side by side."""
         if self._ra_off or int(self._header['reduction_level']) not in (1, 3):
             return None
         ra = self._ra

@@ -506,7 +506,10 @@ class BatchedAccess:
                 except Exception:
                     pass
             if submitted is not None:
-                L.rc_expand_frames_wait(submitted[0], _lib.ptr(np.zeros(submitted[1] + 1, np.uint64)))
+                try:
+                    L.rc_expand_frames_wait(submitted[0], _lib.ptr(np.zeros(submitted[1] + 1, np.uint64)))
+                except Exception:         # (a generator finalised while the interpreter shuts down)
+                    pass
 
     def iter_frames_triplets(self, z0=0, n=None, batch=64, coo=False):
         """Streams frames z0 .. z0+n-1 of a merged file (records z0 .. of a part file: the reference's own read test sums a part file's
@@ -604,7 +607,10 @@ class BatchedAccess:
         finally:
             # a consumer that stops early leaves a batch queued: wait for it before its buffers go away
             if queued is not None and queued[3] is not None:
-                L.rc_expand_frames_wait(queued[2], _lib.ptr(np.zeros(queued[1] + 1, np.uint64)))
+                try:
+                    L.rc_expand_frames_wait(queued[2], _lib.ptr(np.zeros(queued[1] + 1, np.uint64)))
+                except Exception:         # (a generator finalised while the interpreter shuts down)
+                    pass
 
     def get_frames_coo(self, z0, n, out=None):
         """get_frames_triplets in the COO layout: (nnz_prefix, (rows int32, columns int32, values uint16))"""

@@ -152,6 +152,12 @@ class ReCoDeReader(BatchedAccess):
     def sz_frame_metadata(self):
         return self._sz_frame_metadata
 
+    def __del__(self):
+        try:                              # a reader dropped without close(): its read-ahead may hold a batch queued on the device
+            self._close_ra_iter()
+        except Exception:
+            pass
+
     def close(self):
         self._drop_readahead()
         self._fp.close()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# End-of-round measurement pass on the MI355X box: tools/final_pass.sh <round-tag>
+# End-of-round measurement pass on the MI355X box: tools/final_pass.sh <round-tag> [lines]   (lines: step 1 only)
 #   1. unprofiled bench lines of every configuration (+ reader lines + ingest) -> gpurun_out/final_<tag>/
 #   2. tools/prof_round.sh passes (kernel-trace stats + FETCH_SIZE / WRITE_SIZE) for the profiled configurations
 T=$1
@@ -29,6 +29,7 @@ line read_zstd_blob_on_device --read --scheme 1 --blob-on-device --steps 30 --wa
 line read_cfg5 --read --scheme 1 --ny 8184 --nx 11520 --batch 16 --sparsity-ppm 50000 --depth 12 --steps 10 --warmup 2 --min-seconds 1
 python3 tools/foreign_read_rate.py 1 64 32 > $OUT/foreign_zstd.log 2>&1; tail -2 $OUT/foreign_zstd.log
 python3 tools/foreign_read_rate.py 2 64 32 > $OUT/foreign_lz4.log 2>&1; tail -2 $OUT/foreign_lz4.log
+if [ "$2" = "lines" ]; then echo "done (lines only)"; exit 0; fi
 echo "== profiles"
 tools/prof_round.sh ${T}_lz4 > $OUT/prof_lz4.log 2>&1
 tools/prof_round.sh ${T}_zstd --scheme 1 > $OUT/prof_zstd.log 2>&1

@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <functional>
 #include <thread>
+#include <sched.h>
 #include <unistd.h>
 #include <vector>
 
@@ -76,6 +77,34 @@ int copy_out(void *dst, const void *src_dev, uint64_t bytes, hipStream_t s)
     if (!bytes) return RC_OK;
     HIP_TRY(hipMemcpyAsync(dst, src_dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     return RC_OK;
+}
+
+// CPUs this process may REALLY use: the scheduler affinity capped by the cgroup's CPU bandwidth quota (cgroup v2 cpu.max, v1
+// cpu.cfs_quota_us / cpu.cfs_period_us) - the GPU boxes show 256 cores and grant 16; a pool sized from hardware_concurrency() spends the
+// quota early in every accounting period and is throttled for the rest of it (pyrecode_amd/misc.py::effective_cpus is the Python twin).
+uint32_t usable_cpus()
+{
+    static const uint32_t n = [] {
+        uint32_t vis = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) vis = (uint32_t)CPU_COUNT(&set);
+        if (!vis) vis = std::max(1u, std::thread::hardware_concurrency());
+        double quota = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            long long period = 0;
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / (double)period;
+            fclose(f);
+        } else {
+            long long q = -1, period = 0;
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+            if (q > 0 && period > 0) quota = (double)q / (double)period;
+        }
+        if (quota > 0) vis = std::max(1u, std::min(vis, (uint32_t)(quota + 0.999)));
+        return vis;
+    }();
+    return n;
 }
 
 // Every entry point runs on its ctx's (or the utility context's) device and puts the caller's current device back on

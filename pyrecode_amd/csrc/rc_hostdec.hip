@@ -138,7 +138,7 @@ RC_EXPORT int rc_host_decode_streams(uint32_t scheme, const uint8_t *src, uint8_
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return spans[4 * a + 1] > spans[4 * b + 1]; });
-    uint32_t hw = std::thread::hardware_concurrency();
+    uint32_t hw = usable_cpus();   // (not hardware_concurrency(): a cgroup quota grants fewer)
     if (const char *e = getenv("RC_DECODE_THREADS")) hw = (uint32_t)atoi(e);
     uint32_t nthr = threads ? threads : std::min<uint32_t>(16, hw ? hw : 1);
     nthr = std::max<uint32_t>(1, std::min<uint32_t>(nthr, std::min<uint32_t>(n, 64)));

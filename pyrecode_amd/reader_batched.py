@@ -9,6 +9,7 @@ import numpy as np
 
 from . import recode_compressors as compressors
 from . import _lib
+from .misc import effective_cpus
 
 
 class _BatchOut:
@@ -147,6 +148,10 @@ class BatchedAccess:
         batch through the synchronous call, so any number of readers in a process may do this side by side."""
         if self._ra_off or int(self._header['reduction_level']) not in (1, 3):
             return None
+        if self._user_iters:
+            # a caller's own iter_frames_* on THIS reader is alive: it owns the reader's page-locked batch buffers (the read-ahead's
+            # iterator would write the next batch into what that one's arrays view) - these calls go frame by frame meanwhile
+            return None
         ra = self._ra
         fetch = False
         if ra is not None and not (ra[0] <= z < ra[0] + ra[1]):
@@ -185,7 +190,7 @@ class BatchedAccess:
                     # synchronous call for that batch, so readers side by side still all get their frames).
                     if self._ra_iter is None or self._ra_iter_at != z:
                         self._close_ra_iter()
-                        self._ra_iter = self.iter_frames_triplets(z, nz - z, batch=k, coo=True)
+                        self._ra_iter = self._iter_frames_impl(z, nz - z, batch=k, coo=True)
                     try:
                         a, prefix, arrays = next(self._ra_iter)
                     except StopIteration:
@@ -297,14 +302,14 @@ class BatchedAccess:
                     self._foreign_file = not host_only
                     return res
         # per-frame path
-        self.last_batch_path = 'per-frame'  
+        self.last_batch_path = 'per-frame'
         parts, prefix = [], np.zeros(n + 1, np.uint64)
         keep = self._fp.tell()
         for i in range(n):
             self._fp.seek(self._frame_data_start_position + int(self._seek_table[z0 + i, 1]), 0)
-            coo = self._get_frame_sparse(self._frame_metadata[z0 + i])
-            coo = coo[0] if isinstance(coo, tuple) else coo
-            t = np.stack([coo.row.astype(np.uint64), coo.col.astype(np.uint64), coo.data.astype(np.uint64)], axis=1) if coo is not None and coo.nnz \
+            m = self._get_frame_sparse(self._frame_metadata[z0 + i])     # (not `coo`: that is the caller's layout flag, used below)
+            m = m[0] if isinstance(m, tuple) else m
+            t = np.stack([m.row.astype(np.uint64), m.col.astype(np.uint64), m.data.astype(np.uint64)], axis=1) if m is not None and m.nnz \
                 else np.zeros((0, 3), np.uint64)
             parts.append(t)
             prefix[i + 1] = prefix[i] + t.shape[0]
@@ -398,7 +403,7 @@ class BatchedAccess:
                 dec(view[src_off:src_off + src_n], want, pieces[at:at + want])
         try:
             if self._decode_pool is None:
-                self._decode_pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1))
+                self._decode_pool = ThreadPoolExecutor(max_workers=min(16, effective_cpus()[0]))
             spans.sort(key=lambda sp: -sp[1])            # longest streams first: the pool's tail is then a short one
             list(self._decode_pool.map(one, spans))
         except Exception:
@@ -512,6 +517,18 @@ class BatchedAccess:
                     pass
 
     def iter_frames_triplets(self, z0=0, n=None, batch=64, coo=False):
+        """The caller's own streaming iterator (documented at _iter_frames_impl).  The read-ahead under get_frame / get_next_frame keeps
+        an iterator of its own alive on the same page-locked buffers, with one batch queued on the device: it is ended first (its queued
+        batch waited for, the window it serves forgotten), and it stays off while this generator lives."""
+        self._ra = None
+        self._close_ra_iter()
+        self._user_iters += 1
+        try:
+            yield from self._iter_frames_impl(z0, n, batch, coo)
+        finally:
+            self._user_iters -= 1
+
+    def _iter_frames_impl(self, z0=0, n=None, batch=64, coo=False):
         """Streams frames z0 .. z0+n-1 of a merged file (records z0 .. of a part file: the reference's own read test sums a part file's
         frames one get_next_frame at a time, tests/recode_v1_read_test.py:9-21) through the batched device reader, two batches in flight
         (rc_expand_frames_submit / _wait): while the device decodes one batch, the next one is read from the file, its block headers

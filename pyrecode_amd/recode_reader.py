@@ -62,6 +62,7 @@ class ReCoDeReader(BatchedAccess):
         self._ra_last = None             # the frame asked for last
         self._ra_streak = 0              # calls in sequence so far
         self._ra_off = False             # this file gains nothing from it (or a batch failed: the per-frame path reports)
+        self._user_iters = 0             # the caller's own iter_frames_* generators alive on this reader (the read-ahead stays off meanwhile)
         self.readahead_frames_served = 0
 
     # ---- opening -------------------------------------------------------------------------------------------
@@ -253,6 +254,9 @@ class ReCoDeReader(BatchedAccess):
             raise ValueError('Requested frame index is greater than number of frames in dataset')
         coo = self._readahead_frame(int(z))
         if coo is not None:
+            # the file position goes where the frame-at-a-time path would have left it: behind frame z (get_next_frame on a merged file
+            # reads from there when the read-ahead has nothing for it - an empty frame, the last frame)
+            self._fp.seek(self._frame_data_start_position + int(self._seek_table[z, 1]) + int(self._seek_table[z, 0]), 0)
             self._current_frame_index = z + 1
             return self._pack(z, self._frame_metadata[z], coo)
         self._fp.seek(self._frame_data_start_position + int(self._seek_table[z, 1]), 0)

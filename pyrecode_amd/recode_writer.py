@@ -121,7 +121,9 @@ class ReCoDeWriter:
         self._pin_mode = os.environ.get('RC_WRITER_PIN', 'auto')   # auto | register | stage
         # staging copies: a thread moves 5-8 GB/s from pageable memory; the link takes 57 (measured on 2 x 64 cores: 6 threads 46.9 GB/s
         # end to end, 24 threads 51.2)
-        self._copy_threads = int(os.environ.get('RC_WRITER_COPY_THREADS', str(max(6, min(24, (os.cpu_count() or 8) // 8)))))
+        # sized by the cores the cgroup really grants (the GPU box shows 256 and grants 16: 24 copy threads next to the stager, the writer
+        # thread and the library's workers spent the quota and throttled the whole pipeline)
+        self._copy_threads = int(os.environ.get('RC_WRITER_COPY_THREADS', str(max(2, min(24, effective_cpus()[0] // 2)))))
         if ip.compression_scheme == 1 and not _lib.lib().rc_scheme_on_device(1):
             import zstandard as zstd
             self._compressor_context = zstd.ZstdCompressor(level=ip.compression_level, write_content_size=False)

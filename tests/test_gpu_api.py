@@ -1015,3 +1015,143 @@ def test_batched_readers_coo_layout_equals_their_triplets(scheme, level, tmp_pat
             seen += len(pre) - 1
         assert seen == n
         rd.close()
+
+
+@pytest.mark.parametrize("kind", ["level2", "blosc"])
+def test_batched_calls_on_files_that_take_the_per_frame_path(kind, tmp_path, orc):
+    """Level-2 files and mode-1 files of schemes without a batched decoder (blosc = BASELINE config 4's codec) leave the batched calls
+    through their frame-at-a-time fallback: get_frames / get_frames_triplets / get_frames_coo / iter_frames_triplets / iter_frames_coo
+    must deliver the same entries as get_frame there, in both layouts (round 3 left the fallback's loop variable named like the
+    layout flag)."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, d, nz = 72, 136, 12, 7
+    dark, frames = synth_frames(31, nz, ny, nx, 0.05, d)
+    frames[nz - 1] = 0                                                    # the LAST frame empty (the case that handed back triplet rows)
+    g = load_npz("g3_l1z12.npz")
+    level = 2 if kind == "level2" else 1
+    over = dict(num_rows=ny, num_cols=nx, num_frames=nz, num_threads=2, compression_scheme=8 if kind == "blosc" else 2,
+                reduction_level=level, calibration_threshold_epsilon=0)
+    if level == 2:
+        over["l2_statistics"] = 2
+    _write_parts(tmp_path, "pf", dark, frames, 2, g, batch_size=3, **over)
+    merge_parts(str(tmp_path), "pf.rc%d" % level, 2)
+    rd = ReCoDeReader(str(tmp_path / ("pf.rc%d" % level)))
+    rd.open(print_header=False)
+    rd._ra_off = True
+    want = []
+    for z in range(nz):
+        m = rd.get_frame(z)[z]["data"]
+        want.append(m if m is not None and m.nnz else None)
+    for coo in (False, True):
+        prefix, got = rd.get_frames_triplets(0, nz, coo=coo)
+        assert rd.last_batch_path == 'per-frame'
+        pieces = [(0, prefix, got)]
+        pieces += list(rd.iter_frames_triplets(batch=3, coo=coo))
+        for a, pre, body in pieces:
+            for i in range(len(pre) - 1):
+                lo, hi = int(pre[i]), int(pre[i + 1])
+                m = want[a + i]
+                if m is None:
+                    assert hi == lo
+                    continue
+                if coo:
+                    r, c, v = body
+                    assert r.dtype == np.int32 and c.dtype == np.int32 and v.dtype == np.uint16
+                    assert np.array_equal(r[lo:hi], m.row) and np.array_equal(c[lo:hi], m.col) and np.array_equal(v[lo:hi], m.data.astype(np.uint16))
+                else:
+                    assert body.dtype == np.uint64 and body.shape[1] == 3
+                    assert np.array_equal(body[lo:hi, 0], m.row.astype(np.uint64)) and np.array_equal(body[lo:hi, 1], m.col.astype(np.uint64))
+                    assert np.array_equal(body[lo:hi, 2], m.data.astype(np.uint64))
+    fr = rd.get_frames(1, nz - 1)
+    assert rd.last_batch_path == 'per-frame' and sorted(fr) == list(range(1, nz))
+    for z in range(1, nz):
+        m = want[z]
+        if m is None:
+            assert fr[z]["data"].nnz == 0
+        else:
+            assert np.array_equal(np.asarray(fr[z]["data"].todense()), np.asarray(m.todense()))
+    rd.close()
+
+
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_get_frame_out_of_the_readahead_leaves_the_file_where_get_next_frame_needs_it(scheme, tmp_path, orc):
+    """get_frame(z) served from the read-ahead window must leave the file position behind frame z, as the frame-at-a-time path does:
+    a following get_next_frame() that the read-ahead has nothing for - the next frame is EMPTY, or only one frame is left - reads the
+    frame's streams from that position."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, d, nz = 64, 192, 12, 12
+    dark, frames = synth_frames(5, nz, ny, nx, 0.04, d)
+    frames[7] = 0                                                         # get_frame(6) then get_next_frame() lands on an empty frame
+    g = load_npz("g3_l1z12.npz")
+    _write_parts(tmp_path, "fp", dark, frames, 1, g, batch_size=4, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=1,
+                 compression_scheme=scheme, calibration_threshold_epsilon=0)
+    merge_parts(str(tmp_path), "fp.rc1", 1)
+    thr = orc.threshold(dark, 0)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16)
+    for stop in (6, nz - 2):                                              # next frame empty / next frame the file's last
+        rd = ReCoDeReader(str(tmp_path / "fp.rc1"))
+        rd.open(print_header=False)
+        rd._RA_FRAMES = 4
+        ref = ReCoDeReader(str(tmp_path / "fp.rc1"))
+        ref.open(print_header=False)
+        ref._ra_off = True
+        for z in range(stop + 1):
+            fa, fb = rd.get_frame(z), ref.get_frame(z)
+            if frames[z].any():
+                assert _coo_equal(fa[z]["data"], fb[z]["data"])
+            assert rd.get_file_position() == ref.get_file_position(), "after get_frame(%d)" % z
+        assert rd.readahead_frames_served >= stop - 3
+        for z in range(stop + 1, nz):
+            fa, fb = rd.get_next_frame(), ref.get_next_frame()
+            assert (fa is None) == (fb is None)
+            if fa is None:
+                break
+            assert list(fa) == list(fb) == [z]
+            if frames[z].any():
+                assert np.array_equal(np.asarray(fa[z]["data"].todense()), want[z]), "frame %d after get_frame(%d)" % (z, stop)
+            assert rd.get_file_position() == ref.get_file_position()
+        rd.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_own_iterator_and_readahead_on_one_reader_do_not_share_batches(scheme, tmp_path, orc):
+    """The read-ahead under get_frame keeps an iterator alive on the reader's page-locked batch buffers, with one batch queued on the
+    device.  A caller's own iter_frames_* on the SAME reader ends it first and keeps it off while it runs; get_frame calls in between
+    return the right frames (frame by frame), and the read-ahead comes back afterwards."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    ny, nx, d, nz = 64, 160, 12, 26
+    dark, frames = synth_frames(17, nz, ny, nx, 0.05, d)
+    g = load_npz("g3_l1z12.npz")
+    _write_parts(tmp_path, "mix", dark, frames, 1, g, batch_size=5, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=1,
+                 compression_scheme=scheme, calibration_threshold_epsilon=0)
+    merge_parts(str(tmp_path), "mix.rc1", 1)
+    thr = orc.threshold(dark, 0)
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint16)
+    rd = ReCoDeReader(str(tmp_path / "mix.rc1"))
+    rd.open(print_header=False)
+    rd._RA_FRAMES = 4
+
+    def dense(z):
+        return np.asarray(rd.get_frame(z)[z]["data"].todense())
+    for z in range(6):                                                    # the read-ahead is up: a window in hand, the next batch queued
+        assert np.array_equal(dense(z), want[z])
+    assert rd.readahead_frames_served >= 3
+    served = rd.readahead_frames_served
+    seen = 0
+    for a, pre, (r, c, v) in rd.iter_frames_coo(batch=3):
+        r, c, v, pre = r.copy(), c.copy(), v.copy(), pre.copy()
+        # frame-at-a-time calls in between: inside the old window, behind it, and sequentially
+        for z in (4, 5, 6, 7, 8, 9):
+            assert np.array_equal(dense(z), want[z]), "get_frame(%d) next to the iterator's batch at %d" % (z, a)
+        for i in range(len(pre) - 1):
+            lo, hi = int(pre[i]), int(pre[i + 1])
+            img = np.zeros((ny, nx), np.uint16)
+            img[r[lo:hi], c[lo:hi]] = v[lo:hi]
+            assert np.array_equal(img, want[a + i]), "iterator frame %d" % (a + i)
+            seen += 1
+    assert seen == nz and rd.readahead_frames_served == served            # nothing came out of a read-ahead while the iterator lived
+    for z in range(10, 20):
+        assert np.array_equal(dense(z), want[z])
+    assert rd.readahead_frames_served > served                            # and it is back afterwards
+    rd.close()

@@ -6,10 +6,11 @@ name=$1; shift
 cd "$(dirname "$0")/../pyrecode_amd/csrc"
 mkdir -p ../../ab_build
 d=$(mktemp -d)
-for f in rc_api rc_reader rc_codec_api rc_reduce rc_lz4 rc_zstd rc_pix_huff rc_zstd_dec rc_blosc rc_l2 rc_expand; do
+# the file list is the Makefile's (a build that lacks a translation unit lacks its symbols, and _lib.lib() binds them all)
+for f in $(sed -n 's/^SRCS := //p' Makefile | sed 's/\.hip//g'); do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -w "$@" -c $f.hip -o $d/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_build/librecode_hip_$name.so $d/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_build/librecode_hip_$name.so $d/*.o -ldl
 rm -rf $d
 ls -la ../../ab_build/librecode_hip_$name.so

@@ -73,6 +73,9 @@ def parse(argv=None):
     ap.add_argument("--min-seconds", type=float, default=2.0, help="the K-step timed region is repeated until this much time has been measured (>= 3 repeats); the median repeat is reported")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product); gloo only to rehearse on a box with fewer GPUs than ranks")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses two ranks on one device)")
+    ap.add_argument("--gather-every", type=int, default=1, help="steps per metadata all-gather: 1 = every step (default), K = every K steps, 0 = ONE gather per timed region (BASELINE: 'RCCL only for the final merged-index gather')")
+    ap.add_argument("--no-collective", action="store_true", help="rehearsal: the ranks only meet at the fences (barrier, max-over-ranks time); no metadata gather - isolates the HOST side of N step loops from the rehearsal backend's host copies")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin each rank to its share of the usable CPUs")
     pre, _ = ap.parse_known_args(argv)
     if pre.config:
         ap.set_defaults(**CONFIGS[pre.config])
@@ -377,7 +380,7 @@ def launch_children(a, argv):
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, RC_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("OMP_NUM_THREADS", "1")              # N step loops share the host: no rank spins up a thread pool of its own
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for out in proc.stdout:
@@ -433,15 +436,60 @@ def verify_record(a, r, frame, thr_h, frame_id):
     return None
 
 
+def pin_rank_cpus(local_rank, local_world):
+    """N ranks share one host: each keeps to its own share of the CPUs the job may really use (affinity mask capped by the cgroup's
+    quota, pyrecode_amd.misc.effective_cpus) - the first `usable // N` CPUs of the rank's N-th of the visible list, so ranks of the
+    two halves of the node stay on their socket.  Must run BEFORE the first GPU call (the runtimes' helper threads inherit the mask).
+    Returns the CPUs, or None when nothing was changed."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        from pyrecode_amd.misc import effective_cpus
+        usable, _ = effective_cpus()
+        cpus = sorted(os.sched_getaffinity(0))
+        chunk = len(cpus) // local_world
+        if chunk < 1:
+            return None
+        per = max(1, min(chunk, usable // local_world))
+        mine = cpus[local_rank * chunk:local_rank * chunk + per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (OSError, ValueError):
+        return None
+
+
+def pattern_floor(N, B, k_ms):
+    """What the memory system delivers for the reduce kernel's ACCESS PATTERN, from the committed probe (tools/wr_probe.hip,
+    profiles/r02_reduce_stores.md: same grid, XCD mapping, frames per wave and nontemporal 16-byte loads as k_reduce_tiles, no compute):
+    reads alone, and reads plus the three 128-byte lines the product writes per tile and frame.  Measured at 4096x4096 x 64 frames;
+    other geometries are scaled by their bytes (and say so)."""
+    path = os.path.join(REPO, "profiles", "pattern_floor.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    ref_bytes = t["bytes_read"]
+    scale = (B * N * 2) / ref_bytes
+    ro, rw = t["reads_only_ms"] * scale, t["reads_plus_3_lines_ms"] * scale
+    return {"reads_only": round(ro, 4), "reads_plus_3_lines": round(rw, 4), "scaled_by_bytes": abs(scale - 1) > 1e-9, "source": t["source"],
+            "kernel_over_floor": (round(k_ms / rw, 3) if rw > 0 else None)}
+
+
 def run_rank(a):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    pinned = None
+    if world > 1:        # before torch / HIP start their threads
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        if not a.no_pin:
+            pinned = pin_rank_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     import torch
+    if world > 1:
+        torch.set_num_threads(1)
     import torch.distributed as dist
     from pyrecode_amd import _lib as hip
     from pyrecode_amd.parallel import ShardedStepLoop
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (any world size)
     if world != a.gpus:
         raise SystemExit("rank %d: --gpus %d but WORLD_SIZE=%d" % (rank, a.gpus, world))
@@ -485,8 +533,11 @@ def run_rank(a):
     rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
     nb = S // B
     # rank r's frames of step i carry the ids of its contiguous block of the job's frames (recode_writer.py:320-322,385)
-    loop = ShardedStepLoop(ctx, B, lambda i: (stack[(i % nb) * B].data_ptr(), rank * S + (i % nb) * B), out, rec, dev, collective=use_dist)
-    stream, md2 = loop.stream, loop.md2
+    batch_ptr = [stack[j * B].data_ptr() for j in range(nb)]      # (no tensor indexing in the step loop: N loops share the host's cores)
+    collective = use_dist and not a.no_collective
+    loop = ShardedStepLoop(ctx, B, lambda i: (batch_ptr[i % nb], rank * S + (i % nb) * B), out, rec, dev, collective=collective,
+                           gather_every=a.gather_every, region_steps=max(a.steps, a.warmup, 1), fence_barrier=use_dist)
+    stream = loop.stream
     ctx.set_stream(stream.cuda_stream)
     ctx.set_pipelined(not a.no_pipeline)  # batch i+1's reduce kernel may overlap batch i's scans / layout / assembly
     step, fence = loop.step, loop.fence
@@ -499,15 +550,17 @@ def run_rank(a):
             step(i)
         ctx.sync()
         ctx.set_profiling(True)
-        times, k_ms_list, it = [], [], a.warmup
+        times, k_ms_list, it, issue = [], [], a.warmup, []
         more = True
         while more:
             fence()
             t0 = time.perf_counter()
             for i in range(a.steps):
                 step(it + i)
+            t_issued = time.perf_counter()
             fence()
             dt = time.perf_counter() - t0
+            issue.append((t_issued - t0) / a.steps)
             it += a.steps
             ctx.sync()  # also raises if the device flagged a batch
             sums, nbatches = ctx.profile()
@@ -519,33 +572,74 @@ def run_rank(a):
             times.append(float(t.item()))   # the same list on every rank, so every rank leaves the loop together
             k_ms_list.append((sums[0] / nbatches, sums[4] / nbatches, [v / nbatches for v in sums]))
             more = len(times) < 3 or (sum(times) < a.min_seconds and len(times) < 1000)
-    ctx.set_profiling(False)
+        # host side of a step by itself: a short burst into an EMPTY queue (nothing to wait for, no back-pressure), no sync inside
+        ctx.set_profiling(False)
+        burst, enq = min(16, max(a.steps, 1)), []
+        for _ in range(5):
+            fence()
+            t0 = time.perf_counter()
+            for i in range(burst):
+                step(it + i)
+            enq.append((time.perf_counter() - t0) / burst)
+            it += burst
+        fence()
+    host_enqueue_us = sorted(enq)[len(enq) // 2] * 1e6
     order = sorted(range(len(times)), key=lambda i: times[i])
     mid = order[len(order) // 2]
     dt_max = times[mid]
     sums = [v * a.steps for v in k_ms_list[mid][2]]
     nbatches = a.steps
+    issue_us = issue[mid] * 1e6
     last_step = it - 1
     frames_total = world * B * a.steps
     fps = frames_total / dt_max
     rec_h = rec.cpu().numpy()
     assert rec_h[0] == 0 and rec_h[-1] > 0
     gather_verified = loop.verify_gather()   # collective: every rank's block of the gathered table, on every rank
+    gathers_in_region = loop.gathers_issued
 
-    def verify_last_batch():
-        """Outside the timing: one record of the last batch against the oracle."""
-        lo = (last_step % nb) * B
-        z = B // 2
-        frame = stack[lo + z].cpu().numpy().view(np.uint16)
-        thr_h = dark.cpu().numpy().view(np.uint16)
-        r = out[int(rec_h[z]):int(rec_h[z + 1])].cpu().numpy().tobytes()
-        return verify_record(a, r, frame, thr_h, rank * S + lo + z)
+    thr_h = dark.cpu().numpy().view(np.uint16)
+    corrupt = os.environ.get("RC_BENCH_CORRUPT_RECORD")          # test switch: one byte of a record flipped before the check
 
+    def verify_batch(j, z):
+        """Outside the timing: record z of the records `out` holds now - batch j of the stack - against the oracle."""
+        rec_now = rec.cpu().numpy()
+        if corrupt:
+            mid_byte = (int(rec_now[z]) + int(rec_now[z + 1])) // 2
+            out[mid_byte] ^= 0x5A
+        frame = stack[j * B + z].cpu().numpy().view(np.uint16)
+        r = out[int(rec_now[z]):int(rec_now[z + 1])].cpu().numpy().tobytes()
+        try:
+            return bool(verify_record(a, r, frame, thr_h, rank * S + j * B + z))
+        except Exception as e:   # a record the stock decoder rejects is a failed check, not a crashed bench (and every rank goes on
+            print("rank %d: verification of batch %d record %d raised: %r" % (rank, j, z, e), file=sys.stderr)   # through the same steps)
+            return False
+
+    # One record of EVERY distinct batch of the stack: the last timed step's records as they stand, then each other batch run once more
+    # through the same loop (same kernels, same buffers; every rank takes the same steps, so the collectives stay matched).
+    checked, verified = [], True
     try:
-        verified = verify_last_batch()
-    except Exception as e:   # a record the stock decoder rejects is a failed check, not a crashed bench
+        j_last = last_step % nb
+        zs = [(B // 2 + 7 * k) % B for k in range(nb)]
+        ok = verify_batch(j_last, zs[0])
+        checked.append({"batch": j_last, "record": zs[0], "ok": ok})
+        verified = verified and ok
+        with torch.cuda.stream(stream):
+            for k in range(1, nb):
+                j = (j_last + k) % nb
+                i_extra = it + ((j - it) % nb)                   # a step index that maps to batch j
+                fence()
+                step(i_extra)
+                fence()
+                ctx.sync()
+                ok = verify_batch(j, zs[k])
+                checked.append({"batch": j, "record": zs[k], "ok": ok})
+                verified = verified and ok
+    except Exception as e:
         verified = False
         print("rank %d: verification raised: %r" % (rank, e), file=sys.stderr)
+        if use_dist:
+            raise            # (a rank that leaves the steps the others take would leave them waiting at a fence)
     if use_dist:   # every rank checks one of ITS records; the line reports the conjunction
         v = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
@@ -570,7 +664,12 @@ def run_rank(a):
             "repeats": len(times), "timed_seconds_total": round(sum(times), 3),
             "ms_per_step_all_repeats": {"min": round(min(times) / a.steps * 1e3, 4), "median": round(dt_max / a.steps * 1e3, 4),
                                         "max": round(max(times) / a.steps * 1e3, 4)},
-            "verified": verified, "gather_verified": gather_verified,
+            "verified": verified, "records_checked": checked, "gather_verified": gather_verified,
+            # host side of one step (Python loop + ctypes + launches + the collective's enqueue): a burst of steps issued into an empty
+            # queue without any sync; `issue_us_per_step_in_timed_region` is the same loop inside the timed region (includes waiting
+            # for room in the device queue when the host runs ahead)
+            "host_enqueue_us_per_step": round(host_enqueue_us, 1), "issue_us_per_step_in_timed_region": round(issue_us, 1),
+            "host_enqueue_frac_of_step": round(host_enqueue_us / (dt_max / a.steps * 1e6), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {
                 "workload": "%s%dx%d uint16, %s, L%d + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
@@ -579,8 +678,12 @@ def run_rank(a):
                     {2: "LZ4 frame", 1: "zstd frame (%s encoder)" % ("modelled" if a.clevel else "fast"), 8: "blosc-lz4 chunk",
                      0: "reduce-only pieces (the host library compresses them, as the reference does)"}.get(a.scheme, str(a.scheme)),
                     a.depth, B, S),
-                "parallelism": "dp%d (contiguous frame blocks per rank; per step one %s all-gather of the metadata rows, on a side stream under the next step)" % (
-                    world, {"nccl": "RCCL"}.get(backend, backend) if use_dist else "(single process: no)"),
+                "parallelism": "dp%d (contiguous frame blocks per rank; %s)" % (world, (
+                    "no collective: the ranks meet only at the fences (host-side rehearsal)" if use_dist and not collective else
+                    ("%s all-gather of the metadata rows %s, on a side stream under the following steps" % (
+                        {"nccl": "RCCL"}.get(backend, backend), "once per timed region" if a.gather_every == 0 else
+                        ("every step" if a.gather_every == 1 else "every %d steps" % a.gather_every))) if use_dist else "single process: no collective")),
+                "gather_every": a.gather_every, "gathers_issued_in_all": gathers_in_region, "cpus_pinned": (len(pinned) if pinned else None),
                 "record_bytes_per_frame": round(float(rec_h[-1]) / B, 1),
                 "launch": ("bench.py started its own ranks (child torch.distributed.run)" if os.environ.get("RC_BENCH_SELF_LAUNCHED")
                            else ("torch.distributed.run" if use_dist else "single process")),
@@ -592,6 +695,7 @@ def run_rank(a):
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "traffic_ratio": (round(traffic / (B * N * 2), 4) if traffic else None),
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": B * N * 2,
+                         "pattern_floor_ms": pattern_floor(N, B, k_ms),
                          "whole_path_frac": round(fps / world * N * 2 / 1e9 / HBM_PEAK_GBS, 4)},
             # only the events the roofline needs are recorded in the timed region (each costs stream time); the full
             # per-stage split is available with RC_PROFILE_ALL_STAGES=1
@@ -638,6 +742,8 @@ def run_rank(a):
     ctx.close()
     if not ok:
         raise SystemExit("rank %d: the gathered metadata table does not hold every rank's rows" % rank)
+    if not verified:     # a fast wrong answer is not a result: the line above says verified: false, the exit code says it too
+        raise SystemExit("rank %d: a record failed the check against the oracle (verified: false)" % rank)
 
 
 def main():

@@ -254,10 +254,16 @@ class _NullEvent:
 
 class ShardedStepLoop:
     """One rank of the data-parallel hot path as the reference runs it (one writer per node, recode_server.py:350-363;
-    contiguous frame blocks, recode_writer.py:320-322): every step reduces `batch` frames on this rank's GPU and issues the
-    path's one exchange step, the all-gather of the per-frame metadata rows, on a SIDE stream so that it runs
-    under the next step's reduce kernel.  The rows are double-buffered: step i writes md2[i & 1] and gathers it into
-    md_all2[i & 1]; before step i + 2 rewrites md2[i & 1] the main stream waits for that gather's event.
+    contiguous frame blocks, recode_writer.py:320-322): every step reduces `batch` frames on this rank's GPU; the path's one
+    exchange step, the all-gather of the per-frame metadata rows, is issued every `gather_every` steps on a SIDE
+    stream so that it runs under the following steps' reduce kernels.
+
+    gather_every = G >= 1: the rows of G consecutive steps form a group; the step that completes a group gathers it (G = 1: one
+        collective per step, the form of rounds 1-3).  Groups are double-buffered: group g writes md2[g & 1] and is gathered
+        into md_all2[g & 1]; before group g + 2 rewrites md2[g & 1] the main stream waits for that gather's event.
+    gather_every = 0: ONE gather per fenced region - `fence()` gathers whatever the region's steps left (BASELINE's "RCCL only for
+        the final merged-index gather", literally); `region_steps` bounds the steps between two fences.
+    The two events are created once and re-recorded (an event object per step cost a hipEventCreate each).
 
     ctx          the device boundary: enqueue(frames_ptr, n, first_frame_id, out_ptr, out_cap, rec_ptr, md_ptr) and
                  wait_results(stream_handle) (pyrecode_amd._lib.ReduceContext; the CPU test passes a stand-in)
@@ -265,14 +271,21 @@ class ShardedStepLoop:
     device       torch.device: cuda:<local rank> (HIP streams, RCCL) or cpu (no streams, gloo)
     """
 
-    def __init__(self, ctx, batch, frames_of, out, rec, device, collective=True):
+    def __init__(self, ctx, batch, frames_of, out, rec, device, collective=True, gather_every=1, region_steps=1, fence_barrier=False):
         import torch
         self._torch = torch
         self.ctx, self.B, self.frames_of, self.out, self.rec, self.device = ctx, int(batch), frames_of, out, rec, device
         self.dist = _dist() if collective else None
+        # collective=False, fence_barrier=True: no exchange step, but the ranks still meet at the fences (a rehearsal of N host-side
+        # step loops whose timed regions must start and end together)
+        self._fence_dist = self.dist if self.dist else (_dist() if fence_barrier else None)
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
         self.on_gpu = device.type == 'cuda'
+        self.gather_every = int(gather_every)
+        if self.gather_every < 0:
+            raise ValueError('gather_every must be >= 0')
+        self.G = self.gather_every if self.gather_every else max(1, int(region_steps))   # steps a group's buffer holds
         if self.on_gpu:
             if torch.cuda.current_device() != device.index:
                 raise RuntimeError('rank %d: current device cuda:%d is not the loop\'s device %s' % (self.rank, torch.cuda.current_device(), device))
@@ -280,50 +293,76 @@ class ShardedStepLoop:
                 raise RuntimeError('rank %d: ctx lives on cuda:%s, loop on %s' % (self.rank, ctx.device_id, device))
             self.stream = torch.cuda.Stream(device=device)
             self.cstream = torch.cuda.Stream(device=device) if self.dist else None
+            self._events = [torch.cuda.Event(), torch.cuda.Event()] if self.dist else None
         else:
             self.stream, self.cstream = _NullStream(), _NullStream()
-        self.md2 = [torch.zeros((self.B, 3), dtype=torch.int32, device=device) for _ in range(2)]
-        self.md_all2 = [torch.zeros((self.world * self.B, 3), dtype=torch.int32, device=device) for _ in range(2)] if self.dist else None
-        self.gathered = [None, None]
+            self._events = [_NullEvent(), _NullEvent()] if self.dist else None
+        rows = self.G * self.B
+        self.md2 = [torch.zeros((rows, 3), dtype=torch.int32, device=device) for _ in range(2)]
+        self.md_all2 = [torch.zeros((self.world * rows, 3), dtype=torch.int32, device=device) for _ in range(2)] if self.dist else None
+        self.gathered = [None, None]      # the event of the last gather of each buffer (None: never gathered)
+        self._md_ptr = [[m[j * self.B].data_ptr() for j in range(self.G)] for m in self.md2]   # (no tensor indexing in the step loop)
+        self._group, self._pos = 0, 0     # current group, steps it holds so far
+        self.last_gathered = None         # (buffer index, steps in it) of the most recent gather
+        self.gathers_issued = 0
         self.steps_done = 0
 
     def _side(self):
         import contextlib
         return self._torch.cuda.stream(self.cstream) if self.on_gpu else contextlib.nullcontext()
 
-    def step(self, i):
-        k = i & 1
-        if self.dist and self.gathered[k] is not None:
-            self.stream.wait_event(self.gathered[k])   # md2[k] is rewritten below: its previous gather (step i-2) must have read it
-        frames_ptr, first_id = self.frames_of(i)
-        self.ctx.enqueue(frames_ptr, self.B, first_id, self.out.data_ptr(), self.out.numel(), self.rec.data_ptr(), self.md2[k].data_ptr())
-        if self.dist:  # every rank learns every frame's sizes
+    def _gather_group(self):
+        """the current group's rows -> every rank (side stream), then the next group begins"""
+        k = self._group & 1
+        if self.dist and self._pos:
             with self._side():
-                self.ctx.wait_results(self.cstream.cuda_stream)   # the collective's stream waits for this batch's metadata rows
+                self.ctx.wait_results(self.cstream.cuda_stream)   # the collective's stream waits for the group's last batch's metadata rows
                 self.dist.all_gather_into_tensor(self.md_all2[k], self.md2[k])
-                ev = self._torch.cuda.Event() if self.on_gpu else _NullEvent()
-                ev.record(self.cstream)
-                self.gathered[k] = ev
+                self._events[k].record(self.cstream)
+                self.gathered[k] = self._events[k]
+            self.last_gathered = (k, self._pos)
+            self.gathers_issued += 1
+        self._group += 1
+        self._pos = 0
+
+    def step(self, i):
+        k = self._group & 1
+        if self._pos == 0 and self.dist and self.gathered[k] is not None:
+            self.stream.wait_event(self.gathered[k])   # md2[k] is rewritten from here on: its previous gather (two groups back) must have read it
+        frames_ptr, first_id = self.frames_of(i)
+        self.ctx.enqueue(frames_ptr, self.B, first_id, self.out.data_ptr(), self.out.numel(), self.rec.data_ptr(), self._md_ptr[k][self._pos])
+        self._pos += 1
+        if self._pos == self.G:       # (gather_every = 0: only when a region outgrows region_steps - the buffer is full)
+            self._gather_group()
         self.steps_done = i + 1
 
+    def flush(self):
+        """gather a group the steps so far have left incomplete (gather_every = 0: the region's ONE gather)"""
+        if self._pos:
+            self._gather_group()
+
     def fence(self):
-        """Barrier + device synchronize on both sides: what brackets a timed region."""
+        """Barrier + device synchronize on both sides: what brackets a timed region.  Every step's rows have been gathered when it
+        returns (the exchange belongs to the region it closes)."""
+        self.flush()
         if self.on_gpu:
             self._torch.cuda.synchronize(self.device)
-        if self.dist:
-            self.dist.barrier()
+        if self._fence_dist:
+            self._fence_dist.barrier()
         if self.on_gpu:
             self._torch.cuda.synchronize(self.device)
 
     def verify_gather(self):
-        """After fence(): the table the LAST step gathered asynchronously must hold EVERY rank's rows of that step at that
+        """After fence(): the table the LAST gather filled asynchronously must hold EVERY rank's rows of that group at that
         rank's block, on every rank.  Checked against a second, synchronous gather of the same rows; the verdicts are
         combined (min over ranks), so every rank returns the same answer."""
         if not self.dist:
             return None
-        torch, k = self._torch, (self.steps_done - 1) & 1
-        mine = self.md2[k]
-        own = torch.equal(self.md_all2[k][self.rank * self.B:(self.rank + 1) * self.B], mine)
+        if self.last_gathered is None:
+            return False
+        torch, (k, _) = self._torch, self.last_gathered
+        mine, rows = self.md2[k], self.G * self.B
+        own = torch.equal(self.md_all2[k][self.rank * rows:(self.rank + 1) * rows], mine)
         blocks = [torch.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(blocks, mine)
         whole = torch.equal(self.md_all2[k], torch.cat(blocks, dim=0))

@@ -69,3 +69,36 @@ def test_bench_launches_its_own_ranks():
     assert d["config"]["collective_ranks"] == 2 and d["config"]["collective_backend"] == "gloo" and d["config"]["shared_gpu_rehearsal"] is True
     assert d["config"]["launch"].startswith("bench.py started its own ranks")
     assert d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_bench_fails_when_a_record_fails_the_check():
+    """`verified: false` must be an exit code, not only a field: with one byte of a checked record flipped (test switch
+    RC_BENCH_CORRUPT_RECORD) the line still appears and says false, and the process returns non-zero.  Without the switch every
+    distinct batch of the stack has one record checked."""
+    args = [sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--stack", "64", "--batch", "16", "--no-cpu-baseline", "--no-ingest",
+            "--min-seconds", "0.1"]
+    d = _run(args)
+    assert d["verified"] is True and len(d["records_checked"]) == 4 and sorted(c["batch"] for c in d["records_checked"]) == [0, 1, 2, 3]
+    assert all(c["ok"] for c in d["records_checked"])
+    assert d["host_enqueue_us_per_step"] > 0 and d["roofline"]["pattern_floor_ms"]["reads_only"] > 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RC_BENCH_CORRUPT_RECORD="1")
+    p = subprocess.run(args, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0, "a corrupted record went unnoticed"
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["verified"] is False
+    assert "verified: false" in p.stderr.decode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather_every", [0, 3])
+def test_bench_gather_every(gather_every):
+    """Two ranks on the one GPU (gloo rehearsal): the metadata gather once per timed region (0) and every third step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "7", "--warmup", "2", "--stack", "32", "--batch", "16", "--min-seconds", "0.1",
+           "--shared-gpu", "--dist-backend", "gloo", "--gather-every", str(gather_every)]
+    p = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["gather_verified"] is True and d["config"]["gather_every"] == gather_every

@@ -143,22 +143,66 @@ LOOP_WORKER = textwrap.dedent("""
         t[:, 2] = r + 1
         return t
 
-    ctx = StubCtx()
     out, rec = torch.zeros(64, dtype=torch.uint8), torch.zeros(B + 1, dtype=torch.int64)
+    nsteps = 7
+
+    def group_rows(r, steps, G):            # a rank's block of a gathered table: the group's steps, then what an earlier group left there
+        t = np.zeros((G * B, 3), np.int32)
+        for j, i in enumerate(steps):
+            t[j * B:(j + 1) * B] = rows(r, i)
+        return t
+
+    # gather_every = 1: one collective per step, double-buffered (the form of rounds 1-3)
+    ctx = StubCtx()
     loop = ShardedStepLoop(ctx, B, lambda i: (7 * i + rank, rank * 1000 + i * B), out, rec, torch.device("cpu"))
     assert loop.world == world and loop.rank == rank
-    nsteps = 7
     loop.fence()
     for i in range(nsteps):
         loop.step(i)
     loop.fence()
-    assert ctx.waits == nsteps
+    assert ctx.waits == nsteps and loop.gathers_issued == nsteps
     for i in (nsteps - 1, nsteps - 2):       # both buffers: the last step's table and the one before it
         want = np.concatenate([rows(r, i) for r in range(world)])
         assert np.array_equal(loop.md_all2[i & 1].numpy(), want), (rank, i)
     assert loop.verify_gather() is True
     if rank == world - 1:                    # one rank's table damaged: EVERY rank must learn it
         loop.md_all2[(nsteps - 1) & 1][0, 0] += 1
+    assert loop.verify_gather() is False
+
+    # gather_every = 3: groups of three steps; the fence gathers the incomplete last group (7 = 3 + 3 + 1)
+    ctx = StubCtx()
+    loop = ShardedStepLoop(ctx, B, lambda i: (7 * i + rank, rank * 1000 + i * B), out, rec, torch.device("cpu"), gather_every=3)
+    loop.fence()
+    for i in range(nsteps):
+        loop.step(i)
+        assert loop.gathers_issued == (i + 1) // 3
+    loop.fence()
+    assert loop.gathers_issued == 3 and ctx.waits == 3
+    want1 = np.concatenate([group_rows(r, [3, 4, 5], 3) for r in range(world)])           # group 1 -> buffer 1
+    assert np.array_equal(loop.md_all2[1].numpy(), want1)
+    want2 = np.concatenate([np.concatenate([rows(r, 6), rows(r, 1), rows(r, 2)]) for r in range(world)])   # group 2 (step 6) over group 0's rows
+    assert np.array_equal(loop.md_all2[0].numpy(), want2)
+    assert loop.verify_gather() is True
+
+    # gather_every = 0: ONE gather per fenced region (BASELINE: "RCCL only for the final merged-index gather")
+    ctx = StubCtx()
+    loop = ShardedStepLoop(ctx, B, lambda i: (7 * i + rank, rank * 1000 + i * B), out, rec, torch.device("cpu"), gather_every=0, region_steps=nsteps)
+    loop.fence()
+    assert loop.gathers_issued == 0
+    for region, n_here in enumerate((nsteps, nsteps - 2)):      # a full region (its last step issues the gather), a shorter one (the fence does)
+        first = region * nsteps
+        for i in range(n_here):
+            loop.step(first + i)
+            assert loop.gathers_issued == region + (1 if i + 1 == nsteps else 0)
+        loop.fence()
+        assert loop.gathers_issued == region + 1 and ctx.waits == region + 1
+        steps = list(range(first, first + n_here))
+        want = np.concatenate([group_rows(r, steps, nsteps) for r in range(world)])
+        assert np.array_equal(loop.md_all2[region & 1].numpy()[:, :], want) if n_here == nsteps else \
+            all(np.array_equal(loop.md_all2[region & 1].numpy()[r * nsteps * B:r * nsteps * B + n_here * B], group_rows(r, steps, n_here)) for r in range(world))
+    assert loop.verify_gather() is True
+    if rank == 0:
+        loop.md_all2[1][3, 1] ^= 1
     assert loop.verify_gather() is False
     dist.destroy_process_group()
 """)

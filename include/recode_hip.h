@@ -86,9 +86,17 @@ int rc_ctx_set_l2_statistics(rc_ctx *ctx, uint32_t l2_statistics);
  * stream, whose handle is 0, cannot be selected: use a created stream). */
 int rc_ctx_set_stream(rc_ctx *ctx, void *hip_stream);
 
-/* thr = calibration frame + epsilon in uint16 arithmetic (wraps mod 2^16 like NumPy 2):
- * ReCoDeWriter.__init__, recode_writer.py:126-137.  dark: uint16[ny*nx], C order. */
-int rc_set_dark(rc_ctx *ctx, const uint16_t *dark, int64_t epsilon);
+/* Bytes per SOURCE pixel: 2 (default: uint16 frames and dark) or 1 (uint8 frames and dark - what the reference's map_dtype yields for
+ * source_bit_depth <= 8, misc.py:41-49; its Python path takes them, recode_writer.py:126-137,352-354,437-440, only use_c is uint16-only,
+ * :85-87).  Call before rc_set_dark and the first batch.  With 1, every `frames` / `dark` pointer below is uint8[...][ny][nx], a raw
+ * frame is ny*nx bytes (rc_out_capacity, the record bound of recode_writer.py:565-566) and the frame loads move half the bytes;
+ * everything behind the loads (values, d-bit packing, codecs, records) is the same path.  4 (source_bit_depth > 16): RC_ERR_UNSUPPORTED. */
+int rc_ctx_set_source_bytes(rc_ctx *ctx, uint32_t bytes_per_pixel);
+uint32_t rc_ctx_source_bytes(const rc_ctx *ctx);
+
+/* thr = calibration frame + epsilon in the source dtype's arithmetic (wraps mod 2^16 - mod 2^8 for uint8 sources - like NumPy 2):
+ * ReCoDeWriter.__init__, recode_writer.py:126-137.  dark: uint16[ny*nx] (uint8[ny*nx] after rc_ctx_set_source_bytes(ctx, 1)), C order. */
+int rc_set_dark(rc_ctx *ctx, const void *dark, int64_t epsilon);
 /* Or hand over the finished threshold frame (self._calibration_frame_p_threshold). */
 int rc_set_threshold(rc_ctx *ctx, const uint16_t *thr);
 
@@ -99,7 +107,7 @@ uint64_t rc_out_capacity(const rc_ctx *ctx, uint32_t n);
 uint32_t rc_md_fields(const rc_ctx *ctx);
 
 /* n frames in, n part-file records out.
- *   frames         uint16[n][ny][nx] C order (host or device)
+ *   frames         uint16[n][ny][nx] C order (host or device); uint8[n][ny][nx] after rc_ctx_set_source_bytes(ctx, 1)
  *   first_frame_id absolute_frame_index of frames[0] (recode_writer.py:385); frame i gets first_frame_id + i
  *   out            records back to back, byte-identical in layout to what _write_to_frame_buffer assembles
  *                  (recode_writer.py:485-494,518-525,546-550):
@@ -114,14 +122,14 @@ uint32_t rc_md_fields(const rc_ctx *ctx);
  *   md             uint32[n][3]: the record's metadata fields after frame_id, zero padded to 3
  * Synchronous: returns after the records (and offsets, md) are readable by the caller.
  * RC_ERR_RECORD_TOO_LARGE / RC_ERR_OUT_TOO_SMALL leave out undefined. */
-int rc_reduce_compress_batch(rc_ctx *ctx, const uint16_t *frames, uint32_t n, uint32_t first_frame_id,
+int rc_reduce_compress_batch(rc_ctx *ctx, const void *frames, uint32_t n, uint32_t first_frame_id,
                              uint8_t *out, uint64_t out_cap, uint64_t *rec_offsets, uint32_t *md);
 
 /* Asynchronous form for device-resident pipelines: every pointer must be device memory; work is enqueued on the
  * ctx's stream and nothing is read back.  rc_ctx_sync waits for all enqueued batches and returns RC_OK, or the status
  * of the FIRST batch that failed since the previous sync (RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL,
  * RC_ERR_WORKSPACE; rc_last_error names the batch and frame); later batches are unaffected by an earlier failure. */
-int rc_reduce_compress_batch_async(rc_ctx *ctx, const uint16_t *frames_dev, uint32_t n, uint32_t first_frame_id,
+int rc_reduce_compress_batch_async(rc_ctx *ctx, const void *frames_dev, uint32_t n, uint32_t first_frame_id,
                                    uint8_t *out_dev, uint64_t out_cap, uint64_t *rec_offsets_dev, uint32_t *md_dev);
 int rc_ctx_sync(rc_ctx *ctx);
 
@@ -161,7 +169,7 @@ void *rc_host_alloc(uint64_t bytes);
 int rc_host_free(void *p);
 int rc_host_register(void *p, uint64_t bytes);
 int rc_host_unregister(void *p);
-int rc_pipe_submit(rc_ctx *ctx, uint32_t slot, const uint16_t *frames_host, uint32_t n, uint32_t first_frame_id);
+int rc_pipe_submit(rc_ctx *ctx, uint32_t slot, const void *frames_host, uint32_t n, uint32_t first_frame_id);
 int rc_pipe_input_done(rc_ctx *ctx, uint32_t slot);
 int rc_pipe_result(rc_ctx *ctx, uint32_t slot, uint64_t *rec_offsets, uint32_t *md, uint64_t *total);
 int rc_pipe_fetch(rc_ctx *ctx, uint32_t slot, uint8_t *dst_host, uint64_t bytes);

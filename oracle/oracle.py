@@ -64,7 +64,10 @@ def _c16(a):
 
 # ---- per-stage restatements -------------------------------------------------------------------
 def threshold(dark, eps):
-    """A1: recode_writer.py:126-127."""
+    """A1: recode_writer.py:126-127.  uint8 darks (source_bit_depth <= 8, misc.py:41-49): the sum stays uint8 and wraps mod 2^8 under
+    NumPy 2 (numpy restatement; the C loop below is the uint16 case)."""
+    if np.asarray(dark).dtype == np.uint8:
+        return ((np.asarray(dark).astype(np.uint16) + (int(eps) & 0xFF)) & 0xFF).astype(np.uint8)
     dark = _c16(dark)
     thr = np.empty_like(dark)
     lib().orc_threshold(_p(dark, C.c_uint16), int(eps), dark.size, _p(thr, C.c_uint16))

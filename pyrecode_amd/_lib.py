@@ -32,6 +32,8 @@ SIGNATURES = {
     "rc_ctx_create": (C.c_void_p, [C.c_uint32] * 7 + [C.c_int, C.c_uint32, C.POINTER(C.c_int)]),
     "rc_ctx_destroy": (C.c_int, [C.c_void_p]),
     "rc_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rc_ctx_set_source_bytes": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rc_ctx_source_bytes": (C.c_uint32, [C.c_void_p]),
     "rc_set_dark": (C.c_int, [C.c_void_p, _u16p, C.c_int64]),
     "rc_set_threshold": (C.c_int, [C.c_void_p, _u16p]),
     "rc_out_capacity": (C.c_uint64, [C.c_void_p, C.c_uint32]),
@@ -169,8 +171,13 @@ class ReduceContext:
     """One writer's device state: rc_ctx_create .. rc_ctx_destroy.  Mirrors what ReCoDeWriter.start() sets up
     (reference recode_writer.py:212-230) plus the threshold frame of __init__ (:126-137)."""
 
-    def __init__(self, nx, ny, src_bit_depth, reduction_level=1, op_mode=1, scheme=2, clevel=1, device_id=0, max_batch=16):
+    def __init__(self, nx, ny, src_bit_depth, reduction_level=1, op_mode=1, scheme=2, clevel=1, device_id=0, max_batch=16, src_dtype=np.uint16):
+        """src_dtype: numpy dtype of the frames and the dark frame - uint16, or uint8 (source_bit_depth <= 8: rc_ctx_set_source_bytes)"""
         st = C.c_int(0)
+        self.src_dtype = np.dtype(src_dtype)
+        if self.src_dtype not in (np.dtype(np.uint16), np.dtype(np.uint8)):
+            raise NotImplementedError("source dtype %s: the device path takes uint16 and uint8 frames (32-bit sources, "
+                                      "source_bit_depth > 16, are not implemented on device)" % self.src_dtype)
         self._h = lib().rc_ctx_create(nx, ny, src_bit_depth, reduction_level, op_mode, scheme, clevel, device_id, max_batch,
                                       C.byref(st))
         if not self._h:
@@ -180,6 +187,11 @@ class ReduceContext:
         self.n_pixels = nx * ny
         self.bitmap_bytes = (self.n_pixels + 7) // 8
         self.on_device_codec = bool(op_mode == 1 and lib().rc_scheme_on_device(scheme))
+        if self.src_dtype.itemsize != 2:
+            st = lib().rc_ctx_set_source_bytes(self._h, self.src_dtype.itemsize)
+            if st != RC_OK:
+                self.close()
+                check(st, "rc_ctx_set_source_bytes")
 
     @property
     def handle(self):
@@ -196,7 +208,7 @@ class ReduceContext:
         check(lib().rc_ctx_set_stream(self._h, hip_stream), "rc_ctx_set_stream")
 
     def set_dark(self, dark, epsilon=0):
-        dark = np.ascontiguousarray(dark, dtype=np.uint16) if isinstance(dark, np.ndarray) else dark
+        dark = np.ascontiguousarray(dark, dtype=self.src_dtype) if isinstance(dark, np.ndarray) else dark
         check(lib().rc_set_dark(self._h, ptr(dark), int(epsilon)), "rc_set_dark")
 
     def set_threshold(self, thr):
@@ -207,8 +219,8 @@ class ReduceContext:
         return lib().rc_out_capacity(self._h, n)
 
     def reduce_compress_batch(self, frames, first_frame_id=0, out=None):
-        """frames: uint16[n, ny, nx] (numpy).  Returns (out u8 array, rec_offsets u64[n+1], md u32[n,3])."""
-        frames = np.ascontiguousarray(frames, dtype=np.uint16)
+        """frames: uint16[n, ny, nx] (numpy; uint8 for a ctx of uint8 sources).  Returns (out u8 array, rec_offsets u64[n+1], md u32[n,3])."""
+        frames = np.ascontiguousarray(frames, dtype=self.src_dtype)
         n = frames.shape[0]
         if out is None:
             out = np.empty(self.out_capacity(n), np.uint8)

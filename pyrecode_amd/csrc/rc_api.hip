@@ -26,11 +26,12 @@ struct rc_ctx {
     bool pipelined = false;
     bool thr_set = false;
     bool keep_bitmap = true;  // also store the raw binary maps when a device codec is active (rc_get_binary_map)
+    uint32_t src_bytes = 2;   // bytes per source pixel: 2 (uint16 frames and dark) or 1 (uint8: rc_ctx_set_source_bytes)
     uint32_t last_n = 0;
     // staging for host callers
-    uint16_t *d_frames = nullptr; uint64_t d_frames_cap = 0;
+    uint8_t *d_frames = nullptr;  uint64_t d_frames_cap = 0;
     uint8_t *d_out = nullptr;     uint64_t d_out_cap = 0;
-    uint16_t *d_dark = nullptr;   uint64_t d_dark_cap = 0;
+    uint8_t *d_dark = nullptr;    uint64_t d_dark_cap = 0;
     uint64_t *d_rec_off = nullptr;
     uint32_t *d_md = nullptr;
     void *d_ztab = nullptr;               // zstd FSE tables (emit == 1)
@@ -50,7 +51,7 @@ struct rc_ctx {
     bool profile_all = getenv("RC_PROFILE_ALL_STAGES") != nullptr;
     // host streaming form (rc_pipe_*): per slot device buffers, pinned metadata, events
     struct PipeSlot {
-        uint16_t *d_in = nullptr;
+        uint8_t *d_in = nullptr;
         uint8_t *d_out = nullptr;
         uint64_t *d_rec = nullptr, *h_rec = nullptr;
         uint32_t *d_md = nullptr, *h_md = nullptr;
@@ -361,25 +362,40 @@ RC_EXPORT int rc_set_threshold(rc_ctx *c, const uint16_t *thr)
     return RC_OK;
 }
 
-RC_EXPORT int rc_set_dark(rc_ctx *c, const uint16_t *dark, int64_t epsilon)
+RC_EXPORT int rc_set_dark(rc_ctx *c, const void *dark, int64_t epsilon)
 {
     if (!c || !dark) return fail(RC_ERR_BAD_ARG, "ctx / dark is NULL");
     RC_ON_DEVICE(c->device);
-    const uint16_t *src = dark;
+    const void *src = dark;
+    const uint64_t bytes = c->sc.N * c->src_bytes;
     if (!is_device_ptr(dark)) {
-        int r = ensure(c->d_dark, c->d_dark_cap, c->sc.N * 2);
+        int r = ensure(c->d_dark, c->d_dark_cap, bytes);
         if (r != RC_OK) return r;
-        HIP_TRY(hipMemcpyAsync(c->d_dark, dark, c->sc.N * 2, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_dark, dark, bytes, hipMemcpyHostToDevice, c->stream));
         src = c->d_dark;
     }
-    rc::launch_threshold(src, epsilon, c->sc.N, c->sc.thr, c->stream);
+    rc::launch_threshold(src, epsilon, c->sc.N, c->sc.thr, c->stream, c->src_bytes);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->thr_set = true;
     return RC_OK;
 }
 
-RC_EXPORT uint64_t rc_out_capacity(const rc_ctx *c, uint32_t n) { return c ? (uint64_t)n * c->sc.N * 2 : 0; }
+// Source pixels of one byte (source_bit_depth <= 8: the reference's map_dtype gives uint8 frames and dark, misc.py:41-49).  Before
+// rc_set_dark and the first batch; everything behind the frame loads is the same path (values, packing, codecs, records).
+RC_EXPORT int rc_ctx_set_source_bytes(rc_ctx *c, uint32_t bytes_per_pixel)
+{
+    if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
+    if (bytes_per_pixel == 4) return fail(RC_ERR_UNSUPPORTED, "rc_ctx_set_source_bytes: 32-bit sources (source_bit_depth > 16) are not implemented on device");
+    if (bytes_per_pixel != 1 && bytes_per_pixel != 2) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: 1 (uint8) or 2 (uint16)");
+    if (bytes_per_pixel == 1 && c->depth > 8) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: uint8 sources need src_bit_depth <= 8");
+    if (c->batch_seq || c->thr_set) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: call before rc_set_dark / rc_set_threshold and the first batch");
+    c->src_bytes = bytes_per_pixel;
+    return RC_OK;
+}
+RC_EXPORT uint32_t rc_ctx_source_bytes(const rc_ctx *c) { return c ? c->src_bytes : 0; }
+
+RC_EXPORT uint64_t rc_out_capacity(const rc_ctx *c, uint32_t n) { return c ? (uint64_t)n * c->sc.N * c->src_bytes : 0; }
 
 RC_EXPORT uint32_t rc_md_fields(const rc_ctx *c)
 {
@@ -392,7 +408,7 @@ RC_EXPORT uint32_t rc_md_fields(const rc_ctx *c)
 // Modelled zstd: fit the ctx's tables to (up to two frames of) its first batch.  The sample is tokenized by the plain encoder
 // into the scratch set the batch is about to use, k_zstd_sample turns the slots into histograms, the host builds the model
 // (rc_zstd_model.h).  Synchronous, once per ctx; every later frame carries this model's descriptions.
-static int fit_model(rc_ctx *c, const uint16_t *frames_dev, uint32_t n)
+static int fit_model(rc_ctx *c, const void *frames_dev, uint32_t n)
 {
     using namespace rc;
     hipStream_t s = c->stream;
@@ -401,7 +417,7 @@ static int fit_model(rc_ctx *c, const uint16_t *frames_dev, uint32_t n)
     for (int k = 0; k < 2; ++k)
         if (c->post_pending[k]) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
     HIP_TRY(hipMemsetAsync(c->d_sample, 0, sizeof(ZstdSample), s));
-    launch_reduce(sc, frames_dev, ns, c->level == 3 ? 3u : 1u, 1u, false, c->depth, s);
+    launch_reduce(sc, frames_dev, ns, c->level == 3 ? 3u : 1u, 1u, false, c->depth, s, nullptr, c->src_bytes);
     launch_zstd_sample(sc, ns, c->level == 1, c->depth, c->d_sample, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_sample, c->d_sample, sizeof(ZstdSample), hipMemcpyDeviceToHost, s));
@@ -427,7 +443,7 @@ static int fit_model(rc_ctx *c, const uint16_t *frames_dev, uint32_t n)
     return RC_OK;
 }
 
-static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint32_t first_frame_id, uint8_t *out_dev,
+static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t first_frame_id, uint8_t *out_dev,
                          uint64_t out_cap, uint64_t *rec_off_dev, uint32_t *md_dev, bool timed)
 {
     using namespace rc;
@@ -440,7 +456,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     rp.level = c->level == 3 ? 3u : 1u;  // level 2 records are framed exactly like level 1 (statistics in place of residuals)
     rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
     rp.packed_slots = c->level == 1 ? 1u : 0u;
-    rp.frame_bytes = c->sc.N * 2;
+    rp.frame_bytes = c->sc.N * c->src_bytes;   // a record may not exceed the raw frame (recode_writer.py:565-566)
     hipEvent_t *ev = nullptr;
     if (timed) ev = c->ev;
     else if (c->profiling) {
@@ -477,7 +493,7 @@ static int enqueue_batch(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint
     }
     // codec of the fused block encoder: 1 zstd fast, 3 zstd modelled, 2 LZ4 runs (compression_level 0), 4 LZ4 events (>= 1), 8 blosc
     const uint32_t codec = c->modelled ? 3u : (c->emit == RC_SCHEME_LZ4 && c->clevel != 0 ? 4u : c->emit);
-    launch_reduce(sc, frames_dev, n, c->level, codec, c->keep_bitmap || c->emit == 0, c->depth, s, tail);
+    launch_reduce(sc, frames_dev, n, c->level, codec, c->keep_bitmap || c->emit == 0, c->depth, s, tail, c->src_bytes);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);
@@ -530,7 +546,7 @@ static int check_batch_args(rc_ctx *c, const void *frames, uint32_t n, const voi
     return RC_OK;
 }
 
-RC_EXPORT int rc_reduce_compress_batch_async(rc_ctx *c, const uint16_t *frames_dev, uint32_t n, uint32_t first_frame_id,
+RC_EXPORT int rc_reduce_compress_batch_async(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t first_frame_id,
                                              uint8_t *out_dev, uint64_t out_cap, uint64_t *rec_offsets_dev, uint32_t *md_dev)
 {
     int r = check_batch_args(c, frames_dev, n, out_dev, rec_offsets_dev, md_dev);
@@ -591,14 +607,14 @@ RC_EXPORT int rc_ctx_sync(rc_ctx *c)
     return RC_OK;
 }
 
-RC_EXPORT int rc_reduce_compress_batch(rc_ctx *c, const uint16_t *frames, uint32_t n, uint32_t first_frame_id, uint8_t *out,
+RC_EXPORT int rc_reduce_compress_batch(rc_ctx *c, const void *frames, uint32_t n, uint32_t first_frame_id, uint8_t *out,
                                        uint64_t out_cap, uint64_t *rec_offsets, uint32_t *md)
 {
     int r = check_batch_args(c, frames, n, out, rec_offsets, md);
     if (r != RC_OK) return r;
     RC_ON_DEVICE(c->device);
-    const uint64_t frame_bytes = c->sc.N * 2;
-    const uint16_t *fdev = frames;
+    const uint64_t frame_bytes = c->sc.N * c->src_bytes;
+    const void *fdev = frames;
     if (!is_device_ptr(frames)) {
         r = ensure(c->d_frames, c->d_frames_cap, (uint64_t)n * frame_bytes);
         if (r != RC_OK) return r;
@@ -674,7 +690,7 @@ static int pipe_slot_init(rc_ctx *c, rc_ctx::PipeSlot &p)
     const uint64_t B = c->max_batch;
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!c->d2h_stream) HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void **)&p.d_in, B * c->sc.N * 2 + 64));
+    HIP_TRY(hipMalloc((void **)&p.d_in, B * c->sc.N * c->src_bytes + 64));
     HIP_TRY(hipMalloc((void **)&p.d_out, rc_out_capacity(c, (uint32_t)B) + 64));
     HIP_TRY(hipMalloc((void **)&p.d_rec, (B + 1) * 8));
     HIP_TRY(hipMalloc((void **)&p.d_md, B * 12));
@@ -710,7 +726,7 @@ RC_EXPORT int rc_pipe_validation(rc_ctx *c, uint32_t slot, uint32_t *counts)
     return RC_OK;
 }
 
-RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const uint16_t *frames_host, uint32_t n, uint32_t first_frame_id)
+RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const void *frames_host, uint32_t n, uint32_t first_frame_id)
 {
     if (!c || !frames_host || slot >= RC_PIPE_SLOTS) return fail(RC_ERR_BAD_ARG, "NULL argument / slot out of range");
     if (n == 0 || n > c->max_batch) return fail(RC_ERR_BAD_ARG, "n must be in 1..max_batch");
@@ -730,17 +746,17 @@ RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const uint16_t *frames_ho
     // Page-locked (or registered) frames are read by the reduce kernel IN PLACE, over the link: every frame byte is needed
     // exactly once, by wide nontemporal loads, so a copy into device memory first would only add a pass (and the copy
     // engines moved 26-31 GB/s here where the kernel's own reads move what the link gives).  RC_PIPE_COPY=1 forces the copy.
-    const uint16_t *fdev = nullptr;
+    const void *fdev = nullptr;
     static const bool force_copy = getenv("RC_PIPE_COPY") != nullptr;
     if (!force_copy) {
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, frames_host) == hipSuccess) {
-            if (a.type == hipMemoryTypeHost && a.devicePointer) fdev = reinterpret_cast<const uint16_t *>(a.devicePointer);
+            if (a.type == hipMemoryTypeHost && a.devicePointer) fdev = a.devicePointer;
         } else (void)hipGetLastError();
     }
     p.zero_copy = fdev != nullptr;
     if (!fdev) {
-        HIP_TRY(hipMemcpyAsync(p.d_in, frames_host, (uint64_t)n * c->sc.N * 2, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(p.d_in, frames_host, (uint64_t)n * c->sc.N * c->src_bytes, hipMemcpyHostToDevice, c->copy_stream));
         HIP_TRY(hipEventRecord(p.ev_h2d, c->copy_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, p.ev_h2d, 0));
         fdev = p.d_in;
@@ -749,7 +765,7 @@ RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const uint16_t *frames_ho
     if (r != RC_OK) return r;
     p.has_val = c->val_gap != 0;
     if (p.has_val) {   // validation frames of this batch: the dose-rate count, from the frames the reduce kernel has just read
-        rc::launch_roi_components(fdev, c->sc.thr, c->sc.N, c->nx, n, first_frame_id, c->val_gap, c->val_x0, c->val_y0, c->val_w, c->val_h, p.d_val, c->stream);
+        rc::launch_roi_components(fdev, c->sc.thr, c->sc.N, c->nx, n, first_frame_id, c->val_gap, c->val_x0, c->val_y0, c->val_w, c->val_h, p.d_val, c->stream, c->src_bytes);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(p.h_val, p.d_val, (uint64_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(p.ev_val, c->stream));

@@ -67,12 +67,13 @@ struct RecordParams {
 };
 
 // rc_reduce.hip
-void launch_threshold(const uint16_t *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s);
+void launch_threshold(const void *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s, uint32_t src_bytes = 2);   // dark: uint16, or uint8 for src_bytes 1
 // codec: 0 none, 2 LZ4, 1 zstd (plain), 3 zstd (modelled), 8 blosc-lz4.
 // level: 1 residuals, 2 raw values of the set pixels (input of launch_l2), 3 bitmap only.  depth < 16 (level 1 only):
 // every tile's residuals are left in its slot already bit-packed (tile-local LSB-first stream of depth-bit fields)
-void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
-                   uint32_t depth, hipStream_t s, hipStream_t s_tail = nullptr);
+// src_bytes: bytes per source pixel - 2 (uint16 frames) or 1 (uint8 frames, source_bit_depth <= 8)
+void launch_reduce(const Scratch &sc, const void *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
+                   uint32_t depth, hipStream_t s, hipStream_t s_tail = nullptr, uint32_t src_bytes = 2);
 // rc_l2.hip
 void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s);
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);
@@ -111,6 +112,6 @@ void launch_zstd_gather(const Scratch &sc, uint8_t *out, hipStream_t s);
 size_t zstd_tables_bytes();
 void zstd_tables_host(void *dst);  // rc_reduce.hip: FLG | BD << 8 | HC << 16
 
-void launch_roi_components(const uint16_t *frames, const uint16_t *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
-                           uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t *counts, hipStream_t s);
+void launch_roi_components(const void *frames, const uint16_t *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
+                           uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t *counts, hipStream_t s, uint32_t src_bytes = 2);
 }  // namespace rc

@@ -38,6 +38,10 @@ __device__ unsigned long long g_phase[16];
 #ifndef RC_ABLATE
 #define RC_ABLATE 0
 #endif
+#ifndef RC_FUSED12
+#define RC_FUSED12 1   // d = 12: compaction and bit packing in one step (compact_pack12); 0 = compact, then pack_stage (A/B builds)
+#endif
+constexpr bool FUSED12 = RC_FUSED12 != 0;
 __device__ uint32_t g_ablate_sink;
 #define RC_ST(bit, lhs, v) do { if (RC_ABLATE & (bit)) { if ((uint32_t)(v) == 0x9E3779B9u) g_ablate_sink = 1; } else { lhs = (v); } } while (0)
 
@@ -68,37 +72,65 @@ __global__ void k_threshold(const uint16_t *__restrict__ dark, uint32_t eps16, u
     for (; i < N; i += stride) thr[i] = (uint16_t)(dark[i] + eps16);
 }
 
-void launch_threshold(const uint16_t *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s)
+// uint8 sources: the sum wraps in the source dtype (numpy 2: uint8 + python int stays uint8, recode_writer.py:127); the device keeps
+// thresholds as uint16 whatever the source
+__global__ void k_threshold8(const uint8_t *__restrict__ dark, uint32_t eps8, uint64_t N, uint16_t *__restrict__ thr)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < N; i += stride) thr[i] = (uint16_t)(uint8_t)(dark[i] + eps8);
+}
+
+void launch_threshold(const void *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s, uint32_t src_bytes)
 {
     uint32_t blocks = (uint32_t)((N + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_threshold, dim3(blocks), dim3(256), 0, s, dark, (uint32_t)((uint64_t)eps & 0xFFFF), N, thr);
+    if (src_bytes == 1)
+        hipLaunchKernelGGL(k_threshold8, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t *>(dark), (uint32_t)((uint64_t)eps & 0xFF), N, thr);
+    else
+        hipLaunchKernelGGL(k_threshold, dim3(blocks), dim3(256), 0, s, static_cast<const uint16_t *>(dark), (uint32_t)((uint64_t)eps & 0xFFFF), N, thr);
 }
 
 // ---- A2+A3+A4: one pass over the frames ------------------------------------------------------------------
 // Load 8 pixels (one bitmap byte) for this lane at pixel index px0; out-of-frame pixels read as `fill`.
-template <bool ALIGNED, bool STREAM>
-__device__ __forceinline__ u32x4 load8(const uint16_t *__restrict__ base, uint64_t px0, uint64_t N, uint16_t fill)
+// SB = bytes per source pixel: 2 (uint16 frames, the reference's use_c restriction and every BASELINE configuration) or 1 (uint8
+// frames: source_bit_depth <= 8, reference misc.py:41-49).  A lane's 8 pixels of a group are one 16-byte / one 8-byte register set.
+template <int SB> struct Src;
+template <> struct Src<2> { typedef uint16_t T; typedef u32x4 X; };
+template <> struct Src<1> { typedef uint8_t T; typedef u32x2 X; };
+// 8 uint8 pixels -> the same 8 pixels as packed uint16 pairs (what the uint16 path loads)
+__device__ __forceinline__ u32x4 widen8(const u32x2 &v)
 {
+    return u32x4{__builtin_amdgcn_perm(0u, v[0], 0x0C010C00u), __builtin_amdgcn_perm(0u, v[0], 0x0C030C02u),
+                 __builtin_amdgcn_perm(0u, v[1], 0x0C010C00u), __builtin_amdgcn_perm(0u, v[1], 0x0C030C02u)};
+}
+__device__ __forceinline__ u32x4 widen8(const u32x4 &v) { return v; }
+
+template <bool ALIGNED, bool STREAM, int SB = 2>
+__device__ __forceinline__ typename Src<SB>::X load8(const typename Src<SB>::T *__restrict__ base, uint64_t px0, uint64_t N, uint32_t fill)
+{
+    typedef typename Src<SB>::X X;
+    constexpr int PER = 4 / SB;   // pixels per dword
     if (ALIGNED) {
         if (px0 < N) {
             // frames are read exactly once (nontemporal); the threshold tile is shared by other workgroups (cached)
-            const u32x4 *p = reinterpret_cast<const u32x4 *>(base + px0);
+            const X *p = reinterpret_cast<const X *>(base + px0);
             return STREAM ? __builtin_nontemporal_load(p) : *p;
         }
-        const uint32_t f2 = fill | ((uint32_t)fill << 16);
-        return u32x4{f2, f2, f2, f2};
-    } else {
-        u32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t k = px0 + 2 * j;
-            const uint32_t lo = k < N ? base[k] : fill;
-            const uint32_t hi = k + 1 < N ? base[k + 1] : fill;
-            v[j] = lo | (hi << 16);
-        }
-        return v;
     }
+    X v;
+#pragma unroll
+    for (int j = 0; j < 8 / PER; ++j) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const uint64_t k = px0 + (uint64_t)(PER * j + e);
+            const uint32_t val = (!ALIGNED && k < N) ? (uint32_t)base[k] : fill;
+            w |= val << (8 * SB * e);
+        }
+        v[j] = w;
+    }
+    return v;
 }
 
 // Results of one (tile, frame) sitting in wave-private LDS / registers until flush_pending writes them out.  The stores are
@@ -144,6 +176,19 @@ __device__ __forceinline__ void vm_issue_loads(u32x4 (&x)[R], const uint16_t *la
                  "global_load_dwordx4 %3, %4, off offset:3072 nt"
                  : "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]) : "v"(p1) : "memory");
 }
+// uint8 frames: a tile is 4 KiB, a group 512 bytes, a lane's 8 pixels one 8-byte load
+__device__ __forceinline__ void vm_issue_loads(u32x2 (&x)[R], const uint8_t *lane_ptr)
+{
+    asm volatile("global_load_dwordx2 %0, %8, off nt\n\t"
+                 "global_load_dwordx2 %1, %8, off offset:512 nt\n\t"
+                 "global_load_dwordx2 %2, %8, off offset:1024 nt\n\t"
+                 "global_load_dwordx2 %3, %8, off offset:1536 nt\n\t"
+                 "global_load_dwordx2 %4, %8, off offset:2048 nt\n\t"
+                 "global_load_dwordx2 %5, %8, off offset:2560 nt\n\t"
+                 "global_load_dwordx2 %6, %8, off offset:3072 nt\n\t"
+                 "global_load_dwordx2 %7, %8, off offset:3584 nt"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]) : "v"(lane_ptr) : "memory");
+}
 // one of the eight (group r): the rolling form re-arms a group's registers as soon as the group has been consumed
 __device__ __forceinline__ void vm_issue_load1(u32x4 &xr, const uint16_t *lane_ptr, int r)
 {
@@ -155,10 +200,24 @@ __device__ __forceinline__ void vm_issue_load1(u32x4 &xr, const uint16_t *lane_p
     default: asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
     }
 }
+__device__ __forceinline__ void vm_issue_load1(u32x2 &xr, const uint8_t *p, int r)
+{
+    switch (r) {
+    case 0: asm volatile("global_load_dwordx2 %0, %1, off nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    case 1: asm volatile("global_load_dwordx2 %0, %1, off offset:512 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    case 2: asm volatile("global_load_dwordx2 %0, %1, off offset:1024 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    case 3: asm volatile("global_load_dwordx2 %0, %1, off offset:1536 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    case 4: asm volatile("global_load_dwordx2 %0, %1, off offset:2048 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    case 5: asm volatile("global_load_dwordx2 %0, %1, off offset:2560 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    case 6: asm volatile("global_load_dwordx2 %0, %1, off offset:3072 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    default: asm volatile("global_load_dwordx2 %0, %1, off offset:3584 nt" : "=&v"(xr) : "v"(p) : "memory"); break;
+    }
+}
 // Wait until at most `later` vector-memory instructions are outstanding, `later` (wave-uniform) being the number issued
 // BEHIND the loads of x; an over-estimate would let the loads through unfinished, so anything unusual waits for everything.
 // The empty statement at the end names the registers as operands: no use of them can be scheduled in front of the wait.
-__device__ __forceinline__ void vm_wait_loads(uint32_t later, u32x4 (&x)[R])
+template <class X>
+__device__ __forceinline__ void vm_wait_loads(uint32_t later, X (&x)[R])
 {
     switch (later) {
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -345,11 +404,54 @@ __device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const u32x
     }
 }
 
+// A3 + A5 in one step for d = 12 (the detector depth of the one acquisition the reference records, BASELINE cfg 5).  After the transpose
+// a lane owns 64 consecutive pixels; its cnt set pixels take the compact indices exc .. exc + cnt - 1, i.e. the stream bits
+// [12 exc, 12 (exc + cnt)).  Rounds of FOUR values per lane: the lane's next four set pixels are found by bit scans (no loop-carried
+// LDS dependency: all four reads of `val` are in flight together), masked to 12 bits and joined to a 48-bit string that is shifted to
+// its place in the stream and ORed into the zeroed stage (LDS atomics; neighbouring lanes share a dword).  The round loop is
+// wave-uniform: it runs while ANY lane has values left - two rounds at 5 % density where the value-at-a-time loop (above all its
+// serial LDS round trips, then pack_stage's own pass over the compact values) made `compaction + pack` the second longest phase of a
+// wave (profiles/r03_reduce_phase_shares.md: 2856 of 9904 ticks at 11520 x 8184, 5 %).  `out`: the wave's 512-byte stage = 341 fields.
+constexpr uint32_t FUSED12_CAP = (uint32_t)(STAGE_CAP * 16 / 12);   // 12-bit fields the stage holds
+__device__ __forceinline__ void compact_pack12(WaveStage *st, const u32x2 &own, uint32_t exc, uint32_t cnt)
+{
+    const int lane = lane_id();
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(st->out);
+    *reinterpret_cast<u32x2 *>(out32 + 2 * lane) = u32x2{0u, 0u};       // 64 x 8 bytes: the whole stage
+    __builtin_amdgcn_wave_barrier();
+    const uint16_t *mine = st->val + 64 * lane;
+    uint64_t q = (uint64_t)own[0] | ((uint64_t)own[1] << 32);
+    uint32_t left = cnt, P = 12u * exc;                                  // values still to move, stream bit of the next one
+    do {
+        uint32_t x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = q ? (uint32_t)__builtin_ctzll(q) : 0u;   // (nothing left: any of the lane's own addresses, value dropped below)
+            q &= q - 1;
+            x[k] = mine[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = (uint32_t)k < left ? (x[k] & 0xFFFu) : 0u;
+        const uint32_t lo = x[0] | (x[1] << 12) | (x[2] << 24), hi = (x[2] >> 8) | (x[3] << 4);
+        const uint32_t w = P >> 5, sh = P & 31u;                         // (sh is a multiple of 4)
+        const uint64_t a = (uint64_t)lo << sh, b = (uint64_t)hi << sh;
+        const uint32_t d0 = (uint32_t)a, d1 = (uint32_t)(a >> 32) | (uint32_t)b, d2 = (uint32_t)(b >> 32);
+        if (left) {
+            __hip_atomic_fetch_or(&out32[w], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (d1) __hip_atomic_fetch_or(&out32[w + 1], d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (d2) __hip_atomic_fetch_or(&out32[w + 2], d2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        left = left > 4u ? left - 4u : 0u;
+        P += 48u;
+    } while (__builtin_amdgcn_ballot_w64(left != 0) != 0);
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One frame of one tile.  x holds the 8 loaded groups of this lane; each group's registers are re-armed with the NEXT frame's load as
 // soon as the group has been consumed (ASMLOAD), so the loads stay one frame ahead with ONE register set.
 // t: the wave's threshold tile, in registers for all BZ frames (keeping it in LDS or re-reading it from L2 was no faster).
-template <bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
-__device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *__restrict__ cur, const uint16_t *__restrict__ next, bool have_next,
+template <bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL, int SB>
+__device__ __forceinline__ void reduce_one_frame(typename Src<SB>::X (&x)[R], const typename Src<SB>::T *__restrict__ cur, const typename Src<SB>::T *__restrict__ next, bool have_next,
                                                  const u32x4 (&t)[R], uint64_t lane_px0, uint64_t N, bool full,
                                                  uint32_t f, uint32_t tile, uint64_t ft, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
@@ -362,12 +464,12 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *
     // x was fetched by vm_issue_loads during the previous frame: wait for those loads, not for the stores issued since
     if (ASMLOAD) vm_wait_loads(stores_behind, x);
     else if (ALIGNED && full) {   // (the partial last tile of a frame / unaligned frames: plain loads, no prefetch)
-        const u32x4 *p = reinterpret_cast<const u32x4 *>(cur + lane_px0);
+        const typename Src<SB>::X *p = reinterpret_cast<const typename Src<SB>::X *>(cur + lane_px0);
 #pragma unroll
         for (int r = 0; r < R; ++r) x[r] = __builtin_nontemporal_load(p + r * (GROUP_PX / 8));
     } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) x[r] = load8<ALIGNED, true>(cur, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
+        for (int r = 0; r < R; ++r) x[r] = load8<ALIGNED, true, SB>(cur, lane_px0 + (uint64_t)r * GROUP_PX, N, 0);
     }
     RC_PHASE(0);
     // residuals (saturating subtract, in place) and the 8-bit mask of this lane's 8 pixels, per group
@@ -375,19 +477,20 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const u32x4 tt = t[r];
+        u32x4 xv = widen8(x[r]);      // (uint8 frames: the 8 pixels as packed uint16 pairs; uint16 frames: the registers themselves)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[r][k] = pk_sub_sat_u16(x[r][k], tt[k]);
+        for (int k = 0; k < 4; ++k) xv[k] = pk_sub_sat_u16(xv[k], tt[k]);
         // 0 / 1 per pixel (packed min with 1), then four chained 16-bit dot products with the bit weights: pixel j -> bit j
         const uint32_t one = 0x00010001u;
         uint32_t M = 0;
 #pragma unroll
         for (int k = 3; k >= 0; --k)
-            M = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pk_min_u16(x[r][k], one)),
+            M = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pk_min_u16(xv[k], one)),
                                        __builtin_bit_cast(u16x2, (uint32_t)((1u << (2 * k)) | (2u << (2 * k + 16)))), M, false);
         m8[r] = M;
         if (LEVEL1) {
             // the group's values in pixel order -> LDS (level 2 keeps the raw frame value: residual + threshold)
-            u32x4 v = x[r];
+            u32x4 v = xv;
             if (RAWVAL) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = pk_add_u16(v[k], tt[k]);
@@ -423,7 +526,11 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *
         const uint32_t cnt = (uint32_t)__builtin_popcount(pend.own[0]) + (uint32_t)__builtin_popcount(pend.own[1]);
         const uint32_t inc = wave_incl_scan(cnt);
         const uint32_t wave_total = wave_last(inc);
-        if (wave_total <= (uint32_t)STAGE_CAP) {
+        bool packed = false;
+        if (FUSED12 && pend.depth == 12 && wave_total <= FUSED12_CAP) {
+            if (wave_total) compact_pack12(st, pend.own, inc - cnt, cnt);
+            packed = true;
+        } else if (wave_total <= (uint32_t)STAGE_CAP) {
             // (the two 32-pixel halves one after the other: 32-bit bit scans, half the instructions of a 64-bit loop body)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -449,7 +556,7 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *
         }
         __builtin_amdgcn_wave_barrier();
         pend.cnt = wave_total;
-        if (pend.depth < 16 && wave_total) pack_stage(pend.buf, wave_total, pend.depth);
+        if (!packed && pend.depth < 16 && wave_total) pack_stage(pend.buf, wave_total, pend.depth);
     }
     RC_PHASE(4);
     if (CODEC == 2) {
@@ -502,10 +609,10 @@ __device__ __forceinline__ void reduce_one_frame(u32x4 (&x)[R], const uint16_t *
 // Workgroup = RWAVES wavefronts.  The wavefronts of this kernel never talk to each other, so the workgroup size is free
 // (measurements in launch_reduce_t).
 // RWAVES = 3 where the kernel's LDS then lets five workgroups (15 waves) share a CU and the step gains from it, 4 elsewhere (launch_reduce_t)
-template <int RWAVES, int BZ, bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL>
+template <int RWAVES, int BZ, bool ALIGNED, bool ASMLOAD, bool LEVEL1, int CODEC, bool KEEP_BITMAP, bool RAWVAL, int SB>
 // (four waves per SIMD = 128 VGPRs, which the steady-state instantiation fits with its one frame register set; the plain-load ones -
 // a frame's partial last tile, N % 8 != 0, a frame pointer that is not 16-byte aligned - take what they need)
-__global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((ALIGNED && ASMLOAD) ? ((RWAVES == 4 && LEVEL1) ? 3 : 4) : 1))) void k_reduce_tiles(const uint16_t *__restrict__ frames,
+__global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((ALIGNED && ASMLOAD) ? ((RWAVES == 4 && LEVEL1) ? 3 : 4) : 1))) void k_reduce_tiles(const typename Src<SB>::T *__restrict__ frames,
                                                        const uint16_t *__restrict__ thr, uint64_t N, uint32_t ntiles,
                                                        uint32_t tile0, uint32_t tile_end,
                                                        uint32_t B, uint32_t ngroups, uint64_t nb,
@@ -539,11 +646,11 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
     if (f0 >= B) return;
     const bool full = (uint64_t)(tile + 1) * TILE_PX <= N;  // wave-uniform (always true in the ASMLOAD instantiation)
 
-    u32x4 xa[R];
+    typename Src<SB>::X xa[R];
     if (ASMLOAD) vm_issue_loads(xa, frames + (uint64_t)f0 * N + lane_px0);
     u32x4 t[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) t[r] = load8<ALIGNED, false>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
+    for (int r = 0; r < R; ++r) t[r] = load8<ALIGNED, false, 2>(thr, lane_px0 + (uint64_t)r * GROUP_PX, N, 0xFFFF);
     const uint32_t n_blk = (uint32_t)min((uint64_t)TILE_BM, nb - (uint64_t)tile * TILE_BM);  // bitmap bytes of this tile
     Lz4Lds *lz = &s_lz[CODEC ? w : 0];
     uint8_t *bm = s_bm[CODEC ? 0 : w];
@@ -563,7 +670,7 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
         const uint32_t f = f0 + z;
         if (f >= B) break;
         const bool nxt = z + 1 < BZ && f + 1 < B;
-        reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL>(xa, frames + (uint64_t)f * N, frames + (uint64_t)(f + 1) * N, nxt, t,
+        reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL, SB>(xa, frames + (uint64_t)f * N, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
                                                                              blk_size, lz, bm, st, pend, stores_behind, zm);
@@ -572,8 +679,8 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
     flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st);
 }
 
-template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW>
-static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t depth, hipStream_t s, hipStream_t s_tail)
+template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW, int SB>
+static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames, uint32_t B, uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
     const uint32_t ngroups = (B + BZ - 1) / BZ;
     // Workgroup size, measured (bench.py, pipelined, same box; tools/build_def.sh + tools/ab_bench.sh).  With ONE wavefront per
@@ -598,42 +705,44 @@ static void launch_reduce_t(const Scratch &sc, const uint16_t *frames, uint32_t 
         constexpr int RW = decltype(rw)::value;
         auto grid_for = [&](uint32_t nt) { return (((nt + RW - 1) / RW + 7) / 8) * 8 * ngroups; };
         if (nfull)
-            hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, AL, L1, CODEC, KEEP, RAW>), dim3(grid_for(nfull)), dim3(64 * RW), 0, s, frames, sc.thr, sc.N,
+            hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, AL, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(nfull)), dim3(64 * RW), 0, s, frames, sc.thr, sc.N,
                                sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
                                sc.blk_size, depth, sc.status, zm);
         if (nfull < sc.ntiles)   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
-            hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, false, L1, CODEC, KEEP, RAW>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
+            hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, false, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
                                sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
                                sc.blk_slots, sc.blk_size, depth, sc.status, zm);
     };
-    if (three) go(std::integral_constant<int, 3>{});
-    else go(std::integral_constant<int, 4>{});
+    if constexpr (SB == 2) {
+        if (three) { go(std::integral_constant<int, 3>{}); return; }
+    }
+    go(std::integral_constant<int, 4>{});   // (uint8 frames: four-wave workgroups only - half the instantiations)
 }
-template <int BZ, bool AL, bool L1, bool RAW>
-static void launch_reduce_c(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s, hipStream_t s_tail)
+template <int BZ, bool AL, bool L1, bool RAW, int SB>
+static void launch_reduce_c(const Scratch &sc, const typename Src<SB>::T *frames, uint32_t B, uint32_t codec, bool keep, uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
     // raw-value (level 2) instantiations always keep the bitmap: the labelling kernels read it
     if (RAW) keep = true;
 #define RC_CODEC(C)                                                                                          \
     do {                                                                                                     \
-        if (keep) launch_reduce_t<BZ, AL, L1, C, true, RAW>(sc, frames, B, depth, s, s_tail);                \
-        else if (!RAW && C != 0) launch_reduce_t<BZ, AL, L1, C, false, false>(sc, frames, B, depth, s, s_tail); \
+        if (keep) launch_reduce_t<BZ, AL, L1, C, true, RAW, SB>(sc, frames, B, depth, s, s_tail);                \
+        else if (!RAW && C != 0) launch_reduce_t<BZ, AL, L1, C, false, false, SB>(sc, frames, B, depth, s, s_tail); \
     } while (0)
     if (codec == 2) RC_CODEC(2);
     else if (codec == 4) RC_CODEC(4);
     else if (codec == 1) RC_CODEC(1);
     else if (codec == 3) RC_CODEC(3);
     else if (codec == 8) RC_CODEC(8);
-    else launch_reduce_t<BZ, AL, L1, 0, true, RAW>(sc, frames, B, depth, s, s_tail);
+    else launch_reduce_t<BZ, AL, L1, 0, true, RAW, SB>(sc, frames, B, depth, s, s_tail);
 #undef RC_CODEC
 }
-template <int BZ, bool AL>
-static void launch_reduce_a(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep,
+template <int BZ, bool AL, int SB>
+static void launch_reduce_a(const Scratch &sc, const typename Src<SB>::T *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep,
                             uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
-    if (level == 2) launch_reduce_c<BZ, AL, true, true>(sc, frames, B, codec, keep, depth, s, s_tail);
-    else if (level == 1) launch_reduce_c<BZ, AL, true, false>(sc, frames, B, codec, keep, depth, s, s_tail);
-    else launch_reduce_c<BZ, AL, false, false>(sc, frames, B, codec, keep, depth, s, s_tail);
+    if (level == 2) launch_reduce_c<BZ, AL, true, true, SB>(sc, frames, B, codec, keep, depth, s, s_tail);
+    else if (level == 1) launch_reduce_c<BZ, AL, true, false, SB>(sc, frames, B, codec, keep, depth, s, s_tail);
+    else launch_reduce_c<BZ, AL, false, false, SB>(sc, frames, B, codec, keep, depth, s, s_tail);
 }
 #ifdef RC_PHASE_TIMING
 extern "C" __attribute__((visibility("default"))) int rc_debug_phases(unsigned long long *out16)
@@ -647,14 +756,21 @@ extern "C" __attribute__((visibility("default"))) int rc_debug_phases(unsigned l
 #endif
 // s_tail (optional): the stream for the small launch over a frame's partial last tile; it must already be ordered behind
 // whatever produced the frames
-void launch_reduce(const Scratch &sc, const uint16_t *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
-                   uint32_t depth, hipStream_t s, hipStream_t s_tail)
+void launch_reduce(const Scratch &sc, const void *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
+                   uint32_t depth, hipStream_t s, hipStream_t s_tail, uint32_t src_bytes)
 {
     if (depth == 0 || depth > 16) depth = 16;
     if (!s_tail) s_tail = s;
     const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
-    if (aligned) launch_reduce_a<RC_BZ, true>(sc, frames, B, level, codec, keep_bitmap, depth, s, s_tail);
-    else launch_reduce_a<RC_BZ, false>(sc, frames, B, level, codec, keep_bitmap, depth, s, s_tail);
+    if (src_bytes == 1) {   // uint8 frames (source_bit_depth <= 8)
+        const uint8_t *f8 = static_cast<const uint8_t *>(frames);
+        if (aligned) launch_reduce_a<RC_BZ, true, 1>(sc, f8, B, level, codec, keep_bitmap, depth, s, s_tail);
+        else launch_reduce_a<RC_BZ, false, 1>(sc, f8, B, level, codec, keep_bitmap, depth, s, s_tail);
+        return;
+    }
+    const uint16_t *f16 = static_cast<const uint16_t *>(frames);
+    if (aligned) launch_reduce_a<RC_BZ, true, 2>(sc, f16, B, level, codec, keep_bitmap, depth, s, s_tail);
+    else launch_reduce_a<RC_BZ, false, 2>(sc, f16, B, level, codec, keep_bitmap, depth, s, s_tail);
 }
 
 // ---- per-frame scans over tiles ---------------------------------------------------------------------------

@@ -64,9 +64,13 @@ class ReCoDeWriter:
         if not self._input_params.validate():
             raise ValueError('Invalid input params')
         ip = self._input_params
-        if ip.source_numpy_dtype != np.uint16 or ip.target_numpy_dtype != np.uint16:
-            # same restriction the reference places on its native path (recode_writer.py:85-87)
-            raise ValueError('the HIP path requires source and target dtypes to be unsigned 16-bit')
+        # The reference's Python path takes whatever map_dtype yields for (source_data_type, source_bit_depth) - uint8 up to 8 bits, uint16
+        # up to 16, uint32 beyond (misc.py:41-49); only its use_c path is uint16-only (recode_writer.py:85-87).  The device path reads
+        # uint16 and uint8 frames; data handed over in another dtype is cast to the source dtype, as there (:352-354).
+        if np.dtype(ip.source_numpy_dtype) not in (np.dtype(np.uint16), np.dtype(np.uint8)):
+            raise NotImplementedError('source dtype %s (source_data_type %d, source_bit_depth %d): the HIP path takes unsigned sources of up to '
+                                      '16 bits (uint8 / uint16 frames); 32-bit and signed / float sources are not implemented on device'
+                                      % (np.dtype(ip.source_numpy_dtype).name, ip.source_data_type, ip.source_bit_depth))
         if ip.reduction_level not in (1, 2, 3):
             raise NotImplementedError('reduction level 4 (centroiding) is not implemented on device '
                                       '(non-functional in the reference as well, SURVEY.md 0.5)')
@@ -97,7 +101,7 @@ class ReCoDeWriter:
         self._src_dtype = ip.source_numpy_dtype
         if t.dtype != self._src_dtype:
             # reference :131-137 casts after adding epsilon in the dark frame's own dtype; for an integer epsilon
-            # cast-then-add gives the same uint16 frame (floor(x + k) == floor(x) + k), so the sum stays on the device
+            # cast-then-add gives the same frame of the source dtype (floor(x + k) == floor(x) + k), so the sum stays on the device
             warnings.warn('Calibration data type not same as source. Attempting to cast.')
             t = t.astype(self._src_dtype)
         self._calibration_frame = t  # thr = dark + epsilon is formed on the device (rc_set_dark, reference :126-127)
@@ -163,7 +167,8 @@ class ReCoDeWriter:
         if self._batch_size is None:
             self._batch_size = int(max(1, min(64, (1 << 30) // self._frame_sz)))
         self._ctx = _lib.ReduceContext(nx, ny, ip.source_bit_depth, ip.reduction_level, ip.rc_operation_mode,
-                                       ip.compression_scheme, ip.compression_level, self._pick_device(), self._batch_size)
+                                       ip.compression_scheme, ip.compression_level, self._pick_device(), self._batch_size,
+                                       src_dtype=self._src_dtype)
         self._ctx.set_dark(np.ascontiguousarray(self._calibration_frame), ip.calibration_threshold_epsilon)
         if ip.reduction_level == 2:
             self._ctx.set_l2_statistics(ip.L2_statistics)  # 0/1 max, 2 sum (reference :358-365)
@@ -275,7 +280,7 @@ class ReCoDeWriter:
         """Page-locked staging of the streaming form: three input buffers, PIPE_SLOTS output buffers (grown on demand)."""
         if self._pin_in is None:
             B = self._batch_size
-            staged = B * int(self._header['ny']) * int(self._header['nx']) * 2   # the kernel reads uint16, whatever the source dtype
+            staged = B * int(self._header['ny']) * int(self._header['nx']) * np.dtype(self._src_dtype).itemsize   # staged in the source dtype (uint16 / uint8)
             self._pin_in = [_lib.PinnedBuffer(staged) for _ in range(3)]
             self._pin_out = [_lib.PinnedBuffer(max(staged // 8, 1 << 20)) for _ in range(_lib.PIPE_SLOTS)]
 
@@ -288,7 +293,7 @@ class ReCoDeWriter:
         own library call needs the pieces)."""
         from concurrent.futures import ThreadPoolExecutor
         ctx, B = self._ctx, self._batch_size
-        frame_bytes = int(self._header['ny']) * int(self._header['nx']) * 2   # staged as uint16 (copyto casts other source dtypes)
+        frame_bytes = int(self._header['ny']) * int(self._header['nx']) * np.dtype(self._src_dtype).itemsize
         zero = timedelta(0)
         metrics = {k: zero for k in _STAGE_KEYS}
         if n_frames == 0:
@@ -302,7 +307,7 @@ class ReCoDeWriter:
         # (saves the staging copy, costs one page-locking pass over the whole stack up front)
         registered = None
         if self._pin_mode == 'register' and isinstance(data, np.ndarray) and not isinstance(data, np.memmap) \
-                and data.flags['C_CONTIGUOUS'] and data.dtype == np.uint16:
+                and data.flags['C_CONTIGUOUS'] and data.dtype == self._src_dtype:
             try:
                 _lib.check(_lib.lib().rc_host_register(data.ctypes.data, data.nbytes), 'rc_host_register')
                 registered = data.ctypes.data
@@ -323,7 +328,7 @@ class ReCoDeWriter:
                 return data[lo:lo + n]
             if i >= n_in:
                 ctx.pipe_input_done((i - n_in) % slots)
-            view = self._pin_in[i % n_in].array[:n * frame_bytes].view(np.uint16).reshape(n, ny, nx)
+            view = self._pin_in[i % n_in].array[:n * frame_bytes].view(self._src_dtype).reshape(n, ny, nx)
             parts = max(1, min(self._copy_threads * 2, n))
             step = -(-n // parts)
             list(copy_pool.map(lambda a: np.copyto(view[a:a + step], data[lo + a:lo + min(a + step, n)], casting='unsafe'),

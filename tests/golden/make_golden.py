@@ -21,6 +21,7 @@ Fixture groups:
   G7  mode='stream': part files of a writer fed chunk by chunk (recode_writer.py:311-322,422-423)
   G8  validation frames: side file + dose rates      (recode_writer.py:207-211,400-415)
   G9  bz2 / lzma / zlib level 9 / level 3 reduce-only: whole files (recode_compressors.py:82-101)
+  G10 8-bit sources (source dtype uint8, misc.py:41-49): d = 8 (raw bytes) and d = 6 (bit-packed), whole files, one with validation frames
   G4  512-byte header bytes                    (recode_header.py:58-94, 257-275)
   G5  get_frame_sparse triplets                (pyrecode.cpp:95-119, reader.h:10-68)
   G6  321-byte v0.1 header                     (recode_header.py:27-56, 98-127, 257-275)
@@ -363,8 +364,82 @@ def g9():
         print("g9:", tag)
 
 
+# --------------------------------------------------------------------------------------------
+# G10: sources of 8 bits and fewer - the reference's Python path takes whatever map_dtype yields (misc.py:41-49: uint8 for
+# source_bit_depth <= 8); thr, frame > thr and the residuals are uint8 arithmetic, `.tobytes()` is one byte a value at d = 8
+# (recode_writer.py:126-137,437-440,463-464), d = 6 goes through _bit_pack.  Frames handed over as uint16 are cast (:352-354).
+# --------------------------------------------------------------------------------------------
+def synth_stack_u8(seed, nz, ny, nx, sparsity, depth):
+    rng = np.random.default_rng(seed)
+    top = (1 << depth) - 1
+    dark = rng.integers(2, 9, (ny, nx)).astype(np.uint8)
+    frames = np.empty((nz, ny, nx), np.uint8)
+    for z in range(nz):
+        mask = rng.random((ny, nx)) < sparsity
+        amp = rng.integers(1, top - 12, (ny, nx)).astype(np.uint8)
+        below = np.floor(rng.random((ny, nx)) * (dark + 1)).astype(np.uint8)
+        frames[z] = np.where(mask, dark + amp, below)
+    frames[0, 0, 0] = top                      # the largest value the depth holds
+    frames[nz - 1, ny - 1, nx - 1] = top
+    return dark, frames
+
+
+def g10():
+    cases = [
+        # tag      nz ny  nx  s     depth nodes gap  handed over as   overrides
+        ("u8d8",   7, 37, 53, 0.08, 8, 2, -1, np.uint8, dict(calibration_threshold_epsilon=2)),
+        ("u8d6",   5, 24, 40, 0.12, 6, 2, -1, np.uint8, dict()),
+        ("u8d8v",  6, 150, 170, 0.03, 8, 2, 2, np.uint8, dict()),            # validation frames: the side file holds uint8 frames
+        ("u8cast", 4, 24, 40, 0.10, 8, 2, -1, np.uint16, dict()),            # frames handed over as uint16: the writer casts them
+    ]
+    for tag, nz, ny, nx, s, depth, nodes, gap, given, over in cases:
+        tmp = tempfile.mkdtemp()
+        dark, frames = synth_stack_u8(3100 + len(tag) + depth, nz, ny, nx, s, depth)
+        base = "g10_" + tag
+        over = dict(over, source_bit_depth=depth, target_bit_depth=depth)
+        rates, vbytes = [], []
+        for node in range(nodes):
+            ip, cfg = make_params(tmp, num_frames=nz, num_rows=ny, num_cols=nx, num_threads=nodes, **over)
+            w = quiet(ref_writer.ReCoDeWriter, base, dark_data=dark, output_directory=tmp, input_params=ip, mode="batch",
+                      validation_frame_gap=gap, node_id=node)
+            quiet(w.start)
+            m = quiet(w.run, frames.astype(given))
+            quiet(w.close)
+            rates.append(np.asarray(m.get("run_dose_rates", []), np.float64))
+            fn = "%s.rc1_part%03d" % (base, node)
+            shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+            if gap > 0:
+                vbytes.append(np.fromfile(os.path.join(tmp, "%s_part%03d_validation_frames.bin" % (base, node)), np.uint8))
+        fn = base + ".rc1"
+        quiet(ref_reader.merge_parts, tmp, fn, nodes)
+        shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+        rd = ref_reader.ReCoDeReader(os.path.join(tmp, fn), is_intermediate=False)
+        quiet(rd.open, print_header=False)
+        dec = np.zeros_like(frames)
+        dts = set()
+        for z in range(nz):
+            m = quiet(rd.get_frame, z)[z]["data"]
+            dts.add(str(m.dtype))
+            dec[z] = np.asarray(m.todense())
+        rd.close()
+        extra = {}
+        for i, r in enumerate(rates):
+            extra["rates%d" % i] = r
+        for i, v in enumerate(vbytes):
+            extra["vframes%d" % i] = v
+        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
+                            cfg_vals=np.array(list(cfg.values())), n_nodes=nodes, decoded=dec, gap=gap, given=str(np.dtype(given)),
+                            decoded_dtype=",".join(sorted(dts)), **extra)
+        shutil.rmtree(tmp)
+        print("g10:", tag, "decoded dtype", dts, "decoded == where(frame > thr, frame - thr, 0):",
+              bool(np.array_equal(dec, np.where(frames > (dark + cfg["calibration_threshold_epsilon"]).astype(np.uint8),
+                                                  frames - (dark + cfg["calibration_threshold_epsilon"]).astype(np.uint8), 0))))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        g10()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g9":
         g9()
     elif len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8()
@@ -380,3 +455,4 @@ if __name__ == "__main__":
         g7()
         g8()
         g9()
+        g10()

@@ -1155,3 +1155,73 @@ def test_own_iterator_and_readahead_on_one_reader_do_not_share_batches(scheme, t
         assert np.array_equal(dense(z), want[z])
     assert rd.readahead_frames_served > served                            # and it is back afterwards
     rd.close()
+
+
+@pytest.mark.parametrize("tag,gap", [("u8d8", -1), ("u8d6", -1), ("u8d8v", 2), ("u8cast", -1)])
+def test_uint8_sources_reproduce_the_references_files(tag, gap, tmp_path):
+    """G10: files the reference wrote from 8-bit sources (uint8 frames and dark; d = 8 raw bytes, d = 6 bit-packed; validation frames;
+    frames handed over as uint16 and cast) - part files, validation side files, dose rates and merged files byte for byte, and the
+    reader hands back uint8 matrices equal to the reference reader's."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    g = load_npz("g10_%s.npz" % tag)
+    base, nodes = "g10_" + tag, int(g["n_nodes"])
+    frames = g["frames"].astype(np.dtype(str(g["given"])))
+    for node in range(nodes):
+        ip, cfg = _params(tmp_path, g)
+        with __import__("warnings").catch_warnings():
+            __import__("warnings").simplefilter("ignore")
+            w = ReCoDeWriter(base, dark_data=g["dark"], output_directory=str(tmp_path), input_params=ip, mode="batch",
+                             validation_frame_gap=gap, node_id=node, batch_size=2)
+            w.start()
+            m = w.run(frames)
+            w.close()
+        fn = "%s.rc1_part%03d" % (base, node)
+        assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
+        if gap > 0:
+            side = tmp_path / ("%s_part%03d_validation_frames.bin" % (base, node))
+            assert np.array_equal(np.fromfile(side, np.uint8), g["vframes%d" % node])
+            assert np.allclose(np.asarray(m["run_dose_rates"], np.float64), g["rates%d" % node])
+    merged = base + ".rc1"
+    merge_parts(str(tmp_path), merged, nodes)
+    assert (tmp_path / merged).read_bytes() == open(os.path.join(FILES, merged), "rb").read()
+    rd = ReCoDeReader(str(tmp_path / merged))
+    rd.open(print_header=False)
+    for z in range(g["frames"].shape[0]):
+        m = rd.get_frame(z)[z]["data"]
+        assert m.dtype == np.uint8 and np.array_equal(np.asarray(m.todense()), g["decoded"][z])
+    pre, (rows, cols, vals) = rd.get_frames_coo(0, g["frames"].shape[0])
+    img = np.zeros(g["frames"].shape, np.uint8)
+    for z in range(g["frames"].shape[0]):
+        lo, hi = int(pre[z]), int(pre[z + 1])
+        img[z, rows[lo:hi], cols[lo:hi]] = vals[lo:hi]
+    assert np.array_equal(img, g["decoded"])
+    rd.close()
+
+
+def test_uint8_sources_with_a_device_codec_round_trip(tmp_path, orc):
+    """uint8 frames through the streaming writer with the device's own codecs (zstd modelled, LZ4) and back through the batched reader."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    g = load_npz("g10_u8d8.npz")
+    rng = np.random.default_rng(3)
+    ny, nx, nz = 96, 200, 9
+    dark = rng.integers(1, 9, (ny, nx)).astype(np.uint8)
+    frames = np.where(rng.random((nz, ny, nx)) < 0.06, dark + rng.integers(1, 200, (nz, ny, nx)), dark // 2).astype(np.uint8)
+    want = np.where(frames > dark, frames - dark, 0).astype(np.uint8)
+    for scheme in (1, 2):
+        sub = tmp_path / ("s%d" % scheme)
+        sub.mkdir()
+        _write_parts(sub, "u8", dark, frames, 2, g, batch_size=4, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=2,
+                     compression_scheme=scheme, calibration_threshold_epsilon=0)
+        merge_parts(str(sub), "u8.rc1", 2)
+        rd = ReCoDeReader(str(sub / "u8.rc1"))
+        rd.open(print_header=False)
+        got = np.zeros_like(want)
+        for a, pre, (r, c, v) in rd.iter_frames_coo(batch=4):
+            for i in range(len(pre) - 1):
+                lo, hi = int(pre[i]), int(pre[i + 1])
+                got[a + i, r[lo:hi], c[lo:hi]] = v[lo:hi]
+        assert rd.last_batch_path == 'device' and np.array_equal(got, want)
+        for z in range(nz):
+            assert np.array_equal(np.asarray(rd.get_frame(z)[z]["data"].todense()), want[z])
+        rd.close()

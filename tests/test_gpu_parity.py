@@ -1234,3 +1234,75 @@ def test_pipelined_soak(hip, orc, ny, nx, B, rounds, scheme):
             assert torch.equal(outs[k][:e_out.numel()], e_out), "round %d batch %d" % (r, k)
     ctx.set_pipelined(False)
     ctx.close()
+
+
+# ---- uint8 sources (source_bit_depth <= 8: the reference's map_dtype yields uint8 frames and dark, misc.py:41-49) ------------------
+def _synth_u8(seed, nz, ny, nx, sparsity, depth):
+    rng = np.random.default_rng(seed)
+    top = (1 << depth) - 1
+    hi = max(2, min(9, top // 4))
+    dark = rng.integers(1, hi + 1, (ny, nx)).astype(np.uint8)
+    frames = np.empty((nz, ny, nx), np.uint8)
+    for z in range(nz):
+        mask = rng.random((ny, nx)) < sparsity
+        amp = rng.integers(1, max(2, top - hi), (ny, nx)).astype(np.uint8)
+        below = np.floor(rng.random((ny, nx)) * (dark + 1.0)).astype(np.uint8)
+        frames[z] = np.where(mask, dark + amp, below)
+    frames[0].flat[0] = top
+    frames[nz - 1].flat[-1] = top
+    return dark, frames
+
+
+U8_SHAPES = [(ny, nx, s, d8, eps) for (ny, nx, s, _, eps), d8 in zip(SHAPES, (8, 6, 8, 8, 5, 8, 8, 7, 8))]
+
+
+@pytest.mark.parametrize("ny,nx,s,d,eps", U8_SHAPES)
+def test_uint8_sources_reduce_only_records_bit_exact(hip, orc, ny, nx, s, d, eps):
+    """The SHAPES list with uint8 frames and dark (d <= 8) through the uint8 instantiation of the load path: records, metadata and
+    binary maps equal the oracle's on the widened frames (same values, same order; thr wraps mod 2^8)."""
+    dark, frames = _synth_u8(41 + ny, 5, ny, nx, s, d)
+    thr = orc.threshold(dark, eps)
+    assert thr.dtype == np.uint8
+    ctx = hip.ReduceContext(nx, ny, d, 1, 0, 0, 1, 0, max_batch=8, src_dtype=np.uint8)
+    ctx.set_dark(dark, eps)
+    assert ctx.out_capacity(3) == 3 * ny * nx                     # a raw uint8 frame is ny * nx bytes (the record bound)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=100)
+    f16, t16 = frames.astype(np.uint16), thr.astype(np.uint16)
+    for z in range(frames.shape[0]):
+        want, wmd = orc.l1_record(f16[z], t16, d, 100 + z, mode=0)
+        got = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        assert got == want, "frame %d record differs" % z
+        assert md[z, 0] == wmd[0]
+        assert np.array_equal(ctx.binary_map(z), orc.pack_binary_frame(frames[z] > thr))
+    ctx.close()
+
+
+@pytest.mark.parametrize("scheme,clevel", [(2, 1), (2, 0), (1, 1), (1, 0), (8, 1)])
+@pytest.mark.parametrize("ny,nx,s,d,eps", [U8_SHAPES[0], U8_SHAPES[4], U8_SHAPES[5], U8_SHAPES[6]])
+def test_uint8_sources_device_codecs_decode_bit_exact(hip, orc, ny, nx, s, d, eps, scheme, clevel):
+    dark, frames = _synth_u8(57 + nx, 4, ny, nx, s, d)
+    thr = orc.threshold(dark, eps)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, scheme, clevel, 0, max_batch=4, src_dtype=np.uint8)
+    ctx.set_dark(dark, eps)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=9)
+    dec = {2: lambda b, n: orc.lz4f_decode(b, n + 64), 1: lambda b, n: _zstd_system_decode(b), 8: lambda b, n: orc.blosc1_decode(b)}[scheme]
+    for z in range(frames.shape[0]):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        assert fid == 9 + z and (cb, cp, npk) == tuple(int(v) for v in md[z]) and len(r) == 16 + cb + cp
+        binary, pix = orc.binarize_l1(frames[z].astype(np.uint16), thr.astype(np.uint16))
+        bitmap, packed = orc.pack_binary_frame(binary).tobytes(), orc.bit_pack(pix, d).tobytes()
+        assert npk == len(packed) and dec(r[16:16 + cb], len(bitmap)) == bitmap and dec(r[16 + cb:], npk) == packed
+    ctx.close()
+
+
+def test_uint8_source_contexts_refuse_what_they_cannot_take(hip):
+    with pytest.raises(ValueError):                               # uint8 frames cannot carry 12-bit values
+        hip.ReduceContext(64, 64, 12, 1, 0, 0, 1, 0, max_batch=2, src_dtype=np.uint8)
+    with pytest.raises(NotImplementedError):                      # 32-bit sources: not on device, and said so
+        hip.ReduceContext(64, 64, 16, 1, 0, 0, 1, 0, max_batch=2, src_dtype=np.uint32)
+    ctx = hip.ReduceContext(64, 64, 8, 1, 0, 0, 1, 0, max_batch=2)
+    ctx.set_dark(np.zeros((64, 64), np.uint16), 0)
+    assert hip.lib().rc_ctx_set_source_bytes(ctx.handle, 1) == hip.RC_ERR_BAD_ARG     # after the dark frame: too late
+    assert hip.lib().rc_ctx_set_source_bytes(ctx.handle, 4) == hip.RC_ERR_UNSUPPORTED
+    ctx.close()

@@ -118,6 +118,35 @@ def test_g3_records_byte_exact(tag, level):
         assert np.array_equal(g["decoded"], np.where(frames > thr, frames - thr, 0).astype(np.uint16))
 
 
+@pytest.mark.parametrize("tag", ["u8d8", "u8d6", "u8d8v", "u8cast"])
+def test_g10_uint8_sources_records_byte_exact(tag):
+    """G10: the reference's writer on 8-bit sources (source dtype uint8, misc.py:41-49): uint8 threshold sum, compare and residuals
+    (recode_writer.py:126-137,437-440), one byte a value at d = 8 (`.tobytes()`, :463-464), bit-packed at d = 6.  The oracle's uint16
+    restatement on the widened frames must give the same records - values and order are the same, only the container type differs -
+    and the reference's own reader decodes to where(frame > thr, frame - thr, 0) as uint8."""
+    g = load_npz("g10_%s.npz" % tag)
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    dark, frames, nodes = g["dark"], g["frames"], int(g["n_nodes"])
+    assert dark.dtype == np.uint8 and frames.dtype == np.uint8 and str(g["decoded_dtype"]) == "uint8"
+    thr = orc.threshold(dark, cfg["calibration_threshold_epsilon"])
+    assert thr.dtype == np.uint8
+    d = cfg["source_bit_depth"]
+    merged_md, merged_data = [], b""
+    for node in range(nodes):
+        recs = _parse_part(os.path.join(GOLDEN, "files", "g10_%s.rc1_part%03d" % (tag, node)), 1, 1)
+        lo, cnt = orc.node_frames(frames.shape[0], nodes, node)
+        assert len(recs) == cnt
+        for i, ref_rec in enumerate(recs):
+            rec, md = orc.l1_record(frames[lo + i].astype(np.uint16), thr.astype(np.uint16), d, lo + i, 1)
+            assert rec == ref_rec
+            assert md[2] == (int((frames[lo + i] > thr).sum()) * d + 7) // 8
+            merged_md.append(struct.pack("<3I", *md))
+            merged_data += rec[16:]
+    merged = open(os.path.join(GOLDEN, "files", "g10_%s.rc1" % tag), "rb").read()
+    assert merged[512:] == b"".join(merged_md) + merged_data
+    assert np.array_equal(g["decoded"], np.where(frames > thr, frames - thr, 0).astype(np.uint8))
+
+
 def test_g7_stream_mode_records_and_ids():
     """G7: the reference's writer fed chunk after chunk (mode='stream'): every chunk is split by the contiguous-block rule and the ids run
     on from chunk to chunk (recode_writer.py:311-322,383,422) - the oracle's records with those ids are the part files' bytes."""

@@ -324,7 +324,7 @@ def test_readahead_state_machine_without_a_gpu(monkeypatch, host_decoded):
             k = min(batch, z0 + n - a)
             yield (a,) + fake(a, k, out=rd._ra_buf, coo=True)
     monkeypatch.setattr(rd, "get_frames_triplets", fake)
-    monkeypatch.setattr(rd, "iter_frames_triplets", fake_iter)
+    monkeypatch.setattr(rd, "_iter_frames_impl", fake_iter)          # (what the read-ahead drives: the public iterator's body)
     if not host_decoded:
         rd._header["compression_scheme"] = 1             # (a file of this library's own zstd streams ...
         rd._RA_PIPELINED = False                         #  ... through the other form: one synchronous batched call per window)
@@ -350,7 +350,7 @@ def test_readahead_state_machine_without_a_gpu(monkeypatch, host_decoded):
         raise ValueError("a damaged stream")
         yield
     monkeypatch.setattr(rd, "get_frames_triplets", failing)
-    monkeypatch.setattr(rd, "iter_frames_triplets", failing_iter)
+    monkeypatch.setattr(rd, "_iter_frames_impl", failing_iter)
     rd._ra, rd._ra_last, rd._ra_streak = None, 0, 1
     assert rd._readahead_frame(1) is None and rd._ra_off is True
     assert rd._readahead_frame(2) is None

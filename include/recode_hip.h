@@ -61,7 +61,8 @@ int rc_scheme_on_device(uint32_t scheme);        /* 1 if rc_reduce_compress_batc
  * allocates for it (:212-230).  One ctx == one writer (one node_id).
  *
  *   nx, ny            frame shape (header fields nx, ny; recode_header.py:66-67)
- *   src_bit_depth     source_bit_depth: pixvals are bit-packed when it is not a multiple of 8 (recode_writer.py:463-475)
+ *   src_bit_depth     source_bit_depth, 1..16: pixvals are bit-packed when it is not a multiple of 8 (recode_writer.py:463-475);
+ *                     up to 8 the reference's source dtype is uint8: rc_ctx_set_source_bytes(ctx, 1)
  *   reduction_level   1 (binary map + residuals), 2 (binary map + one statistic per 8-connected component, see
  *                     rc_ctx_set_l2_statistics) or 3 (binary map only); 4 -> RC_ERR_UNSUPPORTED
  *   op_mode           rc_operation_mode: 0 reduce only, 1 reduce + compress (recode_writer.py:482,497)

@@ -262,8 +262,8 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
         *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 4 (centroiding) is not implemented on device");
         return nullptr;
     }
-    if (src_bit_depth < 9 || src_bit_depth > 16) {
-        *status = fail(RC_ERR_UNSUPPORTED, "source_bit_depth must be 9..16 (uint16 source frames)");
+    if (src_bit_depth < 1 || src_bit_depth > 16) {   // (<= 8: the reference's source dtype is uint8 - rc_ctx_set_source_bytes(ctx, 1))
+        *status = fail(RC_ERR_UNSUPPORTED, "source_bit_depth must be 1..16 (uint8 / uint16 source frames; 32-bit sources are not implemented on device)");
         return nullptr;
     }
     int ndev = 0;
@@ -417,7 +417,7 @@ static int fit_model(rc_ctx *c, const void *frames_dev, uint32_t n)
     for (int k = 0; k < 2; ++k)
         if (c->post_pending[k]) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
     HIP_TRY(hipMemsetAsync(c->d_sample, 0, sizeof(ZstdSample), s));
-    launch_reduce(sc, frames_dev, ns, c->level == 3 ? 3u : 1u, 1u, false, c->depth, s, nullptr, c->src_bytes);
+    launch_reduce(sc, frames_dev, ns, c->level == 3 ? 3u : 1u, 1u, true, c->depth, s, nullptr, c->src_bytes);   // (with the raw maps: the sample counts all their bytes)
     launch_zstd_sample(sc, ns, c->level == 1, c->depth, c->d_sample, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_sample, c->d_sample, sizeof(ZstdSample), hipMemcpyDeviceToHost, s));
@@ -511,7 +511,8 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
 #else
     constexpr unsigned skip = 0;
 #endif
-    if (c->emit == RC_SCHEME_ZSTD && !(skip & 1)) launch_zstd_fse(sc, n, fitted_seq ? (const void *)&c->d_model->seq : c->d_ztab, fitted_seq, ps);
+    const bool lits_only = c->modelled && (c->h_model->valid & ZM_LITS_ONLY);   // dense maps: no block has sequences, nothing for the FSE chain to do
+    if (c->emit == RC_SCHEME_ZSTD && !(skip & 1) && !lits_only) launch_zstd_fse(sc, n, fitted_seq ? (const void *)&c->d_model->seq : c->d_ztab, fitted_seq, ps);
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], ps));
     if (!(skip & 2)) launch_scans(sc, n, c->level == 1, c->emit != 0, ps);  // (level 2: k_l2_emit has already described its value list)
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], ps));

@@ -1448,7 +1448,13 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
     const bool pixp = rp.level == 1 && rp.packed_slots && !skip_pix;   // (level-2 statistics: one contiguous list, packed at the end of this kernel)
     const bool plain_pos = rp.emit == 0 || flat;   // residual byte b sits at offset b (no stored-chunk headers in between)
     uint8_t *pdst = rec + pix_pos;
-    constexpr int BIT = 4, PIT = 2;  // unrolled 16-dword steps per segment: 256 B of block, 128 B of residuals; longer: loop
+#ifndef RC_ASM_BIT
+#define RC_ASM_BIT 4
+#endif
+#ifndef RC_ASM_PIT
+#define RC_ASM_PIT 2
+#endif
+    constexpr int BIT = RC_ASM_BIT, PIT = RC_ASM_PIT;  // unrolled 16-dword steps per segment: 256 B of block, 128 B of residuals; longer: loop
     uint8_t *bdst[ASM_PASSES], *pdstp[ASM_PASSES];
     const uint8_t *bsrc[ASM_PASSES], *psrc[ASM_PASSES];
     uint32_t bn[ASM_PASSES], pn[ASM_PASSES], ps0[ASM_PASSES];

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include <cstdlib>
 #include "rc_launch.h"
 #include "rc_zstd_block.h"
 #include "rc_zstd_model.h"
@@ -141,6 +142,13 @@ __global__ __launch_bounds__(WG) void k_zstd_sample(Scratch sc, uint32_t B, uint
                 atomicAdd(&s_h.ml[(k >> 6) & 63u], 1u);
             }
         }
+        if ((word & 0xFFFFu) != 4u || !(word & ZW_FINAL)) {   // not an all-zero block (those are RLE blocks in every form): all its bytes
+            const uint64_t b0 = (uint64_t)t * TILE_BM;
+            const uint32_t nbm = (uint32_t)(sc.nb - b0 < (uint64_t)TILE_BM ? sc.nb - b0 : (uint64_t)TILE_BM);
+            const uint8_t *bm = sc.bitmap + (uint64_t)f * sc.nb_stride + b0;
+            for (uint32_t i = lane; i < nbm; i += 64) atomicAdd(&s_h.all[bm[i]], 1u);
+            if (lane == 0) atomicAdd(&s_h.nblk, 1u);
+        }
         if (with_pix) {
             const uint32_t nbytes = (sc.tile_cnt[ft] * depth + 7) >> 3;
             const uint8_t *p = reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * TILE_PX);
@@ -163,7 +171,10 @@ size_t zstd_model_bytes() { return sizeof(ZstdModel); }
 size_t zstd_sample_bytes() { return sizeof(ZstdSample); }
 void zstd_model_from_sample(const void *sample_host, void *model_host)
 {
-    zm_build_model(*reinterpret_cast<const ZstdSample *>(sample_host), *reinterpret_cast<ZstdModel *>(model_host));
+    ZstdSample h = *reinterpret_cast<const ZstdSample *>(sample_host);
+    if (getenv("RC_ZSTD_SEQ_ALWAYS")) h.nblk = 0;   // (A/B runs: never the literals-only block form)
+    if (getenv("RC_ZSTD_LITS_ALWAYS")) { for (auto &v : h.ll) v = 0x100000; h.nblk = h.nblk ? h.nblk : 1; }   // (A/B runs: always; the sequences priced out)
+    zm_build_model(h, *reinterpret_cast<ZstdModel *>(model_host));
 }
 
 size_t zstd_tables_bytes() { return sizeof(ZstdTables); }

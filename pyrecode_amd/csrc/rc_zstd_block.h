@@ -53,10 +53,15 @@ struct ZstdModel {
     uint8_t pix_desc[ZM_DESC_MAX];
     uint8_t seq_desc[ZM_DESC_MAX];        // [LL FSE table description][0x00 = the offset code of RLE mode][ML description]
     uint32_t lit_desc_len, pix_desc_len, seq_desc_len;
-    uint32_t valid;                       // bit 0: lit, bit 1: pix, bit 2: seq usable
+    uint32_t valid;                       // bit 0: lit, bit 1: pix, bit 2: seq usable; bit 3: LITERALS ONLY - the binary maps' blocks carry all
+                                          // their bytes as Huffman-coded literals and no sequences (dense maps: zm_build_model), lit_code
+                                          // is then fitted to ALL bytes of the non-empty blocks
 };
+constexpr uint32_t ZM_LITS_ONLY = 8u;
 struct ZstdSample {   // histograms gathered by k_zstd_sample over a sample of frames
     uint32_t lit[256], pix[256], ll[64], ml[64];
+    uint32_t all[256];                    // every byte of the sample's binary-map blocks that are not all zero (those are RLE blocks either way)
+    uint32_t nblk, pad[3];                // how many such blocks
 };
 
 // (host side) FSE_buildCTable of the reference implementation, restated: spread symbols with step (size/2 + size/8 + 3), low-probability
@@ -375,6 +380,11 @@ inline uint32_t zstd_encode_block_model(const uint8_t *src, uint32_t n, uint8_t 
         const uint32_t h = lastbit | (1u << 1) | (n << 3);
         dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); dst[3] = 0;
         return 4;
+    }
+    if (M.valid & ZM_LITS_ONLY) {   // dense maps: every byte a literal, no sequences (what zstd_tokenize_block_m emits under this model)
+        nseq = 0;
+        nlit = n;
+        for (uint32_t k = 0; k < n; ++k) lits[k] = src[k];
     }
     uint8_t *p = dst + 3;
     uint32_t hb = 0;

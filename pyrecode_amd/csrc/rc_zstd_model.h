@@ -269,13 +269,56 @@ inline bool zm_huf_write_desc(const uint8_t *len, uint8_t *dst, uint32_t cap, ui
 }
 
 // ---- the model ----------------------------------------------------------------------------------------------------------
+// Extra bits of the literal-length / match-length codes (RFC 8878 3.1.1.3.2.1.1), for the size estimate below.
+inline uint32_t zm_ll_extra(int c) { static const uint8_t b[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16}; return c < 36 ? b[c] : 16; }
+inline uint32_t zm_ml_extra(int c) { static const uint8_t b[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16}; return c < 53 ? b[c] : 16; }
+// bits the sample's sequences cost under normalised counts `norm` (table log `log`): state bits ~ log - log2(count) per symbol
+inline double zm_fse_cost(const uint32_t *hist, const int16_t *norm, int nsym, int log)
+{
+    double bits = 0;
+    for (int s = 0; s < nsym; ++s) {
+        if (!hist[s]) continue;
+        const double cnt = norm[s] > 0 ? (double)norm[s] : 1.0;
+        double l2 = 0;
+        for (double v = (double)(1 << log) / cnt; v > 1.0; v /= 2.0) l2 += v >= 2.0 ? 1.0 : (v - 1.0);   // ~log2, no libm
+        bits += hist[s] * l2;
+    }
+    return bits;
+}
+
 inline void zm_build_model(const ZstdSample &h, ZstdModel &m)
 {
     memset(&m, 0, sizeof m);
     uint8_t len[256];
     zm_huf_lengths(h.lit, len);
+    // Two block forms for the binary maps (rc_zstd_wave.h): literals + sequences (zero runs as matches: what pays on sparse maps) or ALL
+    // bytes as Huffman-coded literals and no sequences.  On dense maps (a few per cent of the pixels set: most runs are short, a third
+    // of the bytes are literals anyway) the second form is SMALLER - a byte-wise code reaches the maps' entropy to within a tenth where
+    // the sequences cost 10-20 bits each - and needs neither the FSE chain kernel nor the sequence tables.  Decided once per model,
+    // from the sample: estimated bits of both forms.
+    double bits_seq = 0, bits_all = 0;
+    {
+        uint8_t len_all[256];
+        zm_huf_lengths(h.all, len_all);
+        for (int v = 0; v < 256; ++v) { bits_seq += (double)h.lit[v] * len[v]; bits_all += (double)h.all[v] * len_all[v]; }
+        bits_seq += 8.0 * 9 * h.nblk;    // block header 3, literals header 3, count 1, modes 1, ~1 byte of initial states and padding
+        bits_all += 8.0 * 7 * h.nblk;    // block header 3, literals header 3, count 1
+        bool need_ll[ZM_LL_SYMS], need_ml[ZM_ML_SYMS];
+        for (int s = 0; s < ZM_LL_SYMS; ++s) need_ll[s] = s <= 28;
+        for (int s = 0; s < ZM_ML_SYMS; ++s) need_ml[s] = s <= 45;
+        int16_t nll[ZM_LL_SYMS], nml[ZM_ML_SYMS];
+        if (zm_fse_normalize(h.ll, need_ll, ZM_LL_SYMS, 8, nll) && zm_fse_normalize(h.ml, need_ml, ZM_ML_SYMS, 9, nml))
+            bits_seq += zm_fse_cost(h.ll, nll, ZM_LL_SYMS, 8) + zm_fse_cost(h.ml, nml, ZM_ML_SYMS, 9);
+        for (int c = 0; c < ZM_LL_SYMS; ++c) bits_seq += (double)h.ll[c] * zm_ll_extra(c);
+        for (int c = 0; c < ZM_ML_SYMS; ++c) bits_seq += (double)h.ml[c] * zm_ml_extra(c);
+        if (h.nblk && bits_all < bits_seq) {
+            m.valid |= ZM_LITS_ONLY;
+            memcpy(len, len_all, sizeof len);
+        }
+    }
     zm_huf_codes(len, m.lit_code);
     if (zm_huf_write_desc(len, m.lit_desc, sizeof m.lit_desc, &m.lit_desc_len)) m.valid |= 1u;
+    else m.valid &= ~ZM_LITS_ONLY;
     zm_huf_lengths(h.pix, len);
     zm_huf_codes(len, m.pix_code);
     if (zm_huf_write_desc(len, m.pix_desc, sizeof m.pix_desc, &m.pix_desc_len)) m.valid |= 2u;
@@ -296,7 +339,7 @@ inline void zm_build_model(const ZstdSample &h, ZstdModel &m)
         zm_fse_ctable(nml, ZM_ML_SYMS, ml_log, m.seq.ml_state, m.seq.ml_dnb, m.seq.ml_dfs);
         m.seq.ll_log = ll_log;
         m.seq.ml_log = ml_log;
-        m.valid |= 4u;
+        if (!(m.valid & ZM_LITS_ONLY)) m.valid |= 4u;   // (literals only: no block carries sequences, and none has to leave room for their tables)
     }
 }
 

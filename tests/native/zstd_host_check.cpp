@@ -124,6 +124,9 @@ extern "C" uint32_t zm_check_build(const uint8_t *bitmap, uint64_t nb, const uin
     for (uint64_t o = 0; o < nb; o += rc::ZSTD_BLK) {
         const uint32_t n = (uint32_t)((nb - o) < rc::ZSTD_BLK ? (nb - o) : rc::ZSTD_BLK);
         const uint8_t *src = bitmap + o;
+        bool any = false;
+        for (uint32_t k = 0; k < n; ++k) any |= src[k] != 0;
+        if (any) { for (uint32_t k = 0; k < n; ++k) h.all[src[k]]++; h.nblk++; }   // (what k_zstd_sample counts: rc_zstd.hip)
         uint32_t i = 0, lit_start = 0;
         while (i < n) {
             if (src[i] != 0) { ++i; continue; }

@@ -123,7 +123,9 @@ def test_modelled_bitmap_frames(zm, zstd, density):
     sample = _sparse_bitmap(rng, 64 * 512, density)
     pix = rng.integers(1, 2048, 4096).astype(np.uint16).view(np.uint8)
     m, valid = _model(zm, sample, pix)
-    assert valid == 7
+    # sparse maps keep the sequences (zero runs as matches); dense ones (5 %, 30 %) come out smaller with every byte a Huffman-coded
+    # literal and no sequences at all: bit 3 (ZM_LITS_ONLY), and then no sequence tables (bit 2)
+    assert valid == (7 if density <= 0.01 else 11), valid
     for n in (1, 5, 511, 512, 513, 4096, 200000):
         for d in (density, 0.0, min(1.0, density * 8), 0.6):   # data like the sample, and data the model was not fitted to
             data = _sparse_bitmap(rng, n, d)[:n]
@@ -135,6 +137,9 @@ def test_modelled_bitmap_frames(zm, zstd, density):
             assert np.array_equal(_decode(zstd, dst, k, n), data)
             if n == 200000 and d == density == 0.01:
                 assert k / n < 0.14, k / n
+            if n == 200000 and d == density == 0.05:
+                # the entropy of a 5 % Bernoulli map is 0.286 of raw; the sequences form wrote 0.355 (BASELINE cfg 5's records, round 3)
+                assert k / n < 0.34, k / n
 
 
 def test_modelled_bitmap_frame_with_untrained_model(zm, zstd):

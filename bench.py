@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--scheme", type=int, default=2, help="2 = LZ4 (headline), 1 = zstd, 8 = blosc-lz4, 0 = reduce-only pieces")
     ap.add_argument("--level", type=int, default=1, help="reduction level: 1 (headline), 2 = summary statistics, 3 = bitmap only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--source-bytes", type=int, default=2, choices=[1, 2], help="bytes per source pixel: 2 = uint16 frames (every BASELINE configuration), 1 = uint8 frames (source_bit_depth <= 8: the reference's map_dtype, misc.py:41-49; implies --depth 8 unless given lower, no CPU baseline / ingest legs)")
     ap.add_argument("--read", action="store_true", help="measure the READER instead: stored frames -> device decode of both streams -> sparse expand (rc_expand_frames)")
     ap.add_argument("--blob-on-device", action="store_true", help="--read: the stored frames' bytes already sit in device memory (the decoders without the link)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the extra ingest-inclusive measurement (host frames -> part file)")
@@ -80,6 +81,9 @@ def parse(argv=None):
     if pre.config:
         ap.set_defaults(**CONFIGS[pre.config])
     a = ap.parse_args(argv)
+    if a.source_bytes == 1:
+        a.depth = min(a.depth, 8)
+        a.no_cpu_baseline = a.no_ingest = True
     if a.shared_gpu and a.dist_backend == "nccl":
         ap.error("--shared-gpu needs --dist-backend gloo")
     return a
@@ -164,15 +168,21 @@ def cpu_baseline(frames_h, thr_h, depth, scheme):
     }
 
 
-def ingest_inclusive(stack, dark, a, nframes=128, validation_frame_gap=-1):
+def ingest_inclusive(stack, dark, a, nframes=512, validation_frame_gap=-1, passes=3, data=None):
     """Extra, NOT `value`: ReCoDeWriter.run on frames that start in host memory, records appended to a part file on tmpfs
-    (the reference's whole writer loop, recode_writer.py:292-428): staging copy + link + kernels + records back + file append."""
+    (the reference's whole writer loop, recode_writer.py:292-428): staging copy + link + kernels + records back + file append.
+    >= 512 frames per pass where they fit 16 GiB of host memory (0.4 s at 4096^2: long enough to tell a stall from noise), one warm-up
+    pass (staging buffers, model) and `passes` timed ones: median, min and max are reported."""
     import shutil
     import tempfile
     from pyrecode_amd.params import InputParams
     from pyrecode_amd.recode_writer import ReCoDeWriter
-    n = min(nframes, stack.shape[0])
-    data = stack[:n].cpu().numpy().view(np.uint16).reshape(n, a.ny, a.nx)
+    frame_bytes = a.ny * a.nx * 2
+    n = int(max(min(nframes, (16 << 30) // frame_bytes), min(stack.shape[0], 8)))
+    if data is None:
+        src = stack[:min(n, stack.shape[0])].cpu().numpy().view(np.uint16).reshape(-1, a.ny, a.nx)
+        data = src if src.shape[0] >= n else np.concatenate([src] * (-(-n // src.shape[0])))[:n]   # (the stack's frames again: other ids)
+    n = data.shape[0]
     dark_h = dark.cpu().numpy().view(np.uint16).reshape(a.ny, a.nx)
     ip = InputParams()
     ip._param_map.update(dict(reduction_level=a.level, rc_operation_mode=1, calibration_threshold_epsilon=0, target_bit_depth=a.depth,
@@ -184,8 +194,8 @@ def ingest_inclusive(stack, dark, a, nframes=128, validation_frame_gap=-1):
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     out_dir = tempfile.mkdtemp(dir=base)
     try:
-        best = None
-        for _ in range(2):   # first pass warms the staging buffers and the model
+        times = []
+        for k in range(passes + 1):   # first pass warms the staging buffers and the model
             w = ReCoDeWriter("bench_stack.bin", dark_data=dark_h, output_directory=out_dir, input_params=ip, mode="batch", node_id=0,
                              batch_size=min(32, a.batch), validation_frame_gap=validation_frame_gap)
             w.start()
@@ -193,14 +203,18 @@ def ingest_inclusive(stack, dark, a, nframes=128, validation_frame_gap=-1):
             w.run(data)
             dt = time.perf_counter() - t0
             w.close()
-            best = dt if best is None else min(best, dt)
+            if k:
+                times.append(dt)
+        times.sort()
+        med = times[len(times) // 2]
         part = os.path.join(out_dir, "bench_stack.rc%d_part000" % a.level)
         size = os.path.getsize(part)
-        res = {"frames_per_s": round(n / best, 1), "gb_per_s_in": round(n * a.ny * a.nx * 2 / best / 1e9, 2), "frames": n,
-               "part_file_bytes": size, "what": "ReCoDeWriter.run: host frames -> page-locked staging -> GPU -> records -> part file on %s" % (base or "tmp")}
+        res = {"frames_per_s": round(n / med, 1), "gb_per_s_in": round(n * frame_bytes / med / 1e9, 2), "frames": n, "passes": len(times),
+               "frames_per_s_min_max": [round(n / times[-1], 1), round(n / times[0], 1)], "seconds_per_pass": round(med, 3),
+               "part_file_bytes": size, "what": "ReCoDeWriter.run: host frames -> page-locked staging -> GPU -> records -> part file on %s; median of %d passes" % (base or "tmp", len(times))}
         if validation_frame_gap <= 0 and a.level in (1, 3):
-            res["read_back"] = read_back(part, n, int((data > dark_h[None]).sum()))
-        return res
+            res["read_back"] = read_back(part, n, int(sum(int((data[lo:lo + 64] > dark_h[None]).sum()) for lo in range(0, n, 64))))
+        return res, data
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
 
@@ -524,11 +538,24 @@ def run_rank(a):
         else:
             hip.check(L.rc_synth_frames(local, seed, lo, n, N, a.sparsity_ppm, dark.data_ptr(), stack[lo].data_ptr()))
 
+    src_dtype = np.uint16
+    if a.source_bytes == 1:
+        # uint8 sources: the same events on an 8-bit scale - dark 5..7, an event's residual 1..200, background below the dark level
+        src_dtype = np.uint8
+        dark8 = (dark >> 4).to(torch.uint8)
+        stack8 = torch.empty((S, N), dtype=torch.uint8, device=dev)
+        for lo in range(0, S, 16):
+            f16 = stack[lo:lo + 16]
+            amp = f16 - dark[None]
+            stack8[lo:lo + 16] = torch.where(amp > 0, dark8[None].to(torch.int16) + 1 + amp % 200, f16 >> 5).to(torch.uint8)
+        del stack, dark, f16, amp
+        torch.cuda.empty_cache()
+        stack, dark = stack8, dark8
     op_mode = 1
-    ctx = hip.ReduceContext(a.nx, a.ny, a.depth, a.level, op_mode, a.scheme, a.clevel, local, max_batch=B)
+    ctx = hip.ReduceContext(a.nx, a.ny, a.depth, a.level, op_mode, a.scheme, a.clevel, local, max_batch=B, src_dtype=src_dtype)
     ctx.set_dark(dark.data_ptr(), 0)  # eps = 0 -> thr = dark
     ctx.keep_binary_maps(False)       # no validation frames in this workload: records only (recode_writer.py:402-415)
-    out_cap = B * (N // 2)  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
+    out_cap = B * (N // 2) * (2 if a.source_bytes == 2 else 1)  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
     out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
     nb = S // B
@@ -598,7 +625,7 @@ def run_rank(a):
     gather_verified = loop.verify_gather()   # collective: every rank's block of the gathered table, on every rank
     gathers_in_region = loop.gathers_issued
 
-    thr_h = dark.cpu().numpy().view(np.uint16)
+    thr_h = dark.cpu().numpy().view(src_dtype).astype(np.uint16)
     corrupt = os.environ.get("RC_BENCH_CORRUPT_RECORD")          # test switch: one byte of a record flipped before the check
 
     def verify_batch(j, z):
@@ -607,7 +634,7 @@ def run_rank(a):
         if corrupt:
             mid_byte = (int(rec_now[z]) + int(rec_now[z + 1])) // 2
             out[mid_byte] ^= 0x5A
-        frame = stack[j * B + z].cpu().numpy().view(np.uint16)
+        frame = stack[j * B + z].cpu().numpy().view(src_dtype).astype(np.uint16)   # (uint8 sources: widened - same values - for the uint16 oracle)
         r = out[int(rec_now[z]):int(rec_now[z + 1])].cpu().numpy().tobytes()
         try:
             return bool(verify_record(a, r, frame, thr_h, rank * S + j * B + z))
@@ -647,10 +674,11 @@ def run_rank(a):
 
     if rank == 0:
         k_ms = sums[0] / max(nbatches, 1)
-        achieved = B * N * 2 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        frame_bytes = N * a.source_bytes        # algorithmic bytes: one read of the frame in its source dtype
+        achieved = B * frame_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_note = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        key = "%dx%d_b%d_ppm%d_d%d_s%d" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme)
+        key = "%dx%d_b%d_ppm%d_d%d_s%d%s%s" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme, "_clustered" if a.clustered else "", "_u8" if a.source_bytes == 1 else "")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(key, {}).get("reduce_kernel_hbm_bytes_per_launch")
         if traffic is None:
@@ -659,7 +687,7 @@ def run_rank(a):
             traffic_note = "PMC (2*FETCH_SIZE + WRITE_SIZE) of a separate rocprofv3 --pmc run of this configuration, profiles/traffic.json"
         result = {
             "metric": "frames/sec + GB/s in, 4096x4096 uint16 @1% sparsity, 1/2/4/8 GPU",
-            "value": round(fps, 1), "unit": "frames/s", "gb_per_s_in": round(fps * N * 2 / 1e9, 1),
+            "value": round(fps, 1), "unit": "frames/s", "gb_per_s_in": round(fps * frame_bytes / 1e9, 1),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt_max / a.steps * 1e3, 4),
             "repeats": len(times), "timed_seconds_total": round(sum(times), 3),
             "ms_per_step_all_repeats": {"min": round(min(times) / a.steps * 1e3, 4), "median": round(dt_max / a.steps * 1e3, 4),
@@ -670,10 +698,10 @@ def run_rank(a):
             # for room in the device queue when the host runs ahead)
             "host_enqueue_us_per_step": round(host_enqueue_us, 1), "issue_us_per_step_in_timed_region": round(issue_us, 1),
             "host_enqueue_frac_of_step": round(host_enqueue_us / (dt_max / a.steps * 1e6), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16" if a.source_bytes == 2 else "u8", "data": "synthetic",
             "config": {
-                "workload": "%s%dx%d uint16, %s, L%d + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
-                    ("BASELINE configs[%d]: " % (a.config - 1)) if a.config else "", a.ny, a.nx,
+                "workload": "%s%dx%d %s, %s, L%d + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
+                    ("BASELINE configs[%d]: " % (a.config - 1)) if a.config else "", a.ny, a.nx, "uint16" if a.source_bytes == 2 else "uint8",
                     ("detector-like clusters of 1..6 pixels, %d seeds per million pixels" % a.sparsity_ppm) if a.clustered else "%.2f%% sparsity" % (a.sparsity_ppm / 1e4), a.level,
                     {2: "LZ4 frame", 1: "zstd frame (%s encoder)" % ("modelled" if a.clevel else "fast"), 8: "blosc-lz4 chunk",
                      0: "reduce-only pieces (the host library compresses them, as the reference does)"}.get(a.scheme, str(a.scheme)),
@@ -693,10 +721,10 @@ def run_rank(a):
             "rccl_ranks": (dist.get_world_size() if use_dist and backend == "nccl" else (1 if not use_dist else 0)),
             "roofline": {"bound": "hbm", "kernel": "k_reduce_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                         "traffic_ratio": (round(traffic / (B * N * 2), 4) if traffic else None),
-                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": B * N * 2,
-                         "pattern_floor_ms": pattern_floor(N, B, k_ms),
-                         "whole_path_frac": round(fps / world * N * 2 / 1e9 / HBM_PEAK_GBS, 4)},
+                         "traffic_ratio": (round(traffic / (B * frame_bytes), 4) if traffic else None),
+                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": B * frame_bytes,
+                         "pattern_floor_ms": pattern_floor(N, B, k_ms) if a.source_bytes == 2 else None,
+                         "whole_path_frac": round(fps / world * frame_bytes / 1e9 / HBM_PEAK_GBS, 4)},
             # only the events the roofline needs are recorded in the timed region (each costs stream time); the full
             # per-stage split is available with RC_PROFILE_ALL_STAGES=1
             "stage_ms_per_step": ({"reduce": round(sums[0] / nbatches, 4), "bitmap_codec_kernel": round(sums[1] / nbatches, 4),
@@ -714,9 +742,12 @@ def run_rank(a):
             result["cpu_baseline"] = None
         if world == 1 and not a.no_ingest and a.level in (1, 3):
             try:
-                result["ingest_inclusive"] = ingest_inclusive(stack, dark, a)
-                v = ingest_inclusive(stack, dark, a, validation_frame_gap=10)   # validation frames ride the same stream (recode_writer.py:402-415)
-                result["ingest_inclusive"]["with_validation_frame_gap_10"] = {"frames_per_s": v["frames_per_s"], "gb_per_s_in": v["gb_per_s_in"]}
+                result["ingest_inclusive"], host_frames = ingest_inclusive(stack, dark, a)
+                v, _ = ingest_inclusive(stack, dark, a, validation_frame_gap=10, data=host_frames)   # validation frames ride the same stream (recode_writer.py:402-415)
+                del host_frames
+                result["ingest_inclusive"]["with_validation_frame_gap_10"] = {
+                    "frames_per_s": v["frames_per_s"], "gb_per_s_in": v["gb_per_s_in"], "frames_per_s_min_max": v["frames_per_s_min_max"],
+                    "ratio_to_plain": round(v["frames_per_s"] / max(result["ingest_inclusive"]["frames_per_s"], 1e-9), 3)}
             except Exception as e:   # an extra: never lets the contract line fail
                 result["ingest_inclusive"] = {"error": repr(e)}
         if world == 1 and not a.no_ingest and a.level in (1, 3) and a.scheme in (1, 2):

@@ -422,7 +422,10 @@ static int fit_model(rc_ctx *c, const void *frames_dev, uint32_t n)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_sample, c->d_sample, sizeof(ZstdSample), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    zstd_model_from_sample(c->h_sample, c->h_model);
+    // compression_level -> how much size the faster block form of the binary maps may cost (rc_zstd_model.h): the reference hands the
+    // level to libzstd (recode_writer.py:175-178), where 1 is the fast end too.  Level 1: up to 5 % of the binary-map stream, level 2: 2 %,
+    // from 3 on the smaller form always.
+    zstd_model_from_sample(c->h_sample, c->h_model, c->clevel == 1 ? 50u : (c->clevel == 2 ? 20u : 0u));
     if (c->level != 1) c->h_model->valid &= ~2u;   // level 2 statistics / level 3: no residual-stream code
     {   // a residual stream the byte-wise code cannot shrink (bit-packed depths) is stored instead, in 128 KiB Raw blocks
         uint64_t bits = 0, total = 0;

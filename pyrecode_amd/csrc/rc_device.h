@@ -17,6 +17,10 @@ constexpr int R = 8;                       // 16-byte loads per lane per frame-t
 constexpr int GROUP_PX = 64 * 8;           // 512
 constexpr int TILE_PX = R * GROUP_PX;      // 4096 pixels = 8 KiB of uint16
 constexpr int TILE_BM = TILE_PX / 8;       // 512 bitmap bytes per tile
+#ifndef RC_SLOT_PX
+#define RC_SLOT_PX TILE_PX
+#endif
+constexpr int SLOT_PX = RC_SLOT_PX;         // uint16 values between two tiles' residual slots (experiments: a denser stride; the product: one slot = one tile's worst case)
 constexpr int BLK_SLOT = TILE_BM + 128;    // per-tile scratch slot for an encoded block (4-byte size word + payload), 5 x 128-byte lines
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -106,7 +106,7 @@ void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, bool
 void launch_zstd_sample(const Scratch &sc, uint32_t B, bool with_pix, uint32_t depth, void *sample_dev, hipStream_t s);
 size_t zstd_model_bytes();
 size_t zstd_sample_bytes();
-void zstd_model_from_sample(const void *sample_host, void *model_host);
+void zstd_model_from_sample(const void *sample_host, void *model_host, uint32_t speed_permille = 0);   // (rc_zstd_model.h::zm_build_model)
 struct ZstdModel;
 void launch_zstd_gather(const Scratch &sc, uint8_t *out, hipStream_t s);
 size_t zstd_tables_bytes();

@@ -337,7 +337,7 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
     uint32_t q0 = 0, q1 = 0, bsz = 0;
     if (LEVEL1) {
         s0 = reinterpret_cast<const uint8_t *>(p.buf);
-        d0 = reinterpret_cast<uint8_t *>(pix_slots + p.ft * TILE_PX);   // slots are 8 KiB aligned
+        d0 = reinterpret_cast<uint8_t *>(pix_slots + p.ft * SLOT_PX);   // slots are 8 KiB aligned
         q0 = ((((p.cnt * p.depth + 31) >> 5) + 31u) & ~31u) >> 2;       // whole lines, in 16-byte units
     }
     if (CODEC == 2 || CODEC == 4 || CODEC == 8) {
@@ -700,7 +700,9 @@ static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames
     // stage is long next to the following batch's reduce kernel (zstd at 4096^2, level 2, blosc: the STEP got 1-6 % longer although the
     // kernel got 5 % shorter) keep four-wave workgroups.
     static const char *rw_env = getenv("RC_REDUCE_WG_WAVES");   // (experiments: 3 or 4)
-    const bool three = rw_env ? atoi(rw_env) == 3 : (L1 && !RAW && (CODEC == 2 || CODEC == 4 || sc.ntiles > 8192));
+    // (modelled zstd whose blocks carry literals only - dense maps, rc_zstd_model.h - has no FSE pass behind the reduce kernel: its
+    // second stage is as short as LZ4's, and three-wave workgroups gain 0.5-3 % there as well)
+    const bool three = rw_env ? atoi(rw_env) == 3 : (L1 && !RAW && (CODEC == 2 || CODEC == 4 || sc.ntiles > 8192 || (CODEC == 3 && (sc.zm_valid & ZM_LITS_ONLY))));
     auto go = [&](auto rw) {
         constexpr int RW = decltype(rw)::value;
         auto grid_for = [&](uint32_t nt) { return (((nt + RW - 1) / RW + 7) / 8) * 8 * ngroups; };
@@ -1494,7 +1496,7 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
                     const uint32_t avail = (uint32_t)((dbit + nbits) & 7u);
                     uint32_t n = (uint32_t)(b_hi - b_lo);
                     ps0[ps] = (uint32_t)(8 * b_lo - dbit);
-                    psrc[ps] = reinterpret_cast<const uint8_t *>(sc.pix_slots + (frow + tl) * TILE_PX);
+                    psrc[ps] = reinterpret_cast<const uint8_t *>(sc.pix_slots + (frow + tl) * SLOT_PX);
                     if (avail && n) {  // (n == 0: the tile's few bits all live in a byte that an earlier tile owns)
                         --n;
                         fin_avail[ps] = avail;
@@ -1536,7 +1538,7 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
             fin_ncnt[ps] = 0; fin_nfirst[ps] = 0;
             if (fin_avail[ps] && fin_next[ps] < sc.ntiles) {
                 fin_ncnt[ps] = sc.tile_cnt[frow + fin_next[ps]];
-                fin_nfirst[ps] = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + fin_next[ps]) * TILE_PX);
+                fin_nfirst[ps] = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + fin_next[ps]) * SLOT_PX);
             }
         }
     }
@@ -1587,7 +1589,7 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
                 tt = sc.tile_next[frow + tt];
                 if (tt < sc.ntiles) {
                     cc = sc.tile_cnt[frow + tt];
-                    first = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + tt) * TILE_PX);
+                    first = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + tt) * SLOT_PX);
                 }
             }
             pdst[plain_pos ? fin_b[ps] : stored_pos(ff, fin_b[ps])] = (uint8_t)byte;

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WG) void k_zstd_sample(Scratch sc, uint32_t B, uint
         }
         if (with_pix) {
             const uint32_t nbytes = (sc.tile_cnt[ft] * depth + 7) >> 3;
-            const uint8_t *p = reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * TILE_PX);
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * SLOT_PX);
             for (uint32_t i = lane; i < nbytes; i += 64) atomicAdd(&s_h.pix[p[i]], 1u);
         }
     }
@@ -169,12 +169,12 @@ void launch_zstd_sample(const Scratch &sc, uint32_t B, bool with_pix, uint32_t d
 }
 size_t zstd_model_bytes() { return sizeof(ZstdModel); }
 size_t zstd_sample_bytes() { return sizeof(ZstdSample); }
-void zstd_model_from_sample(const void *sample_host, void *model_host)
+void zstd_model_from_sample(const void *sample_host, void *model_host, uint32_t speed_permille)
 {
     ZstdSample h = *reinterpret_cast<const ZstdSample *>(sample_host);
     if (getenv("RC_ZSTD_SEQ_ALWAYS")) h.nblk = 0;   // (A/B runs: never the literals-only block form)
     if (getenv("RC_ZSTD_LITS_ALWAYS")) { for (auto &v : h.ll) v = 0x100000; h.nblk = h.nblk ? h.nblk : 1; }   // (A/B runs: always; the sequences priced out)
-    zm_build_model(h, *reinterpret_cast<ZstdModel *>(model_host));
+    zm_build_model(h, *reinterpret_cast<ZstdModel *>(model_host), speed_permille);
 }
 
 size_t zstd_tables_bytes() { return sizeof(ZstdTables); }

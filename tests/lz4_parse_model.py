@@ -65,7 +65,10 @@ def parse_events(block):
     cls = [None] + [(int(b[p]).bit_length() - 1) if (b[p] & (b[p] - 1)) == 0 else None for p in ev]
     best = {}                                            # value class -> (key, lane) of the best earlier event
     has, trail, lead, J = [False] * K, [0] * K, [0] * K, [0] * K
+    zbest, zb = [0] * K, 0                               # key of the longest zero run among the lanes in front: min(R, 511) << 6 | lane
     for k in range(K):
+        zbest[k] = zb
+        zb = max(zb, (min(R[k], 511) << 6) | k)
         c = cls[k]
         if c is not None and c in best:
             j = best[c][1]
@@ -87,8 +90,13 @@ def parse_events(block):
         leadn = lead[k + 1] if k + 1 < K else 0
         gs = P1[k] + trail[k] + (0 if has[k] else 1)
         ge = min(Pn[k] - 1 - leadn, n - 5)
+        off = 1
+        L0 = ge - P1[k]
+        if k > 0 and not has[k] and L0 >= 4 and (zbest[k] >> 6) >= L0 and P1[k] + 12 <= n:
+            # no unit copy for this event: the gap behind X comes from inside the longest earlier zero run (no literal zero needed)
+            gs, off = P1[k], P1[k] - P1[zbest[k] & 63]
         if gs + 12 <= n and ge - gs >= 4:
-            matches.append((gs, ge - gs, 1))
+            matches.append((gs, ge - gs, off))
     return matches
 
 

@@ -121,7 +121,12 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
     HIP_TRY(hipMalloc((void **)&sc.status, sizeof(BatchStatus)));
     if (c->level != 3) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2 + 64));
     if (c->emit != 0) {
-        HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * BLK_SLOT + 64));
+        if (c->level == 1 && !getenv("RC_NO_COMBINED_SLOTS")) {   // combined slots (rc_launch.h, Scratch::comb); the env switch: A/B runs
+            sc.comb = c->emit == RC_SCHEME_ZSTD ? 2u : 1u;
+            if (const char *e = getenv("RC_COMB_MODE")) sc.comb = (uint32_t)atoi(e);   // (A/B runs)
+            sc.blk_stride = 1536;                                  // 12 lines: the block image (<= 5) + 7 or more lines of residuals
+        }
+        HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * (uint64_t)sc.blk_stride + 256));
         HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
         HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
     }

@@ -20,7 +20,15 @@ struct Scratch {
     uint32_t *tile_cnt = nullptr;      // [B][ntiles]               set pixels per tile
     uint32_t *tile_off = nullptr;      // [B][ntiles]               exclusive prefix of tile_cnt inside the frame
     uint32_t *tile_next = nullptr;     // [B][ntiles]               next tile index > t with tile_cnt > 0 (ntiles if none)
-    uint8_t *blk_slots = nullptr;      // [B][ntiles][BLK_SLOT]     encoded bitmap blocks (codec dependent)
+    uint8_t *blk_slots = nullptr;      // [B][ntiles][blk_stride]   encoded bitmap blocks (codec dependent); a ctx's level-1 pipeline keeps the
+                                       //                           tile's residual stream in the same slot when both fit (`comb`)
+    uint32_t blk_stride = BLK_SLOT;    // bytes between two tiles' block slots
+    // Combined slots (a ctx with a device codec at level 1): the tile's packed residual stream sits BEHIND its encoded block in the block's
+    // slot - 1: at the next 16-byte boundary behind the block image (LZ4 / blosc: the image is final when the reduce kernel writes it),
+    // 2: at offset BLK_SLOT (zstd: the FSE pass and the frame's definitions still grow the block) - whenever block + residual lines fit
+    // blk_stride; a tile too dense for that keeps its residuals in pix_slots as before.  One run of lines per tile and frame instead of
+    // two runs 8 KiB apart: fewer lines written by the reduce kernel and read by k_assemble (each run wastes half a line on average).
+    uint32_t comb = 0;
     uint32_t *blk_size = nullptr;      // [B][ntiles]               bytes used in each slot
     uint32_t *blk_off = nullptr;       // [B][ntiles]               exclusive prefix of blk_size inside the frame
     uint32_t *frame_nnz = nullptr;     // [B]
@@ -111,6 +119,17 @@ struct ZstdModel;
 void launch_zstd_gather(const Scratch &sc, uint8_t *out, hipStream_t s);
 size_t zstd_tables_bytes();
 void zstd_tables_host(void *dst);  // rc_reduce.hip: FLG | BD << 8 | HC << 16
+
+// where tile ft's packed residual stream starts (see Scratch::comb); bn: the tile's blk_size word as the reduce kernel wrote it
+// (combined form 1 only), cnt: its set pixels, d: bits per value
+__host__ __device__ inline const uint8_t *residual_src(const Scratch &sc, uint64_t ft, uint32_t bn, uint32_t cnt, uint32_t d)
+{
+    if (sc.comb) {
+        const uint32_t ro16 = sc.comb == 2 ? (uint32_t)BLK_SLOT / 16 : (bn + 15) >> 4, r16 = (cnt * d + 127) >> 7;
+        if (16 * (ro16 + r16) <= sc.blk_stride) return sc.blk_slots + ft * sc.blk_stride + 16 * ro16;
+    }
+    return reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * SLOT_PX);
+}
 
 void launch_roi_components(const void *frames, const uint16_t *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
                            uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t *counts, hipStream_t s, uint32_t src_bytes = 2);

@@ -326,7 +326,7 @@ template <bool LEVEL1, int CODEC, bool KEEP_BITMAP>
 __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t tile, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                   uint64_t nb_stride, uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
                                                   uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, Lz4Lds *lz,
-                                                  const WaveStage *st)
+                                                  const WaveStage *st, uint32_t blk_stride, uint32_t comb)
 {
     if (!p.valid) return 0;
     const int lane = lane_id();
@@ -350,8 +350,18 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
     }
     if (CODEC) {
         s1 = lz->out;
-        d1 = blk_slots + p.ft * BLK_SLOT;
+        d1 = blk_slots + p.ft * blk_stride;
         q1 = min((((bsz + 3) >> 2) + 31u) & ~31u, (uint32_t)BLK_SLOT / 4) >> 2;
+    }
+    if (LEVEL1 && CODEC && comb) {
+        // combined slot (Scratch::comb, rc_launch.h::residual_src is the reader's side of this rule): the residual stream behind the
+        // block image, in the block's slot, when both fit it
+        const uint32_t ro16 = comb == 2 ? (uint32_t)BLK_SLOT / 16 : (bsz + 15) >> 4, r16 = (p.cnt * p.depth + 127) >> 7;
+        if (16 * (ro16 + r16) <= blk_stride) {
+            d0 = d1 + 16 * ro16;
+            if (comb == 2) q0 = (r16 + 7u) & ~7u;                                   // two runs of whole lines in one slot
+            else { q1 = ro16; q0 = ((ro16 + r16 + 7u) & ~7u) - ro16; }              // ONE run: block units, then residual units up to the line's end
+        }
     }
     if (!(RC_ABLATE & 1) && !(RC_ABLATE & 2)) { if (q0 + q1) nst += store_lines2(s0, d0, q0, s1, d1, q1); }
     else if (!(RC_ABLATE & 1)) { if (q0) nst += store_lines2(s0, d0, q0, s1, d1, 0); }
@@ -457,7 +467,7 @@ __device__ __forceinline__ void reduce_one_frame(typename Src<SB>::X (&x)[R], co
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
                                                  uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ blk_slots,
                                                  uint32_t *__restrict__ blk_size, Lz4Lds *s_lz, uint8_t *s_bm, WaveStage *st,
-                                                 Pending &pend, uint32_t &stores_behind, const ZmParams &zp)
+                                                 Pending &pend, uint32_t &stores_behind, const ZmParams &zp, uint32_t blk_stride, uint32_t comb)
 {
     const int lane = lane_id();
     RC_PHASE_BEGIN
@@ -581,7 +591,7 @@ __device__ __forceinline__ void reduce_one_frame(typename Src<SB>::X (&x)[R], co
         pend.csize = lz4_encode_block(pend.cown, n_blk, *s_lz);
     }
     RC_PHASE(5);
-    stores_behind = flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st);
+    stores_behind = flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st, blk_stride, comb);
     pend.valid = false;
     RC_PHASE(6);
 }
@@ -619,7 +629,7 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
                                                        uint8_t *__restrict__ bitmap, uint64_t nb_stride,
                                                        uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
                                                        uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, uint32_t depth,
-                                                       BatchStatus *__restrict__ status, ZmParams zm)
+                                                       BatchStatus *__restrict__ status, ZmParams zm, uint32_t blk_stride, uint32_t comb)
 {
     // first kernel of a batch: clears the batch's status word (written later by k_layout / the level-2 kernels)
     if (blockIdx.x == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
@@ -673,10 +683,10 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
         reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL, SB>(xa, frames + (uint64_t)f * N, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
-                                                                             blk_size, lz, bm, st, pend, stores_behind, zm);
+                                                                             blk_size, lz, bm, st, pend, stores_behind, zm, blk_stride, comb);
         if (!nxt) break;
     }
-    flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st);
+    flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st, blk_stride, comb);
 }
 
 template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW, int SB>
@@ -694,6 +704,7 @@ static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames
     // tile (N not a multiple of TILE_PX) gets a second, tiny launch of the plain one
     const uint32_t nfull = AL ? (uint32_t)(sc.N / TILE_PX) : 0u;
     const ZmParams zm{reinterpret_cast<const uint16_t *>(sc.zm_lit_code), sc.zm_valid, sc.zm_budget, sc.zm_seq_bits};
+    const uint32_t comb = (L1 && !RAW && CODEC) ? sc.comb : 0u;   // (level 2 keeps raw values in pix_slots: rc_l2.hip reads them there)
     // Workgroups of THREE waves let five of them (15 waves) share a CU's LDS where four-wave workgroups fit three (12 waves).  Same-box
     // A/B against the two-register-set kernel of round 2 (tools/ab_configs.sh): LZ4 level 1 +1.3..3.5 %, d = 12 +4.5 %, 11520 x 8184
     // zstd +4.5 %; level 3 / mode 0 (nothing to gain from LDS, three-wave workgroups cost 2-4 %) and the configurations whose second
@@ -709,11 +720,11 @@ static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames
         if (nfull)
             hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, AL, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(nfull)), dim3(64 * RW), 0, s, frames, sc.thr, sc.N,
                                sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
-                               sc.blk_size, depth, sc.status, zm);
+                               sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
         if (nfull < sc.ntiles)   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
             hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, false, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
                                sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
-                               sc.blk_slots, sc.blk_size, depth, sc.status, zm);
+                               sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
     };
     if constexpr (SB == 2) {
         if (three) { go(std::integral_constant<int, 3>{}); return; }
@@ -933,7 +944,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_frames(Scratch sc, int with_cou
     if (with_blocks) {
         if (sc.zm_model) {
             const ZstdModel *M = reinterpret_cast<const ZstdModel *>(sc.zm_model);
-            zstd_place_defs(sc.blk_size + fr, n, sc.blk_slots + fr * BLK_SLOT, BLK_SLOT, M->lit_desc, M->lit_desc_len, M->seq_desc,
+            zstd_place_defs(sc.blk_size + fr, n, sc.blk_slots + fr * sc.blk_stride, sc.blk_stride, M->lit_desc, M->lit_desc_len, M->seq_desc,
                             M->seq_desc_len, s_adj);
         }
         scan_row<SCAN_I>(sc.blk_size + fr, sc.blk_off + fr, n, sc.frame_cbytes + f, sm, sc.zm_model ? s_adj : nullptr);
@@ -1108,7 +1119,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_fix(Scratch sc, int with_counts
             sl = t_seq != 0xFFFFFFFFu ? M->seq_desc_len : 0u;
             const uint32_t mine = (t_tree >= lo && t_tree < hi ? 1u : 0u) | (t_seq >= lo && t_seq < hi ? 2u : 0u);
             if (mine) {
-                zstd_rewrite_defs(sc.blk_size + fr, sc.blk_slots + fr * BLK_SLOT, BLK_SLOT, M->lit_desc, tl, M->seq_desc, sl, t_tree, t_seq, mine, s_img, &s_pos);
+                zstd_rewrite_defs(sc.blk_size + fr, sc.blk_slots + fr * sc.blk_stride, sc.blk_stride, M->lit_desc, tl, M->seq_desc, sl, t_tree, t_seq, mine, s_img, &s_pos);
                 if (threadIdx.x == 0) {   // (behind the rewrite, which reads the blocks' clean sizes)
                     if (mine & 1u) sc.blk_size[fr + t_tree] += tl;
                     if (mine & 2u) sc.blk_size[fr + t_seq] += sl;
@@ -1482,7 +1493,7 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
                 bn[ps] = sc.blk_size[frow + tl];
                 const uint32_t boff = bhdr + sc.blk_off[frow + tl];
                 bdst[ps] = rec + bitmap_pos + boff;
-                bsrc[ps] = sc.blk_slots + (frow + tl) * BLK_SLOT;
+                bsrc[ps] = sc.blk_slots + (frow + tl) * sc.blk_stride;
                 if (rp.emit == 8 && sl == 0) store_u32_le(rec + bitmap_pos + 16 + 4 * (uint64_t)tl, boff);  // blosc bstarts[tl]
             }
         }
@@ -1496,7 +1507,7 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
                     const uint32_t avail = (uint32_t)((dbit + nbits) & 7u);
                     uint32_t n = (uint32_t)(b_hi - b_lo);
                     ps0[ps] = (uint32_t)(8 * b_lo - dbit);
-                    psrc[ps] = reinterpret_cast<const uint8_t *>(sc.pix_slots + (frow + tl) * SLOT_PX);
+                    psrc[ps] = residual_src(sc, frow + tl, sc.comb == 1 ? sc.blk_size[frow + tl] : 0u, c, d);
                     if (avail && n) {  // (n == 0: the tile's few bits all live in a byte that an earlier tile owns)
                         --n;
                         fin_avail[ps] = avail;
@@ -1538,7 +1549,8 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
             fin_ncnt[ps] = 0; fin_nfirst[ps] = 0;
             if (fin_avail[ps] && fin_next[ps] < sc.ntiles) {
                 fin_ncnt[ps] = sc.tile_cnt[frow + fin_next[ps]];
-                fin_nfirst[ps] = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + fin_next[ps]) * SLOT_PX);
+                fin_nfirst[ps] = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + fin_next[ps], sc.comb == 1 ? sc.blk_size[frow + fin_next[ps]] : 0u,
+                                                                                 fin_ncnt[ps], d));
             }
         }
     }
@@ -1589,7 +1601,7 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
                 tt = sc.tile_next[frow + tt];
                 if (tt < sc.ntiles) {
                     cc = sc.tile_cnt[frow + tt];
-                    first = *reinterpret_cast<const uint32_t *>(sc.pix_slots + (frow + tt) * SLOT_PX);
+                    first = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + tt, sc.comb == 1 ? sc.blk_size[frow + tt] : 0u, cc, d));
                 }
             }
             pdst[plain_pos ? fin_b[ps] : stored_pos(ff, fin_b[ps])] = (uint8_t)byte;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(FSE_T) void k_zstd_fse(Scratch sc, uint32_t nslots,
     const uint32_t word = sc.blk_size[ft];
     if (word & ZW_FINAL) { sc.blk_size[ft] = word & (0xFFFFu | ZW_TREE); return; }
     const uint32_t P = word & 0xFFFFu, nseq = (word >> 16) & 0xFFu;
-    uint32_t *slot32 = reinterpret_cast<uint32_t *>(sc.blk_slots + (uint64_t)ft * BLK_SLOT);
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(sc.blk_slots + (uint64_t)ft * sc.blk_stride);
     const ZW4 *tok4 = reinterpret_cast<const ZW4 *>(slot32 + (zstd_token_offset(P) >> 2));
     const uint32_t w0 = P >> 2, nb0 = 8 * (P & 3u);
     const uint64_t acc0 = nb0 ? (uint64_t)(slot32[w0] & ((1u << nb0) - 1u)) : 0ull;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WG) void k_zstd_sample(Scratch sc, uint32_t B, uint
         const uint64_t ft = (uint64_t)f * sc.ntiles + t;
         const uint32_t word = sc.blk_size[ft];
         if (!(word & ZW_FINAL)) {
-            const uint8_t *slot = sc.blk_slots + ft * BLK_SLOT;
+            const uint8_t *slot = sc.blk_slots + ft * sc.blk_stride;
             const uint32_t P = word & 0xFFFFu, nseq = word >> 16;
             const uint32_t b3 = slot[3];
             const uint32_t lh = (b3 & 4u) ? 2u : 1u;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WG) void k_zstd_sample(Scratch sc, uint32_t B, uint
         }
         if (with_pix) {
             const uint32_t nbytes = (sc.tile_cnt[ft] * depth + 7) >> 3;
-            const uint8_t *p = reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * SLOT_PX);
+            const uint8_t *p = residual_src(sc, ft, 0u, sc.tile_cnt[ft], depth);   // (zstd: the combined slots' fixed offset, no block size needed)
             for (uint32_t i = lane; i < nbytes; i += 64) atomicAdd(&s_h.pix[p[i]], 1u);
         }
     }

@@ -29,9 +29,47 @@ def _device_stack(torch, hip, seed, n_frames, N, ppm):
     return dark, frames
 
 
+def _stock_lz4f_decompress(data, cap):
+    """STOCK liblz4 (LZ4F_decompress), the library behind the reference's lz4.frame (recode_compressors.py:46-49).  Not optional at
+    full size: the GPU box has it (bench.py's cpu_baseline links the same library) - a missing library FAILS instead of leaving the
+    device's frames to this repo's own from-spec decoder alone."""
+    import ctypes as C
+    import ctypes.util
+    name = ctypes.util.find_library("lz4")
+    assert name, "liblz4 not found: the full-size LZ4 records need the stock decoder as their judge"
+    L = C.CDLL(name)
+    L.LZ4F_createDecompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    L.LZ4F_createDecompressionContext.restype = C.c_size_t
+    L.LZ4F_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
+    L.LZ4F_decompress.restype = C.c_size_t
+    L.LZ4F_isError.argtypes = [C.c_size_t]
+    L.LZ4F_freeDecompressionContext.argtypes = [C.c_void_p]
+    ctx = C.c_void_p()
+    assert not L.LZ4F_isError(L.LZ4F_createDecompressionContext(C.byref(ctx), 100))
+    src = np.frombuffer(data, np.uint8)
+    dst = np.empty(cap + 64, np.uint8)
+    sp = dp = 0
+    try:
+        while sp < src.size:
+            ssz, dsz = C.c_size_t(src.size - sp), C.c_size_t(dst.size - dp)
+            r = L.LZ4F_decompress(ctx, dst.ctypes.data + dp, C.byref(dsz), src.ctypes.data + sp, C.byref(ssz), None)
+            assert not L.LZ4F_isError(r), "stock liblz4 rejected the frame"
+            sp += ssz.value
+            dp += dsz.value
+            if r == 0:
+                break
+            assert ssz.value or dsz.value, "stock liblz4 made no progress"
+    finally:
+        L.LZ4F_freeDecompressionContext(ctx)
+    assert sp == src.size, "stock liblz4 did not consume the whole stream"
+    return dst[:dp].tobytes()
+
+
 def _decode(orc, scheme, stream, cap):
     if scheme == 2:
-        return orc.lz4f_decode(stream, cap)
+        got = orc.lz4f_decode(stream, cap)
+        assert _stock_lz4f_decompress(stream, cap) == got      # both judges, and they agree
+        return got
     from pyrecode_amd.recode_compressors import _zstd_host_decompress
     return _zstd_host_decompress(stream)
 
@@ -121,8 +159,8 @@ def test_4096_host_buffer_path_and_pcie_inclusive_rate(env, capsys):
         r = out[int(rec[z]):int(rec[z + 1])].tobytes()
         _, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
         bitmap, packed, nnz = orc.reduce_frame_l1(frames[z].ravel(), thr, 16)
-        assert orc.lz4f_decode(r[16:16 + cb], bitmap.size + 8) == bitmap.tobytes()
-        assert orc.lz4f_decode(r[16 + cb:], packed.size + 8) == packed.tobytes()
+        assert _decode(orc, 2, r[16:16 + cb], bitmap.size + 8) == bitmap.tobytes()
+        assert _decode(orc, 2, r[16 + cb:], packed.size + 8) == packed.tobytes()
     with capsys.disabled():
         print("\n[pcie-inclusive] %d frames 4096x4096 from pageable host memory: %.1f frames/s (%.2f GB/s in)" % (
             B, B / dt, B * N * 2 / dt / 1e9))

@@ -22,6 +22,10 @@ line zstd_d12 --scheme 1 --depth 12 $Q
 line detector_like_lz4 --clustered --sparsity-ppm 11000 --depth 12 $Q
 line detector_like_zstd --clustered --sparsity-ppm 11000 --depth 12 --scheme 1 $Q
 line rehearsal_2ranks_gloo_shared_gpu --gpus 2 --shared-gpu --dist-backend gloo --stack 128 --min-seconds 1
+line uint8_sources_lz4 --source-bytes 1 $Q
+line uint8_sources_zstd --source-bytes 1 --scheme 1 $Q
+line lz4_2pct_d12 --sparsity-ppm 20000 --depth 12 $Q
+line zstd_2pct_d12 --sparsity-ppm 20000 --depth 12 --scheme 1 $Q
 line read_zstd --read --scheme 1 --steps 30 --warmup 5 --min-seconds 1
 line read_lz4 --read --scheme 2 --steps 30 --warmup 5 --min-seconds 1
 line read_zstd_fast --read --scheme 1 --clevel 0 --steps 30 --warmup 5 --min-seconds 1
@@ -37,5 +41,7 @@ tools/prof_round.sh ${T}_cfg5 --config 5 > $OUT/prof_cfg5.log 2>&1
 tools/prof_round.sh ${T}_cfg5_b16 --config 5 --batch 16 --stack 32 > $OUT/prof_cfg5_b16.log 2>&1
 tools/prof_round.sh ${T}_cfg4 --config 4 > $OUT/prof_cfg4.log 2>&1
 tools/prof_round.sh ${T}_d12 --depth 12 > $OUT/prof_d12.log 2>&1
+tools/prof_round.sh ${T}_det_lz4 --clustered --sparsity-ppm 11000 --depth 12 > $OUT/prof_det_lz4.log 2>&1
+tools/prof_round.sh ${T}_det_zstd --clustered --sparsity-ppm 11000 --depth 12 --scheme 1 > $OUT/prof_det_zstd.log 2>&1
 for s in 1 2; do tools/prof_bench.sh ${T}_read_s$s --read --scheme $s --steps 30 --warmup 5 --min-seconds 0.5 > $OUT/prof_read_s$s.log 2>&1; done
 echo done

@@ -1,18 +1,18 @@
 #!/bin/bash
 # The HOST side of an N-rank run, measured on ONE GPU (the only part of the 8-GPU scaling run a one-GPU box can show): N ranks share
-# cuda:0 (at most 6 processes may use the card on the pool's boxes), each with its own step loop, stack and ctx.  --no-collective: the
+# cuda:0 (at most 6 processes may use the card on the pool's boxes, and the launcher's agent counts: 5 ranks), each with its own step loop, stack and ctx.  --no-collective: the
 # ranks meet only at the fences, so what is compared with the single rank is N Python loops + N x the launches on the box's granted
 # cores; the gloo forms add the rehearsal backend's host copies per gather.  usage: tools/host_side_rehearsal.sh <outdir> [N...]
 OUT=$1; shift
-RANKS=${@:-"2 4 6"}
+RANKS=${@:-"2 4 5"}
 mkdir -p $OUT
 COMMON="--stack 64 --steps 100 --warmup 10 --min-seconds 1.0"
 python3 bench.py $COMMON --no-cpu-baseline --no-ingest > $OUT/ranks1.json 2> $OUT/ranks1.err
 for n in $RANKS; do
   python3 bench.py --gpus $n --shared-gpu --dist-backend gloo --no-collective $COMMON > $OUT/ranks${n}_no_collective.json 2> $OUT/ranks${n}_no_collective.err
-  python3 bench.py --gpus $n --shared-gpu --dist-backend gloo --gather-every 0 $COMMON > $OUT/ranks${n}_gloo_gather_once.json 2> $OUT/ranks${n}_gloo_gather_once.err
 done
 n=$(echo $RANKS | awk '{print $NF}')
+python3 bench.py --gpus $n --shared-gpu --dist-backend gloo --gather-every 0 $COMMON > $OUT/ranks${n}_gloo_gather_once.json 2> $OUT/ranks${n}_gloo_gather_once.err
 python3 bench.py --gpus $n --shared-gpu --dist-backend gloo $COMMON > $OUT/ranks${n}_gloo_gather_every_step.json 2> $OUT/ranks${n}_gloo_gather_every_step.err
 python3 bench.py --gpus $n --shared-gpu --dist-backend gloo --no-collective --no-pin $COMMON > $OUT/ranks${n}_no_collective_unpinned.json 2> $OUT/ranks${n}_no_collective_unpinned.err
 python3 - $OUT <<'PY'

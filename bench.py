@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--read", action="store_true", help="measure the READER instead: stored frames -> device decode of both streams -> sparse expand (rc_expand_frames)")
     ap.add_argument("--blob-on-device", action="store_true", help="--read: the stored frames' bytes already sit in device memory (the decoders without the link)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the extra ingest-inclusive measurement (host frames -> part file)")
+    ap.add_argument("--ingest-frames", type=int, default=512, help="frames per pass of the ingest-inclusive measurement (capped at 16 GiB of host memory)")
     ap.add_argument("--no-pipeline", action="store_true", help="plain stream order: a batch's reduce kernel waits for the previous batch's records")
     ap.add_argument("--clevel", type=int, default=1, help="compression_level: 0 = the fast device encoders, >= 1 = the modelled zstd encoder")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="the K-step timed region is repeated until this much time has been measured (>= 3 repeats); the median repeat is reported")
@@ -742,8 +743,8 @@ def run_rank(a):
             result["cpu_baseline"] = None
         if world == 1 and not a.no_ingest and a.level in (1, 3):
             try:
-                result["ingest_inclusive"], host_frames = ingest_inclusive(stack, dark, a)
-                v, _ = ingest_inclusive(stack, dark, a, validation_frame_gap=10, data=host_frames)   # validation frames ride the same stream (recode_writer.py:402-415)
+                result["ingest_inclusive"], host_frames = ingest_inclusive(stack, dark, a, nframes=a.ingest_frames)
+                v, _ = ingest_inclusive(stack, dark, a, nframes=a.ingest_frames, validation_frame_gap=10, data=host_frames)   # validation frames ride the same stream (recode_writer.py:402-415)
                 del host_frames
                 result["ingest_inclusive"]["with_validation_frame_gap_10"] = {
                     "frames_per_s": v["frames_per_s"], "gb_per_s_in": v["gb_per_s_in"], "frames_per_s_min_max": v["frames_per_s_min_max"],

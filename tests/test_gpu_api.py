@@ -1225,3 +1225,34 @@ def test_uint8_sources_with_a_device_codec_round_trip(tmp_path, orc):
         for z in range(nz):
             assert np.array_equal(np.asarray(rd.get_frame(z)[z]["data"].todense()), want[z])
         rd.close()
+
+
+@pytest.mark.parametrize("given", [np.uint32, np.int64, np.float32])
+def test_frames_handed_over_in_another_dtype_are_cast_like_the_reference(given, tmp_path):
+    """The reference casts whatever array it is handed to the source dtype its parameters name (recode_writer.py:352-354: `data.astype`);
+    so does the staging copy here - G3's 12-bit stack handed over as uint32 / int64 / float32 gives the reference's files byte for byte."""
+    import warnings
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    g = load_npz("g3_l1z12.npz")
+    base, nodes = "g3_l1z12", int(g["n_nodes"])
+    for node in range(nodes):
+        ip, cfg = _params(tmp_path, g)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            w = ReCoDeWriter(base, dark_data=g["dark"].astype(given), output_directory=str(tmp_path), input_params=ip, mode="batch",
+                             validation_frame_gap=-1, node_id=node, batch_size=3)
+            w.start()
+            w.run(g["frames"].astype(given))
+            w.close()
+        fn = "%s.rc1_part%03d" % (base, node)
+        assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
+
+
+def test_sources_beyond_16_bits_are_refused_by_name(tmp_path):
+    """source_bit_depth > 16 maps to uint32 frames (misc.py:41-49): the one source dtype of the reference's Python path the device path does
+    not take - refused when the writer is made, with a message that says which and why (not a fallback, not a wrong file)."""
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    g = load_npz("g3_l1z16.npz")
+    ip, cfg = _params(tmp_path, g, source_bit_depth=24, target_bit_depth=24)
+    with pytest.raises(NotImplementedError, match="uint32"):
+        ReCoDeWriter("x", dark_data=g["dark"], output_directory=str(tmp_path), input_params=ip, mode="batch", node_id=0)

@@ -24,7 +24,7 @@ def _run(cmd):
 @pytest.mark.gpu
 @pytest.mark.parametrize("launcher", ["plain", "torchrun"])
 def test_bench_contract(launcher):
-    args = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--stack", "64", "--no-cpu-baseline", "--min-seconds", "0.2"]
+    args = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--stack", "64", "--no-cpu-baseline", "--min-seconds", "0.2", "--ingest-frames", "64"]
     if launcher == "plain":
         cmd = [sys.executable] + args
     else:
@@ -42,7 +42,7 @@ def test_bench_contract(launcher):
 
 @pytest.mark.gpu
 def test_bench_cpu_baseline_leg():
-    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--stack", "64", "--min-seconds", "0.2"])
+    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--stack", "64", "--min-seconds", "0.2", "--ingest-frames", "64"])
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
 

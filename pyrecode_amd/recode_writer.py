@@ -337,8 +337,25 @@ class ReCoDeWriter:
 
         gap = self._init_params.validation_frame_gap
         dose_rates, val_jobs = [], []
-        val_writer = ThreadPoolExecutor(max_workers=4) if gap > 0 else None
         usable, visible = effective_cpus()
+        # (TWO threads: a tmpfs / page-cache file takes 6.9 GB/s from one or two writers and 3.6-3.8 GB/s from four or eight - they contend for
+        # the file's page allocation, tools/validation_gap_rate.py - and round 3's four, started late, were what cost a third of the rate)
+        val_writer = ThreadPoolExecutor(max_workers=2) if gap > 0 else None
+        if gap > 0:
+            # Validation frames (reference :402-415): WHICH frames go to the side file is known before anything runs - every frame whose id
+            # is a multiple of the gap - and where (frame order), so all their writes are queued now, in 8 MB pieces on threads of their own
+            # (pwrite() at its offset, from the source array's memory, releases the GIL; a tmpfs / page-cache write is a memcpy plus page
+            # allocation: 1-2 GB/s a thread), and run beside the whole stream instead of trailing the batches they belong to (round 3
+            # queued a frame's 32 MB when its batch's records came back: the last batches' frames were written behind the end of the run,
+            # and with every tenth frame a validation frame the side file takes three times the bytes of the records).  Only the dose
+            # rate - the device's component count of the frame's ROI - still arrives with the batch (append() below).
+            fd, piece = self._validation_file.fileno(), 8 << 20
+            for k in range(n_frames):
+                if (first_id + k) % gap == 0:
+                    mv = memoryview(np.ascontiguousarray(data[k])).cast('B')
+                    for lo in range(0, mv.nbytes, piece):
+                        val_jobs.append(val_writer.submit(_pwrite_all, fd, mv[lo:lo + piece], self._val_pos + lo))
+                    self._val_pos += mv.nbytes
         # a quota'd container is this writer's alone (one rank per GPU box: all of its share); a whole node is shared by its ranks
         host_workers = max(2, min(32, usable if usable < visible else visible // 4))
         host_pool = (ThreadPoolExecutor(max_workers=host_workers)
@@ -347,14 +364,8 @@ class ReCoDeWriter:
         def append(i):  # (writer thread) batch i's records: page-locked buffer -> part file
             ctx.pipe_fetch_wait(i % slots)
             n, rec, md, total, counts = info[i]
-            if counts is not None:   # validation frames of this batch, in frame order (reference :402-415)
-                for k in np.nonzero(counts != 0xFFFFFFFF)[0]:
-                    # the raw frame goes to the validation file on a few threads of their own (32 MB per frame at 4096^2: with every
-                    # tenth frame a validation frame that file takes three times the bytes of the records), each at its own offset,
-                    # from the source array's memory without an intermediate copy - pwrite() releases the GIL
-                    mv = memoryview(np.ascontiguousarray(data[i * B + int(k)])).cast('B')
-                    val_jobs.append(val_writer.submit(_pwrite_all, self._validation_file.fileno(), mv, self._val_pos))
-                    self._val_pos += mv.nbytes
+            if counts is not None:   # dose rates of this batch's validation frames, in frame order (reference :402-415; their raw frames
+                for k in np.nonzero(counts != 0xFFFFFFFF)[0]:                                    # are on their way to the side file already)
                     self._vc_dose_rate = int(counts[k]) / self._vc_n_pixels
                     dose_rates.append(self._vc_dose_rate)
             buf = self._pin_out[i % slots].array

@@ -338,12 +338,13 @@ class ReCoDeWriter:
         gap = self._init_params.validation_frame_gap
         dose_rates, val_jobs = [], []
         usable, visible = effective_cpus()
-        # (TWO threads: a tmpfs / page-cache file takes 6.9 GB/s from one or two writers and 3.6-3.8 GB/s from four or eight - they contend for
-        # the file's page allocation, tools/validation_gap_rate.py - and round 3's four, started late, were what cost a third of the rate)
-        val_writer = ThreadPoolExecutor(max_workers=2) if gap > 0 else None
+        # (ONE writer thread: concurrent pwrite()s into one tmpfs / page-cache file contend - same box, 512 frames, gap 10, rate against the
+        # plain run: 1 thread 0.998, 2 threads 0.559, 4 0.527, 8 0.686, 12 0.581 (tools/validation_gap_rate.py, profiles/r04_validation_gap_rate.log);
+        # one thread streams the side file at 6-7 GB/s, which a run with every tenth frame a validation frame needs a fifth of)
+        val_writer = ThreadPoolExecutor(max_workers=int(os.environ.get('RC_WRITER_VAL_THREADS', '1'))) if gap > 0 else None
         if gap > 0:
             # Validation frames (reference :402-415): WHICH frames go to the side file is known before anything runs - every frame whose id
-            # is a multiple of the gap - and where (frame order), so all their writes are queued now, in 8 MB pieces on threads of their own
+            # is a multiple of the gap - and where (frame order), so all their writes are queued now, in 8 MB pieces on a thread of their own
             # (pwrite() at its offset, from the source array's memory, releases the GIL; a tmpfs / page-cache write is a memcpy plus page
             # allocation: 1-2 GB/s a thread), and run beside the whole stream instead of trailing the batches they belong to (round 3
             # queued a frame's 32 MB when its batch's records came back: the last batches' frames were written behind the end of the run,

@@ -1306,3 +1306,45 @@ def test_uint8_source_contexts_refuse_what_they_cannot_take(hip):
     assert hip.lib().rc_ctx_set_source_bytes(ctx.handle, 1) == hip.RC_ERR_BAD_ARG     # after the dark frame: too late
     assert hip.lib().rc_ctx_set_source_bytes(ctx.handle, 4) == hip.RC_ERR_UNSUPPORTED
     ctx.close()
+
+
+@pytest.mark.parametrize("scheme,clevel", [(2, 1), (2, 0), (1, 1), (1, 0), (8, 1), (0, 1)])
+@pytest.mark.parametrize("d", [12, 16, 9])
+def test_tiles_at_the_stage_and_slot_capacities(hip, orc, scheme, clevel, d):
+    """One-tile frames whose set-pixel count sweeps, one pixel at a time, across every capacity the residual path switches on: the
+    fused d = 12 stage (341 fields), the compact stage (256 values), the combined slot (block + residual lines <= 1536 bytes: a few hundred
+    values, depending on the block's size) - plus empty, full and nearly full tiles.  Records against the oracle, frame by frame."""
+    ny = nx = 64                                                  # 4096 pixels = exactly one tile
+    counts = sorted(set(list(range(250, 262)) + list(range(336, 348)) + list(range(440, 460)) + list(range(500, 780, 7)) +
+                        list(range(590, 606)) + list(range(672, 690)) + [0, 1, 2, 4095, 4096, 3000]))
+    counts = [c for c in counts if (c * d + 7) // 8 + 512 + 80 <= ny * nx * 2]   # (a record may not exceed the raw frame: recode_writer.py:565-566)
+    rng = np.random.default_rng(1000 * scheme + d)
+    dark = rng.integers(5, 40, (ny, nx)).astype(np.uint16)
+    frames = np.minimum(dark, rng.integers(0, 40, (len(counts), ny, nx))).astype(np.uint16)
+    top = min((1 << d) - 1, 4000)
+    for z, c in enumerate(counts):
+        at = rng.choice(ny * nx, c, replace=False)
+        f = frames[z].ravel()
+        f[at] = dark.ravel()[at] + rng.integers(1, top - 40, c).astype(np.uint16)
+    thr = orc.threshold(dark, 0)
+    op_mode = 0 if scheme == 0 else 1
+    B = 16
+    ctx = hip.ReduceContext(nx, ny, d, 1, op_mode, scheme, clevel, 0, max_batch=B)
+    ctx.set_dark(dark, 0)
+    dec = {2: lambda b, n: orc.lz4f_decode(b, n + 64), 1: lambda b, n: _zstd_system_decode(b), 8: lambda b, n: orc.blosc1_decode(b)}.get(scheme)
+    for lo in range(0, len(counts), B):
+        out, rec, md = ctx.reduce_compress_batch(frames[lo:lo + B], first_frame_id=lo)
+        for i in range(min(B, len(counts) - lo)):
+            z = lo + i
+            r = out[int(rec[i]):int(rec[i + 1])].tobytes()
+            binary, pix = orc.binarize_l1(frames[z], thr)
+            assert pix.size == counts[z]
+            bitmap, packed = orc.pack_binary_frame(binary).tobytes(), orc.bit_pack(pix, d).tobytes()
+            if scheme == 0:
+                assert r == struct.pack("<II", z, len(packed)) + bitmap + packed, "count %d" % counts[z]
+                continue
+            fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+            assert fid == z and npk == len(packed) and len(r) == 16 + cb + cp, "count %d" % counts[z]
+            assert dec(r[16:16 + cb], len(bitmap)) == bitmap, "count %d: binary map" % counts[z]
+            assert dec(r[16 + cb:], npk) == packed, "count %d: values" % counts[z]
+    ctx.close()

@@ -30,6 +30,24 @@ ip._param_map.update(dict(reduction_level=1, rc_operation_mode=1, calibration_th
                           keep_calibration_data=0, calibration_file_type=0, source_data_type=0, target_data_type=0))
 out_dir = tempfile.mkdtemp(dir='/dev/shm')
 try:
+    sweep = [int(v) for v in os.environ.get("VAL_THREADS_SWEEP", "").split(",") if v]
+    for nthr in sweep:        # validation writer threads, interleaved with the plain run
+        r0, r1 = [], []
+        os.environ["RC_WRITER_VAL_THREADS"] = str(nthr)
+        for rep in range(passes + 1):
+            for gap, acc in ((-1, r0), (10, r1)):
+                w = ReCoDeWriter('stack.bin', dark_data=dark_h, output_directory=out_dir, input_params=ip, mode='batch', node_id=0, batch_size=32,
+                                 validation_frame_gap=gap)
+                w.start()
+                t0 = time.perf_counter()
+                w.run(data)
+                dt = time.perf_counter() - t0
+                w.close()
+                if rep:
+                    acc.append(data.shape[0] / dt)
+        r0.sort(); r1.sort()
+        print("validation writer threads %d: plain %.1f  gap 10 %.1f (min %.1f max %.1f)  ratio %.3f" % (nthr, r0[len(r0) // 2], r1[len(r1) // 2], r1[0], r1[-1], r1[len(r1) // 2] / r0[len(r0) // 2]), flush=True)
+    os.environ.pop("RC_WRITER_VAL_THREADS", None)
     res = {-1: [], 10: []}
     for rep in range(passes + 1):
         for gap in (-1, 10):

@@ -1086,7 +1086,10 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_seg(Scratch sc, int with_counts
         if (first != 0xFFFFFFFFu) atomicMin(&s_min[0], first);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { part->blk_sum = blk_sum; part->cnt_sum = cnt_sum; part->first_nonempty = s_min[0]; part->first_tree = s_min[1]; part->first_seq = s_min[2]; }
+    if (threadIdx.x == 0) {   // (only what this launch computed: the count half and the block half of a batch may run side by side on two streams)
+        if (with_blocks) { part->blk_sum = blk_sum; part->first_tree = s_min[1]; part->first_seq = s_min[2]; }
+        if (with_counts) { part->cnt_sum = cnt_sum; part->first_nonempty = s_min[0]; }
+    }
 }
 
 __global__ __launch_bounds__(SCAN_T) void k_scan_fix(Scratch sc, int with_counts, int with_blocks)

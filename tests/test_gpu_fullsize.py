@@ -313,7 +313,7 @@ def test_4096_detector_like_clusters_full_oracle_compare(env, scheme):
         assert np.array_equal(trip[int(prefix[z]):int(prefix[z + 1])], want_trip[z]), "frame %d" % z
 
 
-@pytest.mark.parametrize("scheme,depth", [(1, 12), (2, 16), (0, 12)])
+@pytest.mark.parametrize("scheme,depth", [(1, 12), (1, 16), (2, 16), (0, 12)])   # (1, 16): Huffman-coded residuals (two second-stage branches)
 def test_frames_with_more_than_4096_tiles_take_the_segmented_scans(env, scheme, depth):
     """ntiles = 4200 (two scan segments, k_scan_seg / k_scan_fix): an ordinary frame, a frame whose first 4150 tiles are EMPTY
     (the first block that needs the zstd tree and tables lies in the second segment; every next-non-empty link of the first

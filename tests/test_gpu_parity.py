@@ -1348,3 +1348,44 @@ def test_tiles_at_the_stage_and_slot_capacities(hip, orc, scheme, clevel, d):
             assert dec(r[16:16 + cb], len(bitmap)) == bitmap, "count %d: binary map" % counts[z]
             assert dec(r[16 + cb:], npk) == packed, "count %d: values" % counts[z]
     ctx.close()
+
+
+@pytest.mark.parametrize("form", ["RC_ZSTD_LITS_ALWAYS", "RC_ZSTD_SEQ_ALWAYS"])
+@pytest.mark.parametrize("ny,nx,s,d,eps", SHAPES)
+def test_zstd_both_block_forms_at_every_density(hip, orc, monkeypatch, ny, nx, s, d, eps, form):
+    """The modelled encoder picks the binary maps' block form from its sample (literals + sequences, or every byte a Huffman-coded
+    literal and no sequences: rc_zstd_model.h), so a density exercises ONE form in the tests above.  Here each form is forced on
+    every shape - sparse maps as literals only, dense ones with sequences - and stock libzstd must expand both to the exact payload;
+    the batched device reader decodes the same records back."""
+    monkeypatch.setenv(form, "1")
+    dark, frames = synth_frames(91 + nx, 4, ny, nx, s, d)
+    thr = orc.threshold(dark, eps)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 1, 1, 1, 0, max_batch=4)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+    blobs, sizes = [], np.zeros((frames.shape[0], 3), np.uint32)
+    for z in range(frames.shape[0]):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        assert fid == z and len(r) == 16 + cb + cp
+        binary, pix = orc.binarize_l1(frames[z], thr)
+        assert _zstd_system_decode(r[16:16 + cb]) == orc.pack_binary_frame(binary).tobytes()
+        packed = orc.bit_pack(pix, d).tobytes()
+        assert npk == len(packed) and _zstd_system_decode(r[16 + cb:]) == packed
+        blobs.append(np.frombuffer(r[16:], np.uint8))
+        sizes[z] = (cb, cp, npk)
+    ctx.close()
+    # and back through the batched device reader (rc_expand_frames decodes both block forms)
+    blob = np.concatenate(blobs)
+    n = frames.shape[0]
+    prefix = np.zeros(n + 1, np.uint64)
+    cap = int((frames > thr).sum()) + 8
+    trip = np.zeros((cap, 3), np.uint64)
+    st = hip.lib().rc_expand_frames(nx, ny, d, 1, 1, 1, hip.ptr(blob), hip.ptr(sizes), n, hip.ptr(prefix), hip.ptr(trip), cap)
+    assert st == hip.RC_OK, hip.last_error()
+    for z in range(n):
+        t = trip[int(prefix[z]):int(prefix[z + 1])]
+        img = np.zeros((ny, nx), np.uint16)
+        img[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16)
+        want = np.where(frames[z] > thr, (frames[z] - thr) & ((1 << d) - 1), 0).astype(np.uint16)
+        assert np.array_equal(img, want), "frame %d" % z

@@ -1389,3 +1389,28 @@ def test_zstd_both_block_forms_at_every_density(hip, orc, monkeypatch, ny, nx, s
         img[t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint16)
         want = np.where(frames[z] > thr, (frames[z] - thr) & ((1 << d) - 1), 0).astype(np.uint16)
         assert np.array_equal(img, want), "frame %d" % z
+
+
+@pytest.mark.parametrize("stat,scheme,mode", [(0, 0, 0), (2, 2, 1), (0, 8, 1)])
+def test_l2_summary_statistics_of_uint8_sources(hip, orc, stat, scheme, mode):
+    """Level 2 on uint8 frames: the components' maxima / sums of the RAW uint8 values (clamped at 2^d - 1 like every value list), in
+    scipy's label order - the uint8 instantiation keeps the raw value of a set pixel as residual + threshold, as the uint16 one does."""
+    ny, nx, d = 120, 136, 8
+    dark, frames = _synth_u8(7 + stat, 3, ny, nx, 0.06, d)
+    thr = orc.threshold(dark, 1)
+    ctx = hip.ReduceContext(nx, ny, d, 2, mode, scheme, 1, 0, max_batch=3, src_dtype=np.uint8)
+    ctx.set_dark(dark, 1)
+    ctx.set_l2_statistics(stat)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+    for z in range(frames.shape[0]):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        binary, vals = _l2_expected(frames[z].astype(np.uint16), thr.astype(np.uint16), stat, d)
+        bitmap, packed = orc.pack_binary_frame(binary).tobytes(), orc.bit_pack(vals, d).tobytes()
+        if mode == 0:
+            assert r == struct.pack("<II", z, len(packed)) + bitmap + packed, "frame %d" % z
+        else:
+            fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+            assert fid == z and npk == len(packed) and len(r) == 16 + cb + cp
+            dec = {2: lambda b, n: orc.lz4f_decode(b, n + 8), 8: lambda b, n: orc.blosc1_decode(b)}[scheme]
+            assert dec(r[16:16 + cb], len(bitmap)) == bitmap and dec(r[16 + cb:], len(packed)) == packed
+    ctx.close()

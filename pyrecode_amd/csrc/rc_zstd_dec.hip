@@ -198,9 +198,11 @@ __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlo
         }
     }
     if (o.op + L.left > cap) { *err = 1; return o.op; }
-    if constexpr (!SPARSE) {
-        // Huffman-coded literals, eight at a time (the body of a value-stream chunk: 1008 of them and nothing else).  While at least
-        // 8 * log bits are left no step of a group can over-read, so the group needs no checks; its eight bytes leave as one store.
+    {
+        // Huffman-coded literals, eight at a time (the body of a value-stream chunk: 1008 of them and nothing else - and, since round 4, of a
+        // binary-map block of the literals-only form: all its 512 bytes).  While at least 8 * log bits are left no step of a group can
+        // over-read, so the group needs no checks; its eight bytes leave as one store (the sparse sink: only when one of them is not zero -
+        // the output was zeroed).
         if (L.mode == 2 && o.al && (o.op & 7u) == 0) {
             const uint32_t log = L.log;
             while (L.left >= 8 && L.hb.left() >= 8 * (int32_t)log) {
@@ -211,7 +213,7 @@ __device__ uint32_t zstd_block_decode(const uint8_t *c, uint32_t bs, const ZdBlo
                     L.hb.bit -= (int32_t)(e >> 8);
                     acc |= (uint64_t)(e & 0xFFu) << (8 * j);
                 }
-                *reinterpret_cast<uint64_t *>(o.g + o.op) = acc;
+                if (!SPARSE || acc) *reinterpret_cast<uint64_t *>(o.g + o.op) = acc;
                 o.op += 8;
                 L.left -= 8;
             }

@@ -61,8 +61,8 @@ int rc_scheme_on_device(uint32_t scheme);        /* 1 if rc_reduce_compress_batc
  * allocates for it (:212-230).  One ctx == one writer (one node_id).
  *
  *   nx, ny            frame shape (header fields nx, ny; recode_header.py:66-67)
- *   src_bit_depth     source_bit_depth, 1..16: pixvals are bit-packed when it is not a multiple of 8 (recode_writer.py:463-475);
- *                     up to 8 the reference's source dtype is uint8: rc_ctx_set_source_bytes(ctx, 1)
+ *   src_bit_depth     source_bit_depth, 1..32: pixvals are bit-packed when it is not a multiple of 8 (recode_writer.py:463-475);
+ *                     up to 8 the reference's source dtype is uint8, beyond 16 uint32: rc_ctx_set_source_bytes(ctx, 1 / 4)
  *   reduction_level   1 (binary map + residuals), 2 (binary map + one statistic per 8-connected component, see
  *                     rc_ctx_set_l2_statistics) or 3 (binary map only); 4 -> RC_ERR_UNSUPPORTED
  *   op_mode           rc_operation_mode: 0 reduce only, 1 reduce + compress (recode_writer.py:482,497)
@@ -87,11 +87,14 @@ int rc_ctx_set_l2_statistics(rc_ctx *ctx, uint32_t l2_statistics);
  * stream, whose handle is 0, cannot be selected: use a created stream). */
 int rc_ctx_set_stream(rc_ctx *ctx, void *hip_stream);
 
-/* Bytes per SOURCE pixel: 2 (default: uint16 frames and dark) or 1 (uint8 frames and dark - what the reference's map_dtype yields for
- * source_bit_depth <= 8, misc.py:41-49; its Python path takes them, recode_writer.py:126-137,352-354,437-440, only use_c is uint16-only,
- * :85-87).  Call before rc_set_dark and the first batch.  With 1, every `frames` / `dark` pointer below is uint8[...][ny][nx], a raw
- * frame is ny*nx bytes (rc_out_capacity, the record bound of recode_writer.py:565-566) and the frame loads move half the bytes;
- * everything behind the loads (values, d-bit packing, codecs, records) is the same path.  4 (source_bit_depth > 16): RC_ERR_UNSUPPORTED. */
+/* Bytes per SOURCE pixel - the reference's Python path takes whatever its map_dtype yields for the source bit depth (misc.py:41-49; only
+ * use_c is uint16-only, recode_writer.py:85-87): 2 (default: uint16 frames and dark, 9..16 bits), 1 (uint8, <= 8 bits) or 4 (uint32, 17..32 bits).
+ * Call before rc_set_dark and the first batch.  Every `frames` / `dark` pointer below is then of that type, a raw frame is ny*nx*bytes
+ * (rc_out_capacity, the record bound of recode_writer.py:565-566).  uint8: a uint8 instantiation of the load path (half the bytes); everything
+ * behind the loads is the uint16 path.  uint32 (levels 1 and 3): a kernel of its own for the reduce step (rc_reduce32.hip: uint32 compare,
+ * residuals and depth-bit fields - four raw bytes a value when the depth is a multiple of 8, 24 included, as `.tobytes()` gives them,
+ * recode_writer.py:463-464), the block encoders as separate launches over the raw maps, zstd with the fast encoder; scans, record layout and
+ * assembly are shared.  rc_set_threshold then takes a uint32 frame. */
 int rc_ctx_set_source_bytes(rc_ctx *ctx, uint32_t bytes_per_pixel);
 uint32_t rc_ctx_source_bytes(const rc_ctx *ctx);
 
@@ -99,7 +102,7 @@ uint32_t rc_ctx_source_bytes(const rc_ctx *ctx);
  * ReCoDeWriter.__init__, recode_writer.py:126-137.  dark: uint16[ny*nx] (uint8[ny*nx] after rc_ctx_set_source_bytes(ctx, 1)), C order. */
 int rc_set_dark(rc_ctx *ctx, const void *dark, int64_t epsilon);
 /* Or hand over the finished threshold frame (self._calibration_frame_p_threshold). */
-int rc_set_threshold(rc_ctx *ctx, const uint16_t *thr);
+int rc_set_threshold(rc_ctx *ctx, const void *thr);   /* uint16[ny*nx] (uint8 and uint16 sources), uint32[ny*nx] (uint32 sources) */
 
 /* Worst-case bytes one batch of n frames can occupy in `out` (n * raw frame size, the reference's own bound,
  * recode_writer.py:217-218,565-566), and the number of u32 metadata fields per frame for this ctx's

@@ -197,6 +197,36 @@ def blosc1_decode(chunk):
 
 
 # ---- record / file assembly (A7, appendix A of SURVEY.md) ----------------------------------------
+# ---- sources beyond 16 bits (uint32 frames: source_bit_depth > 16, pyrecode/misc.py:41-49) - numpy restatements ---------------------------
+def threshold32(dark, eps):
+    """A1 for uint32 darks: recode_writer.py:126-127; the sum stays uint32 and wraps mod 2^32 under NumPy 2."""
+    return ((np.asarray(dark).astype(np.uint64) + (int(eps) & 0xFFFFFFFF)) & 0xFFFFFFFF).astype(np.uint32)
+
+
+def bit_pack32(vals, d):
+    """A5 for uint32 values: recode_writer.py:463-475,637-652 - the low d bits of every value, LSB first, value after value; when d is a
+    multiple of 8 the writer takes `.tobytes()` instead: FOUR bytes a value for a uint32 array, whatever d says (24 and 32 alike)."""
+    vals = np.ascontiguousarray(vals, dtype=np.uint32)
+    if d % 8 == 0:
+        return np.frombuffer(vals.astype('<u4').tobytes(), np.uint8)
+    bits = np.unpackbits(vals.astype('<u4').view(np.uint8).reshape(-1, 4), axis=1, bitorder='little')[:, :d]
+    return np.packbits(bits.reshape(-1), bitorder='little')
+
+
+def l1_record32(frame, thr, d, frame_id, mode=1, compress=lambda b: zlib.compress(b, 1)):
+    """One part-file record for L1 from uint32 frame / threshold (recode_writer.py:437-440,482-525,559-574): as l1_record, in numpy."""
+    frame, thr = np.asarray(frame, np.uint32), np.asarray(thr, np.uint32)
+    binary = frame > thr
+    pix = (frame[binary] - thr[binary]).astype(np.uint32)
+    bitmap = np.packbits(binary.reshape(-1), bitorder='little').tobytes()
+    packed = bit_pack32(pix, d).tobytes()
+    if mode == 0:
+        return struct.pack("<II", frame_id, len(packed)) + bitmap + packed, (len(packed),)
+    cb, cp = compress(bitmap), compress(packed)
+    md = (len(cb), len(cp), len(packed))
+    return struct.pack("<IIII", frame_id, *md) + cb + cp, md
+
+
 def l1_record(frame, thr, d, frame_id, mode=1, compress=lambda b: zlib.compress(b, 1)):
     """One part-file record for L1.  recode_writer.py:482-525, _write_to_frame_buffer :559-574.
     mode 1: u32 frame_id | u32 n_comp_bitmap | u32 n_comp_pix | u32 n_packed_pix | comp_bitmap | comp_pix

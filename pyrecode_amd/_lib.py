@@ -175,9 +175,8 @@ class ReduceContext:
         """src_dtype: numpy dtype of the frames and the dark frame - uint16, or uint8 (source_bit_depth <= 8: rc_ctx_set_source_bytes)"""
         st = C.c_int(0)
         self.src_dtype = np.dtype(src_dtype)
-        if self.src_dtype not in (np.dtype(np.uint16), np.dtype(np.uint8)):
-            raise NotImplementedError("source dtype %s: the device path takes uint16 and uint8 frames (32-bit sources, "
-                                      "source_bit_depth > 16, are not implemented on device)" % self.src_dtype)
+        if self.src_dtype not in (np.dtype(np.uint16), np.dtype(np.uint8), np.dtype(np.uint32)):
+            raise NotImplementedError("source dtype %s: the device path takes unsigned integer frames (uint8, uint16, uint32)" % self.src_dtype)
         self._h = lib().rc_ctx_create(nx, ny, src_bit_depth, reduction_level, op_mode, scheme, clevel, device_id, max_batch,
                                       C.byref(st))
         if not self._h:
@@ -212,7 +211,8 @@ class ReduceContext:
         check(lib().rc_set_dark(self._h, ptr(dark), int(epsilon)), "rc_set_dark")
 
     def set_threshold(self, thr):
-        thr = np.ascontiguousarray(thr, dtype=np.uint16) if isinstance(thr, np.ndarray) else thr
+        if isinstance(thr, np.ndarray):   # uint16 thresholds for uint8 and uint16 sources, uint32 ones for uint32 sources (include/recode_hip.h)
+            thr = np.ascontiguousarray(thr, dtype=np.uint32 if self.src_dtype.itemsize == 4 else np.uint16)
         check(lib().rc_set_threshold(self._h, ptr(thr)), "rc_set_threshold")
 
     def out_capacity(self, n):

@@ -26,7 +26,8 @@ struct rc_ctx {
     bool pipelined = false;
     bool thr_set = false;
     bool keep_bitmap = true;  // also store the raw binary maps when a device codec is active (rc_get_binary_map)
-    uint32_t src_bytes = 2;   // bytes per source pixel: 2 (uint16 frames and dark) or 1 (uint8: rc_ctx_set_source_bytes)
+    uint32_t src_bytes = 2;   // bytes per source pixel: 2 (uint16 frames and dark), 1 (uint8) or 4 (uint32): rc_ctx_set_source_bytes
+    uint32_t *thr32 = nullptr;   // uint32 sources: the threshold frame (sc.thr is the uint16 one)
     uint32_t last_n = 0;
     // staging for host callers
     uint8_t *d_frames = nullptr;  uint64_t d_frames_cap = 0;
@@ -267,8 +268,8 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
         *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 4 (centroiding) is not implemented on device");
         return nullptr;
     }
-    if (src_bit_depth < 1 || src_bit_depth > 16) {   // (<= 8: the reference's source dtype is uint8 - rc_ctx_set_source_bytes(ctx, 1))
-        *status = fail(RC_ERR_UNSUPPORTED, "source_bit_depth must be 1..16 (uint8 / uint16 source frames; 32-bit sources are not implemented on device)");
+    if (src_bit_depth < 1 || src_bit_depth > 32) {   // (<= 8: the reference's source dtype is uint8, > 16: uint32 - rc_ctx_set_source_bytes)
+        *status = fail(RC_ERR_UNSUPPORTED, "source_bit_depth must be 1..32 (uint8 / uint16 / uint32 source frames)");
         return nullptr;
     }
     int ndev = 0;
@@ -331,7 +332,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_sample) (void)hipHostFree(c->h_sample);
-    void *bufs[] = {c->sc.thr, c->d_first_err, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
+    void *bufs[] = {c->sc.thr, c->thr32, c->d_first_err, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
                     c->d_md, c->d_ztab, c->d_model, c->d_sample, c->l2.pos, c->l2.val, c->l2.parent, c->l2.stat, c->l2.word_rank, c->l2.frame_base};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -356,11 +357,14 @@ RC_EXPORT int rc_ctx_set_stream(rc_ctx *c, void *hip_stream)
     return RC_OK;
 }
 
-RC_EXPORT int rc_set_threshold(rc_ctx *c, const uint16_t *thr)
+RC_EXPORT int rc_set_threshold(rc_ctx *c, const void *thr)
 {
     if (!c || !thr) return fail(RC_ERR_BAD_ARG, "ctx / thr is NULL");
+    if (c->depth > 16 && c->src_bytes != 4) return fail(RC_ERR_BAD_ARG, "src_bit_depth > 16 means uint32 sources: rc_ctx_set_source_bytes(ctx, 4) first");
     RC_ON_DEVICE(c->device);
-    HIP_TRY(hipMemcpyAsync(c->sc.thr, thr, c->sc.N * 2, is_device_ptr(thr) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+    // (uint16 thresholds for uint16 AND uint8 sources - the device keeps them as uint16 -, uint32 ones for uint32 sources)
+    HIP_TRY(hipMemcpyAsync(c->src_bytes == 4 ? (void *)c->thr32 : (void *)c->sc.thr, thr, c->sc.N * (c->src_bytes == 4 ? 4 : 2),
+                           is_device_ptr(thr) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->thr_set = true;
@@ -379,7 +383,9 @@ RC_EXPORT int rc_set_dark(rc_ctx *c, const void *dark, int64_t epsilon)
         HIP_TRY(hipMemcpyAsync(c->d_dark, dark, bytes, hipMemcpyHostToDevice, c->stream));
         src = c->d_dark;
     }
-    rc::launch_threshold(src, epsilon, c->sc.N, c->sc.thr, c->stream, c->src_bytes);
+    if (c->depth > 16 && c->src_bytes != 4) return fail(RC_ERR_BAD_ARG, "src_bit_depth > 16 means uint32 sources: rc_ctx_set_source_bytes(ctx, 4) first");
+    if (c->src_bytes == 4) rc::launch_threshold32(static_cast<const uint32_t *>(src), epsilon, c->sc.N, c->thr32, c->stream);
+    else rc::launch_threshold(src, epsilon, c->sc.N, c->sc.thr, c->stream, c->src_bytes);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->thr_set = true;
@@ -391,10 +397,31 @@ RC_EXPORT int rc_set_dark(rc_ctx *c, const void *dark, int64_t epsilon)
 RC_EXPORT int rc_ctx_set_source_bytes(rc_ctx *c, uint32_t bytes_per_pixel)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
-    if (bytes_per_pixel == 4) return fail(RC_ERR_UNSUPPORTED, "rc_ctx_set_source_bytes: 32-bit sources (source_bit_depth > 16) are not implemented on device");
-    if (bytes_per_pixel != 1 && bytes_per_pixel != 2) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: 1 (uint8) or 2 (uint16)");
+    if (bytes_per_pixel != 1 && bytes_per_pixel != 2 && bytes_per_pixel != 4) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: 1 (uint8), 2 (uint16) or 4 (uint32)");
     if (bytes_per_pixel == 1 && c->depth > 8) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: uint8 sources need src_bit_depth <= 8");
+    if (bytes_per_pixel == 2 && c->depth > 16) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: uint16 sources need src_bit_depth <= 16");
     if (c->batch_seq || c->thr_set) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: call before rc_set_dark / rc_set_threshold and the first batch");
+    if (bytes_per_pixel == 4) {
+        // uint32 sources (source_bit_depth > 16, misc.py:41-49): rc_reduce32.hip.  Levels 1 and 3; the residual fields are depth bits wide, or
+        // the values' four raw bytes when the depth is a multiple of 8 (`.tobytes()` of a uint32 array, recode_writer.py:463-464: 32 and 24
+        // alike); zstd takes the fast encoder (the modelled one is fitted inside the uint16 kernel).
+        if (c->depth <= 16) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: uint32 sources are what source_bit_depth > 16 means (misc.py:41-49)");
+        if (c->level == 2) return fail(RC_ERR_UNSUPPORTED, "rc_ctx_set_source_bytes: reduction level 2 is not implemented for uint32 sources");
+        RC_ON_DEVICE(c->device);
+        if (c->depth % 8 == 0) c->depth = 32;
+        c->modelled = false;
+        HIP_TRY(hipMalloc((void **)&c->thr32, c->sc.N * 4));
+        for (rc::Scratch *set : {&c->sets[0], &c->sets[1]}) {
+            set->pix_slot_bytes = rc::TILE_PX * 4;
+            set->comb = 0;
+            if (c->level != 3) {
+                HIP_TRY(hipFree(set->pix_slots));
+                set->pix_slots = nullptr;
+                HIP_TRY(hipMalloc((void **)&set->pix_slots, (uint64_t)c->max_batch * set->ntiles * rc::TILE_PX * 4 + 64));
+            }
+        }
+        c->sc = c->sets[0];
+    }
     c->src_bytes = bytes_per_pixel;
     return RC_OK;
 }
@@ -501,7 +528,14 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     }
     // codec of the fused block encoder: 1 zstd fast, 3 zstd modelled, 2 LZ4 runs (compression_level 0), 4 LZ4 events (>= 1), 8 blosc
     const uint32_t codec = c->modelled ? 3u : (c->emit == RC_SCHEME_LZ4 && c->clevel != 0 ? 4u : c->emit);
-    launch_reduce(sc, frames_dev, n, c->level, codec, c->keep_bitmap || c->emit == 0, c->depth, s, tail, c->src_bytes);
+    if (c->src_bytes == 4) {
+        // uint32 sources: reduce + pack + raw binary maps (rc_reduce32.hip), then the block encoder over the maps as a launch of its own
+        launch_reduce32(sc, static_cast<const uint32_t *>(frames_dev), c->thr32, n, c->level, c->depth, s);
+        if (c->emit == RC_SCHEME_LZ4) launch_lz4_encode_rows(sc, n, s, c->clevel != 0);
+        else if (c->emit == RC_SCHEME_ZSTD) launch_zstd_tokenize_rows(sc, n, s);
+        else if (c->emit == RC_SCHEME_BLOSC_LZ4) launch_blosc_encode_blocks(sc, n, s);
+    } else
+        launch_reduce(sc, frames_dev, n, c->level, codec, c->keep_bitmap || c->emit == 0, c->depth, s, tail, c->src_bytes);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
     // (start, end of the reduce kernel, end of the batch) unless RC_PROFILE_ALL_STAGES is set
     const bool all_ev = ev && (timed || c->profile_all);
@@ -774,7 +808,7 @@ RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const void *frames_host, 
     if (r != RC_OK) return r;
     p.has_val = c->val_gap != 0;
     if (p.has_val) {   // validation frames of this batch: the dose-rate count, from the frames the reduce kernel has just read
-        rc::launch_roi_components(fdev, c->sc.thr, c->sc.N, c->nx, n, first_frame_id, c->val_gap, c->val_x0, c->val_y0, c->val_w, c->val_h, p.d_val, c->stream, c->src_bytes);
+        rc::launch_roi_components(fdev, c->src_bytes == 4 ? (const void *)c->thr32 : (const void *)c->sc.thr, c->sc.N, c->nx, n, first_frame_id, c->val_gap, c->val_x0, c->val_y0, c->val_w, c->val_h, p.d_val, c->stream, c->src_bytes);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(p.h_val, p.d_val, (uint64_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(p.ev_val, c->stream));

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(WG) void k_blosc_blocks(Scratch sc)
     const uint64_t own = bitshuffle_block(elem, n, L);
     const uint32_t csize = lz4_encode_block(own, n, L);
     const uint64_t ft = (uint64_t)f * sc.ntiles + t;
-    uint8_t *slot = sc.blk_slots + ft * BLK_SLOT;
+    uint8_t *slot = sc.blk_slots + ft * sc.blk_stride;
     const uint32_t used = lz4_store_block(slot, own, n, csize, L, true);   // (blosc marks a stored block by csize == size)
     if (lane == 0) sc.blk_size[ft] = used;
 }

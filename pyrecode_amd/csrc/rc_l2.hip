@@ -211,7 +211,7 @@ void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint
 // monotone, so unsynchronised in-place updates reach the same fixed point), and counts the pixels that kept their own
 // label.  counts[i] = 0xFFFFFFFF for frames that are not validation frames.
 constexpr int ROI_MAX = 128, ROI_T = 256;
-__global__ __launch_bounds__(ROI_T) void k_roi_components(const void *__restrict__ frames, const uint16_t *__restrict__ thr, uint64_t N,
+__global__ __launch_bounds__(ROI_T) void k_roi_components(const void *__restrict__ frames, const void *__restrict__ thr_any, uint64_t N,
                                                            uint32_t nx, uint32_t first_frame_id, uint32_t gap, uint32_t x0, uint32_t y0,
                                                            uint32_t w, uint32_t h, uint32_t *__restrict__ counts, uint32_t src_bytes)
 {
@@ -219,8 +219,11 @@ __global__ __launch_bounds__(ROI_T) void k_roi_components(const void *__restrict
     __shared__ uint32_t s_cnt;
     const uint32_t i = blockIdx.x;
     if ((first_frame_id + i) % gap != 0) { if (threadIdx.x == 0) counts[i] = 0xFFFFFFFFu; return; }
-    const uint16_t *fr = static_cast<const uint16_t *>(frames) + (uint64_t)i * N;      // (uint8 sources: fr8)
+    const uint16_t *fr = static_cast<const uint16_t *>(frames) + (uint64_t)i * N;      // (uint8 sources: fr8; uint32 sources: fr32 and a uint32 threshold)
     const uint8_t *fr8 = static_cast<const uint8_t *>(frames) + (uint64_t)i * N;
+    const uint32_t *fr32 = static_cast<const uint32_t *>(frames) + (uint64_t)i * N;
+    const uint16_t *thr = static_cast<const uint16_t *>(thr_any);
+    const uint32_t *thr32 = static_cast<const uint32_t *>(thr_any);
     const uint32_t W = w + 2;
     for (uint32_t k = threadIdx.x; k < (h + 2) * W; k += ROI_T) lab[k] = 0;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(ROI_T) void k_roi_components(const void *__restrict
     for (uint32_t k = threadIdx.x; k < w * h; k += ROI_T) {
         const uint32_t yy = k / w, xx = k - yy * w;
         const uint64_t p = (uint64_t)(y0 + yy) * nx + (x0 + xx);
-        if ((src_bytes == 1 ? (uint32_t)fr8[p] : (uint32_t)fr[p]) > thr[p]) lab[(yy + 1) * W + xx + 1] = (uint16_t)(k + 1);
+        const bool set = src_bytes == 4 ? fr32[p] > thr32[p] : (src_bytes == 1 ? (uint32_t)fr8[p] : (uint32_t)fr[p]) > thr[p];
+        if (set) lab[(yy + 1) * W + xx + 1] = (uint16_t)(k + 1);
     }
     __syncthreads();
     for (uint32_t it = 0; it < (uint32_t)ROI_MAX * ROI_MAX; ++it) {   // (a component's diameter bounds the sweeps)
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(ROI_T) void k_roi_components(const void *__restrict
     __syncthreads();
     if (threadIdx.x == 0) counts[i] = s_cnt;
 }
-void launch_roi_components(const void *frames, const uint16_t *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
+void launch_roi_components(const void *frames, const void *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
                            uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t *counts, hipStream_t s, uint32_t src_bytes)
 {
     hipLaunchKernelGGL(k_roi_components, dim3(n), dim3(ROI_T), 0, s, frames, thr, N, nx, first_frame_id, gap, x0, y0, w, h, counts, src_bytes);

@@ -17,6 +17,7 @@ struct Scratch {
     uint16_t *thr = nullptr;           // [N]
     uint8_t *bitmap = nullptr;         // [B][nb_stride]            packed binary maps
     uint16_t *pix_slots = nullptr;     // [B][ntiles][TILE_PX]      per-tile residuals, row-major inside the tile
+    uint32_t pix_slot_bytes = SLOT_PX * 2;   // bytes between two tiles' residual slots (uint32 sources, rc_reduce32.hip: TILE_PX * 4)
     uint32_t *tile_cnt = nullptr;      // [B][ntiles]               set pixels per tile
     uint32_t *tile_off = nullptr;      // [B][ntiles]               exclusive prefix of tile_cnt inside the frame
     uint32_t *tile_next = nullptr;     // [B][ntiles]               next tile index > t with tile_cnt > 0 (ntiles if none)
@@ -82,6 +83,10 @@ void launch_threshold(const void *dark, int64_t eps, uint64_t N, uint16_t *thr, 
 // src_bytes: bytes per source pixel - 2 (uint16 frames) or 1 (uint8 frames, source_bit_depth <= 8)
 void launch_reduce(const Scratch &sc, const void *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
                    uint32_t depth, hipStream_t s, hipStream_t s_tail = nullptr, uint32_t src_bytes = 2);
+// rc_reduce32.hip: uint32 sources (source_bit_depth > 16) - reduce + d-bit pack + raw binary maps; the block encoders follow as launches of
+// their own (launch_lz4_encode_rows / launch_zstd_tokenize_rows / launch_blosc_encode_blocks)
+void launch_threshold32(const uint32_t *dark, int64_t eps, uint64_t N, uint32_t *thr, hipStream_t s);
+void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s);
 // rc_l2.hip
 void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s);
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);
@@ -98,6 +103,7 @@ void launch_pix_gather(const Scratch &sc, uint32_t B, uint32_t depth, uint32_t l
 // rc_lz4.hip
 struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
 void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s, bool events = false);  // sc.bitmap = the buffer, sc.nb = its length
+void launch_lz4_encode_rows(const Scratch &sc, uint32_t B, hipStream_t s, bool events);   // B rows of sc.bitmap (a batch's raw binary maps)
 void launch_lz4f_gather(const Scratch &sc, uint32_t hdr3, uint8_t *out, hipStream_t s);
 void launch_lz4_decode(const uint8_t *src, const Lz4Block *blks, uint32_t nblk, uint32_t *sizes, const uint64_t *dst_off,
                        uint8_t *dst, uint64_t cap, int linked, int *err, hipStream_t s, uint32_t max_stored = 0);
@@ -109,6 +115,7 @@ void launch_blosc_unshuffle(const uint8_t *in, uint8_t *out, uint64_t nbytes, ui
                             uint32_t shuffle, hipStream_t s);
 // rc_zstd.hip
 void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s);
+void launch_zstd_tokenize_rows(const Scratch &sc, uint32_t B, hipStream_t s);   // the tokenizer half only (launch_zstd_fse finishes the blocks)
 void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, bool fitted, hipStream_t s);  // 2nd half of the fused path
 // modelled encoder (rc_zstd_model.h): histograms of a sample of plain-tokenized frames -> model (host) -> kernels
 void launch_zstd_sample(const Scratch &sc, uint32_t B, bool with_pix, uint32_t depth, void *sample_dev, hipStream_t s);
@@ -128,9 +135,9 @@ __host__ __device__ inline const uint8_t *residual_src(const Scratch &sc, uint64
         const uint32_t ro16 = sc.comb == 2 ? (uint32_t)BLK_SLOT / 16 : (bn + 15) >> 4, r16 = (cnt * d + 127) >> 7;
         if (16 * (ro16 + r16) <= sc.blk_stride) return sc.blk_slots + ft * sc.blk_stride + 16 * ro16;
     }
-    return reinterpret_cast<const uint8_t *>(sc.pix_slots + ft * SLOT_PX);
+    return reinterpret_cast<const uint8_t *>(sc.pix_slots) + ft * sc.pix_slot_bytes;
 }
 
-void launch_roi_components(const void *frames, const uint16_t *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
+void launch_roi_components(const void *frames, const void *thr, uint64_t N, uint32_t nx, uint32_t n, uint32_t first_frame_id, uint32_t gap,
                            uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t *counts, hipStream_t s, uint32_t src_bytes = 2);
 }  // namespace rc

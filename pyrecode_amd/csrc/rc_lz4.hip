@@ -35,13 +35,20 @@ __global__ __launch_bounds__(WG) void k_lz4_buffer(Scratch sc)
     const uint64_t own = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
     const uint32_t csize = lz4_encode_block<EVENTS>(own, n, s_lz[w]);
     const uint64_t ft = (uint64_t)f * sc.ntiles + t;
-    const uint32_t used = lz4_store_block(sc.blk_slots + ft * BLK_SLOT, own, n, csize, s_lz[w]);
+    const uint32_t used = lz4_store_block(sc.blk_slots + ft * sc.blk_stride, own, n, csize, s_lz[w]);
     if (lane == 0) sc.blk_size[ft] = used;
 }
 void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s, bool events)
 {
     if (events) hipLaunchKernelGGL(k_lz4_buffer<true>, dim3((sc.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, s, sc);
     else hipLaunchKernelGGL(k_lz4_buffer<false>, dim3((sc.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, s, sc);
+}
+
+void launch_lz4_encode_rows(const Scratch &sc, uint32_t B, hipStream_t s, bool events)
+{
+    const dim3 grid((sc.ntiles + WAVES - 1) / WAVES, B);
+    if (events) hipLaunchKernelGGL(k_lz4_buffer<true>, grid, dim3(WG), 0, s, sc);
+    else hipLaunchKernelGGL(k_lz4_buffer<false>, grid, dim3(WG), 0, s, sc);
 }
 
 // ---- stand-alone LZ4 frame of an arbitrary byte buffer (seam 2: compress(), recode_compressors.py:91) -----------------

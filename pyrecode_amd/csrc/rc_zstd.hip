@@ -32,7 +32,7 @@ __global__ __launch_bounds__(WG) void k_zstd_buffer(Scratch sc)
     uint32_t staged;
     const uint32_t word = zstd_tokenize_block(own, n, last, s_lz[w], staged);
     const uint64_t ft = (uint64_t)f * sc.ntiles + t;
-    zstd_store_block(sc.blk_slots + ft * BLK_SLOT, n, last, word, staged, s_lz[w]);
+    zstd_store_block(sc.blk_slots + ft * sc.blk_stride, n, last, word, staged, s_lz[w]);
     if (lane == 0) sc.blk_size[ft] = word;
 }
 
@@ -104,6 +104,11 @@ void launch_zstd_fse(const Scratch &sc, uint32_t B, const void *tables_dev, bool
     const uint32_t nslots = B * sc.ntiles;
     hipLaunchKernelGGL(k_zstd_fse, dim3((nslots + FSE_T - 1) / FSE_T), dim3(FSE_T), 0, s, sc, nslots,
                        reinterpret_cast<const ZstdTables *>(tables_dev), fitted ? 1u : 0u);
+}
+
+void launch_zstd_tokenize_rows(const Scratch &sc, uint32_t B, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_zstd_buffer, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc);
 }
 
 void launch_zstd_encode_blocks(const Scratch &sc, uint32_t B, const void *tables_dev, hipStream_t s)

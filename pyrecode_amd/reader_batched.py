@@ -148,6 +148,8 @@ class BatchedAccess:
         batch through the synchronous call, so any number of readers in a process may do this side by side."""
         if self._ra_off or int(self._header['reduction_level']) not in (1, 3):
             return None
+        if int(self._header['target_bit_depth']) > 16:
+            return None        # (the read-ahead's batches come as the COO arrays with uint16 values: wider values keep the frame-at-a-time path)
         if self._user_iters:
             # a caller's own iter_frames_* on THIS reader is alive: it owns the reader's page-locked batch buffers (the read-ahead's
             # iterator would write the next batch into what that one's arrays view) - these calls go frame by frame meanwhile

@@ -65,12 +65,14 @@ class ReCoDeWriter:
             raise ValueError('Invalid input params')
         ip = self._input_params
         # The reference's Python path takes whatever map_dtype yields for (source_data_type, source_bit_depth) - uint8 up to 8 bits, uint16
-        # up to 16, uint32 beyond (misc.py:41-49); only its use_c path is uint16-only (recode_writer.py:85-87).  The device path reads
-        # uint16 and uint8 frames; data handed over in another dtype is cast to the source dtype, as there (:352-354).
-        if np.dtype(ip.source_numpy_dtype) not in (np.dtype(np.uint16), np.dtype(np.uint8)):
-            raise NotImplementedError('source dtype %s (source_data_type %d, source_bit_depth %d): the HIP path takes unsigned sources of up to '
-                                      '16 bits (uint8 / uint16 frames); 32-bit and signed / float sources are not implemented on device'
+        # up to 16, uint32 beyond (misc.py:41-49); only its use_c path is uint16-only (recode_writer.py:85-87).  The device path reads all
+        # three; data handed over in another dtype is cast to the source dtype, as there (:352-354).
+        if np.dtype(ip.source_numpy_dtype) not in (np.dtype(np.uint16), np.dtype(np.uint8), np.dtype(np.uint32)):
+            raise NotImplementedError('source dtype %s (source_data_type %d, source_bit_depth %d): the HIP path takes unsigned integer sources '
+                                      '(uint8 / uint16 / uint32 frames); signed and float sources are not implemented on device'
                                       % (np.dtype(ip.source_numpy_dtype).name, ip.source_data_type, ip.source_bit_depth))
+        if np.dtype(ip.source_numpy_dtype) == np.dtype(np.uint32) and ip.reduction_level == 2:
+            raise NotImplementedError('reduction level 2 is not implemented on device for uint32 sources (source_bit_depth > 16)')
         if ip.reduction_level not in (1, 2, 3):
             raise NotImplementedError('reduction level 4 (centroiding) is not implemented on device '
                                       '(non-functional in the reference as well, SURVEY.md 0.5)')

@@ -22,6 +22,7 @@ Fixture groups:
   G8  validation frames: side file + dose rates      (recode_writer.py:207-211,400-415)
   G9  bz2 / lzma / zlib level 9 / level 3 reduce-only: whole files (recode_compressors.py:82-101)
   G10 8-bit sources (source dtype uint8, misc.py:41-49): d = 8 (raw bytes) and d = 6 (bit-packed), whole files, one with validation frames
+  G11 sources beyond 16 bits (source dtype uint32): d = 20 (bit-packed), d = 32 and d = 24 (`.tobytes()`: four bytes a value), whole files
   G4  512-byte header bytes                    (recode_header.py:58-94, 257-275)
   G5  get_frame_sparse triplets                (pyrecode.cpp:95-119, reader.h:10-68)
   G6  321-byte v0.1 header                     (recode_header.py:27-56, 98-127, 257-275)
@@ -436,8 +437,79 @@ def g10():
                                                   frames - (dark + cfg["calibration_threshold_epsilon"]).astype(np.uint8), 0))))
 
 
+# --------------------------------------------------------------------------------------------
+# G11: sources beyond 16 bits - map_dtype yields uint32 (misc.py:41-49).  d = 20 goes through _bit_pack (20-bit fields), d = 32 and
+# d = 24 through `.tobytes()` (recode_writer.py:463-464: FOUR bytes a value for both - the reader then takes 24-bit fields out of the
+# 32-bit values of a d = 24 file and decodes something else than was written: the files are what is pinned, and what each reader returns).
+# --------------------------------------------------------------------------------------------
+def synth_stack_u32(seed, nz, ny, nx, sparsity, depth):
+    rng = np.random.default_rng(seed)
+    top = (1 << depth) - 1
+    dark = rng.integers(1000, 70000, (ny, nx)).astype(np.uint32)
+    frames = np.empty((nz, ny, nx), np.uint32)
+    for z in range(nz):
+        mask = rng.random((ny, nx)) < sparsity
+        amp = rng.integers(1, top - 70000, (ny, nx), dtype=np.int64).astype(np.uint32)
+        below = np.floor(rng.random((ny, nx)) * (dark + 1.0)).astype(np.uint32)
+        frames[z] = np.where(mask, dark + amp, below)
+    frames[0, 0, 0] = top
+    frames[nz - 1, ny - 1, nx - 1] = top
+    frames[0, 0, 1] = dark[0, 1] + 1              # the smallest residual
+    frames[0, 0, 2] = dark[0, 2] + 65536          # a residual whose low 16 bits are zero
+    return dark, frames
+
+
+def g11():
+    cases = [
+        # tag       nz ny  nx  s     depth nodes overrides
+        ("u32d20",  6, 37, 53, 0.08, 20, 2, dict(calibration_threshold_epsilon=3)),
+        ("u32d32",  4, 24, 40, 0.10, 32, 2, dict()),
+        ("u32d24",  4, 24, 40, 0.10, 24, 2, dict()),
+        ("u32d17",  4, 40, 56, 0.06, 17, 2, dict()),                             # the narrowest uint32 depth
+    ]
+    for tag, nz, ny, nx, s, depth, nodes, over in cases:
+        tmp = tempfile.mkdtemp()
+        dark, frames = synth_stack_u32(3300 + depth, nz, ny, nx, s, depth)
+        base = "g11_" + tag
+        over = dict(over, source_bit_depth=depth, target_bit_depth=depth)
+        ok = True
+        try:
+            cfg = write_parts(tmp, base, dark, frames, nodes, **over)
+        except Exception as e:
+            print("g11:", tag, "the reference's writer raised", repr(e))
+            shutil.rmtree(tmp)
+            continue
+        for node in range(nodes):
+            fn = "%s.rc1_part%03d" % (base, node)
+            shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+        fn = base + ".rc1"
+        quiet(ref_reader.merge_parts, tmp, fn, nodes)
+        shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
+        dec, dts = np.zeros((nz, ny, nx), np.uint64), set()
+        try:
+            rd = ref_reader.ReCoDeReader(os.path.join(tmp, fn), is_intermediate=False)
+            quiet(rd.open, print_header=False)
+            for z in range(nz):
+                m = quiet(rd.get_frame, z)[z]["data"]
+                dts.add(str(m.dtype))
+                dec[z] = np.asarray(m.todense()).astype(np.uint64)
+            rd.close()
+        except Exception as e:
+            print("g11:", tag, "the reference's reader raised", repr(e))
+            ok = False
+        thr = (dark + np.uint32(cfg["calibration_threshold_epsilon"])).astype(np.uint32)
+        want = np.where(frames > thr, frames - thr, 0).astype(np.uint64)
+        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
+                            cfg_vals=np.array(list(cfg.values())), n_nodes=nodes, decoded=dec if ok else np.zeros(0, np.uint64),
+                            decoded_dtype=",".join(sorted(dts)))
+        shutil.rmtree(tmp)
+        print("g11:", tag, "decoded dtype", dts, "reader ok", ok, "decoded == where(frame > thr, frame - thr, 0):", bool(ok and np.array_equal(dec, want)))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":
+        g11()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g10":
         g10()
     elif len(sys.argv) > 1 and sys.argv[1] == "g9":
         g9()
@@ -456,3 +528,4 @@ if __name__ == "__main__":
         g8()
         g9()
         g10()
+        g11()

@@ -1248,11 +1248,53 @@ def test_frames_handed_over_in_another_dtype_are_cast_like_the_reference(given, 
         assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
 
 
-def test_sources_beyond_16_bits_are_refused_by_name(tmp_path):
-    """source_bit_depth > 16 maps to uint32 frames (misc.py:41-49): the one source dtype of the reference's Python path the device path does
-    not take - refused when the writer is made, with a message that says which and why (not a fallback, not a wrong file)."""
+def test_sources_the_device_does_not_take_are_refused_by_name(tmp_path):
+    """Signed sources (source_data_type 1) and reduction level 2 on uint32 sources: refused when the writer is made, with a message that says
+    which and why (not a fallback, not a wrong file)."""
     from pyrecode_amd.recode_writer import ReCoDeWriter
     g = load_npz("g3_l1z16.npz")
-    ip, cfg = _params(tmp_path, g, source_bit_depth=24, target_bit_depth=24)
-    with pytest.raises(NotImplementedError, match="uint32"):
+    ip, cfg = _params(tmp_path, g, source_data_type=1, target_data_type=1)
+    with pytest.raises(NotImplementedError, match="int16"):
         ReCoDeWriter("x", dark_data=g["dark"], output_directory=str(tmp_path), input_params=ip, mode="batch", node_id=0)
+    ip, cfg = _params(tmp_path, g, source_bit_depth=24, target_bit_depth=24, reduction_level=2)
+    with pytest.raises(NotImplementedError, match="level 2"):
+        ReCoDeWriter("x", dark_data=g["dark"].astype(np.uint32), output_directory=str(tmp_path), input_params=ip, mode="batch", node_id=0)
+
+
+@pytest.mark.parametrize("tag", ["u32d20", "u32d32", "u32d24", "u32d17"])
+def test_uint32_sources_reproduce_the_references_files(tag, tmp_path):
+    """G11: files the reference wrote from sources beyond 16 bits (uint32 frames and dark: 20- and 17-bit fields, four raw bytes a value at
+    d = 32 and d = 24) - part files and merged files byte for byte; the reader returns what the reference's reader returned (at d = 24 that
+    is NOT what was written: 24-bit fields read out of 32-bit values, the reference's own behaviour - the fixture holds it)."""
+    import warnings
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    g = load_npz("g11_%s.npz" % tag)
+    base, nodes = "g11_" + tag, int(g["n_nodes"])
+    for node in range(nodes):
+        ip, cfg = _params(tmp_path, g)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            w = ReCoDeWriter(base, dark_data=g["dark"], output_directory=str(tmp_path), input_params=ip, mode="batch",
+                             validation_frame_gap=-1, node_id=node, batch_size=2)
+            w.start()
+            w.run(g["frames"])
+            w.close()
+        fn = "%s.rc1_part%03d" % (base, node)
+        assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
+    merged = base + ".rc1"
+    merge_parts(str(tmp_path), merged, nodes)
+    assert (tmp_path / merged).read_bytes() == open(os.path.join(FILES, merged), "rb").read()
+    rd = ReCoDeReader(str(tmp_path / merged))
+    rd.open(print_header=False)
+    nz = g["frames"].shape[0]
+    for z in range(nz):
+        m = rd.get_frame(z)[z]["data"]
+        assert m.dtype == np.uint32 and np.array_equal(np.asarray(m.todense()).astype(np.uint64), g["decoded"][z]), "frame %d" % z
+    pre, trip = rd.get_frames_triplets(0, nz)                                    # the batched reader: triplet rows hold values of any width
+    img = np.zeros(g["frames"].shape, np.uint64)
+    for z in range(nz):
+        t = trip[int(pre[z]):int(pre[z + 1])]
+        img[z, t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2]
+    assert np.array_equal(img, g["decoded"])
+    rd.close()

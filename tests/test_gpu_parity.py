@@ -1299,12 +1299,16 @@ def test_uint8_sources_device_codecs_decode_bit_exact(hip, orc, ny, nx, s, d, ep
 def test_uint8_source_contexts_refuse_what_they_cannot_take(hip):
     with pytest.raises(ValueError):                               # uint8 frames cannot carry 12-bit values
         hip.ReduceContext(64, 64, 12, 1, 0, 0, 1, 0, max_batch=2, src_dtype=np.uint8)
-    with pytest.raises(NotImplementedError):                      # 32-bit sources: not on device, and said so
+    with pytest.raises(ValueError):                               # uint32 frames are what depths beyond 16 bits mean
         hip.ReduceContext(64, 64, 16, 1, 0, 0, 1, 0, max_batch=2, src_dtype=np.uint32)
+    with pytest.raises(NotImplementedError):                      # signed / float sources: not on device, and said so
+        hip.ReduceContext(64, 64, 16, 1, 0, 0, 1, 0, max_batch=2, src_dtype=np.int16)
+    with pytest.raises(NotImplementedError):                      # level 2 on uint32 sources
+        hip.ReduceContext(64, 64, 24, 2, 0, 0, 1, 0, max_batch=2, src_dtype=np.uint32)
     ctx = hip.ReduceContext(64, 64, 8, 1, 0, 0, 1, 0, max_batch=2)
     ctx.set_dark(np.zeros((64, 64), np.uint16), 0)
     assert hip.lib().rc_ctx_set_source_bytes(ctx.handle, 1) == hip.RC_ERR_BAD_ARG     # after the dark frame: too late
-    assert hip.lib().rc_ctx_set_source_bytes(ctx.handle, 4) == hip.RC_ERR_UNSUPPORTED
+    assert hip.lib().rc_ctx_set_source_bytes(ctx.handle, 4) == hip.RC_ERR_BAD_ARG
     ctx.close()
 
 
@@ -1413,4 +1417,66 @@ def test_l2_summary_statistics_of_uint8_sources(hip, orc, stat, scheme, mode):
             assert fid == z and npk == len(packed) and len(r) == 16 + cb + cp
             dec = {2: lambda b, n: orc.lz4f_decode(b, n + 8), 8: lambda b, n: orc.blosc1_decode(b)}[scheme]
             assert dec(r[16:16 + cb], len(bitmap)) == bitmap and dec(r[16 + cb:], len(packed)) == packed
+    ctx.close()
+
+
+# ---- uint32 sources (source_bit_depth > 16: the reference's map_dtype yields uint32 frames and dark, misc.py:41-49) -----------------
+def _synth_u32(seed, nz, ny, nx, sparsity, depth):
+    rng = np.random.default_rng(seed)
+    top = (1 << depth) - 1
+    dark = rng.integers(100, 70000, (ny, nx)).astype(np.uint32)
+    frames = np.empty((nz, ny, nx), np.uint32)
+    for z in range(nz):
+        mask = rng.random((ny, nx)) < sparsity
+        amp = rng.integers(1, top - 70000, (ny, nx), dtype=np.int64).astype(np.uint32)
+        below = np.floor(rng.random((ny, nx)) * (dark + 1.0)).astype(np.uint32)
+        frames[z] = np.where(mask, dark + amp, below)
+    frames[0].flat[0] = top
+    frames[nz - 1].flat[-1] = top
+    return dark, frames
+
+
+U32_SHAPES = [(ny, nx, s, d32, eps) for (ny, nx, s, _, eps), d32 in zip(SHAPES, (20, 17, 32, 24, 31, 20, 32, 19, 28))]
+
+
+@pytest.mark.parametrize("ny,nx,s,d,eps", U32_SHAPES)
+def test_uint32_sources_reduce_only_records_bit_exact(hip, orc, ny, nx, s, d, eps):
+    """The SHAPES list with uint32 frames and dark (17..32-bit fields; four raw bytes a value at 24 and 32) through rc_reduce32.hip: records,
+    metadata and binary maps equal the oracle's numpy restatement (pinned on fixture G11)."""
+    dark, frames = _synth_u32(61 + ny, 4, ny, nx, s, d)
+    thr = orc.threshold32(dark, eps)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 0, 0, 1, 0, max_batch=8, src_dtype=np.uint32)
+    ctx.set_dark(dark, eps)
+    assert ctx.out_capacity(3) == 3 * ny * nx * 4
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=100)
+    for z in range(frames.shape[0]):
+        want, wmd = orc.l1_record32(frames[z], thr, d, 100 + z, mode=0)
+        got = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        assert got == want, "frame %d record differs" % z
+        assert md[z, 0] == wmd[0]
+        assert np.array_equal(ctx.binary_map(z), orc.pack_binary_frame(frames[z] > thr))
+    ctx.close()
+
+
+@pytest.mark.parametrize("scheme,clevel,level", [(2, 1, 1), (2, 0, 1), (1, 1, 1), (8, 1, 1), (2, 1, 3), (1, 1, 3)])
+@pytest.mark.parametrize("ny,nx,s,d,eps", [U32_SHAPES[0], U32_SHAPES[4], U32_SHAPES[5], U32_SHAPES[8]])
+def test_uint32_sources_device_codecs_decode_bit_exact(hip, orc, ny, nx, s, d, eps, scheme, clevel, level):
+    dark, frames = _synth_u32(73 + nx, 3, ny, nx, s, d)
+    thr = orc.threshold32(dark, eps)
+    ctx = hip.ReduceContext(nx, ny, d, level, 1, scheme, clevel, 0, max_batch=4, src_dtype=np.uint32)
+    ctx.set_threshold(thr)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=9)
+    dec = {2: lambda b, n: orc.lz4f_decode(b, n + 64), 1: lambda b, n: _zstd_system_decode(b), 8: lambda b, n: orc.blosc1_decode(b)}[scheme]
+    for z in range(frames.shape[0]):
+        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+        binary = frames[z] > thr
+        bitmap = orc.pack_binary_frame(binary).tobytes()
+        if level == 3:
+            fid, cb = struct.unpack_from("<II", r, 0)
+            assert fid == 9 + z and len(r) == 8 + cb and dec(r[8:], len(bitmap)) == bitmap
+            continue
+        fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+        assert fid == 9 + z and (cb, cp, npk) == tuple(int(v) for v in md[z]) and len(r) == 16 + cb + cp
+        packed = orc.bit_pack32((frames[z][binary] - thr[binary]).astype(np.uint32), d).tobytes()
+        assert npk == len(packed) and dec(r[16:16 + cb], len(bitmap)) == bitmap and dec(r[16 + cb:], npk) == packed
     ctx.close()

@@ -147,6 +147,36 @@ def test_g10_uint8_sources_records_byte_exact(tag):
     assert np.array_equal(g["decoded"], np.where(frames > thr, frames - thr, 0).astype(np.uint8))
 
 
+@pytest.mark.parametrize("tag", ["u32d20", "u32d32", "u32d24", "u32d17"])
+def test_g11_uint32_sources_records_byte_exact(tag):
+    """G11: the reference's writer on sources beyond 16 bits (uint32 frames, misc.py:41-49): uint32 threshold sum, compare and residuals,
+    20- and 17-bit fields through _bit_pack, four raw bytes a value at d = 32 AND d = 24 (`.tobytes()`, recode_writer.py:463-464).  The
+    oracle's numpy restatement gives the reference's records; its reader returns where(frame > thr, frame - thr, 0) - except at d = 24,
+    where it takes 24-bit fields out of the 32-bit values (the fixture keeps what it returned)."""
+    g = load_npz("g11_%s.npz" % tag)
+    cfg = dict(zip(g["cfg_keys"].tolist(), (int(v) for v in g["cfg_vals"])))
+    dark, frames, nodes = g["dark"], g["frames"], int(g["n_nodes"])
+    assert dark.dtype == np.uint32 and frames.dtype == np.uint32 and str(g["decoded_dtype"]) == "uint32"
+    thr = orc.threshold32(dark, cfg["calibration_threshold_epsilon"])
+    d = cfg["source_bit_depth"]
+    merged_md, merged_data = [], b""
+    for node in range(nodes):
+        recs = _parse_part(os.path.join(GOLDEN, "files", "g11_%s.rc1_part%03d" % (tag, node)), 1, 1)
+        lo, cnt = orc.node_frames(frames.shape[0], nodes, node)
+        assert len(recs) == cnt
+        for i, ref_rec in enumerate(recs):
+            rec, md = orc.l1_record32(frames[lo + i], thr, d, lo + i, 1)
+            assert rec == ref_rec
+            nnz = int((frames[lo + i] > thr).sum())
+            assert md[2] == (4 * nnz if d % 8 == 0 else (nnz * d + 7) // 8)
+            merged_md.append(struct.pack("<3I", *md))
+            merged_data += rec[16:]
+    merged = open(os.path.join(GOLDEN, "files", "g11_%s.rc1" % tag), "rb").read()
+    assert merged[512:] == b"".join(merged_md) + merged_data
+    want = np.where(frames > thr, frames - thr, 0).astype(np.uint64)
+    assert np.array_equal(g["decoded"], want) == (d != 24)
+
+
 def test_g7_stream_mode_records_and_ids():
     """G7: the reference's writer fed chunk after chunk (mode='stream'): every chunk is split by the contiguous-block rule and the ids run
     on from chunk to chunk (recode_writer.py:311-322,383,422) - the oracle's records with those ids are the part files' bytes."""

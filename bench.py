@@ -65,7 +65,7 @@ def parse(argv=None):
     ap.add_argument("--scheme", type=int, default=2, help="2 = LZ4 (headline), 1 = zstd, 8 = blosc-lz4, 0 = reduce-only pieces")
     ap.add_argument("--level", type=int, default=1, help="reduction level: 1 (headline), 2 = summary statistics, 3 = bitmap only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--source-bytes", type=int, default=2, choices=[1, 2], help="bytes per source pixel: 2 = uint16 frames (every BASELINE configuration), 1 = uint8 frames (source_bit_depth <= 8: the reference's map_dtype, misc.py:41-49; implies --depth 8 unless given lower, no CPU baseline / ingest legs)")
+    ap.add_argument("--source-bytes", type=int, default=2, choices=[1, 2, 4], help="bytes per source pixel: 2 = uint16 frames (every BASELINE configuration), 1 = uint8 frames (source_bit_depth <= 8: the reference's map_dtype, misc.py:41-49; implies --depth 8 unless given lower), 4 = uint32 frames (> 16 bits; implies --depth 20 unless given above 16); both without the CPU baseline / ingest legs")
     ap.add_argument("--read", action="store_true", help="measure the READER instead: stored frames -> device decode of both streams -> sparse expand (rc_expand_frames)")
     ap.add_argument("--blob-on-device", action="store_true", help="--read: the stored frames' bytes already sit in device memory (the decoders without the link)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the extra ingest-inclusive measurement (host frames -> part file)")
@@ -84,6 +84,9 @@ def parse(argv=None):
     a = ap.parse_args(argv)
     if a.source_bytes == 1:
         a.depth = min(a.depth, 8)
+        a.no_cpu_baseline = a.no_ingest = True
+    if a.source_bytes == 4:
+        a.depth = a.depth if a.depth > 16 else 20
         a.no_cpu_baseline = a.no_ingest = True
     if a.shared_gpu and a.dist_backend == "nccl":
         ap.error("--shared-gpu needs --dist-backend gloo")
@@ -419,7 +422,12 @@ def verify_record(a, r, frame, thr_h, frame_id):
     the frame's exact binary map and value list.  Level 2 (no runnable reference): scipy.ndimage.label + numpy."""
     import struct
     from oracle import oracle as orc
-    bitmap, packed, nnz = orc.reduce_frame_l1(frame, thr_h, a.depth)
+    if frame.dtype == np.uint32:      # sources beyond 16 bits: the oracle's numpy restatement (pinned on fixture G11)
+        binary = frame > thr_h
+        bitmap, nnz = np.packbits(binary, bitorder="little"), int(binary.sum())
+        packed = orc.bit_pack32((frame[binary] - thr_h[binary]).astype(np.uint32), a.depth)
+    else:
+        bitmap, packed, nnz = orc.reduce_frame_l1(frame, thr_h, a.depth)
     if a.level == 2:
         import scipy.ndimage as nd
         f2, t2 = frame.reshape(a.ny, a.nx), thr_h.reshape(a.ny, a.nx)
@@ -552,11 +560,21 @@ def run_rank(a):
         del stack, dark, f16, amp
         torch.cuda.empty_cache()
         stack, dark = stack8, dark8
+    if a.source_bytes == 4:
+        # uint32 sources: the same events on a 20-bit (or wider) scale - the dark level and the residuals times 64
+        src_dtype = np.uint32
+        stack32 = torch.empty((S, N), dtype=torch.int32, device=dev)
+        for lo in range(0, S, 16):
+            stack32[lo:lo + 16] = stack[lo:lo + 16].to(torch.int32) * 64
+        dark32 = dark.to(torch.int32) * 64
+        del stack, dark
+        torch.cuda.empty_cache()
+        stack, dark = stack32, dark32
     op_mode = 1
     ctx = hip.ReduceContext(a.nx, a.ny, a.depth, a.level, op_mode, a.scheme, a.clevel, local, max_batch=B, src_dtype=src_dtype)
     ctx.set_dark(dark.data_ptr(), 0)  # eps = 0 -> thr = dark
     ctx.keep_binary_maps(False)       # no validation frames in this workload: records only (recode_writer.py:402-415)
-    out_cap = B * (N // 2) * (2 if a.source_bytes == 2 else 1)  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
+    out_cap = B * (N // 2) * a.source_bytes  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
     out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
     nb = S // B
@@ -626,7 +644,7 @@ def run_rank(a):
     gather_verified = loop.verify_gather()   # collective: every rank's block of the gathered table, on every rank
     gathers_in_region = loop.gathers_issued
 
-    thr_h = dark.cpu().numpy().view(src_dtype).astype(np.uint16)
+    thr_h = dark.cpu().numpy().view(src_dtype).astype(np.uint16 if a.source_bytes < 4 else np.uint32)
     corrupt = os.environ.get("RC_BENCH_CORRUPT_RECORD")          # test switch: one byte of a record flipped before the check
 
     def verify_batch(j, z):
@@ -635,7 +653,8 @@ def run_rank(a):
         if corrupt:
             mid_byte = (int(rec_now[z]) + int(rec_now[z + 1])) // 2
             out[mid_byte] ^= 0x5A
-        frame = stack[j * B + z].cpu().numpy().view(src_dtype).astype(np.uint16)   # (uint8 sources: widened - same values - for the uint16 oracle)
+        frame = stack[j * B + z].cpu().numpy().view(src_dtype)
+        frame = frame.astype(np.uint16) if a.source_bytes < 4 else frame   # (uint8 sources: widened - same values - for the uint16 oracle)
         r = out[int(rec_now[z]):int(rec_now[z + 1])].cpu().numpy().tobytes()
         try:
             return bool(verify_record(a, r, frame, thr_h, rank * S + j * B + z))
@@ -679,7 +698,7 @@ def run_rank(a):
         achieved = B * frame_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_note = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        key = "%dx%d_b%d_ppm%d_d%d_s%d%s%s" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme, "_clustered" if a.clustered else "", "_u8" if a.source_bytes == 1 else "")
+        key = "%dx%d_b%d_ppm%d_d%d_s%d%s%s" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme, "_clustered" if a.clustered else "", {1: "_u8", 2: "", 4: "_u32"}[a.source_bytes])
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(key, {}).get("reduce_kernel_hbm_bytes_per_launch")
         if traffic is None:
@@ -699,10 +718,10 @@ def run_rank(a):
             # for room in the device queue when the host runs ahead)
             "host_enqueue_us_per_step": round(host_enqueue_us, 1), "issue_us_per_step_in_timed_region": round(issue_us, 1),
             "host_enqueue_frac_of_step": round(host_enqueue_us / (dt_max / a.steps * 1e6), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16" if a.source_bytes == 2 else "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {1: "u8", 2: "u16", 4: "u32"}[a.source_bytes], "data": "synthetic",
             "config": {
                 "workload": "%s%dx%d %s, %s, L%d + %s, source_bit_depth %d, batch %d frames/GPU/step, %d-frame stack/GPU in HBM" % (
-                    ("BASELINE configs[%d]: " % (a.config - 1)) if a.config else "", a.ny, a.nx, "uint16" if a.source_bytes == 2 else "uint8",
+                    ("BASELINE configs[%d]: " % (a.config - 1)) if a.config else "", a.ny, a.nx, {1: "uint8", 2: "uint16", 4: "uint32"}[a.source_bytes],
                     ("detector-like clusters of 1..6 pixels, %d seeds per million pixels" % a.sparsity_ppm) if a.clustered else "%.2f%% sparsity" % (a.sparsity_ppm / 1e4), a.level,
                     {2: "LZ4 frame", 1: "zstd frame (%s encoder)" % ("modelled" if a.clevel else "fast"), 8: "blosc-lz4 chunk",
                      0: "reduce-only pieces (the host library compresses them, as the reference does)"}.get(a.scheme, str(a.scheme)),

@@ -466,15 +466,27 @@ def g11():
         ("u32d32",  4, 24, 40, 0.10, 32, 2, dict()),
         ("u32d24",  4, 24, 40, 0.10, 24, 2, dict()),
         ("u32d17",  4, 40, 56, 0.06, 17, 2, dict()),                             # the narrowest uint32 depth
+        ("u32d20v", 6, 150, 170, 0.03, 20, 2, dict(_gap=2)),                     # validation frames: the side file holds uint32 frames
     ]
     for tag, nz, ny, nx, s, depth, nodes, over in cases:
         tmp = tempfile.mkdtemp()
         dark, frames = synth_stack_u32(3300 + depth, nz, ny, nx, s, depth)
         base = "g11_" + tag
+        gap = over.pop("_gap", -1)
         over = dict(over, source_bit_depth=depth, target_bit_depth=depth)
         ok = True
+        rates, vbytes = [], []
         try:
-            cfg = write_parts(tmp, base, dark, frames, nodes, **over)
+            for node in range(nodes):
+                ip, cfg = make_params(tmp, num_frames=nz, num_rows=ny, num_cols=nx, num_threads=nodes, **over)
+                w = quiet(ref_writer.ReCoDeWriter, base, dark_data=dark, output_directory=tmp, input_params=ip, mode="batch",
+                          validation_frame_gap=gap, node_id=node)
+                quiet(w.start)
+                m = quiet(w.run, frames)
+                quiet(w.close)
+                rates.append(np.asarray(m.get("run_dose_rates", []), np.float64))
+                if gap > 0:
+                    vbytes.append(np.fromfile(os.path.join(tmp, "%s_part%03d_validation_frames.bin" % (base, node)), np.uint8))
         except Exception as e:
             print("g11:", tag, "the reference's writer raised", repr(e))
             shutil.rmtree(tmp)
@@ -501,7 +513,8 @@ def g11():
         want = np.where(frames > thr, frames - thr, 0).astype(np.uint64)
         np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
                             cfg_vals=np.array(list(cfg.values())), n_nodes=nodes, decoded=dec if ok else np.zeros(0, np.uint64),
-                            decoded_dtype=",".join(sorted(dts)))
+                            decoded_dtype=",".join(sorted(dts)), gap=gap, **{"rates%d" % i: r for i, r in enumerate(rates)},
+                            **{"vframes%d" % i: v for i, v in enumerate(vbytes)})
         shutil.rmtree(tmp)
         print("g11:", tag, "decoded dtype", dts, "reader ok", ok, "decoded == where(frame > thr, frame - thr, 0):", bool(ok and np.array_equal(dec, want)))
 

@@ -1261,7 +1261,7 @@ def test_sources_the_device_does_not_take_are_refused_by_name(tmp_path):
         ReCoDeWriter("x", dark_data=g["dark"].astype(np.uint32), output_directory=str(tmp_path), input_params=ip, mode="batch", node_id=0)
 
 
-@pytest.mark.parametrize("tag", ["u32d20", "u32d32", "u32d24", "u32d17"])
+@pytest.mark.parametrize("tag", ["u32d20", "u32d32", "u32d24", "u32d17", "u32d20v"])
 def test_uint32_sources_reproduce_the_references_files(tag, tmp_path):
     """G11: files the reference wrote from sources beyond 16 bits (uint32 frames and dark: 20- and 17-bit fields, four raw bytes a value at
     d = 32 and d = 24) - part files and merged files byte for byte; the reader returns what the reference's reader returned (at d = 24 that
@@ -1276,12 +1276,16 @@ def test_uint32_sources_reproduce_the_references_files(tag, tmp_path):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             w = ReCoDeWriter(base, dark_data=g["dark"], output_directory=str(tmp_path), input_params=ip, mode="batch",
-                             validation_frame_gap=-1, node_id=node, batch_size=2)
+                             validation_frame_gap=int(g["gap"]), node_id=node, batch_size=2)
             w.start()
-            w.run(g["frames"])
+            m = w.run(g["frames"])
             w.close()
         fn = "%s.rc1_part%03d" % (base, node)
         assert (tmp_path / fn).read_bytes() == open(os.path.join(FILES, fn), "rb").read(), fn
+        if int(g["gap"]) > 0:    # validation frames: uint32 frames in the side file, the device's ROI component counts as dose rates
+            side = tmp_path / ("%s_part%03d_validation_frames.bin" % (base, node))
+            assert np.array_equal(np.fromfile(side, np.uint8), g["vframes%d" % node])
+            assert np.allclose(np.asarray(m["run_dose_rates"], np.float64), g["rates%d" % node])
     merged = base + ".rc1"
     merge_parts(str(tmp_path), merged, nodes)
     assert (tmp_path / merged).read_bytes() == open(os.path.join(FILES, merged), "rb").read()
@@ -1297,4 +1301,31 @@ def test_uint32_sources_reproduce_the_references_files(tag, tmp_path):
         t = trip[int(pre[z]):int(pre[z + 1])]
         img[z, t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2]
     assert np.array_equal(img, g["decoded"])
+    rd.close()
+
+
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_uint32_sources_with_a_device_codec_round_trip(scheme, tmp_path):
+    """uint32 frames (20 bits) through the streaming writer with zstd / LZ4 on the device and back through both readers."""
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    g = load_npz("g11_u32d20.npz")
+    rng = np.random.default_rng(5)
+    ny, nx, nz = 96, 200, 7
+    dark = rng.integers(1000, 70000, (ny, nx)).astype(np.uint32)
+    frames = np.where(rng.random((nz, ny, nx)) < 0.05, dark + rng.integers(1, 900000, (nz, ny, nx)), dark // 2).astype(np.uint32)
+    want = np.where(frames > dark, frames - dark, 0).astype(np.uint32)
+    _write_parts(tmp_path, "u32", dark, frames, 2, g, batch_size=3, num_rows=ny, num_cols=nx, num_frames=nz, num_threads=2,
+                 compression_scheme=scheme, calibration_threshold_epsilon=0)
+    merge_parts(str(tmp_path), "u32.rc1", 2)
+    rd = ReCoDeReader(str(tmp_path / "u32.rc1"))
+    rd.open(print_header=False)
+    for z in range(nz):
+        m = rd.get_frame(z)[z]["data"]
+        assert m.dtype == np.uint32 and np.array_equal(np.asarray(m.todense()), want[z])
+    got = np.zeros_like(want)
+    for a, pre, trip in rd.iter_frames_triplets(batch=3):
+        for i in range(len(pre) - 1):
+            t = trip[int(pre[i]):int(pre[i + 1])]
+            got[a + i, t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.uint32)
+    assert np.array_equal(got, want)
     rd.close()

@@ -147,7 +147,7 @@ def test_g10_uint8_sources_records_byte_exact(tag):
     assert np.array_equal(g["decoded"], np.where(frames > thr, frames - thr, 0).astype(np.uint8))
 
 
-@pytest.mark.parametrize("tag", ["u32d20", "u32d32", "u32d24", "u32d17"])
+@pytest.mark.parametrize("tag", ["u32d20", "u32d32", "u32d24", "u32d17", "u32d20v"])
 def test_g11_uint32_sources_records_byte_exact(tag):
     """G11: the reference's writer on sources beyond 16 bits (uint32 frames, misc.py:41-49): uint32 threshold sum, compare and residuals,
     20- and 17-bit fields through _bit_pack, four raw bytes a value at d = 32 AND d = 24 (`.tobytes()`, recode_writer.py:463-464).  The

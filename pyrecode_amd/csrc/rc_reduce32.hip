@@ -5,20 +5,22 @@
 // residual stream is `source_bit_depth`-bit fields, LSB first (_bit_pack, :637-652) - or the values' four raw bytes when the depth is a
 // multiple of 8 (`.tobytes()`, :463-464: 32 AND 24; the caller passes 32 for both).
 //
-// Not the hot path of any BASELINE configuration (all of them are uint16): one straightforward kernel, a wavefront per tile and frame,
-// no register-resident threshold, no rolling loads, no fused codec.  It leaves what rc_reduce.hip's kernel leaves - the raw binary map
-// (always: the block encoders run over it as separate launches, rc_lz4.hip / rc_zstd.hip / rc_blosc.hip), per tile the packed residual
-// stream in its slot (whole 128-byte lines, zero behind the last field) and the count - so scans, record layout and assembly are the
-// uint16 path's, unchanged (k_assemble concatenates bit streams of any field width up to 32).
+// Not the hot path of any BASELINE configuration (all of them are uint16), but built the way the uint16 kernel is: a wavefront keeps its
+// tile's thresholds in registers (64 VGPRs) over FPW consecutive frames, the next frame's 16 loads of 16 bytes per lane are in flight
+// while the current one is reduced (two register sets), loads are whole 1 KiB runs per instruction (lane l: pixels 4 l .. 4 l + 3 of the
+// group's first and second half), compaction goes from the registers into LDS (one packed wave scan per group), the d-bit pack in place.
+// The codec is not fused: the kernel leaves what rc_reduce.hip's kernel leaves - the raw binary map (always: the block encoders run over
+// it as separate launches, rc_lz4.hip / rc_zstd.hip / rc_blosc.hip), per tile the packed residual stream in its slot (whole 128-byte
+// lines, zero behind the last field) and the count - so scans, record layout and assembly are the uint16 path's, unchanged (k_assemble
+// concatenates bit streams of any field width up to 32).  Algorithmic bytes: 4 N per frame in; the maps (N / 8) and the residual lines out.
 #include "rc_launch.h"
 
 namespace rc {
 
-constexpr int R32_WAVES = 1;   // wavefronts per workgroup: 32.5 KB of LDS each (four of them share a CU)
+constexpr int R32_FPW = 16;    // frames a wavefront keeps its tile for (the thresholds are read once per R32_FPW frames)
 struct __attribute__((aligned(16))) Stage32 {
-    uint32_t val[TILE_PX];     // the tile's residuals in pixel order
-    uint32_t out[TILE_PX];     // compacted, then packed in place
-    uint8_t bm[TILE_BM];       // bitmap bytes, transposed so that a lane owns 64 consecutive pixels
+    uint32_t out[TILE_PX];     // compacted residuals in pixel order, then packed in place
+    uint8_t bm[TILE_BM];       // bitmap bytes in pixel order
 };
 
 __global__ void k_threshold32(const uint32_t *__restrict__ dark, uint32_t eps, uint64_t N, uint32_t *__restrict__ thr)
@@ -34,52 +36,69 @@ void launch_threshold32(const uint32_t *dark, int64_t eps, uint64_t N, uint32_t 
     hipLaunchKernelGGL(k_threshold32, dim3(blocks), dim3(256), 0, s, dark, (uint32_t)(uint64_t)eps, N, thr);
 }
 
-// grid (ceil(ntiles / R32_WAVES), B)
-__global__ __launch_bounds__(64 * R32_WAVES) void k_reduce_tiles32(const uint32_t *__restrict__ frames, const uint32_t *__restrict__ thr, uint64_t N,
-                                                                     uint32_t ntiles, uint8_t *__restrict__ bitmap, uint64_t nb_stride,
-                                                                     uint8_t *__restrict__ pix_slots, uint32_t pix_slot_bytes,
-                                                                     uint32_t *__restrict__ tile_cnt, uint32_t depth, uint32_t level1,
-                                                                     BatchStatus *__restrict__ status)
+// One tile's pixels of one frame (or of the threshold frame) in registers: group g's first half in v[2 g] (lane l: pixels 4 l .. 4 l + 3
+// of the half), its second half in v[2 g + 1].  FULL: the tile lies wholly inside the frame - 16-byte loads (dword alignment is all a
+// global load needs); the partial last tile: guarded single loads, `fill` elsewhere.
+template <bool FULL, bool NT>
+__device__ __forceinline__ void load_tile32(const uint32_t *__restrict__ base, uint64_t px0, uint64_t N, uint32_t fill, u32x4 (&v)[2 * R])
 {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
-    __shared__ Stage32 s_st[R32_WAVES];
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    const uint32_t tile = blockIdx.x * R32_WAVES + w, f = blockIdx.y;
-    if (tile >= ntiles) return;
-    Stage32 &S = s_st[w];
-    const uint32_t *fr = frames + (uint64_t)f * N;
-    // A2 + A3: eight pixels per lane and group (one bitmap byte), residuals staged in pixel order
-#pragma unroll 2
-    for (int r = 0; r < R; ++r) {
-        const uint64_t px0 = (uint64_t)tile * TILE_PX + (uint64_t)r * GROUP_PX + (uint64_t)lane * 8;
-        uint32_t m = 0;
+    const int lane = lane_id();
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t v = 0;
-            if (px0 + k < N) {
-                const uint32_t a = fr[px0 + k], t = thr[px0 + k];
-                if (a > t) { v = a - t; m |= 1u << k; }
+    for (int i = 0; i < 2 * R; ++i) {
+        if (FULL) {
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(base + px0 + (uint64_t)i * 256 + (uint64_t)lane * 4);
+            v[i] = NT ? __builtin_nontemporal_load(p) : *p;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t px = px0 + (uint64_t)i * 256 + (uint64_t)lane * 4 + k;
+                v[i][k] = px < N ? base[px] : fill;
             }
-            S.val[r * GROUP_PX + lane * 8 + k] = v;
         }
-        S.bm[r * 64 + lane] = (uint8_t)m;
+    }
+}
+
+// A2-A5 of one tile of one frame from registers
+__device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R], const u32x4 (&t)[2 * R], uint8_t *__restrict__ bm_dst,
+                                              uint8_t *__restrict__ slot, uint32_t *__restrict__ cnt_dst, uint32_t depth, bool level1)
+{
+    const int lane = lane_id();
+    uint32_t base = 0;
+#pragma unroll
+    for (int g = 0; g < R; ++g) {
+        uint32_t m = 0;   // bits 0..3: first half, 4..7: second half
+        u32x4 ra, rb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = x[2 * g][k], ta = t[2 * g][k], b = x[2 * g + 1][k], tb = t[2 * g + 1][k];
+            m |= (a > ta ? 1u : 0u) << k | (b > tb ? 1u : 0u) << (4 + k);
+            ra[k] = a - ta;
+            rb[k] = b - tb;
+        }
+        // A4: a bitmap byte is two neighbouring lanes' nibbles - the even lane forms the first half's byte, the odd lane the second half's
+        const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        const uint32_t byte = (lane & 1) ? ((other >> 4) | (m & 0xF0u)) : ((m & 0xFu) | ((other & 0xFu) << 4));
+        S.bm[g * 64 + (lane & 1) * 32 + (lane >> 1)] = (uint8_t)byte;
+        if (level1) {
+            // A3: row-major order = the first half's lanes in order, then the second half's
+            const uint32_t ca = (uint32_t)__builtin_popcount(m & 0xFu), cb = (uint32_t)__builtin_popcount(m >> 4);
+            const uint32_t inc = wave_incl_scan(ca | cb << 16);
+            const uint32_t tot = wave_last(inc);
+            if (tot) {
+                uint32_t pa = base + (inc & 0xFFFFu) - ca, pb = base + (tot & 0xFFFFu) + (inc >> 16) - cb;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (m >> k & 1u) S.out[pa++] = ra[k];
+                    if (m >> (4 + k) & 1u) S.out[pb++] = rb[k];
+                }
+            }
+            base += (tot & 0xFFFFu) + (tot >> 16);
+        }
     }
     __builtin_amdgcn_wave_barrier();
-    // A4: after the transpose a lane owns 8 consecutive bitmap bytes = 64 consecutive pixels
-    const u32x2 own = *reinterpret_cast<const u32x2 *>(&S.bm[lane * 8]);
-    *reinterpret_cast<u32x2 *>(bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM + lane * 8) = own;
+    *reinterpret_cast<u32x2 *>(bm_dst + lane * 8) = *reinterpret_cast<const u32x2 *>(&S.bm[lane * 8]);
     if (!level1) return;
-    const uint64_t ft = (uint64_t)f * ntiles + tile;
-    const uint32_t cnt = (uint32_t)__builtin_popcount(own[0]) + (uint32_t)__builtin_popcount(own[1]);
-    const uint32_t inc = wave_incl_scan(cnt);
-    const uint32_t total = wave_last(inc);
-    {   // row-major order is lane order: every lane moves its own set pixels
-        uint64_t q = (uint64_t)own[0] | ((uint64_t)own[1] << 32);
-        uint32_t e = inc - cnt;
-        const uint32_t *mine = S.val + 64 * lane;
-        for (; q; q &= q - 1) S.out[e++] = mine[__builtin_ctzll(q)];
-    }
-    __builtin_amdgcn_wave_barrier();
+    const uint32_t total = base;
     // A5: depth-bit fields, LSB first, in place (output dword j needs values from index 32 j / depth >= j on: at or behind dword j, and
     // every lane of a step reads before any of them writes); whole 128-byte lines, zero behind the last field
     const uint32_t nbits = total * depth;   // <= 4096 * 32
@@ -106,16 +125,62 @@ __global__ __launch_bounds__(64 * R32_WAVES) void k_reduce_tiles32(const uint32_
         for (uint32_t j = total + lane; j < ndw; j += 64) S.out[j] = 0;
         __builtin_amdgcn_wave_barrier();
     }
-    uint32_t *dst = reinterpret_cast<uint32_t *>(pix_slots + ft * pix_slot_bytes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
     for (uint32_t j = lane; j < ndw; j += 64) dst[j] = S.out[j];
-    if (lane == 0) tile_cnt[ft] = total;
+    if (lane == 0) *cnt_dst = total;
+    __builtin_amdgcn_wave_barrier();   // S.out is the next frame's
+}
+
+// FULL: grid (tiles wholly inside the frame, ceil(B / R32_FPW)), two frame register sets; the other instantiation: the partial last tile
+// (tile0 = its index), one set.  One wavefront per workgroup (16.5 KB of LDS: nine of them would share a CU; the registers allow eight)
+template <bool FULL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tiles32(const uint32_t *__restrict__ frames, const uint32_t *__restrict__ thr, uint64_t N,
+                                                       uint32_t ntiles, uint32_t tile0, uint32_t B, uint8_t *__restrict__ bitmap, uint64_t nb_stride,
+                                                       uint8_t *__restrict__ pix_slots, uint32_t pix_slot_bytes,
+                                                       uint32_t *__restrict__ tile_cnt, uint32_t depth, uint32_t level1,
+                                                       BatchStatus *__restrict__ status)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
+    __shared__ Stage32 S;
+    const uint32_t tile = tile0 + blockIdx.x;
+    const uint32_t f0 = blockIdx.y * R32_FPW, f1 = f0 + R32_FPW < B ? f0 + R32_FPW : B;
+    const uint64_t px0 = (uint64_t)tile * TILE_PX;
+    u32x4 t[2 * R], xa[2 * R];
+    load_tile32<FULL, false>(thr, px0, N, 0xFFFFFFFFu, t);
+    if (FULL) {
+        u32x4 xb[2 * R];
+        load_tile32<true, true>(frames + (uint64_t)f0 * N, px0, N, 0, xa);
+        for (uint32_t f = f0; f < f1; f += 2) {
+            if (f + 1 < f1) load_tile32<true, true>(frames + (uint64_t)(f + 1) * N, px0, N, 0, xb);
+            {
+                const uint64_t ft = (uint64_t)f * ntiles + tile;
+                reduce_tile32(S, xa, t, bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM, pix_slots + ft * pix_slot_bytes, tile_cnt + ft, depth, level1 != 0);
+            }
+            if (f + 1 < f1) {
+                if (f + 2 < f1) load_tile32<true, true>(frames + (uint64_t)(f + 2) * N, px0, N, 0, xa);
+                const uint64_t ft = (uint64_t)(f + 1) * ntiles + tile;
+                reduce_tile32(S, xb, t, bitmap + (uint64_t)(f + 1) * nb_stride + (uint64_t)tile * TILE_BM, pix_slots + ft * pix_slot_bytes, tile_cnt + ft, depth, level1 != 0);
+            }
+        }
+    } else {
+        for (uint32_t f = f0; f < f1; ++f) {
+            load_tile32<false, true>(frames + (uint64_t)f * N, px0, N, 0, xa);
+            const uint64_t ft = (uint64_t)f * ntiles + tile;
+            reduce_tile32(S, xa, t, bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM, pix_slots + ft * pix_slot_bytes, tile_cnt + ft, depth, level1 != 0);
+        }
+    }
 }
 
 void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s)
 {
-    const dim3 grid((sc.ntiles + R32_WAVES - 1) / R32_WAVES, B);
-    hipLaunchKernelGGL(k_reduce_tiles32, grid, dim3(64 * R32_WAVES), 0, s, frames, thr32, sc.N, sc.ntiles, sc.bitmap, sc.nb_stride,
-                       reinterpret_cast<uint8_t *>(sc.pix_slots), sc.pix_slot_bytes, sc.tile_cnt, depth, level == 1 ? 1u : 0u, sc.status);
+    const uint32_t nfull = (uint32_t)(sc.N / TILE_PX), fy = (B + R32_FPW - 1) / R32_FPW;
+    uint8_t *slots = reinterpret_cast<uint8_t *>(sc.pix_slots);
+    if (nfull)
+        hipLaunchKernelGGL(k_reduce_tiles32<true>, dim3(nfull, fy), dim3(64), 0, s, frames, thr32, sc.N, sc.ntiles, 0u, B, sc.bitmap, sc.nb_stride,
+                           slots, sc.pix_slot_bytes, sc.tile_cnt, depth, level == 1 ? 1u : 0u, sc.status);
+    if (nfull < sc.ntiles)
+        hipLaunchKernelGGL(k_reduce_tiles32<false>, dim3(1, fy), dim3(64), 0, s, frames, thr32, sc.N, sc.ntiles, nfull, B, sc.bitmap, sc.nb_stride,
+                           slots, sc.pix_slot_bytes, sc.tile_cnt, depth, level == 1 ? 1u : 0u, sc.status);
 }
 
 }  // namespace rc

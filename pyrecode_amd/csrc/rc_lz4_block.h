@@ -25,7 +25,8 @@
 // (offset = distance, no literals: 3 bytes instead of 5), the match reaches back over the zeros in FRONT of X as far as the
 // source has zeros there too, and what is left of a gap is the offset-1 run as before.  Stock liblz4 finds the same repeats
 // with its hash table (0.33 of raw on independent 512-byte blocks, 0.25 with an optimal parse); this parse gives 0.29, the
-// run-only one 0.375.  One event per lane; blocks with more than 62 events (dense data) take the run parser.
+// run-only one 0.375.  One event per lane up to 62 events in the block, two per lane up to 126 (dense maps: 2 % Bernoulli 0.59 -> 0.44 of
+// raw, the detector-like clusters 0.62 -> 0.53; stock liblz4 with 64 KiB blocks: 0.43 / 0.47); beyond that the run parser.
 #pragma once
 #include "rc_device.h"
 
@@ -124,7 +125,9 @@ __device__ __forceinline__ uint32_t wave_excl_pkmax(uint32_t x)
     return x;
 }
 
-constexpr int LZ4_EV_MAX = 62;   // events per block the event parser takes (lane 0 is the block start: at most 2 * 63 matches)
+constexpr int LZ4_EV_MAX = 62;   // events per block the event parser takes with one event per lane (lane 0 is the block start: at most 2 * 63 matches)
+constexpr int LZ4_EV_MAX2 = 126; // ... with two events per lane (lz4_parse_events2: dense maps - 2 % Bernoulli, the detector-like clusters)
+constexpr int LZ4_NM_MAX2 = 126; // ... and the matches it may leave (the position tables and phase 2's two rounds; dense blocks have 40 - 60)
 
 // Event parser (compression_level >= 1).  Lane 0 stands for the block start ("event" at position -1), lane k >= 1 for the
 // k-th non-zero byte X_k at p_k, followed by R_k zeros.  Per lane, with j = the earlier event of the same single-bit value
@@ -137,7 +140,9 @@ constexpr int LZ4_EV_MAX = 62;   // events per block the event parser takes (lan
 //             offset-1 copy then needs one LITERAL zero in front of it): the whole gap copied from inside the longest zero run of
 //             the earlier lanes (one more prefix-max, key = min(R, 511) << 6 | lane) when that run is long enough - no literal;
 //             liblz4's hash chains find the same source (round 4: bitmap stream 0.293 -> 0.283 of raw at 1 %)
-// Returns nm, or 0xFFFFFFFF when the block holds more than LZ4_EV_MAX events (the caller runs lz4_parse_runs).
+// Returns nm, or 0xFFFFFFFF when the block holds more than LZ4_EV_MAX2 events (the caller runs lz4_parse_runs); 63 .. 126 events:
+// lz4_parse_events2 below.
+__device__ __forceinline__ uint32_t lz4_parse_events2(uint32_t nev, uint32_t n, Lz4Lds &L);
 __device__ __forceinline__ uint32_t lz4_parse_events(uint64_t own, uint32_t n, Lz4Lds &L)
 {
     const int lane = lane_id();
@@ -150,10 +155,11 @@ __device__ __forceinline__ uint32_t lz4_parse_events(uint64_t own, uint32_t n, L
     const uint32_t cnt = (uint32_t)__builtin_popcount(nz);
     const uint32_t inc = wave_incl_scan(cnt);
     const uint32_t nev = wave_last(inc);
-    if (nev > (uint32_t)LZ4_EV_MAX) return 0xFFFFFFFFu;
+    if (nev > (uint32_t)LZ4_EV_MAX2) return 0xFFFFFFFFu;
     for (uint32_t k = inc - cnt + 1; nz; nz &= nz - 1) ev[k++] = (uint16_t)(base + __builtin_ctz(nz) + 1);
     if (lane == 0) { ev[0] = 0; ev[nev + 1] = (uint16_t)(n + 1); }
     __builtin_amdgcn_wave_barrier();
+    if (nev > (uint32_t)LZ4_EV_MAX) return lz4_parse_events2(nev, n, L);
     const bool act = (uint32_t)lane <= nev;
     const uint32_t e0 = ev[lane], e1 = ev[lane + 1];
     const uint32_t P1 = act ? e0 : n + 1;                 // p + 1: the first byte behind X
@@ -206,6 +212,98 @@ __device__ __forceinline__ uint32_t lz4_parse_events(uint64_t own, uint32_t n, L
         L.ms[r] = (uint16_t)gs;
         L.fl[r + 1] = (uint16_t)ge;
         L.off[r] = (uint16_t)off2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return nm;
+}
+
+// The event parser with TWO events per lane (63 .. 126 events in the block): lane l stands for events 2l and 2l + 1 (event 0 = the block
+// start), the rules are lz4_parse_events' own.  The prefix maxima run over the lanes' JOINED keys (the same five scans), a lane's second
+// event also looks at its first; event numbers take 7 bits of a key (min(R, 127) << 7 | k, min(R, 511) << 7 | k); what an event needs of
+// its source (run, run in front, position) comes from a 128-entry LDS table that borrows the position tables' space until they are written.
+// ev[] = the list lz4_parse_events has filled.  Returns nm, or 0xFFFFFFFF (more than LZ4_NM_MAX2 matches: the run parser).
+__device__ __forceinline__ uint32_t lz4_parse_events2(uint32_t nev, uint32_t n, Lz4Lds &L)
+{
+    static_assert(sizeof(L.ms) + sizeof(L.fl) >= 128 * 4 && offsetof(Lz4Lds, fl) == offsetof(Lz4Lds, ms) + sizeof(L.ms) && offsetof(Lz4Lds, ms) % 4 == 0, "source table");
+    const int lane = lane_id();
+    const uint16_t *ev = reinterpret_cast<const uint16_t *>(L.out);
+    uint32_t *W = reinterpret_cast<uint32_t *>(L.ms);
+    const uint32_t ka = 2u * (uint32_t)lane, kb = ka + 1u;
+    const bool acta = ka <= nev, actb = kb <= nev;
+    const uint32_t e0 = ev[ka], e1 = ev[ka + 1], e2 = ev[ka + 2];
+    const uint32_t P1a = acta ? e0 : n + 1, P1b = actb ? e1 : n + 1;       // p + 1: the first byte behind X
+    const uint32_t Pna = P1b, Pnb = (kb + 1 <= nev + 1 && actb) ? e2 : n + 1;
+    const uint32_t Xa = L.raw[P1a ? P1a - 1 : 0], Xb = L.raw[P1b - 1 < n ? P1b - 1 : 0];
+    const bool cla = acta && lane > 0 && (Xa & (Xa - 1)) == 0, clb = actb && (Xb & (Xb - 1)) == 0;
+    const uint32_t ca = (uint32_t)__builtin_ctz(Xa | 0x100u), cb = (uint32_t)__builtin_ctz(Xb | 0x100u);
+    const uint32_t Ra = Pna - P1a - 1 + (acta ? 0u : 1u), Rb = Pnb - P1b - 1 + (actb ? 0u : 1u);   // zeros behind X (inactive: 0)
+    const uint32_t keya = cla ? ((min(Ra, 127u) << 7) | ka) : 0u, keyb = clb ? ((min(Rb, 127u) << 7) | kb) : 0u;
+    const uint32_t fa = keya << (16 * (ca & 1u)), fb = keyb << (16 * (cb & 1u));
+    uint32_t A[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) A[q] = wave_excl_pkmax(pk_max_u16((ca >> 1) == q ? fa : 0u, (cb >> 1) == q ? fb : 0u));
+    const uint32_t paira = (ca >> 1) == 0 ? A[0] : ((ca >> 1) == 1 ? A[1] : ((ca >> 1) == 2 ? A[2] : A[3]));
+    const uint32_t pairb = (cb >> 1) == 0 ? A[0] : ((cb >> 1) == 1 ? A[1] : ((cb >> 1) == 2 ? A[2] : A[3]));
+    const uint32_t besta = cla ? ((paira >> (16 * (ca & 1u))) & 0xFFFFu) : 0u;
+    const uint32_t bestb = clb ? max((pairb >> (16 * (cb & 1u))) & 0xFFFFu, (cla && ca == cb) ? keya : 0u) : 0u;
+    // every event's run, the run in front of it and its position, by event number
+    const uint32_t Rbprev = wave_prev(Rb);
+    W[ka] = Ra | (Rbprev << 10) | (P1a << 20);
+    W[kb] = Rb | (Ra << 10) | (P1b << 20);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t wja = W[besta & 127u], wjb = W[bestb & 127u];
+    const uint32_t za = acta ? ((min(Ra, 511u) << 7) | ka) : 0u, zb = actb ? ((min(Rb, 511u) << 7) | kb) : 0u;
+    const uint32_t Z = wave_excl_pkmax(max(za, zb)) & 0xFFFFu;             // the longest zero run in front of the lane (and where it starts)
+    const uint32_t zbesta = Z, zbestb = max(Z, za);
+    const uint32_t P1za = W[zbesta & 127u] >> 20, P1zb = W[zbestb & 127u] >> 20;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                                          // (the table's space becomes the position tables' again)
+    int traila = min(min((int)Ra, (int)(wja & 0x3FFu)), (int)n - 5 - (int)P1a), trailb = min(min((int)Rb, (int)(wjb & 0x3FFu)), (int)n - 5 - (int)P1b);
+    const bool hasa = besta != 0 && P1a + 11 <= n && traila >= 3, hasb = bestb != 0 && P1b + 11 <= n && trailb >= 3;
+    traila = hasa ? traila : 0;
+    trailb = hasb ? trailb : 0;
+    const int da = (int)Ra - traila, db = (int)Rb - trailb;
+    const int dpreva = (int)wave_prev((uint32_t)db);
+    const int leada = hasa ? min(dpreva, (int)((wja >> 10) & 0x3FFu)) : 0, leadb = hasb ? min(da, (int)((wjb >> 10) & 0x3FFu)) : 0;
+    const int leadna = leadb, leadnb = (int)wave_next((uint32_t)leada);
+    int gsa = (int)P1a + traila + (hasa ? 0 : 1), gsb = (int)P1b + trailb + (hasb ? 0 : 1);
+    const int gea = min((int)Pna - 1 - leadna, (int)n - 5), geb = min((int)Pnb - 1 - leadnb, (int)n - 5);
+    const int L0a = gea - (int)P1a, L0b = geb - (int)P1b;
+    const bool zsa = acta && lane > 0 && !hasa && L0a >= 4 && (int)(zbesta >> 7) >= L0a && (int)P1a + 12 <= (int)n;
+    const bool zsb = actb && !hasb && L0b >= 4 && (int)(zbestb >> 7) >= L0b && (int)P1b + 12 <= (int)n;
+    uint32_t off2a = 1, off2b = 1;
+    if (zsa) { gsa = (int)P1a; off2a = P1a - P1za; }
+    if (zsb) { gsb = (int)P1b; off2b = P1b - P1zb; }
+    const bool rlea = acta && gsa + 12 <= (int)n && gea - gsa >= 4, rleb = actb && gsb + 12 <= (int)n && geb - gsb >= 4;
+    const uint32_t c = (hasa ? 1u : 0u) + (rlea ? 1u : 0u) + (hasb ? 1u : 0u) + (rleb ? 1u : 0u);
+    const uint32_t rinc = wave_incl_scan(c);
+    const uint32_t nm = wave_last(rinc);
+    if (nm > (uint32_t)LZ4_NM_MAX2) return 0xFFFFFFFFu;
+    uint32_t r = rinc - c;
+    if (lane == 0) L.fl[0] = 0;
+    if (hasa) {
+        L.ms[r] = (uint16_t)((int)P1a - 1 - leada);
+        L.fl[r + 1] = (uint16_t)((int)P1a + traila);
+        L.off[r] = (uint16_t)(P1a - (wja >> 20));
+        ++r;
+    }
+    if (rlea) {
+        L.ms[r] = (uint16_t)gsa;
+        L.fl[r + 1] = (uint16_t)gea;
+        L.off[r] = (uint16_t)off2a;
+        ++r;
+    }
+    if (hasb) {
+        L.ms[r] = (uint16_t)((int)P1b - 1 - leadb);
+        L.fl[r + 1] = (uint16_t)((int)P1b + trailb);
+        L.off[r] = (uint16_t)(P1b - (wjb >> 20));
+        ++r;
+    }
+    if (rleb) {
+        L.ms[r] = (uint16_t)gsb;
+        L.fl[r + 1] = (uint16_t)geb;
+        L.off[r] = (uint16_t)off2b;
     }
     __builtin_amdgcn_wave_barrier();
     return nm;

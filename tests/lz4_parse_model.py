@@ -4,7 +4,9 @@ on the CPU stock liblz4 must decode what the model emits (the PARSE is format-co
 claims); on the GPU the device's bytes must equal the model's, block for block."""
 import numpy as np
 
-EV_MAX = 62
+EV_MAX = 62      # one event per lane (lane 0 = the block start)
+EV_MAX2 = 126    # two events per lane (rc_lz4_block.h::lz4_parse_events2): the same rules, event numbers take 7 bits of the keys
+NM_MAX2 = 126    # ... and at most this many matches (the position tables' size); beyond either the run parser
 
 
 def emit(block, matches):
@@ -52,12 +54,14 @@ def parse_runs(block):
 
 
 def parse_events(block):
-    """rc_lz4_block.h::lz4_parse_events, lane by lane.  None: more than EV_MAX events (the device takes the run parser)."""
+    """rc_lz4_block.h::lz4_parse_events / lz4_parse_events2, event by event.  None: more than EV_MAX2 events or NM_MAX2 matches
+    (the device takes the run parser)."""
     n = len(block)
     b = np.frombuffer(block, np.uint8)
     ev = np.nonzero(b)[0].tolist()
-    if len(ev) > EV_MAX:
+    if len(ev) > EV_MAX2:
         return None
+    LB = 6 if len(ev) <= EV_MAX else 7                   # bits of the event number inside a key
     P1 = [0] + [p + 1 for p in ev]                       # lane 0 = the block start
     K = len(P1)
     Pn = P1[1:] + [n + 1]
@@ -68,7 +72,7 @@ def parse_events(block):
     zbest, zb = [0] * K, 0                               # key of the longest zero run among the lanes in front: min(R, 511) << 6 | lane
     for k in range(K):
         zbest[k] = zb
-        zb = max(zb, (min(R[k], 511) << 6) | k)
+        zb = max(zb, (min(R[k], 511) << LB) | k)
         c = cls[k]
         if c is not None and c in best:
             j = best[c][1]
@@ -76,7 +80,7 @@ def parse_events(block):
             if P1[k] + 11 <= n and t >= 3:
                 has[k], trail[k], J[k] = True, t, j
         if c is not None:
-            key = (min(R[k], 127) << 6) | k
+            key = (min(R[k], 127) << LB) | k
             if c not in best or key > best[c][0]:
                 best[c] = (key, k)
     d = [R[k] - trail[k] for k in range(K)]
@@ -92,11 +96,13 @@ def parse_events(block):
         ge = min(Pn[k] - 1 - leadn, n - 5)
         off = 1
         L0 = ge - P1[k]
-        if k > 0 and not has[k] and L0 >= 4 and (zbest[k] >> 6) >= L0 and P1[k] + 12 <= n:
+        if k > 0 and not has[k] and L0 >= 4 and (zbest[k] >> LB) >= L0 and P1[k] + 12 <= n:
             # no unit copy for this event: the gap behind X comes from inside the longest earlier zero run (no literal zero needed)
-            gs, off = P1[k], P1[k] - P1[zbest[k] & 63]
+            gs, off = P1[k], P1[k] - P1[zbest[k] & ((1 << LB) - 1)]
         if gs + 12 <= n and ge - gs >= 4:
             matches.append((gs, ge - gs, off))
+    if LB == 7 and len(matches) > NM_MAX2:
+        return None
     return matches
 
 

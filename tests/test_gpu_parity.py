@@ -205,7 +205,8 @@ def test_codec_block_types(hip, orc, scheme, clevel, ny, nx):
 def test_lz4_device_blocks_equal_the_serial_parse_model(hip, orc, level):
     """The device encoder's bytes against tests/lz4_parse_model.py (which stock liblz4 judges on the CPU, test_lz4_format_cpu.py),
     block for block: through the stateless seam on a buffer of special blocks with a ragged tail, and through the fused reduce
-    kernel on frames of 0.2 % .. 12 % density (the event parser up to 62 events per block, the run parser beyond)."""
+    kernel on frames of 0.2 % .. 12 % density (the event parser with one event per lane up to 62 events per block, two per lane up to 126,
+    the run parser beyond)."""
     import lz4_parse_model as model
     from test_lz4_format_cpu import _blocks
     from pyrecode_amd.recode_compressors import device_compress
@@ -219,7 +220,7 @@ def test_lz4_device_blocks_equal_the_serial_parse_model(hip, orc, level):
             assert g == w, "block %d of %d (tail %d)" % (i, len(want), len(tail))
         assert orc.lz4f_decode(device_compress(2, level, buf), len(buf) + 8) == buf
     ny, nx = 96, 512
-    for s in (0.002, 0.01, 0.04, 0.12):
+    for s in (0.002, 0.01, 0.015, 0.02, 0.03, 0.04, 0.12):
         dark, frames = synth_frames(int(s * 1000) + 5, 3, ny, nx, s, 12)
         thr = orc.threshold(dark, 0)
         ctx = hip.ReduceContext(nx, ny, 12, 1, 1, 2, level, 0, max_batch=3)

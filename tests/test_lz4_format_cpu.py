@@ -32,7 +32,8 @@ def _decode(lz4, payload, n):
 def _blocks():
     rng = np.random.default_rng(3)
     out = []
-    for p in (0.0, 0.002, 0.01, 0.02, 0.05, 0.12, 0.3):        # sparse bitmaps up to dense ones (run parser beyond 62 events)
+    for p in (0.0, 0.002, 0.01, 0.015, 0.02, 0.025, 0.03, 0.05, 0.12, 0.3):   # sparse bitmaps up to dense ones (one event per lane up to 62
+                                                                              # events, two up to 126, the run parser beyond)
         for _ in range(40):
             bits = rng.random(4096) < p
             out.append(np.packbits(bits, bitorder="little").tobytes())
@@ -56,6 +57,17 @@ def _blocks():
         if q < 512:
             rep2[q] = 0x80
     out.append(rep2.tobytes())
+    for period, val in ((5, 0x20), (6, 0x01), (7, 0x80)):        # 73 - 103 events of one value: two per lane, every one with a unit copy
+        r = np.zeros(512, np.uint8)
+        r[::period] = val
+        out.append(r.tobytes())
+    r = np.zeros(512, np.uint8)                                  # the same with the eight values in turn and two gap lengths
+    r[::5] = 1 << (np.arange(103) % 8)
+    r[3::35] = 0x40
+    out.append(r.tobytes())
+    dark = synth.dark_frame(11, 512 * 512)                       # detector-like clusters (bytes with several set bits between the single-bit ones)
+    cl = np.packbits(synth.frames_clustered(11, 0, 1, 512, 512, 11000, dark)[0] > dark, bitorder="little")
+    out += [cl[i:i + 512].tobytes() for i in range(0, cl.size, 512)]
     multi = np.zeros(512, np.uint8)                             # bytes with two set bits have no class: literals
     multi[::9] = 0x81
     out.append(multi.tobytes())
@@ -94,3 +106,25 @@ def test_event_parse_ratio_on_survey_data(lz4):
     raw = len(picked) * 512
     assert 0.36 < tot[0] / raw < 0.39          # the run parser (round 1 / 2: 0.375)
     assert tot[1] / raw < 0.30                 # the event parser
+
+
+def test_event_parse_ratio_on_detector_like_maps(lz4):
+    """Dense maps (the reference notebook's acquisition: 4.3 % set pixels in clusters; 2 % Bernoulli): most blocks hold 63 - 126 events, the
+    two-events-per-lane form of the parser.  Stock liblz4 on the same maps: 0.47 / 0.43 with 64 KiB blocks, 0.555 / 0.49 on independent
+    512-byte blocks; the run parser alone: 0.62 / 0.59."""
+    nx = ny = 1024
+    dark = synth.dark_frame(7, nx * ny)
+    for frames, bound, runs_bound in ((synth.frames_clustered(7, 0, 1, nx, ny, 11000, dark), 0.54, 0.60), (synth.frames(7, 0, 1, nx * ny, 20000, dark), 0.45, 0.57)):
+        bm = np.packbits(frames[0] > dark, bitorder="little")
+        tot = {0: 0, 1: 0}
+        two = 0
+        for i in range(bm.size // 512):
+            blk = bm[i * 512:(i + 1) * 512].tobytes()
+            two += model.EV_MAX < np.count_nonzero(bm[i * 512:(i + 1) * 512]) <= model.EV_MAX2
+            for level in (0, 1):
+                w, payload = model.encode_block(blk, level)
+                if not w & 0x80000000:
+                    assert _decode(lz4, payload, 512) == blk
+                tot[level] += 4 + len(payload)
+        assert two > 0.9 * (bm.size // 512)
+        assert tot[1] / bm.size < bound and tot[0] / bm.size > runs_bound

@@ -584,7 +584,8 @@ def run_rank(a):
     loop = ShardedStepLoop(ctx, B, lambda i: (batch_ptr[i % nb], rank * S + (i % nb) * B), out, rec, dev, collective=collective,
                            gather_every=a.gather_every, region_steps=max(a.steps, a.warmup, 1), fence_barrier=use_dist)
     stream = loop.stream
-    ctx.set_stream(stream.cuda_stream)
+    if not os.environ.get("RC_BENCH_OWN_STREAM"):     # (experiments with a CU-masked stream of the library's own: RC_RSTREAM_EXCL)
+        ctx.set_stream(stream.cuda_stream)
     ctx.set_pipelined(not a.no_pipeline)  # batch i+1's reduce kernel may overlap batch i's scans / layout / assembly
     step, fence = loop.step, loop.fence
 

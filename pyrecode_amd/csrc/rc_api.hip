@@ -174,7 +174,18 @@ static int ctx_alloc(rc_ctx *c)
     using namespace rc;
     const uint64_t B = c->max_batch;
     RC_ON_DEVICE(c->device);
-    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    {
+        // Experiment knob: RC_PSTREAM_CUS=n with RC_RSTREAM_EXCL=1 - the ctx's own stream (the reduce kernel, when the caller sets no stream) is
+        // confined to the CUs the second stage is NOT confined to: the two stages share no CU at all.
+        const char *e = getenv("RC_PSTREAM_CUS");
+        const int ncu = e ? atoi(e) : 0;
+        if (ncu > 0 && ncu < 256 && getenv("RC_RSTREAM_EXCL")) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = ncu; i < 256; ++i) mask[i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&c->own_stream, 8, mask) != hipSuccess) { (void)hipGetLastError(); c->own_stream = nullptr; }
+        }
+    }
+    if (!c->own_stream) HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     // (a high-priority second-stage stream was measured: no gain with LZ4 or zstd, 2 % slower at 11520x8184 - tools/ab_bench.sh)
     if (getenv("RC_PSTREAM_PRIO")) {   // experiment knob: the second stage on a high-priority stream
         int lo = 0, hi = 0;

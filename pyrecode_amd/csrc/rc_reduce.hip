@@ -237,7 +237,10 @@ __device__ __forceinline__ void vm_wait_loads(uint32_t later, X (&x)[R])
 // lane); sparse tiles are compacted from there into `out`, tiles with more than STAGE_CAP set pixels are compacted inside `val`,
 // STAGE_CAP values at a time through `out` (compact_dense_in_place).  STAGE_CAP = 256 (6.25 % of a tile) is what lets FIVE workgroups of
 // three waves share a CU's 160 KB: 3 x (this + Lz4Lds) = 31.9 KB.
-constexpr int STAGE_CAP = 256;
+#ifndef RC_STAGE_CAP
+#define RC_STAGE_CAP 256
+#endif
+constexpr int STAGE_CAP = RC_STAGE_CAP;   // (experiments: a smaller stage - 16 waves per CU)
 struct __attribute__((aligned(16))) WaveStage {
     uint16_t val[TILE_PX];
     uint16_t out[STAGE_CAP];

@@ -692,6 +692,9 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
     flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st, blk_stride, comb);
 }
 
+#ifndef RC_RW_ALT
+#define RC_RW_ALT 3   // waves per workgroup of the smaller form (experiments: 2)
+#endif
 template <int BZ, bool AL, bool L1, int CODEC, bool KEEP, bool RAW, int SB>
 static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames, uint32_t B, uint32_t depth, hipStream_t s, hipStream_t s_tail)
 {
@@ -730,7 +733,7 @@ static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames
                                sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
     };
     if constexpr (SB == 2) {
-        if (three) { go(std::integral_constant<int, 3>{}); return; }
+        if (three) { go(std::integral_constant<int, RC_RW_ALT>{}); return; }
     }
     go(std::integral_constant<int, 4>{});   // (uint8 frames: four-wave workgroups only - half the instantiations)
 }

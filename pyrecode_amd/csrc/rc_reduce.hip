@@ -727,10 +727,18 @@ static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames
             hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, AL, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(nfull)), dim3(64 * RW), 0, s, frames, sc.thr, sc.N,
                                sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
                                sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
-        if (nfull < sc.ntiles)   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
-            hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, false, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
-                               sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
-                               sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
+        if (nfull < sc.ntiles) {   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
+            // the partial last tile: guarded single loads when the frame does not end on a bitmap byte (N % 8 != 0: its last group of
+            // eight pixels reaches past the frame), the plain vector-load instantiation otherwise
+            if (AL && sc.N % 8 != 0)
+                hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, false, false, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
+                                   sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
+                                   sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
+            else
+                hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, false, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
+                                   sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
+                                   sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
+        }
     };
     if constexpr (SB == 2) {
         if (three) { go(std::integral_constant<int, RC_RW_ALT>{}); return; }
@@ -780,7 +788,11 @@ void launch_reduce(const Scratch &sc, const void *frames, uint32_t B, uint32_t l
 {
     if (depth == 0 || depth > 16) depth = 16;
     if (!s_tail) s_tail = s;
-    const bool aligned = (sc.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);
+    // Vector loads (16 bytes per lane; 8 for uint8 frames) for every tile that lies wholly inside its frame: a global load needs dword
+    // alignment only, so what it takes is frames that start on dwords - an even number of uint16 pixels (a multiple of four uint8 ones)
+    // and a dword-aligned base.  (3838 x 3710, a common detector format: N % 8 = 4 - until late in round 4 such frames took the
+    // guarded single loads throughout, at a sixth of the rate.)  Odd N: guarded single loads.
+    const bool aligned = ((sc.N * src_bytes) % 4 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 3) == 0);
     if (src_bytes == 1) {   // uint8 frames (source_bit_depth <= 8)
         const uint8_t *f8 = static_cast<const uint8_t *>(frames);
         if (aligned) launch_reduce_a<RC_BZ, true, 1>(sc, f8, B, level, codec, keep_bitmap, depth, s, s_tail);

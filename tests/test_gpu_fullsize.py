@@ -77,9 +77,19 @@ def _decode(orc, scheme, stream, cap):
 @pytest.mark.parametrize("depth,ppm,scheme", [(16, 10000, 2), (12, 10000, 2), (16, 1000, 2), (16, 10000, 1), (12, 1000, 1)])
 def test_4096_device_codec_records_full_oracle_compare(env, depth, ppm, scheme):
     """configs[1] / configs[2] (and d = 12 / 0.1 % variants): 4096x4096 uint16, L1 + LZ4 or zstd, device-resident in and out."""
+    _full_oracle_compare(env, 4096, 4096, 6, depth, ppm, scheme)
+
+
+@pytest.mark.parametrize("depth,ppm,scheme", [(12, 10000, 2), (14, 20000, 1)])
+def test_3838x3710_frames_full_oracle_compare(env, depth, ppm, scheme):
+    """A common detector format whose frames do not end on a bitmap byte (N % 8 = 4; every other frame of a stack starts 8 bytes off a
+    16-byte boundary): the tiles inside the frame take the vector-load kernel, the partial last tile the guarded loads."""
+    _full_oracle_compare(env, 3710, 3838, 5, depth, ppm, scheme)
+
+
+def _full_oracle_compare(env, ny, nx, B, depth, ppm, scheme):
     torch, hip, synth, orc = env
-    ny = nx = 4096
-    N, B = ny * nx, 6
+    N = ny * nx
     dark_d, frames_d = _device_stack(torch, hip, 7, B, N, ppm)
     ctx = hip.ReduceContext(nx, ny, depth, 1, 1, scheme, 1, 0, max_batch=B)
     ctx.set_dark(dark_d.data_ptr(), 0)

@@ -82,6 +82,8 @@ SHAPES = [  # ny, nx, sparsity, depth, eps
     (1000, 1100, 0.01, 16, 0),
     (300, 1000, 0.001, 13, 0),
     (256, 1024, 0.60, 14, 0),   # dense
+    (62, 202, 0.03, 12, 2),     # N % 8 = 4 (like 3838 x 3710): dword-aligned frames - vector loads inside the frame, guarded loads for the partial last tile
+    (101, 126, 0.01, 11, 0),    # N % 8 = 6
 ]
 
 

@@ -113,8 +113,11 @@ __device__ __forceinline__ typename Src<SB>::X load8(const typename Src<SB>::T *
     constexpr int PER = 4 / SB;   // pixels per dword
     if (ALIGNED) {
         if (px0 < N) {
-            // frames are read exactly once (nontemporal); the threshold tile is shared by other workgroups (cached)
-            const X *p = reinterpret_cast<const X *>(base + px0);
+            // frames are read exactly once (nontemporal); the threshold tile is shared by other workgroups (cached).  The vector type is
+            // declared with the pixel's alignment: a frame may start on any pixel boundary (amdhsa runs gfx9+ in unaligned access mode,
+            // the compiler itself emits global_load_dwordx4 for such a load)
+            typedef X XU __attribute__((aligned(SB)));
+            const XU *p = reinterpret_cast<const XU *>(base + px0);
             return STREAM ? __builtin_nontemporal_load(p) : *p;
         }
     }
@@ -477,7 +480,8 @@ __device__ __forceinline__ void reduce_one_frame(typename Src<SB>::X (&x)[R], co
     // x was fetched by vm_issue_loads during the previous frame: wait for those loads, not for the stores issued since
     if (ASMLOAD) vm_wait_loads(stores_behind, x);
     else if (ALIGNED && full) {   // (the partial last tile of a frame / unaligned frames: plain loads, no prefetch)
-        const typename Src<SB>::X *p = reinterpret_cast<const typename Src<SB>::X *>(cur + lane_px0);
+        typedef typename Src<SB>::X XU __attribute__((aligned(SB)));
+        const XU *p = reinterpret_cast<const XU *>(cur + lane_px0);
 #pragma unroll
         for (int r = 0; r < R; ++r) x[r] = __builtin_nontemporal_load(p + r * (GROUP_PX / 8));
     } else {
@@ -788,11 +792,12 @@ void launch_reduce(const Scratch &sc, const void *frames, uint32_t B, uint32_t l
 {
     if (depth == 0 || depth > 16) depth = 16;
     if (!s_tail) s_tail = s;
-    // Vector loads (16 bytes per lane; 8 for uint8 frames) for every tile that lies wholly inside its frame: a global load needs dword
-    // alignment only, so what it takes is frames that start on dwords - an even number of uint16 pixels (a multiple of four uint8 ones)
-    // and a dword-aligned base.  (3838 x 3710, a common detector format: N % 8 = 4 - until late in round 4 such frames took the
-    // guarded single loads throughout, at a sixth of the rate.)  Odd N: guarded single loads.
-    const bool aligned = ((sc.N * src_bytes) % 4 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 3) == 0);
+    // Vector loads (16 bytes per lane; 8 for uint8 frames) for every tile that lies wholly inside its frame, whatever the frame's
+    // alignment: amdhsa runs gfx9+ in unaligned access mode (the compiler emits global_load_dwordx4 for an align-1 16-byte load
+    // itself), so a frame may start on any pixel.  Until late in round 4 the rule here was N % 8 == 0 and a 16-byte aligned base, and
+    // 3838 x 3710 frames - a common detector format, N % 8 = 4 - took the guarded single loads throughout, at a sixth of the rate.
+    // (RC_REDUCE_GUARDED_LOADS=1: the guarded instantiation for every tile - tests keep it alive.)
+    const bool aligned = getenv("RC_REDUCE_GUARDED_LOADS") == nullptr;   // (read per launch: a test switches it inside one process)
     if (src_bytes == 1) {   // uint8 frames (source_bit_depth <= 8)
         const uint8_t *f8 = static_cast<const uint8_t *>(frames);
         if (aligned) launch_reduce_a<RC_BZ, true, 1>(sc, f8, B, level, codec, keep_bitmap, depth, s, s_tail);

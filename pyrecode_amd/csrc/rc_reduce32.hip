@@ -46,7 +46,8 @@ __device__ __forceinline__ void load_tile32(const uint32_t *__restrict__ base, u
 #pragma unroll
     for (int i = 0; i < 2 * R; ++i) {
         if (FULL) {
-            const u32x4 *p = reinterpret_cast<const u32x4 *>(base + px0 + (uint64_t)i * 256 + (uint64_t)lane * 4);
+            typedef u32x4 u32x4_dw __attribute__((aligned(4)));   // (frames start on dwords, not on 16-byte boundaries)
+            const u32x4_dw *p = reinterpret_cast<const u32x4_dw *>(base + px0 + (uint64_t)i * 256 + (uint64_t)lane * 4);
             v[i] = NT ? __builtin_nontemporal_load(p) : *p;
         } else {
 #pragma unroll

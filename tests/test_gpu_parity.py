@@ -73,11 +73,11 @@ def _zstd_system_decode(data):
 
 
 SHAPES = [  # ny, nx, sparsity, depth, eps
-    (37, 53, 0.10, 12, 0),      # N not a multiple of 8 -> scalar-load path, ragged last bitmap byte
+    (37, 53, 0.10, 12, 0),      # N not a multiple of 8, less than a tile -> guarded loads, ragged last bitmap byte
     (40, 56, 0.05, 12, 7),
     (64, 64, 0.01, 10, 0),
     (128, 128, 0.30, 16, 0),    # exactly one tile
-    (129, 127, 0.02, 9, 3),     # odd everything, two tiles
+    (129, 127, 0.02, 9, 3),     # odd everything: three whole tiles of frames that start on odd pixels (vector loads 2 bytes off a dword) + a partial one
     (512, 512, 0.145, 12, 0),   # the reference test's shape / density (tests/minimal_read_write_test.py:16-25)
     (1000, 1100, 0.01, 16, 0),
     (300, 1000, 0.001, 13, 0),
@@ -102,6 +102,14 @@ def test_reduce_only_records_bit_exact(hip, orc, ny, nx, s, d, eps):
         assert md[z, 0] == wmd[0] and md[z, 1] == 0 and md[z, 2] == 0
         assert np.array_equal(ctx.binary_map(z), orc.pack_binary_frame(frames[z] > thr))
     ctx.close()
+
+
+@pytest.mark.parametrize("ny,nx,s,d,eps", [SHAPES[1], SHAPES[4], SHAPES[6]])
+def test_guarded_load_instantiation_stays_bit_exact(hip, orc, ny, nx, s, d, eps, monkeypatch):
+    """Frames take the vector-load kernel at any alignment (odd N: every other frame starts 2 bytes off a dword); the guarded
+    single-load instantiation now serves partial last tiles only.  RC_REDUCE_GUARDED_LOADS=1 sends every tile through it."""
+    monkeypatch.setenv("RC_REDUCE_GUARDED_LOADS", "1")
+    test_reduce_only_records_bit_exact(hip, orc, ny, nx, s, d, eps)
 
 
 @pytest.mark.parametrize("clevel", [0, 1])   # 0: zero runs only, >= 1: the event parser (rc_lz4_block.h)

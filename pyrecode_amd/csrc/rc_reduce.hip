@@ -111,7 +111,9 @@ __device__ __forceinline__ typename Src<SB>::X load8(const typename Src<SB>::T *
 {
     typedef typename Src<SB>::X X;
     constexpr int PER = 4 / SB;   // pixels per dword
-    if (ALIGNED) {
+    // (the guarded form: a group of eight pixels that lies wholly inside the frame is one vector load as well; single loads with a
+    // bounds check only for the group the frame ends in)
+    if (ALIGNED || px0 + 8 <= N) {
         if (px0 < N) {
             // frames are read exactly once (nontemporal); the threshold tile is shared by other workgroups (cached).  The vector type is
             // declared with the pixel's alignment: a frame may start on any pixel boundary (amdhsa runs gfx9+ in unaligned access mode,

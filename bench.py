@@ -740,7 +740,7 @@ def run_rank(a):
                 "shared_gpu_rehearsal": bool(a.shared_gpu),
             },
             "rccl_ranks": (dist.get_world_size() if use_dist and backend == "nccl" else (1 if not use_dist else 0)),
-            "roofline": {"bound": "hbm", "kernel": "k_reduce_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_reduce_tiles32" if a.source_bytes == 4 else "k_reduce_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "traffic_ratio": (round(traffic / (B * frame_bytes), 4) if traffic else None),
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": B * frame_bytes,

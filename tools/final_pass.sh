@@ -24,6 +24,11 @@ line detector_like_zstd --clustered --sparsity-ppm 11000 --depth 12 --scheme 1 $
 line rehearsal_2ranks_gloo_shared_gpu --gpus 2 --shared-gpu --dist-backend gloo --stack 128 --min-seconds 1
 line uint8_sources_lz4 --source-bytes 1 $Q
 line uint8_sources_zstd --source-bytes 1 --scheme 1 $Q
+line uint32_sources_lz4 --source-bytes 4 $Q
+line uint32_sources_zstd --source-bytes 4 --scheme 1 $Q
+line k2_3838x3710_lz4 --ny 3710 --nx 3838 --batch 64 --stack 128 $Q
+line k2_3838x3710_zstd_d12 --ny 3710 --nx 3838 --batch 64 --stack 128 --scheme 1 --depth 12 $Q
+line odd_1023x1023_lz4 --ny 1023 --nx 1023 --batch 1024 --stack 2048 $Q
 line lz4_2pct_d12 --sparsity-ppm 20000 --depth 12 $Q
 line zstd_2pct_d12 --sparsity-ppm 20000 --depth 12 --scheme 1 $Q
 line read_zstd --read --scheme 1 --steps 30 --warmup 5 --min-seconds 1
@@ -43,5 +48,8 @@ tools/prof_round.sh ${T}_cfg4 --config 4 > $OUT/prof_cfg4.log 2>&1
 tools/prof_round.sh ${T}_d12 --depth 12 > $OUT/prof_d12.log 2>&1
 tools/prof_round.sh ${T}_det_lz4 --clustered --sparsity-ppm 11000 --depth 12 > $OUT/prof_det_lz4.log 2>&1
 tools/prof_round.sh ${T}_det_zstd --clustered --sparsity-ppm 11000 --depth 12 --scheme 1 > $OUT/prof_det_zstd.log 2>&1
+tools/prof_round.sh ${T}_u32 --source-bytes 4 > $OUT/prof_u32.log 2>&1
+tools/prof_round.sh ${T}_u8 --source-bytes 1 > $OUT/prof_u8.log 2>&1
+tools/prof_round.sh ${T}_k2 --ny 3710 --nx 3838 --batch 64 --stack 128 > $OUT/prof_k2.log 2>&1
 for s in 1 2; do tools/prof_bench.sh ${T}_read_s$s --read --scheme $s --steps 30 --warmup 5 --min-seconds 0.5 > $OUT/prof_read_s$s.log 2>&1; done
 echo done

@@ -32,6 +32,14 @@
 
 namespace rc {
 
+#ifdef RC_LZ4_PHASE   // development builds (-DRC_PHASE_TIMING, rc_reduce.hip): s_memtime ticks of the encoder's sub-phases, lane 0 of one workgroup in 64
+#define LZ4_PH_BEGIN unsigned long long lzt_ = __builtin_amdgcn_s_memtime();
+#define LZ4_PH(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0 && (blockIdx.x & 63u) == 0) atomicAdd(&g_phase[8 + (i)], n_ - lzt_); lzt_ = n_; } while (0)
+#else
+#define LZ4_PH_BEGIN
+#define LZ4_PH(i) do { } while (0)
+#endif
+
 constexpr int LZ4_BLK = TILE_BM;       // 512
 constexpr int LZ4_MAXSEQ = LZ4_BLK / 4 + 2;  // LZ4: runs >= 5 (at most 104 sequences); zstd (rc_zstd_wave.h): runs >= 4 (128)
 
@@ -321,11 +329,14 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
     // ---- phase 1: the parse ----------------------------------------------------------------------------------------------
     uint32_t nm = 0xFFFFFFFFu;
     bool off1 = true;
+    LZ4_PH_BEGIN
     if (EVENTS) {
         nm = lz4_parse_events(own, n, L);
         off1 = nm == 0xFFFFFFFFu;
     }
+    LZ4_PH(0);
     if (nm == 0xFFFFFFFFu) nm = lz4_parse_runs(own, n, L);
+    LZ4_PH(1);
 
     // ---- phase 2: one sequence per lane ------------------------------------------------------------------------------
     uint32_t carry = 0, total = 0;
@@ -357,6 +368,7 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
         }
     }
     total = carry;
+    LZ4_PH(2);
     if (total >= n) return total;  // would not shrink: caller stores the block raw
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
@@ -387,6 +399,8 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
             }
         }
     }
+    LZ4_PH(3);   // (measured and dropped in round 4: a sequence's bytes put together in a register and written with byte-aligned ds_write_b32 /
+                 //  b16 - the compiler emits them, LDS runs in unaligned access mode - instead of one byte-write each: 1-2 % SLOWER everywhere)
     return total;
 }
 

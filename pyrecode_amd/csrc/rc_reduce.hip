@@ -11,6 +11,10 @@
 #include <type_traits>
 
 #include "rc_launch.h"
+#ifdef RC_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+#define RC_LZ4_PHASE 1   // (rc_lz4_block.h: sub-phases of the LZ4 encoder into g_phase[8..13])
+#endif
 #include "rc_lz4_block.h"
 #include "rc_zstd_wave.h"
 
@@ -23,7 +27,6 @@ namespace rc {
 // g_phase[] (rc_debug_phases reads and clears them).  s_memtime waits for the wave's outstanding LDS / scalar traffic, so the phases do
 // not overlap as they do in the product build: the SHARES are what the numbers are good for.
 #ifdef RC_PHASE_TIMING
-__device__ unsigned long long g_phase[16];
 // (sampled: one workgroup in 64 records, each wave's sums leave in one burst at the end of reduce_one_frame's last phase)
 #define RC_PHASE_BEGIN unsigned long long ph_t_ = __builtin_amdgcn_s_memtime(); unsigned long long ph_a_[8] = {};
 #define RC_PHASE(i) do { const unsigned long long ph_n_ = __builtin_amdgcn_s_memtime(); ph_a_[i] = ph_n_ - ph_t_; ph_t_ = ph_n_; \

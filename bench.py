@@ -75,7 +75,7 @@ def parse(argv=None):
     ap.add_argument("--min-seconds", type=float, default=2.0, help="the K-step timed region is repeated until this much time has been measured (>= 3 repeats); the median repeat is reported")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product); gloo only to rehearse on a box with fewer GPUs than ranks")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses two ranks on one device)")
-    ap.add_argument("--gather-every", type=int, default=1, help="steps per metadata all-gather: 1 = every step (default), K = every K steps, 0 = ONE gather per timed region (BASELINE: 'RCCL only for the final merged-index gather')")
+    ap.add_argument("--gather-every", type=int, default=0, help="steps per metadata all-gather: 0 = ONE gather per timed region (default - BASELINE: 'RCCL only for the final merged-index gather'), 1 = every step (the form of rounds 1-3), K = every K steps")
     ap.add_argument("--no-collective", action="store_true", help="rehearsal: the ranks only meet at the fences (barrier, max-over-ranks time); no metadata gather - isolates the HOST side of N step loops from the rehearsal backend's host copies")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin each rank to its share of the usable CPUs")
     pre, _ = ap.parse_known_args(argv)

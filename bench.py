@@ -433,7 +433,7 @@ def verify_record(a, r, frame, thr_h, frame_id):
         f2, t2 = frame.reshape(a.ny, a.nx), thr_h.reshape(a.ny, a.nx)
         labels, n = nd.label(f2 > t2, structure=np.ones((3, 3), int))          # recode_writer.py:166,443
         vals = nd.maximum(f2.astype(np.int64), labels, np.arange(1, n + 1)) if n else np.zeros(0)   # l2_statistics 0: max
-        packed = orc.bit_pack(np.minimum(np.asarray(vals, np.int64), (1 << a.depth) - 1).astype(np.uint16), a.depth)
+        packed = orc.bit_pack((np.asarray(vals, np.int64) & ((1 << a.depth) - 1)).astype(np.uint16), a.depth)   # (a sum wraps at d bits, as the reference's cast + pack would)
     bitmap, packed = bitmap.tobytes(), packed.tobytes()
     if a.scheme == 2:
         dec = lambda b, n: orc.lz4f_decode(b, n + 8)

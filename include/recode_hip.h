@@ -76,8 +76,9 @@ rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth, uint32_t
 int rc_ctx_destroy(rc_ctx *ctx);
 
 /* Reduction level 2 only: which statistic of the RAW frame values each connected component contributes (header field
- * L2_statistics, recode_writer.py:358-365): 0 or 1 = maximum, 2 = sum, clamped at 2^src_bit_depth - 1 (the value is
- * stored in src_bit_depth bits like every pixel value; a sum that does not fit saturates instead of wrapping).
+ * L2_statistics, recode_writer.py:358-365): 0 or 1 = maximum, 2 = sum modulo 2^src_bit_depth - the reference casts the
+ * statistic to the source dtype and stores it in src_bit_depth bits like every pixel value (recode_writer.py:446,463-475),
+ * so a sum that does not fit wraps.
  * Components are listed in scipy.ndimage.label order, i.e. by their first pixel in row-major order
  * (recode_writer.py:443-446, utils/converters.py:262-297 - restated by intent, the reference's own code cannot run). */
 int rc_ctx_set_l2_statistics(rc_ctx *ctx, uint32_t l2_statistics);

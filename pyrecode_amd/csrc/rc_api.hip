@@ -559,7 +559,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     }
     if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
         launch_scans(sc, n, true, false, ps);
-        launch_l2(sc, c->l2, n, c->nx, c->l2_sum ? (1u << c->depth) - 1u : 0u, ps);
+        launch_l2(sc, c->l2, n, c->nx, c->l2_sum, ps);
     }
 #ifdef RC_DEV_SKIP   // development builds only (tools/build_def.sh): leave second-stage kernels out (WRONG records) to see what each costs the
                      // reduce kernel running next to it - bits: 1 FSE, 2 scans, 4 residual Huffman chain, 8 layout, 16 assemble, 32 gather

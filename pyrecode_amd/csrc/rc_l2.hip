@@ -105,9 +105,11 @@ __global__ __launch_bounds__(WG) void k_l2_union(Scratch sc, L2Work w, uint32_t 
     }
 }
 
-// use_sum: 0 = maximum; otherwise the SATURATION value of the sum, 2^d - 1 for source_bit_depth d: the statistic is stored
-// in d bits like every other pixel value, so a sum that no longer fits is clamped instead of silently wrapping (the
-// reference's own code cannot run; clamping is the reading of its intent that loses the least).
+// use_sum: 0 = maximum, 1 = sum.  The sum wraps the way the reference's arithmetic would: its statistic is cast to the source dtype
+// (recode_writer.py:446 hands `self._src_dtype` to get_summary_stats_nb) and stored in src_bit_depth bits (_bit_pack drops the bits above,
+// recode_writer.py:637-652) - i.e. the sum modulo 2^d.  The accumulator is 32 bits wide (2^d divides 2^32: wrapping it changes nothing),
+// k_l2_emit keeps its low 16 bits, the d-bit pack the low d.  (Rounds 2-3 clamped at 2^d - 1 instead - the builder's reading; the
+// reference's own code cannot run, SURVEY 0.5, so this is specification by intent either way, now the literal one.)
 __global__ __launch_bounds__(WG) void k_l2_stats(Scratch sc, L2Work w, uint32_t use_sum)
 {
     const uint32_t f = blockIdx.y;
@@ -118,15 +120,8 @@ __global__ __launch_bounds__(WG) void k_l2_stats(Scratch sc, L2Work w, uint32_t 
         const uint32_t g = (uint32_t)(base + c);
         const uint32_t r = uf_find(w.parent, g);
         w.parent[g] = r;  // flattened: k_l2_emit only asks "is g its own root"
-        if (use_sum) {
-            uint32_t cur = __hip_atomic_load(&w.stat[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (cur < use_sum) {  // saturating add (CAS): once the root holds the clamp value nothing more is added
-                const uint32_t nv = min(cur + (uint32_t)w.val[g], use_sum);
-                const uint32_t prev = atomicCAS(&w.stat[r], cur, nv);
-                if (prev == cur) break;
-                cur = prev;
-            }
-        } else atomicMax(&w.stat[r], (uint32_t)w.val[g]);
+        if (use_sum) atomicAdd(&w.stat[r], (uint32_t)w.val[g]);
+        else atomicMax(&w.stat[r], (uint32_t)w.val[g]);
     }
 }
 

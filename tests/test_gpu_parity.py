@@ -990,8 +990,9 @@ def _l2_expected(frame, thr, stat, d=16):
     idx = np.arange(1, n + 1)
     f = frame.astype(np.int64)
     vals = nd.maximum(f, labels, idx) if stat in (0, 1) else nd.sum(f, labels, idx)
-    # the statistic is stored in d bits like every pixel value: a sum that does not fit is clamped at 2^d - 1 (rc_l2.hip)
-    return binary, np.minimum(np.asarray(vals, np.int64), (1 << d) - 1).astype(np.uint16) if n else np.zeros(0, np.uint16)
+    # the statistic is cast to the source dtype and stored in d bits like every pixel value (recode_writer.py:446,463-475): a sum that does
+    # not fit wraps - the sum modulo 2^d (rc_l2.hip)
+    return binary, (np.asarray(vals, np.int64) & ((1 << d) - 1)).astype(np.uint16) if n else np.zeros(0, np.uint16)
 
 
 @pytest.mark.parametrize("ny,nx,s,d,stat,scheme,mode", [
@@ -1408,7 +1409,7 @@ def test_zstd_both_block_forms_at_every_density(hip, orc, monkeypatch, ny, nx, s
 
 @pytest.mark.parametrize("stat,scheme,mode", [(0, 0, 0), (2, 2, 1), (0, 8, 1)])
 def test_l2_summary_statistics_of_uint8_sources(hip, orc, stat, scheme, mode):
-    """Level 2 on uint8 frames: the components' maxima / sums of the RAW uint8 values (clamped at 2^d - 1 like every value list), in
+    """Level 2 on uint8 frames: the components' maxima / sums of the RAW uint8 values (a sum modulo 2^d, like every value list), in
     scipy's label order - the uint8 instantiation keeps the raw value of a set pixel as residual + threshold, as the uint16 one does."""
     ny, nx, d = 120, 136, 8
     dark, frames = _synth_u8(7 + stat, 3, ny, nx, 0.06, d)

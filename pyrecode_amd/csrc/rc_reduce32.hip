@@ -50,10 +50,13 @@ __device__ __forceinline__ void load_tile32(const uint32_t *__restrict__ base, u
             const u32x4_dw *p = reinterpret_cast<const u32x4_dw *>(base + px0 + (uint64_t)i * 256 + (uint64_t)lane * 4);
             v[i] = NT ? __builtin_nontemporal_load(p) : *p;
         } else {
+            const uint64_t px = px0 + (uint64_t)i * 256 + (uint64_t)lane * 4;
+            if (px + 4 <= N) {   // (whole groups of four as vectors here too: single loads only where the frame ends)
+                typedef u32x4 u32x4_dw __attribute__((aligned(4)));
+                v[i] = *reinterpret_cast<const u32x4_dw *>(base + px);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t px = px0 + (uint64_t)i * 256 + (uint64_t)lane * 4 + k;
-                v[i][k] = px < N ? base[px] : fill;
+                for (int k = 0; k < 4; ++k) v[i][k] = px + k < N ? base[px + k] : fill;
             }
         }
     }

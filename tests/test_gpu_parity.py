@@ -246,6 +246,18 @@ def test_lz4_device_blocks_equal_the_serial_parse_model(hip, orc, level):
         ctx.close()
 
 
+def test_lz4_device_blocks_equal_the_model_on_random_structures(hip, orc):
+    """8 000 random 512-byte blocks (Bernoulli bits of six densities, few-valued events, jittered periodic units, clusters, events at the
+    block's ends, growing gaps) through the stateless seam, both parsers: the device's bytes equal the serial model's block for block
+    (tools/fuzz_lz4_blocks.py; 48 000 encodings by hand: clean)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_lz4_blocks", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_lz4_blocks.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    tot, two, bad = fz.run(2, 3, quiet=True)
+    assert tot == 8000 and bad == 0 and two > 500   # (a good share of the blocks takes the two-events-per-lane form)
+
+
 def test_lz4_event_parser_ratio_on_bench_like_data(hip, orc):
     """SURVEY 8d data at 1 %: the binary-map stream must come out below 0.30 of raw at compression_level >= 1 (the run parser:
     0.375; stock liblz4 on the same bytes in one 64 KiB-block frame: 0.26)."""

@@ -104,6 +104,36 @@ def test_reduce_only_records_bit_exact(hip, orc, ny, nx, s, d, eps):
     ctx.close()
 
 
+def test_random_geometries_reduce_only_records_bit_exact(hip, orc):
+    """Thirty random geometries - any ny x nx (odd sizes, N % 8 of every kind, less than a tile up to sixty tiles), 1 .. 9 frames (odd frames of an odd N
+    start 2 bytes off a dword), densities from empty to 40 %, depths 9 .. 16, eps 0 .. 9, batches smaller than max_batch - reduce-only records against
+    the oracle byte for byte, through LZ4 as well: frames of any size and alignment take the vector-load kernel, the guarded loads serve the tail."""
+    rng = np.random.default_rng(20261004)
+    for case in range(30):
+        ny, nx = int(rng.integers(3, 500)), int(rng.integers(8, 520))
+        nz, d, eps = int(rng.integers(1, 10)), int(rng.integers(9, 17)), int(rng.integers(0, 10))
+        s = float(rng.choice([0.0, 0.001, 0.01, 0.03, 0.1, 0.4]))
+        dark, frames = synth_frames(1000 + case, nz, ny, nx, s, d)
+        thr = orc.threshold(dark, eps)
+        ctx = hip.ReduceContext(nx, ny, d, 1, 0, 0, 1, 0, max_batch=nz + int(rng.integers(0, 3)))
+        ctx.set_dark(dark, eps)
+        out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=7)
+        for z in range(nz):
+            want, wmd = orc.l1_record(frames[z], thr, d, 7 + z, mode=0)
+            assert out[int(rec[z]):int(rec[z + 1])].tobytes() == want, "case %d (%d x %d, %d frames, d %d): frame %d" % (case, ny, nx, nz, d, z)
+        ctx.close()
+        ctx = hip.ReduceContext(nx, ny, d, 1, 1, 2, 1, 0, max_batch=nz)
+        ctx.set_dark(dark, eps)
+        out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+        for z in range(nz):
+            r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+            fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+            binary, pix = orc.binarize_l1(frames[z], thr)
+            _check_lz4(orc, r[16:16 + cb], orc.pack_binary_frame(binary).tobytes())
+            _check_lz4(orc, r[16 + cb:], orc.bit_pack(pix, d).tobytes())
+        ctx.close()
+
+
 @pytest.mark.parametrize("ny,nx,s,d,eps", [SHAPES[1], SHAPES[4], SHAPES[6]])
 def test_guarded_load_instantiation_stays_bit_exact(hip, orc, ny, nx, s, d, eps, monkeypatch):
     """Frames take the vector-load kernel at any alignment (odd N: every other frame starts 2 bytes off a dword); the guarded

@@ -68,7 +68,7 @@ int rc_scheme_on_device(uint32_t scheme);        /* 1 if rc_reduce_compress_batc
  *   op_mode           rc_operation_mode: 0 reduce only, 1 reduce + compress (recode_writer.py:482,497)
  *   scheme, clevel    compression_scheme / compression_level (recode_writer.py:503-511)
  *   device_id         HIP device ordinal
- *   max_batch         largest n later passed to rc_reduce_compress_batch; sizes the device scratch
+ *   max_batch         largest n later passed to rc_reduce_compress_batch (1 .. 65535: a batch's frames are a launch's grid.y); sizes the device scratch
  */
 rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth, uint32_t reduction_level,
                       uint32_t op_mode, uint32_t scheme, uint32_t clevel, int device_id, uint32_t max_batch,

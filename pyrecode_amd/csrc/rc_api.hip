@@ -267,8 +267,8 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
     int dummy;
     if (!status) status = &dummy;
     *status = RC_OK;
-    if (nx == 0 || ny == 0 || max_batch == 0 || op_mode > 1) {
-        *status = fail(RC_ERR_BAD_ARG, "nx, ny, max_batch must be > 0 and op_mode 0 or 1");
+    if (nx == 0 || ny == 0 || max_batch == 0 || max_batch > 65535u || op_mode > 1) {   // (a batch's frames are a launch's grid.y)
+        *status = fail(RC_ERR_BAD_ARG, "nx, ny, max_batch must be > 0, max_batch <= 65535 and op_mode 0 or 1");
         return nullptr;
     }
     if ((uint64_t)nx * ny >= (1ull << 32)) {

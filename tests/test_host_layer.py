@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol():
     assert L.rc_strerror(-5).decode() == "Buffer size smaller than compressed data size"
 
 
+def test_ctx_arguments_are_checked_before_any_device_is_touched():
+    """rc_ctx_create refuses what no launch could take - with or without a GPU: zero sizes, a batch beyond a launch's grid.y, depths beyond 32."""
+    from pyrecode_amd import _lib
+    for kw, pat in ((dict(max_batch=0), "max_batch"), (dict(max_batch=65536), "65535"), (dict(nx=0), "nx"), (dict(depth=33), "source_bit_depth")):
+        a = dict(nx=64, ny=64, depth=12, max_batch=4)
+        a.update(kw)
+        with pytest.raises((_lib.RecodeHipError, ValueError, NotImplementedError), match=pat):
+            _lib.ReduceContext(a["nx"], a["ny"], a["depth"], max_batch=a["max_batch"])
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     from pyrecode_amd import _lib
     if _lib.device_count() > 0:

@@ -86,7 +86,8 @@ void launch_reduce(const Scratch &sc, const void *frames, uint32_t B, uint32_t l
 // rc_reduce32.hip: uint32 sources (source_bit_depth > 16) - reduce + d-bit pack + raw binary maps; the block encoders follow as launches of
 // their own (launch_lz4_encode_rows / launch_zstd_tokenize_rows / launch_blosc_encode_blocks)
 void launch_threshold32(const uint32_t *dark, int64_t eps, uint64_t N, uint32_t *thr, hipStream_t s);
-void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s);
+void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s,
+                     uint32_t codec = 0, bool keep_bitmap = true);   // codec 2 / 4: the LZ4 block encoder (runs / events) fused
 // rc_l2.hip
 void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s);
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);

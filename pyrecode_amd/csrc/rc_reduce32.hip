@@ -9,18 +9,22 @@
 // tile's thresholds in registers (64 VGPRs) over FPW consecutive frames, the next frame's 16 loads of 16 bytes per lane are in flight
 // while the current one is reduced (two register sets), loads are whole 1 KiB runs per instruction (lane l: pixels 4 l .. 4 l + 3 of the
 // group's first and second half), compaction goes from the registers into LDS (one packed wave scan per group), the d-bit pack in place.
-// The codec is not fused: the kernel leaves what rc_reduce.hip's kernel leaves - the raw binary map (always: the block encoders run over
-// it as separate launches, rc_lz4.hip / rc_zstd.hip / rc_blosc.hip), per tile the packed residual stream in its slot (whole 128-byte
-// lines, zero behind the last field) and the count - so scans, record layout and assembly are the uint16 path's, unchanged (k_assemble
-// concatenates bit streams of any field width up to 32).  Algorithmic bytes: 4 N per frame in; the maps (N / 8) and the residual lines out.
+// The LZ4 block encoder (rc_lz4_block.h) runs inside the kernel on the tile's map in LDS, as in the uint16 kernel; for zstd / blosc / reduce-only
+// records the kernel leaves the raw binary map and their block encoders run over it as separate launches (rc_zstd.hip / rc_blosc.hip).  Either
+// way it leaves what rc_reduce.hip's kernel leaves - per tile the encoded block (or the map), the packed residual stream in its slot (whole
+// 128-byte lines, zero behind the last field) and the count - so scans, record layout and assembly are the uint16 path's, unchanged
+// (k_assemble concatenates bit streams of any field width up to 32).  Algorithmic bytes: 4 N per frame in; blocks and residual lines out.
+#include <type_traits>
+
 #include "rc_launch.h"
+#include "rc_lz4_block.h"
 
 namespace rc {
 
 constexpr int R32_FPW = 16;    // frames a wavefront keeps its tile for (the thresholds are read once per R32_FPW frames)
 struct __attribute__((aligned(16))) Stage32 {
     uint32_t out[TILE_PX];     // compacted residuals in pixel order, then packed in place
-    uint8_t bm[TILE_BM];       // bitmap bytes in pixel order
+    Lz4Lds lz;                 // lz.raw: the tile's bitmap bytes in pixel order = the block image of the LZ4 encoder (fused: CODEC 2 / 4)
 };
 
 __global__ void k_threshold32(const uint32_t *__restrict__ dark, uint32_t eps, uint64_t N, uint32_t *__restrict__ thr)
@@ -63,8 +67,12 @@ __device__ __forceinline__ void load_tile32(const uint32_t *__restrict__ base, u
 }
 
 // A2-A5 of one tile of one frame from registers
+// CODEC: 0 = none (the raw map leaves for the block encoder's own launch), 2 / 4 = the LZ4 block encoder (runs / events) on the tile's map
+// here: the encoded block goes to the tile's block slot, the raw map only where the caller keeps binary maps (bm_dst != nullptr)
+template <int CODEC>
 __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R], const u32x4 (&t)[2 * R], uint8_t *__restrict__ bm_dst,
-                                              uint8_t *__restrict__ slot, uint32_t *__restrict__ cnt_dst, uint32_t depth, bool level1)
+                                              uint8_t *__restrict__ slot, uint32_t *__restrict__ cnt_dst, uint32_t depth, bool level1,
+                                              uint8_t *__restrict__ blk_slot, uint32_t *__restrict__ blk_size_dst, uint32_t n_blk)
 {
     const int lane = lane_id();
     uint32_t base = 0;
@@ -82,7 +90,7 @@ __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R
         // A4: a bitmap byte is two neighbouring lanes' nibbles - the even lane forms the first half's byte, the odd lane the second half's
         const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         const uint32_t byte = (lane & 1) ? ((other >> 4) | (m & 0xF0u)) : ((m & 0xFu) | ((other & 0xFu) << 4));
-        S.bm[g * 64 + (lane & 1) * 32 + (lane >> 1)] = (uint8_t)byte;
+        S.lz.raw[g * 64 + (lane & 1) * 32 + (lane >> 1)] = (uint8_t)byte;
         if (level1) {
             // A3: row-major order = the first half's lanes in order, then the second half's
             const uint32_t ca = (uint32_t)__builtin_popcount(m & 0xFu), cb = (uint32_t)__builtin_popcount(m >> 4);
@@ -100,7 +108,15 @@ __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R
         }
     }
     __builtin_amdgcn_wave_barrier();
-    *reinterpret_cast<u32x2 *>(bm_dst + lane * 8) = *reinterpret_cast<const u32x2 *>(&S.bm[lane * 8]);
+    const u32x2 ownv = *reinterpret_cast<const u32x2 *>(&S.lz.raw[lane * 8]);
+    if (bm_dst) *reinterpret_cast<u32x2 *>(bm_dst + lane * 8) = ownv;
+    if (CODEC) {
+        const uint64_t own = (uint64_t)ownv[0] | ((uint64_t)ownv[1] << 32);
+        const uint32_t csize = lz4_encode_block<CODEC == 4>(own, n_blk, S.lz);
+        const uint32_t used = lz4_store_block(blk_slot, own, n_blk, csize, S.lz);
+        if (lane == 0) *blk_size_dst = used;
+        __builtin_amdgcn_wave_barrier();   // S.lz is the next frame's
+    }
     if (!level1) return;
     const uint32_t total = base;
     // A5: depth-bit fields, LSB first, in place (output dword j needs values from index 32 j / depth >= j on: at or behind dword j, and
@@ -136,55 +152,69 @@ __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R
 }
 
 // FULL: grid (tiles wholly inside the frame, ceil(B / R32_FPW)), two frame register sets; the other instantiation: the partial last tile
-// (tile0 = its index), one set.  One wavefront per workgroup (16.5 KB of LDS: nine of them would share a CU; the registers allow eight)
-template <bool FULL>
+// (tile0 = its index), one set.  One wavefront per workgroup (18.4 KB of LDS: eight of them share a CU, what the registers allow)
+template <bool FULL, int CODEC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tiles32(const uint32_t *__restrict__ frames, const uint32_t *__restrict__ thr, uint64_t N,
                                                        uint32_t ntiles, uint32_t tile0, uint32_t B, uint8_t *__restrict__ bitmap, uint64_t nb_stride,
                                                        uint8_t *__restrict__ pix_slots, uint32_t pix_slot_bytes,
                                                        uint32_t *__restrict__ tile_cnt, uint32_t depth, uint32_t level1,
-                                                       BatchStatus *__restrict__ status)
+                                                       BatchStatus *__restrict__ status, uint8_t *__restrict__ blk_slots, uint32_t blk_stride,
+                                                       uint32_t *__restrict__ blk_size, uint64_t nb)
 {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
     __shared__ Stage32 S;
     const uint32_t tile = tile0 + blockIdx.x;
     const uint32_t f0 = blockIdx.y * R32_FPW, f1 = f0 + R32_FPW < B ? f0 + R32_FPW : B;
     const uint64_t px0 = (uint64_t)tile * TILE_PX;
+    const uint32_t n_blk = (uint32_t)min((uint64_t)TILE_BM, nb - (uint64_t)tile * TILE_BM);   // bitmap bytes of this tile
     u32x4 t[2 * R], xa[2 * R];
     load_tile32<FULL, false>(thr, px0, N, 0xFFFFFFFFu, t);
+    auto one = [&](const u32x4 (&x)[2 * R], uint32_t f) {
+        const uint64_t ft = (uint64_t)f * ntiles + tile;
+        reduce_tile32<CODEC>(S, x, t, bitmap ? bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM : nullptr, pix_slots + ft * pix_slot_bytes,
+                             tile_cnt + ft, depth, level1 != 0, blk_slots + ft * blk_stride, blk_size + ft, n_blk);
+    };
     if (FULL) {
         u32x4 xb[2 * R];
         load_tile32<true, true>(frames + (uint64_t)f0 * N, px0, N, 0, xa);
         for (uint32_t f = f0; f < f1; f += 2) {
             if (f + 1 < f1) load_tile32<true, true>(frames + (uint64_t)(f + 1) * N, px0, N, 0, xb);
-            {
-                const uint64_t ft = (uint64_t)f * ntiles + tile;
-                reduce_tile32(S, xa, t, bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM, pix_slots + ft * pix_slot_bytes, tile_cnt + ft, depth, level1 != 0);
-            }
+            one(xa, f);
             if (f + 1 < f1) {
                 if (f + 2 < f1) load_tile32<true, true>(frames + (uint64_t)(f + 2) * N, px0, N, 0, xa);
-                const uint64_t ft = (uint64_t)(f + 1) * ntiles + tile;
-                reduce_tile32(S, xb, t, bitmap + (uint64_t)(f + 1) * nb_stride + (uint64_t)tile * TILE_BM, pix_slots + ft * pix_slot_bytes, tile_cnt + ft, depth, level1 != 0);
+                one(xb, f + 1);
             }
         }
     } else {
         for (uint32_t f = f0; f < f1; ++f) {
             load_tile32<false, true>(frames + (uint64_t)f * N, px0, N, 0, xa);
-            const uint64_t ft = (uint64_t)f * ntiles + tile;
-            reduce_tile32(S, xa, t, bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM, pix_slots + ft * pix_slot_bytes, tile_cnt + ft, depth, level1 != 0);
+            one(xa, f);
         }
     }
 }
 
-void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s)
+// codec: 0 = the raw maps only (zstd / blosc / reduce-only: their block encoders run as launches of their own), 2 / 4 = LZ4 runs / events
+// fused; keep_bitmap: the raw maps leave as well (validation frames, rc_get_binary_map)
+void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s,
+                     uint32_t codec, bool keep_bitmap)
 {
     const uint32_t nfull = (uint32_t)(sc.N / TILE_PX), fy = (B + R32_FPW - 1) / R32_FPW;
     uint8_t *slots = reinterpret_cast<uint8_t *>(sc.pix_slots);
-    if (nfull)
-        hipLaunchKernelGGL(k_reduce_tiles32<true>, dim3(nfull, fy), dim3(64), 0, s, frames, thr32, sc.N, sc.ntiles, 0u, B, sc.bitmap, sc.nb_stride,
-                           slots, sc.pix_slot_bytes, sc.tile_cnt, depth, level == 1 ? 1u : 0u, sc.status);
-    if (nfull < sc.ntiles)
-        hipLaunchKernelGGL(k_reduce_tiles32<false>, dim3(1, fy), dim3(64), 0, s, frames, thr32, sc.N, sc.ntiles, nfull, B, sc.bitmap, sc.nb_stride,
-                           slots, sc.pix_slot_bytes, sc.tile_cnt, depth, level == 1 ? 1u : 0u, sc.status);
+    uint8_t *bitmap = (codec == 0 || keep_bitmap) ? sc.bitmap : nullptr;
+    auto go = [&](auto full, auto cd) {
+        constexpr bool FULL = decltype(full)::value;
+        constexpr int CODEC = decltype(cd)::value;
+        hipLaunchKernelGGL((k_reduce_tiles32<FULL, CODEC>), FULL ? dim3(nfull, fy) : dim3(1, fy), dim3(64), 0, s, frames, thr32, sc.N, sc.ntiles, FULL ? 0u : nfull, B,
+                           bitmap, sc.nb_stride, slots, sc.pix_slot_bytes, sc.tile_cnt, depth, level == 1 ? 1u : 0u, sc.status, sc.blk_slots, sc.blk_stride,
+                           sc.blk_size, sc.nb);
+    };
+    auto both = [&](auto cd) {
+        if (nfull) go(std::true_type{}, cd);
+        if (nfull < sc.ntiles) go(std::false_type{}, cd);
+    };
+    if (codec == 2) both(std::integral_constant<int, 2>{});
+    else if (codec == 4) both(std::integral_constant<int, 4>{});
+    else both(std::integral_constant<int, 0>{});
 }
 
 }  // namespace rc

@@ -9,8 +9,8 @@
 // tile's thresholds in registers (64 VGPRs) over FPW consecutive frames, the next frame's 16 loads of 16 bytes per lane are in flight
 // while the current one is reduced (two register sets), loads are whole 1 KiB runs per instruction (lane l: pixels 4 l .. 4 l + 3 of the
 // group's first and second half), compaction goes from the registers into LDS (one packed wave scan per group), the d-bit pack in place.
-// The LZ4 block encoder (rc_lz4_block.h) runs inside the kernel on the tile's map in LDS, as in the uint16 kernel; for zstd / blosc / reduce-only
-// records the kernel leaves the raw binary map and their block encoders run over it as separate launches (rc_zstd.hip / rc_blosc.hip).  Either
+// The LZ4 and blosc-lz4 block encoders (rc_lz4_block.h) run inside the kernel on the tile's map in LDS, as in the uint16 kernel; for zstd and
+// reduce-only records the kernel leaves the raw binary map (the zstd tokenizer runs over it as a launch of its own, rc_zstd.hip).  Either
 // way it leaves what rc_reduce.hip's kernel leaves - per tile the encoded block (or the map), the packed residual stream in its slot (whole
 // 128-byte lines, zero behind the last field) and the count - so scans, record layout and assembly are the uint16 path's, unchanged
 // (k_assemble concatenates bit streams of any field width up to 32).  Algorithmic bytes: 4 N per frame in; blocks and residual lines out.
@@ -67,7 +67,8 @@ __device__ __forceinline__ void load_tile32(const uint32_t *__restrict__ base, u
 }
 
 // A2-A5 of one tile of one frame from registers
-// CODEC: 0 = none (the raw map leaves for the block encoder's own launch), 2 / 4 = the LZ4 block encoder (runs / events) on the tile's map
+// CODEC: 0 = none (the raw map leaves for the block encoder's own launch), 2 / 4 = the LZ4 block encoder (runs / events), 8 = blosc1's
+// bit-shuffle + LZ4 runs on the tile's map
 // here: the encoded block goes to the tile's block slot, the raw map only where the caller keeps binary maps (bm_dst != nullptr)
 template <int CODEC>
 __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R], const u32x4 (&t)[2 * R], uint8_t *__restrict__ bm_dst,
@@ -111,9 +112,10 @@ __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R
     const u32x2 ownv = *reinterpret_cast<const u32x2 *>(&S.lz.raw[lane * 8]);
     if (bm_dst) *reinterpret_cast<u32x2 *>(bm_dst + lane * 8) = ownv;
     if (CODEC) {
-        const uint64_t own = (uint64_t)ownv[0] | ((uint64_t)ownv[1] << 32);
+        uint64_t own = (uint64_t)ownv[0] | ((uint64_t)ownv[1] << 32);
+        if (CODEC == 8) own = bitshuffle_block(own, n_blk, S.lz);   // blosc1: the block's bit-shuffle in front of the LZ4 run encoder
         const uint32_t csize = lz4_encode_block<CODEC == 4>(own, n_blk, S.lz);
-        const uint32_t used = lz4_store_block(blk_slot, own, n_blk, csize, S.lz);
+        const uint32_t used = lz4_store_block(blk_slot, own, n_blk, csize, S.lz, CODEC == 8);
         if (lane == 0) *blk_size_dst = used;
         __builtin_amdgcn_wave_barrier();   // S.lz is the next frame's
     }
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
-// codec: 0 = the raw maps only (zstd / blosc / reduce-only: their block encoders run as launches of their own), 2 / 4 = LZ4 runs / events
+// codec: 0 = the raw maps only (zstd / reduce-only: the zstd tokenizer runs as a launch of its own), 2 / 4 = LZ4 runs / events, 8 = blosc-lz4
 // fused; keep_bitmap: the raw maps leave as well (validation frames, rc_get_binary_map)
 void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s,
                      uint32_t codec, bool keep_bitmap)
@@ -214,6 +216,7 @@ void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *
     };
     if (codec == 2) both(std::integral_constant<int, 2>{});
     else if (codec == 4) both(std::integral_constant<int, 4>{});
+    else if (codec == 8) both(std::integral_constant<int, 8>{});
     else both(std::integral_constant<int, 0>{});
 }
 

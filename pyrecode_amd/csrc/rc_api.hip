@@ -541,10 +541,10 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     const uint32_t codec = c->modelled ? 3u : (c->emit == RC_SCHEME_LZ4 && c->clevel != 0 ? 4u : c->emit);
     if (c->src_bytes == 4) {
         // uint32 sources: reduce + pack + raw binary maps (rc_reduce32.hip), then the block encoder over the maps as a launch of its own
-        // (LZ4 / blosc-lz4: the block encoder runs inside the kernel, as in the uint16 path; zstd: the tokenizer's own launch over the raw maps, below)
+        // (every device codec's block encoder runs inside the kernel, as in the uint16 path; zstd in its fast form)
         launch_reduce32(sc, static_cast<const uint32_t *>(frames_dev), c->thr32, n, c->level, c->depth, s,
-                        c->emit == RC_SCHEME_LZ4 ? (c->clevel != 0 ? 4u : 2u) : (c->emit == RC_SCHEME_BLOSC_LZ4 ? 8u : 0u),
-                        c->keep_bitmap || (c->emit != RC_SCHEME_LZ4 && c->emit != RC_SCHEME_BLOSC_LZ4));
+                        c->emit == RC_SCHEME_LZ4 ? (c->clevel != 0 ? 4u : 2u) : (c->emit == RC_SCHEME_BLOSC_LZ4 ? 8u : (c->emit == RC_SCHEME_ZSTD ? 1u : 0u)),
+                        c->keep_bitmap || c->emit == 0);
     } else
         launch_reduce(sc, frames_dev, n, c->level, codec, c->keep_bitmap || c->emit == 0, c->depth, s, tail, c->src_bytes);
     // every event costs a few microseconds of stream time: the asynchronous path records only the ones it needs
@@ -554,9 +554,6 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     hipEvent_t red = ev ? ev[1] : c->ev_red[k];
     HIP_TRY(hipEventRecord(red, s));
     HIP_TRY(hipStreamWaitEvent(ps, red, 0));
-    // uint32 sources, zstd: the tokenizer over the raw maps opens the second stage, next to the following batch's reduce kernel (same-box A/B
-    // against the tokenizer on the reduce kernel's stream: the step within +-1.5 % - the work is conserved)
-    if (c->src_bytes == 4 && c->emit == RC_SCHEME_ZSTD) launch_zstd_tokenize_rows(sc, n, ps);
     if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
         launch_scans(sc, n, true, false, ps);
         launch_l2(sc, c->l2, n, c->nx, c->l2_sum, ps);

@@ -9,8 +9,8 @@
 // tile's thresholds in registers (64 VGPRs) over FPW consecutive frames, the next frame's 16 loads of 16 bytes per lane are in flight
 // while the current one is reduced (two register sets), loads are whole 1 KiB runs per instruction (lane l: pixels 4 l .. 4 l + 3 of the
 // group's first and second half), compaction goes from the registers into LDS (one packed wave scan per group), the d-bit pack in place.
-// The LZ4 and blosc-lz4 block encoders (rc_lz4_block.h) run inside the kernel on the tile's map in LDS, as in the uint16 kernel; for zstd and
-// reduce-only records the kernel leaves the raw binary map (the zstd tokenizer runs over it as a launch of its own, rc_zstd.hip).  Either
+// The block encoders - LZ4, blosc-lz4 (rc_lz4_block.h), the zstd tokenizer (rc_zstd_wave.h, the fast form; k_zstd_fse finishes its blocks) -
+// run inside the kernel on the tile's map in LDS, as in the uint16 kernel; reduce-only records take the raw binary map.  Either
 // way it leaves what rc_reduce.hip's kernel leaves - per tile the encoded block (or the map), the packed residual stream in its slot (whole
 // 128-byte lines, zero behind the last field) and the count - so scans, record layout and assembly are the uint16 path's, unchanged
 // (k_assemble concatenates bit streams of any field width up to 32).  Algorithmic bytes: 4 N per frame in; blocks and residual lines out.
@@ -18,6 +18,7 @@
 
 #include "rc_launch.h"
 #include "rc_lz4_block.h"
+#include "rc_zstd_wave.h"
 
 namespace rc {
 
@@ -67,13 +68,13 @@ __device__ __forceinline__ void load_tile32(const uint32_t *__restrict__ base, u
 }
 
 // A2-A5 of one tile of one frame from registers
-// CODEC: 0 = none (the raw map leaves for the block encoder's own launch), 2 / 4 = the LZ4 block encoder (runs / events), 8 = blosc1's
-// bit-shuffle + LZ4 runs on the tile's map
+// CODEC: 0 = none (only the raw map leaves), 1 = the zstd tokenizer (fast form), 2 / 4 = the LZ4 block encoder (runs / events), 8 = blosc1's
+// bit-shuffle + LZ4 runs - on the tile's map
 // here: the encoded block goes to the tile's block slot, the raw map only where the caller keeps binary maps (bm_dst != nullptr)
 template <int CODEC>
 __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R], const u32x4 (&t)[2 * R], uint8_t *__restrict__ bm_dst,
                                               uint8_t *__restrict__ slot, uint32_t *__restrict__ cnt_dst, uint32_t depth, bool level1,
-                                              uint8_t *__restrict__ blk_slot, uint32_t *__restrict__ blk_size_dst, uint32_t n_blk)
+                                              uint8_t *__restrict__ blk_slot, uint32_t *__restrict__ blk_size_dst, uint32_t n_blk, bool last_blk)
 {
     const int lane = lane_id();
     uint32_t base = 0;
@@ -111,7 +112,13 @@ __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R
     __builtin_amdgcn_wave_barrier();
     const u32x2 ownv = *reinterpret_cast<const u32x2 *>(&S.lz.raw[lane * 8]);
     if (bm_dst) *reinterpret_cast<u32x2 *>(bm_dst + lane * 8) = ownv;
-    if (CODEC) {
+    if (CODEC == 1) {   // zstd, the fast encoder's wave-collective half (k_zstd_fse finishes the block)
+        uint32_t staged;
+        const uint32_t word = zstd_tokenize_block((uint64_t)ownv[0] | ((uint64_t)ownv[1] << 32), n_blk, last_blk, S.lz, staged);
+        zstd_store_block(blk_slot, n_blk, last_blk, word, staged, S.lz);
+        if (lane == 0) *blk_size_dst = word;
+        __builtin_amdgcn_wave_barrier();
+    } else if (CODEC) {
         uint64_t own = (uint64_t)ownv[0] | ((uint64_t)ownv[1] << 32);
         if (CODEC == 8) own = bitshuffle_block(own, n_blk, S.lz);   // blosc1: the block's bit-shuffle in front of the LZ4 run encoder
         const uint32_t csize = lz4_encode_block<CODEC == 4>(own, n_blk, S.lz);
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto one = [&](const u32x4 (&x)[2 * R], uint32_t f) {
         const uint64_t ft = (uint64_t)f * ntiles + tile;
         reduce_tile32<CODEC>(S, x, t, bitmap ? bitmap + (uint64_t)f * nb_stride + (uint64_t)tile * TILE_BM : nullptr, pix_slots + ft * pix_slot_bytes,
-                             tile_cnt + ft, depth, level1 != 0, blk_slots + ft * blk_stride, blk_size + ft, n_blk);
+                             tile_cnt + ft, depth, level1 != 0, blk_slots + ft * blk_stride, blk_size + ft, n_blk, tile + 1 == ntiles);
     };
     if (FULL) {
         u32x4 xb[2 * R];
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
-// codec: 0 = the raw maps only (zstd / reduce-only: the zstd tokenizer runs as a launch of its own), 2 / 4 = LZ4 runs / events, 8 = blosc-lz4
+// codec: 0 = the raw maps only (reduce-only records), 1 = zstd (fast form; k_zstd_fse follows), 2 / 4 = LZ4 runs / events, 8 = blosc-lz4
 // fused; keep_bitmap: the raw maps leave as well (validation frames, rc_get_binary_map)
 void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s,
                      uint32_t codec, bool keep_bitmap)
@@ -217,6 +224,7 @@ void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *
     if (codec == 2) both(std::integral_constant<int, 2>{});
     else if (codec == 4) both(std::integral_constant<int, 4>{});
     else if (codec == 8) both(std::integral_constant<int, 8>{});
+    else if (codec == 1) both(std::integral_constant<int, 1>{});
     else both(std::integral_constant<int, 0>{});
 }
 

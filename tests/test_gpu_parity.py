@@ -1533,4 +1533,9 @@ def test_uint32_sources_device_codecs_decode_bit_exact(hip, orc, ny, nx, s, d, e
         assert fid == 9 + z and (cb, cp, npk) == tuple(int(v) for v in md[z]) and len(r) == 16 + cb + cp
         packed = orc.bit_pack32((frames[z][binary] - thr[binary]).astype(np.uint32), d).tobytes()
         assert npk == len(packed) and dec(r[16:16 + cb], len(bitmap)) == bitmap and dec(r[16 + cb:], npk) == packed
+        assert np.array_equal(ctx.binary_map(z), np.frombuffer(bitmap, np.uint8))     # the raw maps a caller keeps (validation frames)
+    # the block encoders run inside the uint32 kernel: without kept maps (no raw map leaves the kernel at all) the records are the same bytes
+    ctx.keep_binary_maps(False)
+    out2, rec2, md2 = ctx.reduce_compress_batch(frames, first_frame_id=9)
+    assert np.array_equal(rec2, rec) and np.array_equal(out2[:int(rec2[-1])], out[:int(rec[-1])])
     ctx.close()

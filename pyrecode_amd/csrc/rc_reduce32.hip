@@ -22,6 +22,11 @@
 
 namespace rc {
 
+#ifndef RC_R32_WAVES
+#define RC_R32_WAVES 1
+#endif
+constexpr int R32_WAVES = RC_R32_WAVES;   // wavefronts per workgroup (each with its own tile and LDS stage); 1 stays: 2 / 4 per workgroup ran LZ4 6-8 % slower
+                                          // (72.6 k -> 68.0 / 67.1 k frames/s), zstd the same (same box, -DRC_R32_WAVES)
 constexpr int R32_FPW = 16;    // frames a wavefront keeps its tile for (the thresholds are read once per R32_FPW frames)
 struct __attribute__((aligned(16))) Stage32 {
     uint32_t out[TILE_PX];     // compacted residuals in pixel order, then packed in place
@@ -163,16 +168,19 @@ __device__ __forceinline__ void reduce_tile32(Stage32 &S, const u32x4 (&x)[2 * R
 // FULL: grid (tiles wholly inside the frame, ceil(B / R32_FPW)), two frame register sets; the other instantiation: the partial last tile
 // (tile0 = its index), one set.  One wavefront per workgroup (18.4 KB of LDS: eight of them share a CU, what the registers allow)
 template <bool FULL, int CODEC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tiles32(const uint32_t *__restrict__ frames, const uint32_t *__restrict__ thr, uint64_t N,
-                                                       uint32_t ntiles, uint32_t tile0, uint32_t B, uint8_t *__restrict__ bitmap, uint64_t nb_stride,
+__global__ __launch_bounds__(64 * R32_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tiles32(const uint32_t *__restrict__ frames, const uint32_t *__restrict__ thr, uint64_t N,
+                                                       uint32_t ntiles, uint32_t tile0, uint32_t tile_n, uint32_t B, uint8_t *__restrict__ bitmap, uint64_t nb_stride,
                                                        uint8_t *__restrict__ pix_slots, uint32_t pix_slot_bytes,
                                                        uint32_t *__restrict__ tile_cnt, uint32_t depth, uint32_t level1,
                                                        BatchStatus *__restrict__ status, uint8_t *__restrict__ blk_slots, uint32_t blk_stride,
                                                        uint32_t *__restrict__ blk_size, uint64_t nb)
 {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { status->code = 0; status->frame = 0; status->total = 0; }
-    __shared__ Stage32 S;
-    const uint32_t tile = tile0 + blockIdx.x;
+    __shared__ Stage32 s_st[R32_WAVES];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Stage32 &S = s_st[wv];
+    const uint32_t tile = tile0 + blockIdx.x * R32_WAVES + wv;
+    if (tile >= (FULL ? tile0 + tile_n : ntiles)) return;   // (no barrier anywhere: a wavefront may leave alone)
     const uint32_t f0 = blockIdx.y * R32_FPW, f1 = f0 + R32_FPW < B ? f0 + R32_FPW : B;
     const uint64_t px0 = (uint64_t)tile * TILE_PX;
     const uint32_t n_blk = (uint32_t)min((uint64_t)TILE_BM, nb - (uint64_t)tile * TILE_BM);   // bitmap bytes of this tile
@@ -213,7 +221,8 @@ void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *
     auto go = [&](auto full, auto cd) {
         constexpr bool FULL = decltype(full)::value;
         constexpr int CODEC = decltype(cd)::value;
-        hipLaunchKernelGGL((k_reduce_tiles32<FULL, CODEC>), FULL ? dim3(nfull, fy) : dim3(1, fy), dim3(64), 0, s, frames, thr32, sc.N, sc.ntiles, FULL ? 0u : nfull, B,
+        hipLaunchKernelGGL((k_reduce_tiles32<FULL, CODEC>), FULL ? dim3((nfull + R32_WAVES - 1) / R32_WAVES, fy) : dim3(1, fy), dim3(64 * R32_WAVES), 0, s, frames, thr32, sc.N, sc.ntiles,
+                           FULL ? 0u : nfull, FULL ? nfull : 1u, B,
                            bitmap, sc.nb_stride, slots, sc.pix_slot_bytes, sc.tile_cnt, depth, level == 1 ? 1u : 0u, sc.status, sc.blk_slots, sc.blk_stride,
                            sc.blk_size, sc.nb);
     };

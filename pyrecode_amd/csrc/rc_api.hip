@@ -118,7 +118,7 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
     HIP_TRY(hipMalloc((void **)&sc.tile_next, B * T * 4));
     HIP_TRY(hipMalloc((void **)&sc.frame_nnz, B * 4));
     HIP_TRY(hipMalloc((void **)&sc.frame_cbytes, B * 4));
-    HIP_TRY(hipMalloc((void **)&sc.scan_part, B * ((T + 4095) / 4096) * 32));
+    HIP_TRY(hipMalloc((void **)&sc.scan_part, B * ((T + 255) / 256) * 32));   // (a row of partials per scan segment; room for segments down to 256 tiles: RC_SCAN_T experiments)
     HIP_TRY(hipMalloc((void **)&sc.status, sizeof(BatchStatus)));
     if (c->level != 3) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2 + 64));
     if (c->emit != 0) {

@@ -289,12 +289,12 @@ __device__ __forceinline__ void pack_stage(uint16_t *pix, uint32_t cnt, uint32_t
         __builtin_amdgcn_wave_barrier();
         return;
     }
-    const uint32_t inv = 0xFFFFFFFFu / d + 1u;  // floor(n / d) = umulhi(n, inv) for n * d < 2^32
+    const uint32_t inv = 0xFFFFFFFFu / d + 1u;  // floor(n / d) = umulhi(n, inv) for n * d < 2^32  (d = 1: the constant wraps to 0 - taken apart below)
     const uint32_t dmask = (1u << d) - 1u;
     uint32_t *out = reinterpret_cast<uint32_t *>(pix);
     for (uint32_t w0 = 0; w0 < ndw; w0 += 64) {
         const uint32_t w = w0 + lane;
-        uint32_t v = __umulhi(32u * w, inv);
+        uint32_t v = d == 1 ? 32u * w : __umulhi(32u * w, inv);
         const uint32_t o = 32u * w - v * d;
         uint64_t acc = 0;
         uint32_t filled = 0;

@@ -104,6 +104,38 @@ def test_reduce_only_records_bit_exact(hip, orc, ny, nx, s, d, eps):
     ctx.close()
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 7, 8, 11, 13, 15])
+def test_every_small_and_odd_depth_packs_like_the_reference(hip, orc, d):
+    """source_bit_depth from 1 bit on (the bits of a residual above d are dropped, recode_writer.py:637-652): the tile-local pack inside the
+    reduce kernel and the bit-granular assembly against the oracle, reduce-only records byte for byte and through LZ4 / zstd.  (d = 1 took a
+    reciprocal constant that wraps to zero until round 4's parameter sweep found it.)"""
+    ny, nx = 130, 260
+    dark, frames = synth_frames(500 + d, 3, ny, nx, 0.04, 12)
+    thr = orc.threshold(dark, 0)
+    ctx = hip.ReduceContext(nx, ny, d, 1, 0, 0, 1, 0, max_batch=3)
+    ctx.set_dark(dark, 0)
+    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+    for z in range(3):
+        want, wmd = orc.l1_record(frames[z], thr, d, z, mode=0)
+        assert out[int(rec[z]):int(rec[z + 1])].tobytes() == want, "d %d frame %d" % (d, z)
+    ctx.close()
+    for scheme in (2, 1):
+        ctx = hip.ReduceContext(nx, ny, d, 1, 1, scheme, 1, 0, max_batch=3)
+        ctx.set_dark(dark, 0)
+        out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
+        for z in range(3):
+            r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+            fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+            binary, pix = orc.binarize_l1(frames[z], thr)
+            packed = orc.bit_pack(pix, d).tobytes()
+            assert npk == len(packed)
+            if scheme == 2:
+                _check_lz4(orc, r[16 + cb:], packed)
+            else:
+                assert _zstd_system_decode(r[16 + cb:]) == packed
+        ctx.close()
+
+
 def test_random_geometries_reduce_only_records_bit_exact(hip, orc):
     """Thirty random geometries - any ny x nx (odd sizes, N % 8 of every kind, less than a tile up to sixty tiles), 1 .. 9 frames (odd frames of an odd N
     start 2 bytes off a dword), densities from empty to 40 %, depths 9 .. 16, eps 0 .. 9, batches smaller than max_batch - reduce-only records against

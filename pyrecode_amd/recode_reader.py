@@ -415,6 +415,13 @@ class ReCoDeReader(BatchedAccess):
         # level 2: the value stream holds one statistic per connected component, in scipy label order (reference :473-481,
         # whose count formula and unpacker are defective - SURVEY appendix B; the intended semantics are implemented)
         n_stats = (len(values) * 8) // d
+        if d < 8 and n_stats and (8 * (len(values) - 1)) // d + 1 < n_stats:
+            # fields narrower than a byte: the stream's length (all the record holds) fits more than one count - the padding behind the last
+            # statistic can be as wide as a field.  The count is the number of 8-connected components of the binary map, as the writer's was.
+            import scipy.ndimage as nd
+            dense = np.zeros((int(h['ny']), int(h['nx'])), dtype=bool)
+            dense[coo.row, coo.col] = True
+            n_stats = min(n_stats, int(nd.label(dense, structure=np.ones((3, 3), dtype=int))[1]))
         stats = np.zeros(max(n_stats, 1), dtype=np.uint64)
         if n_stats:
             self._c_reader.bit_unpack_pixel_intensities(n_stats, values, stats)

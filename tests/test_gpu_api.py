@@ -1345,7 +1345,8 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
         d = int(rng.integers(1, 9)) if sb == 1 else (int(rng.integers(9, 17)) if sb == 2 else int(rng.choice([17, 19, 20, 24, 27, 32])))
         dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[sb]
         ny, nx, nz = int(rng.integers(5, 160)), int(rng.integers(8, 200)), int(rng.integers(1, 9))
-        level = int(rng.choice([1, 1, 1, 3]))
+        level = int(rng.choice([1, 1, 1, 3] + ([2] if sb != 4 else [])))    # (level 2: uint8 / uint16 sources)
+        l2stat = int(rng.integers(0, 3))
         scheme = int(rng.choice([0, 1, 2, 8]))
         mode = int(rng.choice([1, 1, 1, 0]))
         nodes, eps = int(rng.integers(1, 4)), int(rng.integers(0, 6))
@@ -1354,7 +1355,7 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
         dark = rng.integers(0, max(2, min(top // 3, 200)), (ny, nx)).astype(dt)
         amp = rng.integers(1, max(2, min(top, 1 << 20)), (nz, ny, nx))
         frames = np.where(rng.random((nz, ny, nx)) < s, np.minimum(dark.astype(np.int64) + eps + amp, np.iinfo(dt).max), dark // 2).astype(dt)
-        if mode == 0:   # reduce-only files: the reference's reader takes an EMPTY frame for the end of the file (recode_reader.py:203-213,392-396:
+        if mode == 0 or level == 2:   # reduce-only files (and level 2): the reference's reader takes an EMPTY frame for the end of the file (recode_reader.py:203-213,392-396:
             for z in range(nz):   # get_frame returns None and cuts nz) - mirrored here, so every frame gets an event
                 frames[z].flat[z] = min(int(dark.flat[z]) + eps + 1, np.iinfo(dt).max)
         base = "fz%03d" % case
@@ -1365,7 +1366,7 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
             warnings.simplefilter("ignore")
             _write_parts(sub, base, dark, frames, nodes, g, batch_size=int(rng.integers(1, 5)), num_rows=ny, num_cols=nx, num_frames=nz,
                          num_threads=nodes, compression_scheme=scheme, calibration_threshold_epsilon=eps, reduction_level=level,
-                         rc_operation_mode=mode, source_bit_depth=d, target_bit_depth=d, source_data_type=0, target_data_type=0)
+                         rc_operation_mode=mode, source_bit_depth=d, target_bit_depth=d, source_data_type=0, target_data_type=0, l2_statistics=l2stat)
         merged = "%s.rc%d" % (base, level)
         merge_parts(str(sub), merged, nodes)
         thr = (dark.astype(np.int64) + eps) & np.iinfo(dt).max
@@ -1373,7 +1374,7 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
             continue    # (24-bit fields of 32-bit values: the reference's reader returns something else - fixture G11 holds that)
         mask = (1 << d) - 1 if d < 32 else 0xFFFFFFFF
         want = np.where(frames.astype(np.int64) > thr, (frames.astype(np.int64) - thr) & mask, 0)
-        if level == 3:
+        if level in (2, 3):
             want = (frames.astype(np.int64) > thr).astype(np.int64)
         rd = ReCoDeReader(str(sub / merged))
         rd.open(print_header=False)
@@ -1386,6 +1387,17 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
             m = f[z]["data"] if f is not None else None
             got = np.zeros((ny, nx), np.int64) if m is None else np.asarray(m.todense()).astype(np.int64)
             assert np.array_equal(got, want[z]), tag + " frame %d" % z
+            if level == 2 and f is not None:   # one statistic per 8-connected component of the map, scipy label order, modulo 2^d
+                import scipy.ndimage as nd
+                labels, n = nd.label(want[z] != 0, structure=np.ones((3, 3), int))
+                raw = frames[z].astype(np.int64)
+                st = nd.sum(raw, labels, np.arange(1, n + 1)) if l2stat == 2 else nd.maximum(raw, labels, np.arange(1, n + 1))
+                gs, ws = np.asarray(f[z]["summary_stats"]).astype(np.int64), np.asarray(st, np.int64) & mask
+                assert np.array_equal(gs, ws), tag + " frame %d statistics (stat %d): got %d values %s, want %d %s (raw %s)" % (
+                    z, l2stat, gs.size, gs[:12].tolist(), ws.size, ws[:12].tolist(), np.asarray(st, np.int64)[:12].tolist())
+        if level == 2:
+            rd.close()
+            continue
         got = np.zeros_like(want)
         for a, pre, trip in rd.iter_frames_triplets(batch=3):
             for i in range(len(pre) - 1):

@@ -1395,9 +1395,25 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
                 gs, ws = np.asarray(f[z]["summary_stats"]).astype(np.int64), np.asarray(st, np.int64) & mask
                 assert np.array_equal(gs, ws), tag + " frame %d statistics (stat %d): got %d values %s, want %d %s (raw %s)" % (
                     z, l2stat, gs.size, gs[:12].tolist(), ws.size, ws[:12].tolist(), np.asarray(st, np.int64)[:12].tolist())
+        rd.close()
+        # the part files frame by frame (get_next_frame on intermediate files): every node's frames under their absolute ids
+        seen = 0
+        for node in range(nodes):
+            pr = ReCoDeReader(str(sub / ("%s_part%03d" % (merged, node))), is_intermediate=True)
+            pr.open(print_header=False)
+            while True:
+                f = pr.get_next_frame()
+                if f is None:
+                    break
+                (fid, fd), = f.items()
+                assert np.array_equal(np.asarray(fd["data"].todense()).astype(np.int64), want[fid]), tag + " part %d frame id %d" % (node, fid)
+                seen += 1
+            pr.close()
+        assert seen == nz or (s == 0.0 and seen <= nz), tag + ": %d frames in the part files" % seen   # (an empty frame ends a reduce-only part file, as in the reference)
         if level == 2:
-            rd.close()
             continue
+        rd = ReCoDeReader(str(sub / merged))
+        rd.open(print_header=False)
         got = np.zeros_like(want)
         for a, pre, trip in rd.iter_frames_triplets(batch=3):
             for i in range(len(pre) - 1):

@@ -1362,11 +1362,28 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
         tag = "case %d: %s d=%d %dx%dx%d level %d scheme %d mode %d nodes %d eps %d s %g" % (case, dt.__name__, d, nz, ny, nx, level, scheme, mode, nodes, eps, s)
         sub = tmp_path / base
         sub.mkdir()
+        over = dict(num_rows=ny, num_cols=nx, num_frames=nz, num_threads=nodes, compression_scheme=scheme, calibration_threshold_epsilon=eps,
+                    reduction_level=level, rc_operation_mode=mode, source_bit_depth=d, target_bit_depth=d, source_data_type=0, target_data_type=0,
+                    l2_statistics=l2stat)
+        stream = bool(rng.integers(0, 3) == 0)       # a third of the cases: mode='stream', the frames handed over in random chunks
+        gap = int(rng.choice([-1, -1, 2, 3]))        # ... and half of them with validation frames (side file + dose rates)
+        cuts = sorted(set(rng.integers(1, nz + 1, int(rng.integers(1, 4))).tolist() + [nz])) if stream else [nz]
+        if stream:
+            over["num_frames"] = 1                   # (as in fixture G7: no more than the smallest chunk holds - recode_writer.py:284-285; stream mode takes every frame of a chunk)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            _write_parts(sub, base, dark, frames, nodes, g, batch_size=int(rng.integers(1, 5)), num_rows=ny, num_cols=nx, num_frames=nz,
-                         num_threads=nodes, compression_scheme=scheme, calibration_threshold_epsilon=eps, reduction_level=level,
-                         rc_operation_mode=mode, source_bit_depth=d, target_bit_depth=d, source_data_type=0, target_data_type=0, l2_statistics=l2stat)
+            from pyrecode_amd.recode_writer import ReCoDeWriter
+            for node in range(nodes):
+                ip, cfg = _params(sub, g, **over)
+                w = ReCoDeWriter(base, dark_data=dark, output_directory=str(sub), input_params=ip, mode="stream" if stream else "batch",
+                                 validation_frame_gap=gap, node_id=node, run_name=base, batch_size=int(rng.integers(1, 5)))
+                w.start()
+                at = 0
+                for c in cuts:
+                    w.run(frames[at:c])
+                    at = c
+                w.close()
+        tag += " %s cuts %s gap %d" % ("stream" if stream else "batch", cuts, gap)
         merged = "%s.rc%d" % (base, level)
         merge_parts(str(sub), merged, nodes)
         thr = (dark.astype(np.int64) + eps) & np.iinfo(dt).max

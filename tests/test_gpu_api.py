@@ -1437,4 +1437,17 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
                 t = trip[int(pre[i]):int(pre[i + 1])]
                 got[a + i, t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)] = t[:, 2].astype(np.int64)
         assert np.array_equal(got, want), tag + " (batched)"
+        # ... the same through get_frames (many frames per device call, COO matrices) from a random start
+        z0 = int(rng.integers(0, nz))
+        many = rd.get_frames(z0, nz - z0)
+        assert sorted(many) == list(range(z0, nz)), tag + " (get_frames keys)"
+        for z, fd in many.items():
+            assert np.array_equal(np.asarray(fd["data"].todense()).astype(np.int64), want[z]), tag + " (get_frames) frame %d" % z
+        if d <= 16:     # and as the COO layout's three arrays
+            got = np.zeros_like(want)
+            for a, pre, (rows, cols, vals) in rd.iter_frames_coo(batch=int(rng.integers(1, 5))):
+                for i in range(len(pre) - 1):
+                    lo, hi = int(pre[i]), int(pre[i + 1])
+                    got[a + i, rows[lo:hi], cols[lo:hi]] = vals[lo:hi]
+            assert np.array_equal(got, want), tag + " (COO layout)"
         rd.close()

@@ -1342,7 +1342,7 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
     rng = np.random.default_rng(int(os.environ.get("RC_FUZZ_SEED", "424242")))   # (by hand: other seeds, RC_FUZZ_CASES=200)
     for case in range(int(os.environ.get("RC_FUZZ_CASES", "24"))):
         sb = int(rng.choice([1, 2, 2, 2, 4]))
-        d = int(rng.integers(1, 9)) if sb == 1 else (int(rng.integers(9, 17)) if sb == 2 else int(rng.choice([17, 19, 20, 24, 27, 32])))
+        d = int(rng.integers(1, 9)) if sb == 1 else (int(rng.integers(9, 17)) if sb == 2 else int(rng.integers(17, 33)))
         dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[sb]
         ny, nx, nz = int(rng.integers(5, 160)), int(rng.integers(8, 200)), int(rng.integers(1, 9))
         level = int(rng.choice([1, 1, 1, 3] + ([2] if sb != 4 else [])))    # (level 2: uint8 / uint16 sources)

@@ -1345,6 +1345,8 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
         d = int(rng.integers(1, 9)) if sb == 1 else (int(rng.integers(9, 17)) if sb == 2 else int(rng.integers(17, 33)))
         dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[sb]
         ny, nx, nz = int(rng.integers(5, 160)), int(rng.integers(8, 200)), int(rng.integers(1, 9))
+        if os.environ.get("RC_FUZZ_BIG"):   # (by hand: frames of a hundred tiles and more)
+            ny, nx, nz = int(rng.integers(300, 900)), int(rng.integers(400, 1200)), int(rng.integers(1, 6))
         level = int(rng.choice([1, 1, 1, 3] + ([2] if sb != 4 else [])))    # (level 2: uint8 / uint16 sources)
         l2stat = int(rng.integers(0, 3))
         scheme = int(rng.choice([0, 1, 2, 8]))

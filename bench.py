@@ -525,6 +525,16 @@ def run_rank(a):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = a.dist_backend
+    # one line per rank on stderr, so that a multi-GPU log explains itself: who runs where, on which CPUs, over what
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        cpu_txt = "%d CPUs [%s]%s" % (len(cpus), ",".join(str(c) for c in cpus[:8]) + (",..." if len(cpus) > 8 else ""), " (pinned)" if pinned else "")
+    except (AttributeError, OSError):
+        cpu_txt = "CPU set unknown"
+    print("bench.py start: rank %d of world %d (local rank %d), visible GPUs %d, device cuda:%d (%s), launch %s, backend %s, gather every %s, %s"
+          % (rank, world, local, visible, local, torch.cuda.get_device_name(local),
+             "torch.distributed.run" if use_dist else "single process", (backend if use_dist else "none"),
+             ("region" if a.gather_every == 0 else "%d step(s)" % a.gather_every), cpu_txt), file=sys.stderr, flush=True)
     if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -574,7 +584,7 @@ def run_rank(a):
     ctx = hip.ReduceContext(a.nx, a.ny, a.depth, a.level, op_mode, a.scheme, a.clevel, local, max_batch=B, src_dtype=src_dtype)
     ctx.set_dark(dark.data_ptr(), 0)  # eps = 0 -> thr = dark
     ctx.keep_binary_maps(False)       # no validation frames in this workload: records only (recode_writer.py:402-415)
-    out_cap = B * (N // 2) * a.source_bytes  # ample for sparse frames; the device reports RC_ERR_OUT_TOO_SMALL otherwise
+    out_cap = int(L.rc_out_capacity(ctx.handle, B))   # the worst case the library itself states: B raw frames (a record may not exceed its frame, recode_writer.py:565-566)
     out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
     nb = S // B
@@ -668,10 +678,16 @@ def run_rank(a):
     checked, verified = [], True
     try:
         j_last = last_step % nb
-        zs = [(B // 2 + 7 * k) % B for k in range(nb)]
-        ok = verify_batch(j_last, zs[0])
-        checked.append({"batch": j_last, "record": zs[0], "ok": ok})
-        verified = verified and ok
+        zs = [(B // 2 + 7 * k) % max(B - 1, 1) for k in range(nb)]   # one record inside the batch ...
+
+        def check_two(j, z):   # ... and the batch's LAST record (behind every other record's bytes: a wrong size anywhere in the batch moves it)
+            ok_all = True
+            for zz in sorted({z, B - 1}):
+                ok1 = verify_batch(j, zz)
+                checked.append({"batch": j, "record": zz, "ok": ok1})
+                ok_all = ok_all and ok1
+            return ok_all
+        verified = check_two(j_last, zs[0]) and verified
         with torch.cuda.stream(stream):
             for k in range(1, nb):
                 j = (j_last + k) % nb
@@ -680,9 +696,7 @@ def run_rank(a):
                 step(i_extra)
                 fence()
                 ctx.sync()
-                ok = verify_batch(j, zs[k])
-                checked.append({"batch": j, "record": zs[k], "ok": ok})
-                verified = verified and ok
+                verified = check_two(j, zs[k]) and verified
     except Exception as e:
         verified = False
         print("rank %d: verification raised: %r" % (rank, e), file=sys.stderr)

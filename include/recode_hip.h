@@ -94,8 +94,8 @@ int rc_ctx_set_stream(rc_ctx *ctx, void *hip_stream);
  * (rc_out_capacity, the record bound of recode_writer.py:565-566).  uint8: a uint8 instantiation of the load path (half the bytes); everything
  * behind the loads is the uint16 path.  uint32 (levels 1 and 3): a kernel of its own for the reduce step (rc_reduce32.hip: uint32 compare,
  * residuals and depth-bit fields - four raw bytes a value when the depth is a multiple of 8, 24 included, as `.tobytes()` gives them,
- * recode_writer.py:463-464), the block encoders as separate launches over the raw maps, zstd with the fast encoder; scans, record layout and
- * assembly are shared.  rc_set_threshold then takes a uint32 frame. */
+ * recode_writer.py:463-464) with every device codec's block encoder fused into it as in the uint16 kernel (LZ4, blosc-lz4, zstd in its fast
+ * form - the modelled encoder and reduction level 2 are uint16 / uint8 only); scans, record layout and assembly are shared.  rc_set_threshold then takes a uint32 frame. */
 int rc_ctx_set_source_bytes(rc_ctx *ctx, uint32_t bytes_per_pixel);
 uint32_t rc_ctx_source_bytes(const rc_ctx *ctx);
 

@@ -122,9 +122,12 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
     HIP_TRY(hipMalloc((void **)&sc.status, sizeof(BatchStatus)));
     if (c->level != 3) HIP_TRY(hipMalloc((void **)&sc.pix_slots, B * T * TILE_PX * 2 + 64));
     if (c->emit != 0) {
-        if (c->level == 1 && !getenv("RC_NO_COMBINED_SLOTS")) {   // combined slots (rc_launch.h, Scratch::comb); the env switch: A/B runs
+        if (c->level == 1 && !RC_KNOB("RC_NO_COMBINED_SLOTS")) {   // combined slots (rc_launch.h, Scratch::comb); the knob: A/B runs
             sc.comb = c->emit == RC_SCHEME_ZSTD ? 2u : 1u;
-            if (const char *e = getenv("RC_COMB_MODE")) sc.comb = (uint32_t)atoi(e);   // (A/B runs)
+            if (const char *e = RC_KNOB("RC_COMB_MODE")) {   // (A/B runs; zstd's blocks still grow behind the reduce kernel: form 1 would put residuals in their way)
+                const uint32_t m = (uint32_t)atoi(e);
+                if (m <= 2 && !(c->emit == RC_SCHEME_ZSTD && m == 1)) sc.comb = m;
+            }
             sc.blk_stride = 1536;                                  // 12 lines: the block image (<= 5) + 7 or more lines of residuals
         }
         HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * (uint64_t)sc.blk_stride + 256));
@@ -177,9 +180,9 @@ static int ctx_alloc(rc_ctx *c)
     {
         // Experiment knob: RC_PSTREAM_CUS=n with RC_RSTREAM_EXCL=1 - the ctx's own stream (the reduce kernel, when the caller sets no stream) is
         // confined to the CUs the second stage is NOT confined to: the two stages share no CU at all.
-        const char *e = getenv("RC_PSTREAM_CUS");
+        const char *e = RC_KNOB("RC_PSTREAM_CUS");
         const int ncu = e ? atoi(e) : 0;
-        if (ncu > 0 && ncu < 256 && getenv("RC_RSTREAM_EXCL")) {
+        if (ncu > 0 && ncu < 256 && RC_KNOB("RC_RSTREAM_EXCL")) {
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = ncu; i < 256; ++i) mask[i / 32] |= 1u << (i % 32);
             if (hipExtStreamCreateWithCUMask(&c->own_stream, 8, mask) != hipSuccess) { (void)hipGetLastError(); c->own_stream = nullptr; }
@@ -187,7 +190,7 @@ static int ctx_alloc(rc_ctx *c)
     }
     if (!c->own_stream) HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     // (a high-priority second-stage stream was measured: no gain with LZ4 or zstd, 2 % slower at 11520x8184 - tools/ab_bench.sh)
-    if (getenv("RC_PSTREAM_PRIO")) {   // experiment knob: the second stage on a high-priority stream
+    if (RC_KNOB("RC_PSTREAM_PRIO")) {   // experiment knob: the second stage on a high-priority stream
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(hipStreamCreateWithPriority(&c->pstream_all, hipStreamNonBlocking, hi));
@@ -200,7 +203,7 @@ static int ctx_alloc(rc_ctx *c)
         // bench.py, same box: LZ4 123.7 k frames/s unmasked, 126.2 k with n = 104 (96: 125.6-127.6 k, 128: 128.5 k on a
         // faster box, 64: no gain, spread-out masks: worse) - but zstd, whose second stage also carries the FSE kernel,
         // drops from 112 k to 103 k: the confined stage becomes the longer one.  +2 % on one codec does not pay for that.
-        const char *e = getenv("RC_PSTREAM_CUS");
+        const char *e = RC_KNOB("RC_PSTREAM_CUS");
         const int ncu = e ? atoi(e) : 0;
         c->pstream_masked = nullptr;
         if (ncu > 0 && ncu < 256) {
@@ -419,17 +422,34 @@ RC_EXPORT int rc_ctx_set_source_bytes(rc_ctx *c, uint32_t bytes_per_pixel)
         if (c->depth <= 16) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: uint32 sources are what source_bit_depth > 16 means (misc.py:41-49)");
         if (c->level == 2) return fail(RC_ERR_UNSUPPORTED, "rc_ctx_set_source_bytes: reduction level 2 is not implemented for uint32 sources");
         RC_ON_DEVICE(c->device);
+        // Everything that can fail happens first, into temporaries; the ctx changes only once all of it has succeeded (a failed
+        // allocation leaves the uint16 ctx as it was).
+        uint32_t *thr32 = nullptr;
+        uint16_t *slots[2] = {nullptr, nullptr};
+        bool ok = hipMalloc((void **)&thr32, c->sc.N * 4) == hipSuccess;
+        for (int k = 0; ok && k < 2 && c->level != 3; ++k)
+            ok = hipMalloc((void **)&slots[k], (uint64_t)c->max_batch * c->sets[k].ntiles * rc::TILE_PX * 4 + 64) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (thr32) (void)hipFree(thr32);
+            for (uint16_t *p : slots) if (p) (void)hipFree(p);
+            return fail(RC_ERR_DEVICE, "rc_ctx_set_source_bytes: out of device memory for the uint32 threshold / residual slots");
+        }
         if (c->depth % 8 == 0) c->depth = 32;
         c->modelled = false;
-        HIP_TRY(hipMalloc((void **)&c->thr32, c->sc.N * 4));
-        for (rc::Scratch *set : {&c->sets[0], &c->sets[1]}) {
+        c->thr32 = thr32;
+        for (int k = 0; k < 2; ++k) {
+            rc::Scratch *set = &c->sets[k];
             set->pix_slot_bytes = rc::TILE_PX * 4;
             set->comb = 0;
             if (c->level != 3) {
-                HIP_TRY(hipFree(set->pix_slots));
-                set->pix_slots = nullptr;
-                HIP_TRY(hipMalloc((void **)&set->pix_slots, (uint64_t)c->max_batch * set->ntiles * rc::TILE_PX * 4 + 64));
+                (void)hipFree(set->pix_slots);
+                set->pix_slots = slots[k];
             }
+            // the modelled zstd encoder's residual-stream scratch (alloc_set sized it for uint16 sources): not used by this path
+            void **unused[] = {(void **)&set->pixraw, (void **)&set->pix_chunks, (void **)&set->chunk_size, (void **)&set->chunk_off, (void **)&set->frame_pbytes};
+            for (void **q : unused) { if (*q) (void)hipFree(*q); *q = nullptr; }
+            set->pixraw_stride = 0; set->nchunk_max = 0;
         }
         c->sc = c->sets[0];
     }
@@ -540,8 +560,8 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     // codec of the fused block encoder: 1 zstd fast, 3 zstd modelled, 2 LZ4 runs (compression_level 0), 4 LZ4 events (>= 1), 8 blosc
     const uint32_t codec = c->modelled ? 3u : (c->emit == RC_SCHEME_LZ4 && c->clevel != 0 ? 4u : c->emit);
     if (c->src_bytes == 4) {
-        // uint32 sources: reduce + pack + raw binary maps (rc_reduce32.hip), then the block encoder over the maps as a launch of its own
-        // (every device codec's block encoder runs inside the kernel, as in the uint16 path; zstd in its fast form)
+        // uint32 sources (rc_reduce32.hip): reduce + pack with the codec's block encoder inside the kernel, as in the uint16 path (zstd in its
+        // fast form)
         launch_reduce32(sc, static_cast<const uint32_t *>(frames_dev), c->thr32, n, c->level, c->depth, s,
                         c->emit == RC_SCHEME_LZ4 ? (c->clevel != 0 ? 4u : 2u) : (c->emit == RC_SCHEME_BLOSC_LZ4 ? 8u : (c->emit == RC_SCHEME_ZSTD ? 1u : 0u)),
                         c->keep_bitmap || c->emit == 0);
@@ -801,7 +821,7 @@ RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const void *frames_host, 
     // exactly once, by wide nontemporal loads, so a copy into device memory first would only add a pass (and the copy
     // engines moved 26-31 GB/s here where the kernel's own reads move what the link gives).  RC_PIPE_COPY=1 forces the copy.
     const void *fdev = nullptr;
-    static const bool force_copy = getenv("RC_PIPE_COPY") != nullptr;
+    static const bool force_copy = RC_KNOB("RC_PIPE_COPY") != nullptr;
     if (!force_copy) {
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, frames_host) == hipSuccess) {

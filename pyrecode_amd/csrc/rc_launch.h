@@ -83,8 +83,8 @@ void launch_threshold(const void *dark, int64_t eps, uint64_t N, uint16_t *thr, 
 // src_bytes: bytes per source pixel - 2 (uint16 frames) or 1 (uint8 frames, source_bit_depth <= 8)
 void launch_reduce(const Scratch &sc, const void *frames, uint32_t B, uint32_t level, uint32_t codec, bool keep_bitmap,
                    uint32_t depth, hipStream_t s, hipStream_t s_tail = nullptr, uint32_t src_bytes = 2);
-// rc_reduce32.hip: uint32 sources (source_bit_depth > 16) - reduce + d-bit pack + raw binary maps; the block encoders follow as launches of
-// their own (launch_lz4_encode_rows / launch_zstd_tokenize_rows / launch_blosc_encode_blocks)
+// rc_reduce32.hip: uint32 sources (source_bit_depth > 16) - reduce + d-bit pack, the block encoder of `codec` fused (2 / 4 LZ4 runs / events,
+// 8 blosc-lz4, 1 zstd fast form); raw binary maps only with keep_bitmap
 void launch_threshold32(const uint32_t *dark, int64_t eps, uint64_t N, uint32_t *thr, hipStream_t s);
 void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s,
                      uint32_t codec = 0, bool keep_bitmap = true);   // codec 2 / 4: the LZ4 block encoder (runs / events) fused

@@ -12,6 +12,12 @@ from . import _lib
 from .misc import effective_cpus
 
 
+def _split_wide(trip):
+    """uint64 triplet rows -> the COO layout's three arrays with uint32 values (files whose values do not fit the device's uint16 COO form)."""
+    trip = np.asarray(trip).reshape(-1, 3)
+    return trip[:, 0].astype(np.int32), trip[:, 1].astype(np.int32), trip[:, 2].astype(np.uint32)
+
+
 class _BatchOut:
     """Where a batch's expanded entries go and how they are laid out: the reference's uint64 (row, col, value) rows (24 bytes a set
     pixel; rc_expand_frames), or the three arrays of the COO matrix its reader wraps them into - int32 rows | int32 columns | uint16
@@ -235,6 +241,13 @@ class BatchedAccess:
         self._ra_buf = None
 
     # ---- batched access (device-resident decode + expand; no counterpart in the reference, which reads frame by frame) ------
+    def _wide_values(self):
+        """Level-1 files whose values are wider than 16 bits (target_bit_depth > 16: uint32 sources, recode_reader.py:56 / misc.py:41-49):
+        rc_expand_frames_coo carries uint16 values (include/recode_hip.h), so the COO forms of the batched calls take such files through the
+        24-byte triplets and split them on the host - same arrays, values as uint32."""
+        h = self._header
+        return int(h['reduction_level']) == 1 and int(h['target_bit_depth']) > 16
+
     def get_frames_triplets(self, z0, n, out=None, coo=False):
         """Frames z0 .. z0+n-1 of a merged file - or records z0 .. z0+n-1 of a part file, whose frame ids are part_frame_ids[z] - in ONE
         device call (rc_expand_frames): both streams of every frame are
@@ -247,8 +260,11 @@ class BatchedAccess:
         valid until the next call with the same holder.
         coo=True: instead of the triplet rows, (rows int32[total], columns int32[total], values uint16[total]) - the arrays of the COO
         matrices the frame-at-a-time calls return, 10 instead of 24 bytes per set pixel over the link (rc_expand_frames_coo)."""
-        dst = _BatchOut(coo, out)
         h = self._header
+        if coo and self._wide_values():
+            prefix, trip = self.get_frames_triplets(z0, n, out=out, coo=False)
+            return prefix, _split_wide(trip)
+        dst = _BatchOut(coo, out)
         nz = self._batch_frames()
         if z0 < 0 or n <= 0 or z0 + n > nz:
             raise ValueError('Requested frame index is greater than number of frames in dataset')
@@ -540,6 +556,10 @@ class BatchedAccess:
         get_frames_triplets batch by batch.  coo=True: the third item is (rows int32, columns int32, values uint16) instead of the
         triplet rows - 10 instead of 24 bytes per set pixel over the link (rc_expand_frames_coo_submit)."""
         h = self._header
+        if coo and self._wide_values():   # values beyond uint16: the device's COO layout does not hold them - triplets, split on the host
+            for a, prefix, trip in self._iter_frames_impl(z0, n, batch, coo=False):
+                yield a, prefix, _split_wide(trip)
+            return
         nz = self._batch_frames()
         n = nz - z0 if n is None else n
         if z0 < 0 or n < 0 or z0 + n > nz or batch <= 0:

@@ -353,8 +353,10 @@ class ReCoDeWriter:
             # and with every tenth frame a validation frame the side file takes three times the bytes of the records).  Only the dose
             # rate - the device's component count of the frame's ROI - still arrives with the batch (append() below).
             fd, piece = self._validation_file.fileno(), 8 << 20
+            val_pos_start, n_val_queued = self._val_pos, 0
             for k in range(n_frames):
                 if (first_id + k) % gap == 0:
+                    n_val_queued += 1
                     mv = memoryview(np.ascontiguousarray(data[k])).cast('B')
                     for lo in range(0, mv.nbytes, piece):
                         val_jobs.append(val_writer.submit(_pwrite_all, fd, mv[lo:lo + piece], self._val_pos + lo))
@@ -419,6 +421,25 @@ class ReCoDeWriter:
                     f.result()
             for f in val_jobs:
                 f.result()
+            if gap > 0 and len(dose_rates) != n_val_queued:   # the host's choice of validation frames (ids % gap) and the device's counts must agree
+                raise RuntimeError('validation frames: %d written to the side file, %d dose rates from the device' % (n_val_queued, len(dose_rates)))
+        except BaseException:
+            # The side file was queued ahead of the batches (above): after a failed run (a record larger than its frame, a device error) it is
+            # cut back to the validation frames of the batches whose records DID reach the part file - what the reference's frame-at-a-time
+            # loop would have left (recode_writer.py:402-415 writes a validation frame only behind its record).
+            if gap > 0:
+                for f in [w for w in written if w is not None] + val_jobs:   # what is on its way lands first (appends decide how far the run got)
+                    try:
+                        f.result()
+                    except Exception:   # noqa: BLE001 - already failing
+                        pass
+                self._val_pos = val_pos_start + len(dose_rates) * frame_bytes
+                try:
+                    self._validation_file.flush()
+                    os.ftruncate(self._validation_file.fileno(), self._val_pos)
+                except OSError:
+                    pass
+            raise
         finally:
             for pool in (stager, writer, copy_pool, val_writer, host_pool):
                 if pool is not None:

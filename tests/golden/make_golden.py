@@ -52,7 +52,10 @@ with contextlib.redirect_stdout(io.StringIO()):
     from pyrecode.recode_header import ReCoDeHeader
     import c_recode as ref_c
 
-FILES = os.path.join(HERE, "files")
+# where the fixtures go: tests/golden itself, or RC_GOLDEN_OUT (tests/test_oracle_golden.py::test_committed_fixtures_are_what_the_reference_writes_today
+# regenerates everything into a scratch directory and compares it with the committed set)
+OUT = os.environ.get("RC_GOLDEN_OUT") or HERE
+FILES = os.path.join(OUT, "files")
 os.makedirs(FILES, exist_ok=True)
 
 PARAM_DEFAULTS = dict(
@@ -135,7 +138,7 @@ def g1_g2():
     for d in (1, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16):
         out[f"g2_bitpack_d{d}"] = np.asarray(ref_writer._bit_pack(vals, d), np.uint8)
     # the reference C packer called directly (first call into a zeroed buffer == intended semantics)
-    np.savez_compressed(os.path.join(HERE, "g1_g2_reduce.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "g1_g2_reduce.npz"), **out)
     print("g1_g2:", len(out), "arrays")
 
 
@@ -190,7 +193,7 @@ def g3_g4():
                 fr = quiet(rd.get_frame, z)
                 dec[z] = np.asarray(fr[z]["data"].todense()).astype(np.uint16)
             rd.close()
-        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames,
+        np.savez_compressed(os.path.join(OUT, base + ".npz"), dark=dark, frames=frames,
                             cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array(list(cfg.values())),
                             n_nodes=nodes, decoded=dec if dec is not None else np.zeros(0))
         meta[tag] = names
@@ -221,7 +224,7 @@ def g5():
         out[f"g5_{tag}_packed"] = packed
         out[f"g5_{tag}_vals"] = vals
         out[f"g5_{tag}_triplets"] = trip
-    np.savez_compressed(os.path.join(HERE, "g5_expand.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "g5_expand.npz"), **out)
     print("g5:", len(out), "arrays")
 
 
@@ -239,7 +242,7 @@ def g6():
         quiet(h.serialize, path)
         d = h.as_dict()
         keys = [k for k in d if not isinstance(d[k], (str, np.ndarray))]
-        np.savez_compressed(os.path.join(HERE, "g6_header_v01.npz"), keys=np.array(keys), vals=np.array([int(d[k]) for k in keys], np.int64),
+        np.savez_compressed(os.path.join(OUT, "g6_header_v01.npz"), keys=np.array(keys), vals=np.array([int(d[k]) for k in keys], np.int64),
                             source_file_name=np.array(str(d["source_file_name"])), calibration_file_name=np.array(str(d["calibration_file_name"])))
         print("g6: %d bytes, %d scalar fields" % (os.path.getsize(path), len(keys)))
     finally:
@@ -281,7 +284,7 @@ def g7():
                 mine.append(int(list(f.keys())[0]))
             rd.close()
             ids.append(mine)
-        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, chunks=np.array(chunks),
+        np.savez_compressed(os.path.join(OUT, base + ".npz"), dark=dark, frames=frames, chunks=np.array(chunks),
                             cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array(list(cfg.values())), n_nodes=nodes,
                             ids_part0=np.array(ids[0]), ids_part1=np.array(ids[1]))
         print("g7:", ids)
@@ -322,7 +325,7 @@ def g8():
             fn = "%s.rc1_part%03d" % (base, node)
             shutil.copy(os.path.join(tmp, fn), os.path.join(FILES, fn))
             vbytes.append(np.frombuffer(open(os.path.join(tmp, "%s_part%03d_validation_frames.bin" % (base, node)), "rb").read(), np.uint8))
-        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, gap=gap,
+        np.savez_compressed(os.path.join(OUT, base + ".npz"), dark=dark, frames=frames, gap=gap,
                             cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array(list(cfg.values())), n_nodes=nodes,
                             rates_part0=rates[0], rates_part1=rates[1], validation_part0=vbytes[0], validation_part1=vbytes[1])
         print("g8:", [r.tolist() for r in rates], [v.size for v in vbytes])
@@ -359,7 +362,7 @@ def g9():
             for z in range(nz):
                 dec[z] = np.asarray(quiet(rd.get_frame, z)[z]["data"].todense()).astype(np.uint16)
             rd.close()
-        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
+        np.savez_compressed(os.path.join(OUT, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
                             cfg_vals=np.array(list(cfg.values())), n_nodes=nodes, decoded=dec)
         shutil.rmtree(tmp)
         print("g9:", tag)
@@ -428,7 +431,7 @@ def g10():
             extra["rates%d" % i] = r
         for i, v in enumerate(vbytes):
             extra["vframes%d" % i] = v
-        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
+        np.savez_compressed(os.path.join(OUT, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
                             cfg_vals=np.array(list(cfg.values())), n_nodes=nodes, decoded=dec, gap=gap, given=str(np.dtype(given)),
                             decoded_dtype=",".join(sorted(dts)), **extra)
         shutil.rmtree(tmp)
@@ -511,7 +514,7 @@ def g11():
             ok = False
         thr = (dark + np.uint32(cfg["calibration_threshold_epsilon"])).astype(np.uint32)
         want = np.where(frames > thr, frames - thr, 0).astype(np.uint64)
-        np.savez_compressed(os.path.join(HERE, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
+        np.savez_compressed(os.path.join(OUT, base + ".npz"), dark=dark, frames=frames, cfg_keys=np.array(list(cfg.keys())),
                             cfg_vals=np.array(list(cfg.values())), n_nodes=nodes, decoded=dec if ok else np.zeros(0, np.uint64),
                             decoded_dtype=",".join(sorted(dts)), gap=gap, **{"rates%d" % i: r for i, r in enumerate(rates)},
                             **{"vframes%d" % i: v for i, v in enumerate(vbytes)})

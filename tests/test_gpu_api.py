@@ -552,6 +552,37 @@ def test_validation_frames_ride_the_streaming_path(tmp_path, orc):
     assert parts["with"] == parts["without"]
 
 
+def test_failed_run_leaves_the_validation_file_where_the_part_file_ends(tmp_path):
+    """The streaming writer queues a run's validation frames for the side file before the batches are processed.  A run that fails
+    half way - here a frame whose record would exceed its raw size, the reference's ValueError (recode_writer.py:565-566) - must not
+    leave the side file ahead of the part file: it is cut back to the validation frames of the batches whose records were appended."""
+    from pyrecode_amd import synth
+    from pyrecode_amd.params import InputParams
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    ny, nx, nz, gap = 120, 250, 11, 3
+    dark = synth.dark_frame(9, ny * nx).reshape(ny, nx)
+    data = synth.frames(9, 0, nz, ny * nx, 20000, dark.reshape(-1)).reshape(nz, ny, nx)
+    data[9] = 40000                                          # every pixel set at 16 bits: bitmap + 2 N bytes > the raw frame
+    ip = InputParams()
+    ip._param_map.update(dict(reduction_level=1, rc_operation_mode=1, calibration_threshold_epsilon=0, target_bit_depth=16,
+                              source_bit_depth=16, num_cols=nx, num_rows=ny, num_frames=nz, frame_offset=0, num_calibration_frames=1,
+                              calibration_frame_offset=0, keep_part_files=1, num_threads=1, l2_statistics=0, l4_centroiding=0,
+                              compression_scheme=2, compression_level=1, source_file_type=0, source_header_length=0,
+                              keep_calibration_data=0, calibration_file_type=0, source_data_type=0, target_data_type=0))
+    w = ReCoDeWriter("stack.bin", dark_data=dark, output_directory=str(tmp_path), input_params=ip, mode="batch", validation_frame_gap=gap,
+                     node_id=0, batch_size=4)
+    w.start()
+    with pytest.raises(ValueError, match="Buffer size smaller than compressed data size"):
+        w.run(data)
+    w.close()
+    # batches [0..3] and [4..7] made it: eight records, validation frames 0, 3, 6 - frame 9's batch did not
+    v = np.fromfile(tmp_path / "stack_part000_validation_frames.bin", np.uint16).reshape(-1, ny, nx)
+    assert v.shape[0] == 3 and all(np.array_equal(v[k], data[z]) for k, z in enumerate((0, 3, 6)))
+    from pyrecode_amd import parallel
+    ids = [r[0] for r in parallel.read_part_records(str(tmp_path / "stack.rc1_part000"))[1]]
+    assert ids == list(range(8))
+
+
 def _stock_encoders():
     """{scheme: bytes -> stock-encoded frame} through the system libraries (ctypes), as the reference's packages would write them:
     libzstd level 1 (4-stream literals, real offsets, 128 KiB blocks), liblz4 frames with default preferences (linked 64 KiB blocks)."""
@@ -1445,11 +1476,18 @@ def test_random_configurations_round_trip_through_the_public_api(tmp_path):
         assert sorted(many) == list(range(z0, nz)), tag + " (get_frames keys)"
         for z, fd in many.items():
             assert np.array_equal(np.asarray(fd["data"].todense()).astype(np.int64), want[z]), tag + " (get_frames) frame %d" % z
-        if d <= 16:     # and as the COO layout's three arrays
-            got = np.zeros_like(want)
-            for a, pre, (rows, cols, vals) in rd.iter_frames_coo(batch=int(rng.integers(1, 5))):
-                for i in range(len(pre) - 1):
-                    lo, hi = int(pre[i]), int(pre[i + 1])
-                    got[a + i, rows[lo:hi], cols[lo:hi]] = vals[lo:hi]
-            assert np.array_equal(got, want), tag + " (COO layout)"
+        # and as the COO layout's three arrays (values beyond 16 bits: the same arrays with uint32 values, through the triplets)
+        got = np.zeros_like(want)
+        for a, pre, (rows, cols, vals) in rd.iter_frames_coo(batch=int(rng.integers(1, 5))):
+            assert rows.dtype == np.int32 and cols.dtype == np.int32 and vals.dtype == (np.uint32 if d > 16 else np.uint16), tag
+            for i in range(len(pre) - 1):
+                lo, hi = int(pre[i]), int(pre[i + 1])
+                got[a + i, rows[lo:hi], cols[lo:hi]] = vals[lo:hi]
+        assert np.array_equal(got, want), tag + " (COO layout)"
+        pre, (rows, cols, vals) = rd.get_frames_coo(z0, nz - z0)
+        got = np.zeros_like(want[z0:])
+        for i in range(nz - z0):
+            lo, hi = int(pre[i]), int(pre[i + 1])
+            got[i, rows[lo:hi], cols[lo:hi]] = vals[lo:hi]
+        assert np.array_equal(got, want[z0:]), tag + " (get_frames_coo)"
         rd.close()

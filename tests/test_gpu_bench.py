@@ -102,3 +102,24 @@ def test_bench_gather_every(gather_every):
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["verified"] is True and d["gather_verified"] is True and d["config"]["gather_every"] == gather_every
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather_every", [0, 1])
+def test_bench_under_torchrun_with_a_one_rank_rccl_communicator(gather_every):
+    """What the driver's N > 1 run does, with the one GPU a test box has: torch.distributed.run, backend nccl (= RCCL), the metadata
+    all-gather issued on the device - once per timed region (0, the default) and every step (1).  A real all_gather_into_tensor runs,
+    its table is verified, and every rank says on stderr where it runs (the first lines of a scaling log)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29541 + gather_every), "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--stack", "64",
+           "--no-cpu-baseline", "--no-ingest", "--min-seconds", "0.2", "--dist-backend", "nccl", "--gather-every", str(gather_every)]
+    p = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["gather_verified"] is True and d["verified"] is True
+    assert d["config"]["gather_every"] == gather_every
+    start = [l for l in p.stderr.decode().splitlines() if l.startswith("bench.py start:")]
+    assert len(start) == 1 and "rank 0 of world 1" in start[0] and "visible GPUs" in start[0] and "cuda:0" in start[0] and "backend nccl" in start[0]

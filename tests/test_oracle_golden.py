@@ -328,3 +328,35 @@ def test_v01_header_written_by_the_reference_loads():
     assert d["is_bit_packed"] == 1 and d["source_header_length"] == 0 and d["source_dtype"] == 0 and d["target_dtype"] == 0
     # and the table round-trips byte for byte
     assert h.to_bytes() == open(path, "rb").read()
+
+
+def test_committed_fixtures_are_what_the_reference_writes_today(tmp_path):
+    """The pin itself: where the reference is present (this container, never the GPU box), tests/golden/make_golden.py is run
+    again into a scratch directory and everything it writes is compared with the committed set - files byte for byte, the arrays of
+    every .npz one by one.  A fixture edited by hand, a generator that drifted from its fixtures, or a reference that changed under the
+    generator would show here."""
+    import subprocess
+    import sys
+    ref = os.environ.get("RECODE_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "pyrecode")):
+        pytest.skip("the reference is not present here (the GPU box): the fixtures cannot be regenerated")
+    out = str(tmp_path / "golden")
+    os.makedirs(out)
+    env = dict(os.environ, RC_GOLDEN_OUT=out)
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    made_files = sorted(os.listdir(os.path.join(out, "files")))
+    have_files = sorted(f for f in os.listdir(os.path.join(GOLDEN, "files")) if not f.startswith("recode_params_"))   # (the reference's own parameter file: data it ships, not an output)
+    assert made_files == have_files
+    for fn in made_files:
+        a = open(os.path.join(out, "files", fn), "rb").read()
+        b = open(os.path.join(GOLDEN, "files", fn), "rb").read()
+        assert a == b, "files/%s differs from what the reference writes now" % fn
+    made_npz = sorted(f for f in os.listdir(out) if f.endswith(".npz"))
+    have_npz = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert made_npz == have_npz
+    for fn in made_npz:
+        with np.load(os.path.join(out, fn), allow_pickle=False) as a, np.load(os.path.join(GOLDEN, fn), allow_pickle=False) as b:
+            assert sorted(a.files) == sorted(b.files), fn
+            for k in a.files:
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), "%s[%s] differs" % (fn, k)

@@ -37,9 +37,9 @@ typedef enum rc_status {
     RC_ERR_RECORD_TOO_LARGE = -5, /* a record exceeds the raw frame size; python: ValueError('Buffer size smaller
                                      than compressed data size') (recode_writer.py:565-566) */
     RC_ERR_CORRUPT = -6,          /* malformed compressed stream / bitmap-vs-pixvals mismatch on the read side */
-    RC_ERR_WORKSPACE = -7         /* reduction level 2: more foreground pixels in the batch than the ctx's workspace holds - only
-                                     when the full-size workspace could not be allocated at rc_ctx_create; the synchronous
-                                     entry point then grows it and retries, the asynchronous ones report; python: ValueError */
+    RC_ERR_WORKSPACE = -7         /* reserved (rounds 2-4: reduction level 2 with more foreground pixels than a compacted workspace
+                                     held; since round 5 the level-2 workspace has an entry per pixel and no batch can exceed
+                                     it); never returned */
 } rc_status;
 
 /* compression_scheme codes of the reference (recode_compressors.py:3-4, config/README.md). Device codecs:
@@ -132,8 +132,8 @@ int rc_reduce_compress_batch(rc_ctx *ctx, const void *frames, uint32_t n, uint32
 
 /* Asynchronous form for device-resident pipelines: every pointer must be device memory; work is enqueued on the
  * ctx's stream and nothing is read back.  rc_ctx_sync waits for all enqueued batches and returns RC_OK, or the status
- * of the FIRST batch that failed since the previous sync (RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL,
- * RC_ERR_WORKSPACE; rc_last_error names the batch and frame); later batches are unaffected by an earlier failure. */
+ * of the FIRST batch that failed since the previous sync (RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL;
+ * rc_last_error names the batch and frame); later batches are unaffected by an earlier failure. */
 int rc_reduce_compress_batch_async(rc_ctx *ctx, const void *frames_dev, uint32_t n, uint32_t first_frame_id,
                                    uint8_t *out_dev, uint64_t out_cap, uint64_t *rec_offsets_dev, uint32_t *md_dev);
 int rc_ctx_sync(rc_ctx *ctx);

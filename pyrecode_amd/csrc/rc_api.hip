@@ -150,25 +150,15 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
     return RC_OK;
 }
 
-// (re)allocate the level-2 workspace for `cap` set pixels per batch
-static int l2_alloc(rc_ctx *c, uint64_t cap)
+// the level-2 workspace (rc_launch.h::L2Work): sized by the geometry alone - every pixel of a batch has its entry, no batch can exceed it
+static int l2_alloc(rc_ctx *c)
 {
     using namespace rc;
     L2Work &w = c->l2;
-    void *old[] = {w.pos, w.val, w.parent, w.stat};
-    for (void *b : old) if (b) HIP_TRY(hipFree(b));
-    w.pos = nullptr; w.val = nullptr; w.parent = nullptr; w.stat = nullptr;
-    const uint64_t all = (uint64_t)c->max_batch * c->sc.N;
-    w.cap = std::min<uint64_t>(std::min<uint64_t>(cap, all), 0xFFFFFFF0ull);
-    HIP_TRY(hipMalloc((void **)&w.pos, w.cap * 4));
-    HIP_TRY(hipMalloc((void **)&w.val, w.cap * 2));
-    HIP_TRY(hipMalloc((void **)&w.parent, w.cap * 4));
-    HIP_TRY(hipMalloc((void **)&w.stat, w.cap * 4));
-    if (!w.word_rank) {
-        w.words_per_frame = (uint64_t)c->sc.ntiles * (TILE_PX / 64);
-        HIP_TRY(hipMalloc((void **)&w.word_rank, (uint64_t)c->max_batch * w.words_per_frame * 4));
-        HIP_TRY(hipMalloc((void **)&w.frame_base, ((uint64_t)c->max_batch + 1) * 8));
-    }
+    w.ids_per_frame = (uint64_t)c->sc.ntiles * TILE_PX;
+    HIP_TRY(hipMalloc((void **)&w.parent, (uint64_t)c->max_batch * w.ids_per_frame * 4));
+    HIP_TRY(hipMalloc((void **)&w.stat, (uint64_t)c->max_batch * w.ids_per_frame * 4));
+    HIP_TRY(hipMalloc((void **)&w.word_base, (uint64_t)c->max_batch * c->sc.ntiles * 64 * 2));
     return RC_OK;
 }
 
@@ -228,14 +218,9 @@ static int ctx_alloc(rc_ctx *c)
     }
     c->sc = c->sets[0];
     if (c->level == 2) {
-        // compact-pixel workspace: room for EVERY pixel of a batch (14 bytes each - 7.5 GB for 32 frames of 4096^2, nothing
-        // next to 288 GB), so that no batch can exceed it; should that allocation fail, 12.5 % mean foreground, grown on demand
-        // by the synchronous entry point (RC_ERR_WORKSPACE from the asynchronous ones)
-        int r = getenv("RC_L2_SMALL_WORKSPACE") ? RC_ERR_DEVICE : l2_alloc(c, B * c->sc.N);   // (the env switch: tests of the growth path)
-        if (r != RC_OK) {
-            (void)hipGetLastError();
-            r = l2_alloc(c, std::max<uint64_t>(B * c->sc.N / 8, 1ull << 16));
-        }
+        // parent / accumulator entries for every pixel of a batch (8 bytes each: 8.6 GB for 64 frames of 4096^2, of which only the set
+        // pixels' entries are ever touched) - nothing next to 288 GB, and no batch can exceed it
+        int r = l2_alloc(c);
         if (r != RC_OK) return r;
     }
     if (c->emit == RC_SCHEME_ZSTD) {
@@ -347,7 +332,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_sample) (void)hipHostFree(c->h_sample);
     void *bufs[] = {c->sc.thr, c->thr32, c->d_first_err, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
-                    c->d_md, c->d_ztab, c->d_model, c->d_sample, c->l2.pos, c->l2.val, c->l2.parent, c->l2.stat, c->l2.word_rank, c->l2.frame_base};
+                    c->d_md, c->d_ztab, c->d_model, c->d_sample, c->l2.parent, c->l2.stat, c->l2.word_base};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     hipEvent_t sync_ev[] = {c->ev_red[0], c->ev_red[1], c->ev_post[0], c->ev_post[1], c->ev_in[0], c->ev_in[1]};
@@ -521,7 +506,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     RecordParams rp;
     rp.level = c->level == 3 ? 3u : 1u;  // level 2 records are framed exactly like level 1 (statistics in place of residuals)
     rp.emit = c->emit; rp.depth = c->depth; rp.first_frame_id = first_frame_id;
-    rp.packed_slots = c->level == 1 ? 1u : 0u;
+    rp.packed_slots = 1u;   // (level 2: k_l2_emit leaves its statistics as tile-local packed streams, like level-1 residuals)
     rp.frame_bytes = c->sc.N * c->src_bytes;   // a record may not exceed the raw frame (recode_writer.py:565-566)
     hipEvent_t *ev = nullptr;
     if (timed) ev = c->ev;
@@ -574,10 +559,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     hipEvent_t red = ev ? ev[1] : c->ev_red[k];
     HIP_TRY(hipEventRecord(red, s));
     HIP_TRY(hipStreamWaitEvent(ps, red, 0));
-    if (c->level == 2) {  // per-tile counts -> per-frame prefix, then connected components on the compacted pixels
-        launch_scans(sc, n, true, false, ps);
-        launch_l2(sc, c->l2, n, c->nx, c->l2_sum, ps);
-    }
+    if (c->level == 2) launch_l2(sc, c->l2, n, c->nx, c->l2_sum, c->depth, ps);   // the tiles' raw values -> their components' statistics (rc_l2.hip)
 #ifdef RC_DEV_SKIP   // development builds only (tools/build_def.sh): leave second-stage kernels out (WRONG records) to see what each costs the
                      // reduce kernel running next to it - bits: 1 FSE, 2 scans, 4 residual Huffman chain, 8 layout, 16 assemble, 32 gather
     static const unsigned skip = getenv("RC_DEV_SKIP_BITS") ? (unsigned)atoi(getenv("RC_DEV_SKIP_BITS")) : 0u;
@@ -587,7 +569,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     const bool lits_only = c->modelled && (c->h_model->valid & ZM_LITS_ONLY);   // dense maps: no block has sequences, nothing for the FSE chain to do
     if (c->emit == RC_SCHEME_ZSTD && !(skip & 1) && !lits_only) launch_zstd_fse(sc, n, fitted_seq ? (const void *)&c->d_model->seq : c->d_ztab, fitted_seq, ps);
     if (all_ev) HIP_TRY(hipEventRecord(ev[2], ps));
-    if (!(skip & 2)) launch_scans(sc, n, c->level == 1, c->emit != 0, ps);  // (level 2: k_l2_emit has already described its value list)
+    if (!(skip & 2)) launch_scans(sc, n, c->level != 3, c->emit != 0, ps);
     if (all_ev) HIP_TRY(hipEventRecord(ev[3], ps));
     // modelled zstd, level 1: the residual stream is laid out flat, Huffman-coded in chunks, and placed behind the bitmap stream
     // (rc_pix_huff.hip); its encoded size is part of the record layout
@@ -708,18 +690,6 @@ RC_EXPORT int rc_reduce_compress_batch(rc_ctx *c, const void *frames, uint32_t n
     r = enqueue_batch(c, fdev, n, first_frame_id, odev, cap, c->d_rec_off, c->d_md, true);
     if (r != RC_OK) return r;
     r = rc_ctx_sync(c);
-    if (r == RC_ERR_WORKSPACE && c->level == 2) {
-        // more foreground than the level-2 workspace holds: the batch's total is known now - grow (with headroom) and run it again
-        uint64_t total = 0;
-        HIP_TRY(hipMemcpy(&total, c->l2.frame_base + n, 8, hipMemcpyDeviceToHost));
-        if (total > c->l2.cap) {
-            r = l2_alloc(c, total + total / 4 + 4096);
-            if (r != RC_OK) return r;
-            r = enqueue_batch(c, fdev, n, first_frame_id, odev, cap, c->d_rec_off, c->d_md, true);
-            if (r != RC_OK) return r;
-            r = rc_ctx_sync(c);
-        }
-    }
     for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&c->stage_ms[4], c->ev[0], c->ev[4]);
     if (r != RC_OK) return r;

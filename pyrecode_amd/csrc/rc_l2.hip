@@ -6,20 +6,29 @@
 //   (pyrecode/utils/converters.py:262-297)                                     frame values, cast to the source dtype
 // The record then carries the full binary map and the statistics where L1 carries the residuals (recode_writer.py:461-525).
 //
-// Device formulation - everything works on the COMPACTED list of set pixels (about 1 % of the frame), never on a label image:
-//   k_l2_index   wave per tile: global compact index of every set pixel (frame base + tile prefix + rank), its linear position
-//                and raw value; a rank directory (compact index of the first set pixel at/after each 64-pixel word)
-//   k_l2_union   thread per set pixel: union-find with the smaller compact index as root over the W, NW, N, NE neighbours
-//                (neighbour -> compact index through the rank directory + a popcount); atomicMin links, path halving
-//   k_l2_stats   thread per set pixel: full find, atomicMax / atomicAdd of the raw value into the root's accumulator
-//   k_l2_emit    workgroup per frame: roots in compact order ARE the components in scipy's label order (a root is its
-//                component's first pixel in raster order): prefix-count the roots, write their statistics as a contiguous
-//                uint16 list into the frame's value slots and describe it as full pseudo-tiles, so that record layout,
-//                bit-packing and compression run exactly as for L1.
+// Device formulation (round 5).  The reduce kernel leaves, per tile of 4096 pixels, the raw binary map (64 words of 64 pixels) and the
+// raw values of its set pixels in raster order (the tile's value slot).  A set pixel's ID inside its frame is tile * 4096 + its rank
+// among the tile's set pixels: ids grow in raster order, need no per-frame prefix (no scan in front of this stage) and address two
+// sparse arrays, parent[] and stat[], of which only the entries of set pixels are ever touched.  Four passes, a wavefront per tile:
+//   k_l2_prep    a lane per word: popcount, wave scan -> the word's rank base inside its tile (u16 directory); parent[id] = id and
+//                stat[id] = 0 for the tile's set pixels (rank-parallel, whole lines)
+//   k_l2_link    a lane per word: which of its pixels have a set neighbour among W, NW, N, NE comes from WORD arithmetic on the word, its
+//                left neighbour and the three words around it one row up (funnel-shifted: the row length need not be a multiple of
+//                64) - at 1 % Bernoulli 96 % of the set pixels have none and are done.  The others union with N, or with W / NW and
+//                NE (the rest of the four are connected to those through their own links): neighbour id = directory entry + a
+//                popcount; union-find with the smaller id as root (atomicMin links, path halving)
+//   k_l2_stats   a lane per set pixel: a pixel that is not its own root finds it and adds its raw value (atomicMax / atomicAdd)
+//   k_l2_emit    a lane per set pixel: roots - in id order, i.e. in scipy's label order - leave their statistic (their own value
+//                joined with what the others added) as the tile's NEW value list: compacted in LDS, bit-packed to the tile-local d-bit
+//                stream exactly as the reduce kernel leaves level-1 residuals, written back to the tile's slot with the tile's new
+//                count.  From there on the batch IS a level-1 batch: scans, record layout, k_gather and every codec run unchanged.
+// Before round 5 the stage compacted every set pixel into batch-global arrays (position, value, parent, accumulator: 14 bytes each), looked
+// every pixel's four neighbours up in the map one by one, and emitted per frame with ONE workgroup: 870 us per 64 frames of 4096^2 at 1 %
+// (k_l2_union 281, k_l2_index 216, k_l2_emit 161, k_l2_stats 99; profiles/r05_exp4), 1.5 ms on clustered events.
 #include "rc_launch.h"
+#include "rc_pack.h"
 
 namespace rc {
-
 
 __device__ __forceinline__ uint32_t uf_find(uint32_t *__restrict__ parent, uint32_t x)
 {
@@ -45,62 +54,79 @@ __device__ __forceinline__ void uf_union(uint32_t *__restrict__ parent, uint32_t
     }
 }
 
-// grid (ceil(ntiles/WAVES), B).  Lane L of the tile's wave owns bitmap word L of the tile (64 pixels).
-__global__ __launch_bounds__(WG) void k_l2_index(Scratch sc, L2Work w, uint32_t B)
+// 64 map bits from bit position q of the frame's map on (q may be negative: the bits in front of the map are 0; the map's rows are padded
+// to whole tiles with zeros and `nwords` words long)
+__device__ __forceinline__ uint64_t map_bits(const uint64_t *__restrict__ bm, uint32_t nwords, int64_t q)
+{
+    if (q <= -64) return 0;
+    if (q < 0) return bm[0] << (uint32_t)(-q);
+    const uint32_t idx = (uint32_t)(q >> 6), sh = (uint32_t)(q & 63);
+    if (idx >= nwords) return 0;
+    const uint64_t lo = bm[idx];
+    if (!sh) return lo;
+    const uint64_t hi = idx + 1 < nwords ? bm[idx + 1] : 0ull;
+    return (lo >> sh) | (hi << (64u - sh));
+}
+
+// grid (ceil(ntiles / WAVES), B), a wavefront per tile
+__global__ __launch_bounds__(WG) void k_l2_prep(Scratch sc, L2Work w)
 {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
     if (t >= sc.ntiles) return;
-    const uint64_t frow = (uint64_t)f * sc.ntiles;
-    const u32x2 v = reinterpret_cast<const u32x2 *>(sc.bitmap + (uint64_t)f * sc.nb_stride + (uint64_t)t * TILE_BM)[lane];
-    uint64_t bits = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    const uint64_t *bm = reinterpret_cast<const uint64_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride);
+    const uint64_t bits = bm[(uint64_t)t * 64 + lane];
     const uint32_t cnt = (uint32_t)__builtin_popcountll(bits);
     const uint32_t inc = wave_incl_scan(cnt);
-    const uint32_t rank0 = inc - cnt;                               // set pixels of this tile before this word
-    const uint64_t base = (uint64_t)w.frame_base[f] + sc.tile_off[frow + t];
-    const uint64_t g0 = base + rank0;
-    w.word_rank[(uint64_t)f * w.words_per_frame + (uint64_t)t * 64 + lane] = (uint32_t)min(g0, (uint64_t)0xFFFFFFFFu);
-    const uint16_t *slot = sc.pix_slots + (frow + t) * TILE_PX;
-    const uint32_t px0 = t * (uint32_t)TILE_PX + (uint32_t)lane * 64u;
-    for (uint32_t j = 0; bits; bits &= bits - 1, ++j) {
-        const uint64_t g = g0 + j;
-        if (g >= w.cap) break;                                       // workspace exceeded: k_l2_emit reports it
-        w.pos[g] = px0 + (uint32_t)__builtin_ctzll(bits);
-        w.val[g] = slot[rank0 + j];
-        w.parent[g] = (uint32_t)g;
-        w.stat[g] = 0;
+    w.word_base[((uint64_t)f * sc.ntiles + t) * 64 + lane] = (uint16_t)(inc - cnt);   // (< 4096: the last word's base is at most 4032)
+    const uint32_t total = wave_last(inc);
+    const uint64_t fbase = (uint64_t)f * w.ids_per_frame;
+    const uint32_t id0 = t * (uint32_t)TILE_PX;
+    for (uint32_t r = lane; r < total; r += 64) {
+        w.parent[fbase + id0 + r] = id0 + r;
+        w.stat[fbase + id0 + r] = 0;
     }
 }
 
-// compact index of the set pixel at linear position k of frame f (caller has checked the bit)
-__device__ __forceinline__ bool l2_neighbour(const Scratch &sc, const L2Work &w, uint32_t f, uint32_t k, uint32_t &g)
+// id of the set pixel at linear position p of the frame (the caller has seen its bit)
+__device__ __forceinline__ uint32_t l2_id(const uint64_t *__restrict__ bm, const uint16_t *__restrict__ wbase, uint32_t p)
 {
-    const uint8_t *bm = sc.bitmap + (uint64_t)f * sc.nb_stride;
-    const u32x2 v = reinterpret_cast<const u32x2 *>(bm)[k >> 6];
-    const uint64_t word = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
-    if (!((word >> (k & 63)) & 1ull)) return false;
-    g = w.word_rank[(uint64_t)f * w.words_per_frame + (k >> 6)] + (uint32_t)__builtin_popcountll(word & ((1ull << (k & 63)) - 1ull));
-    return true;
+    const uint32_t wi = p >> 6;
+    return (p >> 12) * (uint32_t)TILE_PX + wbase[wi] + (uint32_t)__builtin_popcountll(bm[wi] & ((1ull << (p & 63u)) - 1ull));
 }
 
-// grid (L2_GRID, B), grid-stride over the frame's set pixels
-__global__ __launch_bounds__(WG) void k_l2_union(Scratch sc, L2Work w, uint32_t nx)
+// grid (ceil(ntiles / WAVES), B), a wavefront per tile, a lane per word
+__global__ __launch_bounds__(WG) void k_l2_link(Scratch sc, L2Work w, uint32_t nx)
 {
-    const uint32_t f = blockIdx.y;
-    const uint64_t base = w.frame_base[f];
-    const uint32_t n = sc.frame_nnz[f];
-    if (base + n > w.cap) return;
-    for (uint32_t c = blockIdx.x * WG + threadIdx.x; c < n; c += gridDim.x * WG) {
-        const uint32_t g = (uint32_t)(base + c);
-        const uint32_t k = w.pos[g];
-        const uint32_t row = k / nx, col = k - row * nx;
-        uint32_t h;
-        if (col > 0 && l2_neighbour(sc, w, f, k - 1, h)) uf_union(w.parent, g, h);                 // W
-        if (row > 0) {
-            const uint32_t up = k - nx;
-            if (l2_neighbour(sc, w, f, up, h)) uf_union(w.parent, g, h);                           // N
-            if (col > 0 && l2_neighbour(sc, w, f, up - 1, h)) uf_union(w.parent, g, h);            // NW
-            if (col + 1 < nx && l2_neighbour(sc, w, f, up + 1, h)) uf_union(w.parent, g, h);       // NE
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
+    if (t >= sc.ntiles) return;
+    const uint32_t nwords = sc.ntiles * 64u;
+    const uint64_t *bm = reinterpret_cast<const uint64_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride);
+    const uint16_t *wbase = w.word_base + (uint64_t)f * nwords;
+    const uint32_t wi = t * 64u + (uint32_t)lane;
+    const uint64_t W = bm[wi];
+    if (!W) return;                       // (nothing below crosses lanes)
+    const uint32_t p0 = wi * 64u;         // first pixel of the word (N < 2^32)
+    // pixels of this word in the first / last column of their row
+    uint64_t col0 = 0, colL = 0;
+    for (uint64_t r = (((uint64_t)p0 + nx - 1) / nx) * nx; r < (uint64_t)p0 + 64; r += nx) col0 |= 1ull << (r - p0);        // row starts inside the word
+    for (uint64_t r = (((uint64_t)p0 + nx) / nx) * nx; r < (uint64_t)p0 + 65; r += nx) colL |= 1ull << (r - 1 - p0);        // pixel r - 1 ends a row
+    // neighbour maps, bit i = "pixel p0 + i has that neighbour set"
+    const uint64_t west = map_bits(bm, nwords, (int64_t)p0 - 1) & ~col0;
+    const uint64_t A = map_bits(bm, nwords, (int64_t)p0 - nx - 1), Bn = map_bits(bm, nwords, (int64_t)p0 - nx + 63);
+    const uint64_t nw = A & ~col0, north = (A >> 1) | (Bn << 63), ne = ((A >> 2) | (Bn << 62)) & ~colL;
+    uint32_t *parent = w.parent + (uint64_t)f * w.ids_per_frame;
+    const uint32_t id0 = t * (uint32_t)TILE_PX + wbase[wi];
+    for (uint64_t todo = W & (west | nw | north | ne); todo; todo &= todo - 1) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+        const uint64_t bit = 1ull << i;
+        const uint32_t p = p0 + i, self = id0 + (uint32_t)__builtin_popcountll(W & (bit - 1ull));
+        if (north & bit) uf_union(parent, self, l2_id(bm, wbase, p - nx));            // (W, NW, NE hang on N through their own links)
+        else {
+            if (west & bit) uf_union(parent, self, l2_id(bm, wbase, p - 1));          // (NW is W's northern neighbour)
+            else if (nw & bit) uf_union(parent, self, l2_id(bm, wbase, p - nx - 1));
+            if (ne & bit) uf_union(parent, self, l2_id(bm, wbase, p - nx + 1));
         }
     }
 }
@@ -108,94 +134,73 @@ __global__ __launch_bounds__(WG) void k_l2_union(Scratch sc, L2Work w, uint32_t 
 // use_sum: 0 = maximum, 1 = sum.  The sum wraps the way the reference's arithmetic would: its statistic is cast to the source dtype
 // (recode_writer.py:446 hands `self._src_dtype` to get_summary_stats_nb) and stored in src_bit_depth bits (_bit_pack drops the bits above,
 // recode_writer.py:637-652) - i.e. the sum modulo 2^d.  The accumulator is 32 bits wide (2^d divides 2^32: wrapping it changes nothing),
-// k_l2_emit keeps its low 16 bits, the d-bit pack the low d.  (Rounds 2-3 clamped at 2^d - 1 instead - the builder's reading; the
-// reference's own code cannot run, SURVEY 0.5, so this is specification by intent either way, now the literal one.)
+// k_l2_emit keeps its low 16 bits, the d-bit pack the low d.
 __global__ __launch_bounds__(WG) void k_l2_stats(Scratch sc, L2Work w, uint32_t use_sum)
 {
-    const uint32_t f = blockIdx.y;
-    const uint64_t base = w.frame_base[f];
-    const uint32_t n = sc.frame_nnz[f];
-    if (base + n > w.cap) return;
-    for (uint32_t c = blockIdx.x * WG + threadIdx.x; c < n; c += gridDim.x * WG) {
-        const uint32_t g = (uint32_t)(base + c);
-        const uint32_t r = uf_find(w.parent, g);
-        w.parent[g] = r;  // flattened: k_l2_emit only asks "is g its own root"
-        if (use_sum) atomicAdd(&w.stat[r], (uint32_t)w.val[g]);
-        else atomicMax(&w.stat[r], (uint32_t)w.val[g]);
-    }
-}
-
-constexpr int L2_T = 1024, L2_W = L2_T / 64;
-// one workgroup per frame
-__global__ __launch_bounds__(L2_T) void k_l2_emit(Scratch sc, L2Work w)
-{
-    __shared__ uint32_t sm[L2_W];
-    const uint32_t f = blockIdx.x;
-    const uint64_t base = w.frame_base[f];
-    const uint32_t n = sc.frame_nnz[f];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
+    if (t >= sc.ntiles) return;
     const uint64_t frow = (uint64_t)f * sc.ntiles;
-    uint16_t *vals = sc.pix_slots + frow * TILE_PX;  // the frame's value slots, reused as ONE contiguous list
-    uint32_t ncomp = 0;
-    if (base + n > w.cap) {
-        if (threadIdx.x == 0) { sc.status->code = -7; sc.status->frame = f; }  // RC_ERR_WORKSPACE
-    } else {
-        for (uint32_t c0 = 0; c0 < n; c0 += L2_T) {
-            const uint32_t c = c0 + threadIdx.x;
-            uint32_t isroot = 0, g = 0;
-            if (c < n) {
-                g = (uint32_t)(base + c);
-                isroot = w.parent[g] == g;
+    const uint32_t total = sc.tile_cnt[frow + t];
+    uint32_t *parent = w.parent + (uint64_t)f * w.ids_per_frame, *stat = w.stat + (uint64_t)f * w.ids_per_frame;
+    const uint16_t *vals = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(sc.pix_slots) + (frow + t) * sc.pix_slot_bytes);
+    const uint32_t id0 = t * (uint32_t)TILE_PX;
+    for (uint32_t r = lane; r < total; r += 64) {
+        const uint32_t id = id0 + r;
+        if (parent[id] == id) continue;                      // a root (every pixel without neighbours): its own value joins at the emit
+        const uint32_t root = uf_find(parent, id);
+        parent[id] = root;
+        if (use_sum) atomicAdd(&stat[root], (uint32_t)vals[r]);
+        else atomicMax(&stat[root], (uint32_t)vals[r]);
+    }
+}
+
+// The tile's roots -> its new value list (see the head of the file).  The workgroup's LDS holds a tile's worst case per wavefront.
+__global__ __launch_bounds__(WG) void k_l2_emit(Scratch sc, L2Work w, uint32_t use_sum, uint32_t depth)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[WAVES][TILE_PX];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
+    if (t >= sc.ntiles) return;
+    const uint64_t frow = (uint64_t)f * sc.ntiles;
+    const uint32_t total = sc.tile_cnt[frow + t];
+    if (total == 0) return;               // (the tile stays empty)
+    const uint32_t *parent = w.parent + (uint64_t)f * w.ids_per_frame, *stat = w.stat + (uint64_t)f * w.ids_per_frame;
+    uint16_t *slot = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(sc.pix_slots) + (frow + t) * sc.pix_slot_bytes);
+    uint16_t *list = s_list[wv];
+    const uint32_t id0 = t * (uint32_t)TILE_PX;
+    uint32_t nroot = 0;
+    for (uint32_t r0 = 0; r0 < total; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        uint32_t isroot = 0, v = 0;
+        if (r < total) {
+            const uint32_t id = id0 + r;
+            isroot = parent[id] == id ? 1u : 0u;
+            if (isroot) {
+                const uint32_t own = slot[r], acc = stat[id];
+                v = use_sum ? acc + own : max(acc, own);
             }
-            // block exclusive scan of the root flags
-            const int wv = threadIdx.x >> 6;
-            const uint32_t inc = wave_incl_scan(isroot);
-            if (lane_id() == 63) sm[wv] = inc;
-            __syncthreads();
-            uint32_t before = 0, tot = 0;
-#pragma unroll
-            for (int i = 0; i < L2_W; ++i) {
-                const uint32_t x = sm[i];
-                if (i < wv) before += x;
-                tot += x;
-            }
-            __syncthreads();
-            if (isroot) vals[ncomp + before + inc - 1] = (uint16_t)w.stat[g];
-            ncomp += tot;
         }
+        const uint32_t inc = wave_incl_scan(isroot);
+        if (isroot) list[nroot + inc - 1] = (uint16_t)v;
+        nroot += wave_last(inc);
     }
-    // describe the list as full pseudo-tiles of TILE_PX values
-    for (uint32_t t = threadIdx.x; t < sc.ntiles; t += L2_T) {
-        const uint32_t lo = min(t * (uint32_t)TILE_PX, ncomp);
-        const uint32_t hi = min((t + 1) * (uint32_t)TILE_PX, ncomp);
-        sc.tile_off[frow + t] = lo;
-        sc.tile_cnt[frow + t] = hi - lo;
-        sc.tile_next[frow + t] = (t + 1) * (uint32_t)TILE_PX < ncomp ? t + 1 : sc.ntiles;
-    }
-    if (threadIdx.x == 0) sc.frame_nnz[f] = ncomp;
+    __builtin_amdgcn_wave_barrier();
+    if (depth < 16 && nroot) pack_stage(list, nroot, depth);
+    __builtin_amdgcn_wave_barrier();
+    // whole lines, like the reduce kernel's residual lines (k_gather reads whole 16-byte pieces of the stream)
+    const uint32_t ndw = (((nroot * (depth < 16 ? depth : 16u) + 31) >> 5) + 31u) & ~31u;
+    for (uint32_t i = lane; i < ndw; i += 64) reinterpret_cast<uint32_t *>(slot)[i] = reinterpret_cast<const uint32_t *>(list)[i];
+    if (lane == 0) sc.tile_cnt[frow + t] = nroot;
 }
 
-// exclusive prefix of frame_nnz over the frames of the batch -> frame_base[0..B]; single workgroup
-__global__ __launch_bounds__(WG) void k_l2_bases(const uint32_t *__restrict__ frame_nnz, uint64_t *__restrict__ frame_base, uint32_t B)
+void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, uint32_t depth, hipStream_t s)
 {
-    __shared__ uint64_t part[WG];
-    const uint32_t per = (B + WG - 1) / WG, lo = threadIdx.x * per, hi = min(lo + per, B);
-    uint64_t s = 0;
-    for (uint32_t f = lo; f < hi; ++f) s += frame_nnz[f];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    uint64_t base = 0;
-    for (uint32_t i = 0; i < threadIdx.x; ++i) base += part[i];
-    for (uint32_t f = lo; f < hi; ++f) { frame_base[f] = base; base += frame_nnz[f]; }
-    if (threadIdx.x == WG - 1) frame_base[B] = base;
-}
-
-void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_l2_bases, dim3(1), dim3(WG), 0, s, sc.frame_nnz, w.frame_base, B);
-    hipLaunchKernelGGL(k_l2_index, dim3((sc.ntiles + WAVES - 1) / WAVES, B), dim3(WG), 0, s, sc, w, B);
-    hipLaunchKernelGGL(k_l2_union, dim3(128, B), dim3(WG), 0, s, sc, w, nx);
-    hipLaunchKernelGGL(k_l2_stats, dim3(128, B), dim3(WG), 0, s, sc, w, use_sum);
-    hipLaunchKernelGGL(k_l2_emit, dim3(B), dim3(L2_T), 0, s, sc, w);
+    const dim3 grid((sc.ntiles + WAVES - 1) / WAVES, B);
+    hipLaunchKernelGGL(k_l2_prep, grid, dim3(WG), 0, s, sc, w);
+    hipLaunchKernelGGL(k_l2_link, grid, dim3(WG), 0, s, sc, w, nx);
+    hipLaunchKernelGGL(k_l2_stats, grid, dim3(WG), 0, s, sc, w, use_sum);
+    hipLaunchKernelGGL(k_l2_emit, grid, dim3(WG), 0, s, sc, w, use_sum, depth);
 }
 
 // ---- validation frames (reference recode_writer.py:402-415): the dose-rate count on the streaming path ---------------------

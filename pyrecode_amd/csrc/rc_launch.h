@@ -52,15 +52,13 @@ struct Scratch {
     uint32_t zm_valid = 0, zm_budget = 0, zm_seq_bits = 12;
 };
 
-// workspace of reduction level 2 (connected-component statistics), indexed by the batch-global compact pixel index
+// workspace of reduction level 2 (connected-component statistics, rc_l2.hip): a set pixel's id inside its frame is tile * TILE_PX + its rank
+// among the tile's set pixels; parent / stat are indexed by frame * ids_per_frame + id (sparse: only set pixels' entries are touched)
 struct L2Work {
-    uint32_t *pos = nullptr;         // [cap] linear pixel position inside its frame
-    uint16_t *val = nullptr;         // [cap] raw frame value
-    uint32_t *parent = nullptr;      // [cap] union-find parent (smaller index wins)
-    uint32_t *stat = nullptr;        // [cap] per-root accumulator
-    uint32_t *word_rank = nullptr;   // [B][words_per_frame] compact index of the first set pixel at/after each 64-pixel word
-    uint64_t *frame_base = nullptr;  // [B+1] compact index of each frame's first set pixel
-    uint64_t cap = 0, words_per_frame = 0;
+    uint32_t *parent = nullptr;      // [B][ids_per_frame] union-find parent (smaller id wins)
+    uint32_t *stat = nullptr;        // [B][ids_per_frame] per-root accumulator of the OTHER pixels' raw values
+    uint16_t *word_base = nullptr;   // [B][ntiles * 64]   set pixels of the tile in front of each 64-pixel word
+    uint64_t ids_per_frame = 0;      // ntiles * TILE_PX
 };
 
 struct RecordParams {
@@ -89,12 +87,15 @@ void launch_threshold32(const uint32_t *dark, int64_t eps, uint64_t N, uint32_t 
 void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s,
                      uint32_t codec = 0, bool keep_bitmap = true);   // codec 2 / 4: the LZ4 block encoder (runs / events) fused
 // rc_l2.hip
-void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, hipStream_t s);
+void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, uint32_t depth, hipStream_t s);
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);
 void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
                    uint32_t *md, hipStream_t s);
 void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off,
                      uint32_t batch_seq, hipStream_t s);
+// rc_gather.hip: k_gather, what launch_assemble runs for everything but level-2 value lists
+void launch_gather(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off, uint32_t hdr_bitmap, uint32_t hdr_pix,
+                   uint32_t batch_seq, hipStream_t s);
 // rc_pix_huff.hip: the packed residual stream of every frame (Scratch::pixraw) -> Huffman-coded zstd blocks -> the records
 constexpr uint32_t PIX_CHUNK = 1008, PIX_SLOT = 1024;
 void launch_pix_huff(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t s);
@@ -130,7 +131,8 @@ void zstd_tables_host(void *dst);  // rc_reduce.hip: FLG | BD << 8 | HC << 16
 
 // where tile ft's packed residual stream starts (see Scratch::comb); bn: the tile's blk_size word as the reduce kernel wrote it
 // (combined form 1 only), cnt: its set pixels, d: bits per value
-__host__ __device__ inline const uint8_t *residual_src(const Scratch &sc, uint64_t ft, uint32_t bn, uint32_t cnt, uint32_t d)
+template <class S>
+__host__ __device__ inline const uint8_t *residual_src(const S &sc, uint64_t ft, uint32_t bn, uint32_t cnt, uint32_t d)
 {
     if (sc.comb) {
         const uint32_t ro16 = sc.comb == 2 ? (uint32_t)BLK_SLOT / 16 : (bn + 15) >> 4, r16 = (cnt * d + 127) >> 7;

@@ -136,6 +136,11 @@ __device__ __forceinline__ uint32_t wave_excl_pkmax(uint32_t x)
 constexpr int LZ4_EV_MAX = 62;   // events per block the event parser takes with one event per lane (lane 0 is the block start: at most 2 * 63 matches)
 constexpr int LZ4_EV_MAX2 = 126; // ... with two events per lane (lz4_parse_events2: dense maps - 2 % Bernoulli, the detector-like clusters)
 constexpr int LZ4_NM_MAX2 = 126; // ... and the matches it may leave (the position tables and phase 2's two rounds; dense blocks have 40 - 60)
+// A block with more non-zero bytes than this is stored without a parse (compression_level >= 1): beyond ~9 % of the pixels set a 512-byte
+// block of a binary map no longer shrinks under LZ4 (Bernoulli maps, tests/lz4_parse_model.py: at 10 % the stream is 0.9955 of raw and half the
+// blocks do not shrink at all, at 12 % 0.9993), while the run parser and phase 2 still cost their ~180 vector instructions per tile and
+// frame.  The threshold gives up < 0.5 % of the stream at 9 - 10 % and nothing measurable elsewhere.
+constexpr int LZ4_NZ_STORE = 272;
 
 // Event parser (compression_level >= 1).  Lane 0 stands for the block start ("event" at position -1), lane k >= 1 for the
 // k-th non-zero byte X_k at p_k, followed by R_k zeros.  Per lane, with j = the earlier event of the same single-bit value
@@ -151,7 +156,7 @@ constexpr int LZ4_NM_MAX2 = 126; // ... and the matches it may leave (the positi
 // Returns nm, or 0xFFFFFFFF when the block holds more than LZ4_EV_MAX2 events (the caller runs lz4_parse_runs); 63 .. 126 events:
 // lz4_parse_events2 below.
 __device__ __forceinline__ uint32_t lz4_parse_events2(uint32_t nev, uint32_t n, Lz4Lds &L);
-__device__ __forceinline__ uint32_t lz4_parse_events(uint64_t own, uint32_t n, Lz4Lds &L)
+__device__ __forceinline__ uint32_t lz4_parse_events(uint64_t own, uint32_t n, Lz4Lds &L, uint32_t &nev_out)
 {
     const int lane = lane_id();
     const int base = 8 * lane;
@@ -163,6 +168,7 @@ __device__ __forceinline__ uint32_t lz4_parse_events(uint64_t own, uint32_t n, L
     const uint32_t cnt = (uint32_t)__builtin_popcount(nz);
     const uint32_t inc = wave_incl_scan(cnt);
     const uint32_t nev = wave_last(inc);
+    nev_out = nev;
     if (nev > (uint32_t)LZ4_EV_MAX2) return 0xFFFFFFFFu;
     for (uint32_t k = inc - cnt + 1; nz; nz &= nz - 1) ev[k++] = (uint16_t)(base + __builtin_ctz(nz) + 1);
     if (lane == 0) { ev[0] = 0; ev[nev + 1] = (uint16_t)(n + 1); }
@@ -331,8 +337,10 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
     bool off1 = true;
     LZ4_PH_BEGIN
     if (EVENTS) {
-        nm = lz4_parse_events(own, n, L);
+        uint32_t nev = 0;
+        nm = lz4_parse_events(own, n, L, nev);
         off1 = nm == 0xFFFFFFFFu;
+        if (nev > (uint32_t)LZ4_NZ_STORE) return n;   // hopeless (see LZ4_NZ_STORE): the caller stores the block
     }
     LZ4_PH(0);
     if (nm == 0xFFFFFFFFu) nm = lz4_parse_runs(own, n, L);

@@ -11,6 +11,8 @@
 #include <type_traits>
 
 #include "rc_launch.h"
+#include "rc_record.h"
+#include "rc_pack.h"
 #ifdef RC_PHASE_TIMING
 __device__ unsigned long long g_phase[16];
 #define RC_LZ4_PHASE 1   // (rc_lz4_block.h: sub-phases of the LZ4 encoder into g_phase[8..13])
@@ -253,62 +255,6 @@ struct __attribute__((aligned(16))) WaveStage {
     uint16_t val[TILE_PX];
     uint16_t out[STAGE_CAP];
 };
-
-// A5 inside the tile: the cnt compacted values (uint16, in the wave's LDS stage) become the tile-local LSB-first stream of
-// their low d bits, IN PLACE: output dword w needs values >= 32w/d >= 2w, which lie at or behind byte 4w, and all lanes
-// of a step read before any of them writes.  The rest of the last 128-byte line is zeroed (k_assemble ORs across tiles).
-__device__ __forceinline__ void pack_stage(uint16_t *pix, uint32_t cnt, uint32_t d)
-{
-    const int lane = lane_id();
-    const uint32_t nbits = cnt * d;
-    const uint32_t ndw = (((nbits + 31) >> 5) + 31u) & ~31u;
-    if (d == 12) {
-        // the common detector depth: 8 values = 3 dwords per lane and step, one 16-byte LDS read, no inner loop.  In place is
-        // safe for the same reason as below (12g <= 16g: a group's output lies at or in front of its input, and a step's
-        // reads all happen before its writes); the padding up to the line boundary is zeroed behind.
-        uint32_t *out = reinterpret_cast<uint32_t *>(pix);
-        const uint32_t ngrp = (cnt + 7) >> 3;
-        for (uint32_t g0 = 0; g0 < ngrp; g0 += 64) {
-            const uint32_t g = g0 + lane;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (g < ngrp) v = *reinterpret_cast<const u32x4 *>(pix + 8 * g);
-            uint32_t x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t h = (j & 1) ? (v[j >> 1] >> 16) : (v[j >> 1] & 0xFFFFu);
-                x[j] = 8 * g + j < cnt ? (h & 0xFFFu) : 0u;
-            }
-            const uint32_t w0 = x[0] | (x[1] << 12) | (x[2] << 24);
-            const uint32_t w1 = (x[2] >> 8) | (x[3] << 4) | (x[4] << 16) | (x[5] << 28);
-            const uint32_t w2 = (x[5] >> 4) | (x[6] << 8) | (x[7] << 20);
-            __builtin_amdgcn_wave_barrier();
-            if (g < ngrp) { out[3 * g] = w0; out[3 * g + 1] = w1; out[3 * g + 2] = w2; }
-            __builtin_amdgcn_wave_barrier();
-        }
-        for (uint32_t w = 3 * ngrp + lane; w < ndw; w += 64) out[w] = 0;
-        __builtin_amdgcn_wave_barrier();
-        return;
-    }
-    const uint32_t inv = 0xFFFFFFFFu / d + 1u;  // floor(n / d) = umulhi(n, inv) for n * d < 2^32  (d = 1: the constant wraps to 0 - taken apart below)
-    const uint32_t dmask = (1u << d) - 1u;
-    uint32_t *out = reinterpret_cast<uint32_t *>(pix);
-    for (uint32_t w0 = 0; w0 < ndw; w0 += 64) {
-        const uint32_t w = w0 + lane;
-        uint32_t v = d == 1 ? 32u * w : __umulhi(32u * w, inv);
-        const uint32_t o = 32u * w - v * d;
-        uint64_t acc = 0;
-        uint32_t filled = 0;
-        if (v < cnt) { acc = (pix[v] & dmask) >> o; filled = d - o; ++v; }
-        while (filled < 32 && v < cnt) {
-            acc |= (uint64_t)(pix[v] & dmask) << filled;
-            filled += d;
-            ++v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (w < ndw) out[w] = (uint32_t)acc;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
 
 // All line-sized results of one (tile, frame) - the residual stream's lines and the encoded block's lines, both complete images
 // in the wave's LDS - leave through ONE kind of store: every lane moves 16 bytes (ds_read_b128 + global_store_dwordx4), the
@@ -943,8 +889,6 @@ __device__ __forceinline__ void zstd_place_defs(const uint32_t *__restrict__ row
     zstd_rewrite_defs(row, slots, stride, tree, tl, sdesc, sl, t_tree, t_seq, 3u, s_img, &s_pos);
 }
 
-__host__ __device__ inline uint32_t packed_bytes(uint32_t nnz, uint32_t depth);
-
 // Residual stream of the modelled zstd encoder (rc_pix_huff.hip): per frame, sizes of the encoded chunks -> offsets, total;
 // the tree goes into the first Huffman-coded chunk.
 __global__ __launch_bounds__(SCAN_T) void k_pix_scan(Scratch sc, uint32_t depth)
@@ -1190,39 +1134,7 @@ void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blo
     else hipLaunchKernelGGL(k_scan_frames<16>, dim3(B), dim3(SCAN_T), 0, s, sc, with_counts ? 1 : 0, with_blocks ? 1 : 0);
 }
 
-// ---- record layout: sizes, offsets, metadata, status ------------------------------------------------------------
-// Framing of the two per-frame streams for the device codecs.  The bitmap stream is [hdr][encoded blocks][end]; the pixel
-// stream is stored ("raw") chunks: [hdr]{[chunk header][<= 2^chunk_shift bytes]}[end].
-//   LZ4 frame  (lz4_Frame_format.md): 7-byte header, 4-byte block words (bit 31 = stored), 4-byte EndMark, 4 MiB chunks
-//   zstd frame (RFC 8878):            6-byte header (magic, descriptor, window), 3-byte block headers, Last_Block bit on the
-//                                     final block instead of an end mark, 128 KiB chunks (Block_Maximum_Size), >= 1 block
-//   blosc1 chunk (scheme 8):          bitmap: 16-byte header + int32 bstarts[ntiles] + blocks; pixels: 16-byte header with the
-//                                     "memcpyed" flag + the bytes (what c-blosc itself emits for incompressible input)
-struct FrameFmt { uint32_t hdr, end, chunk_shift, chunk_hdr, min_chunks; };
-__host__ __device__ inline FrameFmt frame_fmt(uint32_t emit)
-{
-    return emit == 1 ? FrameFmt{6, 0, 17, 3, 1} : emit == 8 ? FrameFmt{16, 0, 31, 0, 0} : FrameFmt{7, 4, 22, 4, 0};
-}
-// bytes in front of the encoded bitmap blocks
-__host__ __device__ inline uint32_t bitmap_hdr(const FrameFmt &ff, uint32_t emit, uint32_t ntiles)
-{
-    return emit == 8 ? 16u + 4u * ntiles : ff.hdr;
-}
-
-__host__ __device__ inline uint32_t packed_bytes(uint32_t nnz, uint32_t depth)
-{
-    return depth == 16 ? nnz * 2u : (uint32_t)(((uint64_t)nnz * depth + 7) >> 3);
-}
-__host__ __device__ inline uint32_t stored_chunks(const FrameFmt &ff, uint32_t n)
-{
-    const uint32_t c = (n + (1u << ff.chunk_shift) - 1) >> ff.chunk_shift;
-    return c < ff.min_chunks ? ff.min_chunks : c;
-}
-__host__ __device__ inline uint32_t stored_size(const FrameFmt &ff, uint32_t n)
-{
-    return ff.hdr + n + ff.chunk_hdr * stored_chunks(ff, n) + ff.end;
-}
-
+// ---- record layout: sizes, offsets, metadata, status (stream framing: rc_record.h) ----------------------------------------
 #ifndef RC_SMALL_WG
 #define RC_SMALL_WG 0
 #endif
@@ -1290,11 +1202,6 @@ void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64
 }
 
 // ---- record assembly ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_u32_le(uint8_t *p, uint32_t v)
-{
-    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
-}
-
 // ---- wave-cooperative copy of small segments with any destination alignment -----------------------------------------
 // A segment is n bytes at a 4-byte aligned source going to an arbitrarily aligned destination.  The body is written as
 // aligned dwords: destination dword j = source bytes [head + 4j, head + 4j + 4) = byte funnel shift (v_alignbyte_b32) of
@@ -1362,73 +1269,6 @@ __device__ __forceinline__ uint32_t pix_fetch(const PixSrc &s, uint32_t v)
         tt = s.next[tt];
     }
     return 0;
-}
-
-// position of packed-pixel byte b inside the pixel stream's frame (stored chunks)
-__device__ __forceinline__ uint64_t stored_pos(const FrameFmt &ff, uint64_t b)
-{
-    return ff.hdr + ff.chunk_hdr * ((b >> ff.chunk_shift) + 1) + b;
-}
-
-// The fixed fields of frame f's record (ids, sizes, the two streams' frame headers / end marks / stored-chunk headers): written by ONE lane.
-__device__ __forceinline__ void record_fixed_fields(const Scratch &sc, const RecordParams &rp, uint32_t f, uint8_t *rec, uint64_t bitmap_pos, uint64_t pix_pos,
-                                                    uint32_t cb, uint32_t npk, const FrameFmt &ff, bool skip_pix, uint32_t lz4f_hdr_bitmap, uint32_t lz4f_hdr_pix)
-{
-    store_u32_le(rec, rp.first_frame_id + f);
-    if (rp.emit == 0) {
-        if (rp.level == 1) store_u32_le(rec + 4, npk);
-    } else {
-        store_u32_le(rec + 4, cb);
-        uint8_t *bf = rec + bitmap_pos;
-        if (rp.emit == 1) {  // zstd: magic, Frame_Header_Descriptor 0 (no content size, window descriptor follows), 1 KiB window
-            store_u32_le(bf, 0xFD2FB528u);
-            bf[4] = 0; bf[5] = 0x00;
-        } else if (rp.emit == 8) {  // blosc1 header: version 2, LZ4 format version 1, bit-shuffle | not split | LZ4, typesize 8
-            bf[0] = 2; bf[1] = 1; bf[2] = 0x34; bf[3] = 8;
-            store_u32_le(bf + 4, (uint32_t)sc.nb);
-            store_u32_le(bf + 8, (uint32_t)min((uint64_t)TILE_BM, sc.nb));
-            store_u32_le(bf + 12, cb);
-        } else {
-            store_u32_le(bf, 0x184D2204u);
-            bf[4] = (uint8_t)(lz4f_hdr_bitmap & 0xFF); bf[5] = (uint8_t)((lz4f_hdr_bitmap >> 8) & 0xFF);
-            bf[6] = (uint8_t)((lz4f_hdr_bitmap >> 16) & 0xFF);
-            store_u32_le(bf + cb - ff.end, 0);
-        }
-        if (rp.level == 1 && skip_pix) {
-            store_u32_le(rec + 8, ff.hdr + sc.frame_pbytes[f]);
-            store_u32_le(rec + 12, npk);
-        } else if (rp.level == 1) {
-            const uint32_t cp = stored_size(ff, npk);
-            store_u32_le(rec + 8, cp);
-            store_u32_le(rec + 12, npk);
-            uint8_t *pf = rec + pix_pos;
-            const uint32_t chunk = 1u << ff.chunk_shift, nch = stored_chunks(ff, npk);
-            if (rp.emit == 8) {  // blosc1 header with the "memcpyed" flag: the packed residuals follow unchanged
-                pf[0] = 2; pf[1] = 1; pf[2] = 0x36; pf[3] = 8;
-                store_u32_le(pf + 4, npk);
-                store_u32_le(pf + 8, npk);
-                store_u32_le(pf + 12, 16 + npk);
-            } else if (rp.emit == 1) {  // 128 KiB window so that 128 KiB raw blocks are legal
-                store_u32_le(pf, 0xFD2FB528u);
-                pf[4] = 0; pf[5] = 7u << 3;
-                for (uint32_t k = 0; k < nch; ++k) {
-                    const uint32_t o = k * chunk, len = npk > o ? min(chunk, npk - o) : 0u;
-                    const uint32_t h = (k + 1 == nch ? 1u : 0u) | (len << 3);  // Raw_Block
-                    uint8_t *q = pf + ff.hdr + (uint64_t)k * (chunk + 3);
-                    q[0] = (uint8_t)h; q[1] = (uint8_t)(h >> 8); q[2] = (uint8_t)(h >> 16);
-                }
-            } else {
-                store_u32_le(pf, 0x184D2204u);
-                pf[4] = (uint8_t)(lz4f_hdr_pix & 0xFF); pf[5] = (uint8_t)((lz4f_hdr_pix >> 8) & 0xFF);
-                pf[6] = (uint8_t)((lz4f_hdr_pix >> 16) & 0xFF);
-                for (uint32_t k = 0; k < nch; ++k) {
-                    const uint32_t o = k * chunk, len = min(chunk, npk - o);
-                    store_u32_le(pf + ff.hdr + (uint64_t)k * (chunk + 4), len | 0x80000000u);
-                }
-                store_u32_le(pf + cp - ff.end, 0);
-            }
-        }
-    }
 }
 
 // a quarter-wave handles one tile per pass; 2 passes (8 tiles per wavefront) keep the kernel at ~80 VGPRs: measured 44 us
@@ -1674,240 +1514,6 @@ __global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, u
 }
 
 
-// ---- record assembly, second form (round 5): k_gather ---------------------------------------------------------------------------------
-// k_assemble above gives every tile a quarter-wave: 32 768 short-lived wavefronts per 64 frames of 4096^2, each with three dependent
-// round trips (indices, data, stores) for 1.8 KB of payload, in four-wave workgroups that only start where a reduce workgroup of the
-// NEXT batch has just retired - 85 us alone, 300 us next to the reduce kernel, and what it takes from that kernel is what the step
-// loses (profiles/r04_decompose_*.log).  k_gather does the same copy with few, long-lived, one-wave workgroups that need no LDS
-// and few registers, so that they live in what the reduce kernel's workgroups leave free on a CU (its 15 waves of 128 registers
-// leave one SIMD a quarter empty) instead of displacing them:
-//   - an ITEM is 64 consecutive tiles of one frame, a lane per tile for the bookkeeping: sizes, offsets (from the scans) and where
-//     the tile's two segments - encoded block, packed residuals - come from and go to;
-//   - the copy itself is PIECE-parallel: a piece is 16 bytes of a segment, the item's pieces are numbered through (exclusive scan of
-//     the tiles' piece counts), lane j of round i takes piece 64 i + j, finds its tile by a binary search over the scan (six
-//     ds_bpermute) and moves it: one aligned 16-byte load from the slot, one 16-byte store at the destination's byte alignment
-//     (unaligned access mode), a segment's last piece as 8 + 4 + 2 + 1 bytes.  Every lane of every round carries 16 bytes, whatever
-//     the tiles' sizes;
-//   - residual streams of d-bit fields (d % 8 != 0, BITS) are funnel-shifted by the destination's bit phase on the way (a fifth dword
-//     per piece); the stream byte a tile shares with its successor is completed from the successor's leading bits - in registers when
-//     the successor is a tile of the same item, from the first tile behind the item otherwise (fetched with the item's bookkeeping),
-//     through tile_next in the rare rest.
-// Same bytes as k_assemble in every mode it takes (launch_assemble: everything but level-2 value lists).
-typedef u32x4 u32x4_u __attribute__((aligned(1)));
-typedef u32x2 u32x2_u __attribute__((aligned(1)));
-typedef uint32_t u32_u __attribute__((aligned(1)));
-typedef uint16_t u16_u __attribute__((aligned(1)));
-
-__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src_lane)   // v of lane src_lane (every lane must be active)
-{
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src_lane), (int)v);
-}
-
-// one piece: y = the 160-bit string (x, e) >> sh, its first `valid` (1..16) bytes to p
-template <bool BITS>
-__device__ __forceinline__ void put_piece(uint8_t *p, const u32x4 &x, uint32_t e, uint32_t sh, uint32_t valid)
-{
-    u32x4 y = x;
-    if (BITS) {
-        y[0] = __builtin_amdgcn_alignbit(x[1], x[0], sh); y[1] = __builtin_amdgcn_alignbit(x[2], x[1], sh);
-        y[2] = __builtin_amdgcn_alignbit(x[3], x[2], sh); y[3] = __builtin_amdgcn_alignbit(e, x[3], sh);
-    }
-    if (valid >= 16) { *reinterpret_cast<u32x4_u *>(p) = y; return; }
-    uint32_t a0 = y[0], a1 = y[1];
-    if (valid & 8u) { *reinterpret_cast<u32x2_u *>(p) = u32x2{a0, a1}; p += 8; a0 = y[2]; a1 = y[3]; }
-    if (valid & 4u) { *reinterpret_cast<u32_u *>(p) = a0; p += 4; a0 = a1; }
-    if (valid & 2u) { *reinterpret_cast<u16_u *>(p) = (uint16_t)a0; p += 2; a0 >>= 16; }
-    if (valid & 1u) *p = (uint8_t)a0;
-}
-
-#ifndef RC_GATHER_U
-#define RC_GATHER_U 4   // rounds of pieces whose loads are in flight together
-#endif
-#ifndef RC_GATHER_WPE
-#define RC_GATHER_WPE 4   // waves per SIMD the register allocation aims at (8: at most 64 VGPRs)
-#endif
-template <bool BITS, int U>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WPE))) void k_gather(Scratch sc, RecordParams rp, uint8_t *__restrict__ out, const uint64_t *__restrict__ rec_off,
-                                               uint32_t lz4f_hdr_bitmap, uint32_t lz4f_hdr_pix, uint32_t batch_seq, uint32_t gpf, uint32_t nitems)
-{
-    if (sc.status->code != 0) {   // (as k_assemble: the batch's last kernel remembers the first failure across asynchronously enqueued batches)
-        if (blockIdx.x == 0 && threadIdx.x == 0 && sc.first_err && sc.first_err->code == 0) {
-            sc.first_err->frame = sc.status->frame;
-            sc.first_err->total = batch_seq;
-            sc.first_err->code = sc.status->code;
-        }
-        return;
-    }
-    const uint32_t lane = (uint32_t)lane_id();
-    const bool flat = rp.pix_mode == 1, skip_pix = rp.pix_mode == 2;
-    const bool pixp = rp.level == 1 && rp.packed_slots && !skip_pix;
-    const bool plain_pos = rp.emit == 0 || flat;
-    const uint32_t d = rp.depth;
-    const FrameFmt ff = frame_fmt(rp.emit);
-    const uint32_t bhdr = bitmap_hdr(ff, rp.emit, sc.ntiles);
-    const uint8_t *pix_base = reinterpret_cast<const uint8_t *>(sc.pix_slots);
-    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const uint32_t f = item / gpf, g = item - f * gpf, t0 = 64u * g, t = t0 + lane;
-        const bool have = t < sc.ntiles;
-        const uint64_t frow = (uint64_t)f * sc.ntiles;
-        uint8_t *rec = flat ? sc.pixraw + (uint64_t)f * sc.pixraw_stride : out + rec_off[f];
-        const uint32_t nnz = rp.level == 1 ? sc.frame_nnz[f] : 0;
-        const uint32_t npk = rp.level == 1 ? packed_bytes(nnz, d) : 0;
-        uint64_t bitmap_pos = 0, pix_pos = 0;
-        uint32_t cb = 0;
-        if (!flat) {
-            if (rp.emit == 0) { bitmap_pos = rp.level == 1 ? 8 : 4; pix_pos = bitmap_pos + sc.nb; }
-            else { cb = bhdr + sc.frame_cbytes[f] + ff.end; bitmap_pos = rp.level == 1 ? 16 : 8; pix_pos = bitmap_pos + cb; }
-        }
-        if (g == 0 && lane == 0 && !flat) record_fixed_fields(sc, rp, f, rec, bitmap_pos, pix_pos, cb, npk, ff, skip_pix, lz4f_hdr_bitmap, lz4f_hdr_pix);
-        uint8_t *pdst = rec + pix_pos;
-
-        // ---- bookkeeping, a lane per tile -------------------------------------------------------------------------------------------
-        // block segment: bsz bytes from the slot's start (mode 0: from the raw binary map) to rec + bdst
-        // residual segment: rn whole stream bytes, source bit ps0 of the tile's packed stream onwards, to rec + rdst; source at slot + rs
-        // (rs = ~0: the tile's residual slot)
-        uint32_t word = 0, bsz = 0, bdst = 0, cnt = 0, rn = 0, rdst = 0, rs = 0xFFFFFFFFu, ps0 = 0, blo = 0;
-        uint32_t fin_avail = 0, fin_q = 0, fin_b = 0, slow_n = 0;
-        if (have && rp.emit != 0 && (!flat || (sc.comb == 1 && pixp))) word = sc.blk_size[frow + t];
-        if (have && !flat) {
-            if (rp.emit == 0) {
-                const uint64_t b0 = (uint64_t)t * TILE_BM;
-                bsz = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
-                bdst = (uint32_t)(bitmap_pos + b0);
-            } else {
-                bsz = word;
-                const uint32_t boff = bhdr + sc.blk_off[frow + t];
-                bdst = (uint32_t)bitmap_pos + boff;
-                if (rp.emit == 8) store_u32_le(rec + bitmap_pos + 16 + 4 * (uint64_t)t, boff);   // blosc bstarts[t]
-            }
-        }
-        if (have && pixp) {
-            cnt = sc.tile_cnt[frow + t];
-            if (cnt) {
-                const uint64_t dbit = (uint64_t)sc.tile_off[frow + t] * d;   // stream position of the tile's first bit
-                const uint32_t nbits = cnt * d;
-                const uint64_t b_lo = (dbit + 7) >> 3, b_hi = (dbit + nbits + 7) >> 3;
-                const uint32_t avail = (uint32_t)((dbit + nbits) & 7u);
-                uint32_t n = (uint32_t)(b_hi - b_lo);
-                ps0 = (uint32_t)(8 * b_lo - dbit);
-                blo = (uint32_t)b_lo;
-                if (avail && n) {   // (n == 0: the tile's few bits all live in a byte that an earlier tile owns)
-                    --n;
-                    fin_avail = avail; fin_q = 8 * n + ps0; fin_b = (uint32_t)(b_hi - 1);
-                }
-                if (sc.comb) {   // (rc_launch.h::residual_src)
-                    const uint32_t ro16 = sc.comb == 2 ? (uint32_t)BLK_SLOT / 16 : (word + 15) >> 4, r16 = (cnt * d + 127) >> 7;
-                    if (16 * (ro16 + r16) <= sc.blk_stride) rs = 16 * ro16;
-                }
-                if (n && !plain_pos && (b_lo >> ff.chunk_shift) != ((b_lo + n - 1) >> ff.chunk_shift)) slow_n = n;   // straddles a stored-chunk header: below
-                else rn = n;
-                rdst = (uint32_t)(pix_pos + (plain_pos ? b_lo : stored_pos(ff, b_lo)));
-            }
-        }
-        // the first tile behind the item, for the last tile's shared byte (BITS)
-        uint32_t ext_cnt = 0, ext_first = 0;
-        if (BITS && pixp && t0 + 64 < sc.ntiles) {
-            ext_cnt = sc.tile_cnt[frow + t0 + 64];
-            if (ext_cnt)
-                ext_first = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + t0 + 64, sc.comb == 1 ? sc.blk_size[frow + t0 + 64] : 0u, ext_cnt, d));
-        }
-        const uint8_t *slot = rp.emit == 0 ? sc.bitmap + (uint64_t)f * sc.nb_stride + (uint64_t)t0 * TILE_BM : sc.blk_slots + (frow + t0) * sc.blk_stride;
-        const uint32_t slot_stride = rp.emit == 0 ? (uint32_t)TILE_BM : sc.blk_stride;
-        const uint8_t *rslot = pix_base + (frow + t0) * sc.pix_slot_bytes;
-
-        // ---- pieces -------------------------------------------------------------------------------------------------------------------
-        const uint32_t nb16 = (bsz + 15) >> 4, tot = nb16 + ((rn + 15) >> 4);
-        const uint32_t incl = wave_incl_scan(tot), cum = incl - tot, T = wave_last(incl);
-        const uint32_t packed = bsz | (ps0 << 10) | (rn << 13);   // bsz <= 644, ps0 <= 7, rn <= 16 384
-        for (uint32_t i0 = 0; 64u * i0 < T; i0 += U) {
-            u32x4 x[U];
-            uint32_t e[U], dsto[U], meta[U];   // meta: valid bytes | shift << 8
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t P = 64u * (i0 + u) + lane;
-                uint32_t k = 0;   // the tile of piece P: the last one whose first piece is <= P
-#pragma unroll
-                for (uint32_t step = 32; step; step >>= 1) {
-                    const uint32_t c = lane_get(cum, k + step);
-                    if (c <= P) k += step;
-                }
-                const uint32_t ck = lane_get(cum, k), pk = lane_get(packed, k), bd = lane_get(bdst, k), rd = lane_get(rdst, k), rsk = lane_get(rs, k);
-                const uint32_t bsz_k = pk & 1023u, ps0_k = (pk >> 10) & 7u, rn_k = pk >> 13;
-                const uint32_t idx = P - ck, nbk = (bsz_k + 15) >> 4;
-                const bool isb = idx < nbk;
-                const uint32_t j = isb ? idx : idx - nbk;
-                const uint32_t left = (isb ? bsz_k : rn_k) - 16u * j;
-                const bool act = P < T;
-                const uint8_t *src = isb ? slot + (uint64_t)k * slot_stride + 16u * j
-                                         : (rsk == 0xFFFFFFFFu ? rslot + (uint64_t)k * sc.pix_slot_bytes : slot + (uint64_t)k * slot_stride + rsk) + 16u * j;
-                dsto[u] = (isb ? bd : rd) + 16u * j;
-                meta[u] = act ? (min(left, 16u) | ((isb ? 0u : ps0_k) << 8)) : 0u;
-                x[u] = u32x4{0u, 0u, 0u, 0u};
-                e[u] = 0;
-                if (act) {
-                    x[u] = *reinterpret_cast<const u32x4 *>(src);
-                    if (BITS && !isb && ps0_k) e[u] = *reinterpret_cast<const uint32_t *>(src + 16);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (meta[u] & 0xFFu) put_piece<BITS>(rec + dsto[u], x[u], e[u], meta[u] >> 8, meta[u] & 0xFFu);
-        }
-        if (!pixp) continue;
-
-        // ---- a tile whose residual bytes straddle a stored-chunk header of the pixel frame (once per 4 MiB / 128 KiB): byte by byte --------
-        for (uint64_t m = __builtin_amdgcn_ballot_w64(slow_n != 0); m; m &= m - 1) {
-            const uint32_t k = (uint32_t)__builtin_ctzll(m);
-            const uint32_t n = lane_get(slow_n, k), p0 = lane_get(ps0, k), b0 = lane_get(blo, k), rsk = lane_get(rs, k);
-            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(rsk == 0xFFFFFFFFu ? rslot + (uint64_t)k * sc.pix_slot_bytes : slot + (uint64_t)k * slot_stride + rsk);
-            for (uint32_t i = lane; i < n; i += 64) {
-                const uint32_t q = 8 * i + p0;
-                pdst[stored_pos(ff, (uint64_t)b0 + i)] = (uint8_t)__builtin_amdgcn_alignbit(s32[(q >> 5) + 1], s32[q >> 5], q & 31u);
-            }
-        }
-        if (!BITS) continue;
-
-        // ---- the stream byte a tile shares with its successor(s) --------------------------------------------------------------------------
-        const uint8_t *psrc = rs == 0xFFFFFFFFu ? rslot + (uint64_t)lane * sc.pix_slot_bytes : slot + (uint64_t)lane * slot_stride + rs;
-        const uint32_t first = cnt ? *reinterpret_cast<const uint32_t *>(psrc) : 0u;
-        uint32_t byte = 0, got = 8;
-        if (fin_avail) {
-            byte = (*reinterpret_cast<const u32_u *>(psrc + (fin_q >> 3)) >> (fin_q & 7u)) & ((1u << fin_avail) - 1u);
-            got = fin_avail;
-        }
-        const uint64_t nonempty = __builtin_amdgcn_ballot_w64(cnt != 0);
-        uint32_t cur = lane;   // the last tile of the item whose bits the byte has (64: the first tile behind the item)
-        while (__builtin_amdgcn_ballot_w64(got < 8 && cur < 64) != 0) {   // wave-uniform: lane_get needs every lane
-            const uint64_t higher = cur >= 63 ? 0ull : nonempty & (~0ull << (cur + 1));
-            const uint32_t nxt = higher ? (uint32_t)__builtin_ctzll(higher) : 64u;
-            const uint32_t cc = lane_get(cnt, nxt & 63u), fd = lane_get(first, nxt & 63u);
-            if (got < 8 && cur < 64) {
-                const bool in = nxt < 64;
-                const uint32_t c2 = in ? cc : ext_cnt, f2 = in ? fd : ext_first;
-                if (in || c2) {
-                    const uint32_t take = min(8u - got, c2 * d);
-                    byte |= (f2 & ((1u << take) - 1u)) << got;
-                    got += take;
-                    cur = nxt;
-                } else cur = 65;   // the tile behind the item is empty (or the frame ends): tile_next from the item's last tile
-            }
-        }
-        if (got < 8) {   // rare: the chain leaves the item's neighbourhood
-            uint32_t tt = cur == 65 ? (t0 + 63 < sc.ntiles ? sc.tile_next[frow + t0 + 63] : sc.ntiles) : (t0 + 64 < sc.ntiles ? sc.tile_next[frow + t0 + 64] : sc.ntiles);
-            while (tt < sc.ntiles) {
-                const uint32_t cc = sc.tile_cnt[frow + tt];
-                const uint32_t fd = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + tt, sc.comb == 1 ? sc.blk_size[frow + tt] : 0u, cc, d));
-                const uint32_t take = min(8u - got, cc * d);
-                byte |= (fd & ((1u << take) - 1u)) << got;
-                got += take;
-                if (got >= 8) break;
-                tt = sc.tile_next[frow + tt];
-            }
-        }
-        if (fin_avail) pdst[plain_pos ? (uint64_t)fin_b : stored_pos(ff, fin_b)] = (uint8_t)byte;
-    }
-}
-
 // xxHash32 of the two descriptor bytes -> LZ4 frame header checksum byte (lz4_Frame_format.md, "HC")
 static uint32_t xxh32_small(const uint8_t *p, size_t n)
 {
@@ -1933,19 +1539,11 @@ void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint
 {
     static const uint32_t hdr_bitmap = lz4f_descriptor(0x40);  // 64 KiB max block (blocks are <= 2 KiB)
     static const uint32_t hdr_pix = lz4f_descriptor(0x70);     // 4 MiB max block (stored chunks)
-    // Everything but level-2 value lists (uint16 values that k_assemble packs on the way) goes through k_gather: few one-wave workgroups,
-    // each walking items of 64 tiles.  How many: enough to finish inside the step the stage is hidden behind, few enough to live in what the
-    // next batch's reduce kernel leaves free on the CUs (one wave per CU; measured: tools/r05_gather_grid.sh).
-    static const char *old_env = RC_KNOB("RC_OLD_ASSEMBLE"), *wgs_env = RC_KNOB("RC_GATHER_WGS");
+    // Everything but level-2 value lists (uint16 values that k_assemble packs on the way) goes through k_gather (rc_gather.hip)
+    static const char *old_env = RC_KNOB("RC_OLD_ASSEMBLE");
     const bool lists = rp.level == 1 && !rp.packed_slots && rp.pix_mode != 2;
     if (!lists && !old_env) {
-        const uint32_t gpf = (sc.ntiles + 63) / 64, nitems = gpf * B;
-        uint32_t wgs = wgs_env ? (uint32_t)atoi(wgs_env) : 0u;   // 0: a workgroup per item
-        if (wgs == 0 || wgs > nitems) wgs = nitems;
-        if (rp.level == 1 && rp.depth % 8 != 0)
-            hipLaunchKernelGGL((k_gather<true, RC_GATHER_U>), dim3(wgs), dim3(64), 0, s, sc, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems);
-        else
-            hipLaunchKernelGGL((k_gather<false, RC_GATHER_U>), dim3(wgs), dim3(64), 0, s, sc, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems);
+        launch_gather(sc, rp, B, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, s);
         return;
     }
     const uint32_t per_wg = AWAVES * ASM_TPW;

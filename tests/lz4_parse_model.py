@@ -7,6 +7,7 @@ import numpy as np
 EV_MAX = 62      # one event per lane (lane 0 = the block start)
 EV_MAX2 = 126    # two events per lane (rc_lz4_block.h::lz4_parse_events2): the same rules, event numbers take 7 bits of the keys
 NM_MAX2 = 126    # ... and at most this many matches (the position tables' size); beyond either the run parser
+NZ_STORE = 272   # compression_level >= 1: a block with more non-zero bytes than this is stored without a parse (rc_lz4_block.h::LZ4_NZ_STORE)
 
 
 def emit(block, matches):
@@ -108,6 +109,8 @@ def parse_events(block):
 
 def encode_block(block, level):
     """(size word, payload) as they stand in an LZ4 frame: the compressed block, or the block stored (bit 31) if that is not smaller"""
+    if level and int(np.count_nonzero(np.frombuffer(block, np.uint8))) > NZ_STORE:
+        return len(block) | 0x80000000, bytes(block)
     m = parse_events(block) if level else None
     if m is None:
         m = parse_runs(block)

@@ -75,11 +75,12 @@ def test_bench_launches_its_own_ranks():
 def test_bench_fails_when_a_record_fails_the_check():
     """`verified: false` must be an exit code, not only a field: with one byte of a checked record flipped (test switch
     RC_BENCH_CORRUPT_RECORD) the line still appears and says false, and the process returns non-zero.  Without the switch every
-    distinct batch of the stack has one record checked."""
+    distinct batch of the stack has two records checked - one inside it and its last."""
     args = [sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--stack", "64", "--batch", "16", "--no-cpu-baseline", "--no-ingest",
             "--min-seconds", "0.1"]
     d = _run(args)
-    assert d["verified"] is True and len(d["records_checked"]) == 4 and sorted(c["batch"] for c in d["records_checked"]) == [0, 1, 2, 3]
+    assert d["verified"] is True and len(d["records_checked"]) == 8 and sorted(c["batch"] for c in d["records_checked"]) == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert sum(1 for c in d["records_checked"] if c["record"] == 15) == 4          # every batch's last record is among them
     assert all(c["ok"] for c in d["records_checked"])
     assert d["host_enqueue_us_per_step"] > 0 and d["roofline"]["pattern_floor_ms"]["reads_only"] > 0
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RC_BENCH_CORRUPT_RECORD="1")

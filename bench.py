@@ -7,8 +7,8 @@ touched the GPU - relays rank 0's line and exits non-zero if any rank fails; lau
 (one rank per GPU, RCCL).
 
   step      one pass of the hot path over one batch of B synthetic frames per GPU, inputs resident in HBM:
-            rc_reduce_compress_batch_async = reduce kernel (LZ4 bitmap encoder fused in) -> scans -> record layout ->
-            assembly (zstd: its block encoder runs as a kernel of its own after the reduce kernel),
+            rc_reduce_compress_batch_async = reduce kernel (every device codec's block encoder fused in) -> scans -> record
+            layout -> k_gather (zstd: the serial FSE chain and the residuals' Huffman stage are kernels of their own in between),
             records + offsets + metadata left in HBM; for N > 1 each step also issues the path's one exchange step, the
             RCCL all-gather of the per-frame metadata (12 B / frame), on a side stream so that it overlaps
             the next step (metadata rows double-buffered; all of them are complete inside the timed region):
@@ -16,12 +16,13 @@ touched the GPU - relays rank 0's line and exits non-zero if any rank fails; lau
   workload  BASELINE.json configs[1]: 4096x4096 uint16, 1 % sparsity, L1 + LZ4 (d = 16 primary; --depth 12 secondary);
             --config 1..5 = the other BASELINE configurations, --clustered = detector-like events.
   value     frames/s, whole job (all ranks' frames / max-over-ranks time); gb_per_s_in = value * 2*nx*ny.
-  verified  every rank decodes one record of its last batch with the stock library / the oracle's decoders and compares it with the
-            oracle's reduce of that frame (level 2: scipy.ndimage.label); gather_verified: every rank's block of the metadata table
-            the last step gathered, on every rank.
+  verified  every rank decodes TWO records of every distinct batch of its stack - one inside the batch and its last - with the stock
+            library / the oracle's decoders and compares them with the oracle's reduce of those frames (level 2: scipy.ndimage.label);
+            gather_verified: every rank's block of the metadata table the last step gathered, on every rank.
   roofline  dominant kernel = the reduce kernel (k_reduce_tiles): algorithmic bytes per launch = B * 2*nx*ny
             (one read of the uint16 frames) / its mean duration, measured with HIP events on the ctx's
-            stream inside the timed region; peak = 8000 GB/s (MI355X_MICROARCH.md).
+            stream inside the timed region - around every --kernel-events-every-th launch (default 4: the events are packets of
+            their own between two reduce kernels); peak = 8000 GB/s (MI355X_MICROARCH.md).
   cpu_baseline  the oracle's C restatement (+ stock liblz4 for the LZ4 stage) on the box's host cores, bounded sample.
 """
 import argparse
@@ -68,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--source-bytes", type=int, default=2, choices=[1, 2, 4], help="bytes per source pixel: 2 = uint16 frames (every BASELINE configuration), 1 = uint8 frames (source_bit_depth <= 8: the reference's map_dtype, misc.py:41-49; implies --depth 8 unless given lower), 4 = uint32 frames (> 16 bits; implies --depth 20 unless given above 16); both without the CPU baseline / ingest legs")
     ap.add_argument("--read", action="store_true", help="measure the READER instead: stored frames -> device decode of both streams -> sparse expand (rc_expand_frames)")
     ap.add_argument("--blob-on-device", action="store_true", help="--read: the stored frames' bytes already sit in device memory (the decoders without the link)")
+    ap.add_argument("--kernel-events-every", type=int, default=4, help="HIP events around every k-th reduce-kernel launch of the timed region (roofline.kernel_ms is their mean; "
+                    "1: every launch).  A timing event is a packet of its own between two reduce kernels: with events around every launch the step is 1.3 %% longer "
+                    "(same box, profiles/r05_exp12_level2_listed_words_events.log)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the extra ingest-inclusive measurement (host frames -> part file)")
     ap.add_argument("--ingest-frames", type=int, default=512, help="frames per pass of the ingest-inclusive measurement (capped at 16 GiB of host memory)")
     ap.add_argument("--no-pipeline", action="store_true", help="plain stream order: a batch's reduce kernel waits for the previous batch's records")
@@ -606,7 +610,7 @@ def run_rank(a):
         for i in range(a.warmup):
             step(i)
         ctx.sync()
-        ctx.set_profiling(True)
+        ctx.set_profiling(True, every=a.kernel_events_every)
         times, k_ms_list, it, issue = [], [], a.warmup, []
         more = True
         while more:
@@ -621,8 +625,8 @@ def run_rank(a):
             it += a.steps
             ctx.sync()  # also raises if the device flagged a batch
             sums, nbatches = ctx.profile()
-            ctx.set_profiling(True)   # clears the sums for the next repeat
-            assert nbatches == a.steps
+            ctx.set_profiling(True, every=a.kernel_events_every)   # clears the sums for the next repeat
+            assert nbatches == -(-a.steps // a.kernel_events_every)   # every k-th launch of the region carries events, the first included
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             if use_dist:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -757,7 +761,7 @@ def run_rank(a):
             "roofline": {"bound": "hbm", "kernel": "k_reduce_tiles32" if a.source_bytes == 4 else "k_reduce_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "traffic_ratio": (round(traffic / (B * frame_bytes), 4) if traffic else None),
-                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": B * frame_bytes,
+                         "kernel_ms": round(k_ms, 4), "kernel_events_every": a.kernel_events_every, "algorithmic_bytes_per_launch": B * frame_bytes,
                          "pattern_floor_ms": pattern_floor(N, B, k_ms) if a.source_bytes == 2 else None,
                          "whole_path_frac": round(fps / world * frame_bytes / 1e9 / HBM_PEAK_GBS, 4)},
             # only the events the roofline needs are recorded in the timed region (each costs stream time); the full

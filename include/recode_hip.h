@@ -208,7 +208,9 @@ int rc_get_stage_ms(rc_ctx *ctx, float ms[5]);
 
 /* Stage timing of the ASYNCHRONOUS path: with profiling on, every rc_reduce_compress_batch_async brackets its stages
  * with HIP events on the ctx's stream; rc_ctx_sync folds them into running sums (same 5 slots as rc_get_stage_ms).
- * rc_ctx_set_profiling also clears the sums.  Used by bench.py to measure the dominant kernel inside the timed region. */
+ * rc_ctx_set_profiling also clears the sums.  Used by bench.py to measure the dominant kernel inside the timed region.
+ * on = k > 1: events around every k-th batch only, starting with the next one (a timing event is a packet of its own on the
+ * stream, a few microseconds between two reduce kernels; rc_ctx_get_profile's `batches` counts the bracketed ones). */
 int rc_ctx_set_profiling(rc_ctx *ctx, int on);
 int rc_ctx_get_profile(rc_ctx *ctx, double sum_ms[5], uint64_t *batches);
 

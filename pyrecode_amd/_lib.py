@@ -291,8 +291,9 @@ class ReduceContext:
     def keep_binary_maps(self, on=True):
         check(lib().rc_ctx_keep_binary_maps(self._h, 1 if on else 0))
 
-    def set_profiling(self, on=True):
-        check(lib().rc_ctx_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on=True, every=1):
+        """Stage events on the asynchronous path; every = k > 1: around every k-th batch only."""
+        check(lib().rc_ctx_set_profiling(self._h, (max(int(every), 1) if on else 0)))
 
     def profile(self):
         """(sum_ms[5], batches) accumulated by the asynchronous path since set_profiling()."""

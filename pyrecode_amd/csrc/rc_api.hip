@@ -40,8 +40,8 @@ struct rc_ctx {
     bool modelled = false, model_ready = false;
     rc::ZstdModel *d_model = nullptr, *h_model = nullptr;
     rc::ZstdSample *d_sample = nullptr, *h_sample = nullptr;
-    rc::L2Work l2;                        // level 2 workspace
     uint32_t l2_sum = 0;                  // L2_statistics: 0/1 max, 2 sum
+    rc::u32x2 *d_l2_node = nullptr;       // level 2: the labelling stage's nodes (rc_l2.hip), shared by both scratch sets
     rc::BatchStatus *h_status = nullptr;  // pinned: [0] most recent batch, [1] first failed batch since the last sync
     rc::BatchStatus *d_first_err = nullptr;
     uint32_t batch_seq = 0;               // batches enqueued since the last rc_ctx_sync
@@ -49,6 +49,7 @@ struct rc_ctx {
     float stage_ms[5] = {};
     // optional per-enqueue stage events for the asynchronous path (rc_ctx_set_profiling)
     bool profiling = false;
+    uint32_t prof_every = 1, prof_phase = 0;   // events around every prof_every-th batch (rc_ctx_set_profiling(ctx, k))
     bool profile_all = getenv("RC_PROFILE_ALL_STAGES") != nullptr;
     // host streaming form (rc_pipe_*): per slot device buffers, pinned metadata, events
     struct PipeSlot {
@@ -112,7 +113,7 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
 {
     using namespace rc;
     const uint64_t B = c->max_batch, T = sc.ntiles;
-    HIP_TRY(hipMalloc((void **)&sc.bitmap, B * sc.nb_stride + 64));  // + slack: wave_copy reads <= 4 B past a tile
+    HIP_TRY(hipMalloc((void **)&sc.bitmap, B * sc.nb_stride + 64));  // + slack: k_gather reads whole 16-byte pieces
     HIP_TRY(hipMalloc((void **)&sc.tile_cnt, B * T * 4));
     HIP_TRY(hipMalloc((void **)&sc.tile_off, B * T * 4));
     HIP_TRY(hipMalloc((void **)&sc.tile_next, B * T * 4));
@@ -147,18 +148,6 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
     HIP_TRY(hipMemset(sc.frame_nnz, 0, B * 4));
     HIP_TRY(hipMemset(sc.frame_cbytes, 0, B * 4));
     HIP_TRY(hipMemset(sc.status, 0, sizeof(BatchStatus)));
-    return RC_OK;
-}
-
-// the level-2 workspace (rc_launch.h::L2Work): sized by the geometry alone - every pixel of a batch has its entry, no batch can exceed it
-static int l2_alloc(rc_ctx *c)
-{
-    using namespace rc;
-    L2Work &w = c->l2;
-    w.ids_per_frame = (uint64_t)c->sc.ntiles * TILE_PX;
-    HIP_TRY(hipMalloc((void **)&w.parent, (uint64_t)c->max_batch * w.ids_per_frame * 4));
-    HIP_TRY(hipMalloc((void **)&w.stat, (uint64_t)c->max_batch * w.ids_per_frame * 4));
-    HIP_TRY(hipMalloc((void **)&w.word_base, (uint64_t)c->max_batch * c->sc.ntiles * 64 * 2));
     return RC_OK;
 }
 
@@ -216,13 +205,17 @@ static int ctx_alloc(rc_ctx *c)
         int r = alloc_set(c, set);
         if (r != RC_OK) return r;
     }
-    c->sc = c->sets[0];
     if (c->level == 2) {
-        // parent / accumulator entries for every pixel of a batch (8 bytes each: 8.6 GB for 64 frames of 4096^2, of which only the set
-        // pixels' entries are ever touched) - nothing next to 288 GB, and no batch can exceed it
-        int r = l2_alloc(c);
-        if (r != RC_OK) return r;
+        // level 2 (rc_l2.hip): a node {parent, accumulator} for every pixel of a batch (8 bytes each: 8.6 GB for 64 frames of 4096^2, of
+        // which only the entries of set pixels with neighbours are ever touched), at rest - zero - between batches.  One workspace for
+        // both scratch sets (the labelling stages of two batches never overlap: they share the second-stage stream); sized by the
+        // geometry, so no batch can exceed it.
+        const uint64_t ids = (uint64_t)c->sc.ntiles * rc::TILE_PX;
+        HIP_TRY(hipMalloc((void **)&c->d_l2_node, B * ids * 8));
+        HIP_TRY(hipMemset(c->d_l2_node, 0, B * ids * 8));
+        for (Scratch &set : c->sets) { set.l2_node = c->d_l2_node; set.l2_ids_per_frame = ids; }
     }
+    c->sc = c->sets[0];
     if (c->emit == RC_SCHEME_ZSTD) {
         std::vector<uint8_t> tab(zstd_tables_bytes());
         zstd_tables_host(tab.data());
@@ -265,6 +258,10 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
     }
     if (reduction_level < 1 || reduction_level > 3) {
         *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 4 (centroiding) is not implemented on device");
+        return nullptr;
+    }
+    if (reduction_level == 2 && nx > 65535u) {   // (the labelling stage keeps the word bases of a row's worth of tiles in LDS; the reference's C type holds nx in 16 bits, pyrecode.cpp:21-22)
+        *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 2 needs nx <= 65535");
         return nullptr;
     }
     if (src_bit_depth < 1 || src_bit_depth > 32) {   // (<= 8: the reference's source dtype is uint8, > 16: uint32 - rc_ctx_set_source_bytes)
@@ -314,7 +311,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (rc::Scratch &sc : c->sets) {
         void *per_set[] = {sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
-                           sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.scan_part, sc.status, sc.pixraw, sc.pix_chunks, sc.chunk_size,
+                           sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.scan_part, sc.status, sc.pixraw, sc.pix_chunks, sc.chunk_size, 
                            sc.chunk_off, sc.frame_pbytes};
         for (void *b : per_set)
             if (b) (void)hipFree(b);
@@ -332,7 +329,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_sample) (void)hipHostFree(c->h_sample);
     void *bufs[] = {c->sc.thr, c->thr32, c->d_first_err, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
-                    c->d_md, c->d_ztab, c->d_model, c->d_sample, c->l2.parent, c->l2.stat, c->l2.word_base};
+                    c->d_md, c->d_ztab, c->d_model, c->d_sample, c->d_l2_node};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     hipEvent_t sync_ev[] = {c->ev_red[0], c->ev_red[1], c->ev_post[0], c->ev_post[1], c->ev_in[0], c->ev_in[1]};
@@ -510,7 +507,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     rp.frame_bytes = c->sc.N * c->src_bytes;   // a record may not exceed the raw frame (recode_writer.py:565-566)
     hipEvent_t *ev = nullptr;
     if (timed) ev = c->ev;
-    else if (c->profiling) {
+    else if (c->profiling && (c->prof_phase++ % c->prof_every) == 0) {
         if (c->prof_used + 5 > c->prof_ev.size()) {
             for (int i = 0; i < 5; ++i) {
                 hipEvent_t e;
@@ -531,7 +528,16 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     c->sc = c->sets[k];
     const rc::Scratch &sc = c->sets[k];
     hipStream_t ps = c->pstream;
-    if (c->post_pending[k]) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));  // the batch two calls ago has left this set
+    if (c->post_pending[k]) {   // the batch two calls ago must have left this set
+        // ... which it usually has long ago: then nothing is put on the stream (every packet between two reduce kernels - a wait, an
+        // event record - is a few microseconds during which the chip drains: 18.6 us between consecutive reduce kernels with three of
+        // them, profiles/r05_exp7_phase_shares_batch_gaps.log)
+        if (hipEventQuery(c->ev_post[k]) == hipSuccess) c->post_pending[k] = false;
+        else {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
+        }
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     // every device codec's block encoder runs inside the reduce kernel (LZ4; blosc = bit-shuffle + LZ4; zstd: the
     // byte-parallel half - literals, sequence tokens - with the serial FSE half lane-per-block behind it)
@@ -559,7 +565,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     hipEvent_t red = ev ? ev[1] : c->ev_red[k];
     HIP_TRY(hipEventRecord(red, s));
     HIP_TRY(hipStreamWaitEvent(ps, red, 0));
-    if (c->level == 2) launch_l2(sc, c->l2, n, c->nx, c->l2_sum, c->depth, ps);   // the tiles' raw values -> their components' statistics (rc_l2.hip)
+    if (c->level == 2) launch_l2(sc, n, c->nx, c->l2_sum, c->depth, ps);   // the tiles' raw values -> their components' statistics (rc_l2.hip)
 #ifdef RC_DEV_SKIP   // development builds only (tools/build_def.sh): leave second-stage kernels out (WRONG records) to see what each costs the
                      // reduce kernel running next to it - bits: 1 FSE, 2 scans, 4 residual Huffman chain, 8 layout, 16 assemble, 32 gather
     static const unsigned skip = getenv("RC_DEV_SKIP_BITS") ? (unsigned)atoi(getenv("RC_DEV_SKIP_BITS")) : 0u;
@@ -899,6 +905,8 @@ RC_EXPORT int rc_ctx_set_profiling(rc_ctx *c, int on)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
     c->profiling = on != 0;
+    c->prof_every = on > 1 ? (uint32_t)on : 1u;
+    c->prof_phase = 0;
     for (double &v : c->prof_sum_ms) v = 0;
     c->prof_batches = 0;
     return RC_OK;

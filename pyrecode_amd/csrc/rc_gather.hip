@@ -8,7 +8,7 @@
 namespace rc {
 
 // ---- record assembly, second form (round 5): k_gather ---------------------------------------------------------------------------------
-// k_assemble above gives every tile a quarter-wave: 32 768 short-lived wavefronts per 64 frames of 4096^2, each with three dependent
+// Its predecessor, k_assemble (rounds 1-4), gave every tile a quarter-wave: 32 768 short-lived wavefronts per 64 frames of 4096^2, each with three dependent
 // round trips (indices, data, stores) for 1.8 KB of payload, in four-wave workgroups that only start where a reduce workgroup of the
 // NEXT batch has just retired - 85 us alone, 300 us next to the reduce kernel, and what it takes from that kernel is what the step
 // loses (profiles/r04_decompose_*.log).  k_gather does the same copy with few, long-lived, one-wave workgroups that need no LDS
@@ -25,7 +25,7 @@ namespace rc {
 //     per piece); the stream byte a tile shares with its successor is completed from the successor's leading bits - in registers when
 //     the successor is a tile of the same item, from the first tile behind the item otherwise (fetched with the item's bookkeeping),
 //     through tile_next in the rare rest.
-// Same bytes as k_assemble in every mode it takes (launch_assemble: everything but level-2 value lists).
+// Same bytes as k_assemble in every mode (same-box A/B and the whole suite, round 5); level 2 arrives here as tile-local packed streams too.
 // what k_gather needs of the scratch set (same member names as Scratch: the kernel's argument block stays small - the whole Scratch is
 // 60 scalar registers of pointers the kernel never touches, and the spills they cause sit in the item loop)
 struct GatherArgs {
@@ -97,7 +97,7 @@ template <bool BITS, int U>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WPE))) void k_gather(GatherArgs sc, RecordParams rp, uint8_t *__restrict__ out, const uint64_t *__restrict__ rec_off,
                                                uint32_t lz4f_hdr_bitmap, uint32_t lz4f_hdr_pix, uint32_t batch_seq, uint32_t gpf, uint32_t nitems)
 {
-    if (sc.status->code != 0) {   // (as k_assemble: the batch's last kernel remembers the first failure across asynchronously enqueued batches)
+    if (sc.status->code != 0) {   // (the batch's last kernel remembers the first failure across asynchronously enqueued batches)
         if (blockIdx.x == 0 && threadIdx.x == 0 && sc.first_err && sc.first_err->code == 0) {
             sc.first_err->frame = sc.status->frame;
             sc.first_err->total = batch_seq;

@@ -6,201 +6,350 @@
 //   (pyrecode/utils/converters.py:262-297)                                     frame values, cast to the source dtype
 // The record then carries the full binary map and the statistics where L1 carries the residuals (recode_writer.py:461-525).
 //
-// Device formulation (round 5).  The reduce kernel leaves, per tile of 4096 pixels, the raw binary map (64 words of 64 pixels) and the
-// raw values of its set pixels in raster order (the tile's value slot).  A set pixel's ID inside its frame is tile * 4096 + its rank
-// among the tile's set pixels: ids grow in raster order, need no per-frame prefix (no scan in front of this stage) and address two
-// sparse arrays, parent[] and stat[], of which only the entries of set pixels are ever touched.  Four passes, a wavefront per tile:
-//   k_l2_prep    a lane per word: popcount, wave scan -> the word's rank base inside its tile (u16 directory); parent[id] = id and
-//                stat[id] = 0 for the tile's set pixels (rank-parallel, whole lines)
-//   k_l2_link    a lane per word: which of its pixels have a set neighbour among W, NW, N, NE comes from WORD arithmetic on the word, its
-//                left neighbour and the three words around it one row up (funnel-shifted: the row length need not be a multiple of
-//                64) - at 1 % Bernoulli 96 % of the set pixels have none and are done.  The others union with N, or with W / NW and
-//                NE (the rest of the four are connected to those through their own links): neighbour id = directory entry + a
-//                popcount; union-find with the smaller id as root (atomicMin links, path halving)
-//   k_l2_stats   a lane per set pixel: a pixel that is not its own root finds it and adds its raw value (atomicMax / atomicAdd)
-//   k_l2_emit    a lane per set pixel: roots - in id order, i.e. in scipy's label order - leave their statistic (their own value
-//                joined with what the others added) as the tile's NEW value list: compacted in LDS, bit-packed to the tile-local d-bit
-//                stream exactly as the reduce kernel leaves level-1 residuals, written back to the tile's slot with the tile's new
-//                count.  From there on the batch IS a level-1 batch: scans, record layout, k_gather and every codec run unchanged.
-// Before round 5 the stage compacted every set pixel into batch-global arrays (position, value, parent, accumulator: 14 bytes each), looked
-// every pixel's four neighbours up in the map one by one, and emitted per frame with ONE workgroup: 870 us per 64 frames of 4096^2 at 1 %
-// (k_l2_union 281, k_l2_index 216, k_l2_emit 161, k_l2_stats 99; profiles/r05_exp4), 1.5 ms on clustered events.
+// Device formulation (round 5).  The reduce kernel leaves, per tile of 4096 pixels, the raw binary map (64 words of 64 pixels), the raw
+// values of its set pixels in raster order (the tile's value slot) - exactly what it left in rounds 2-4.  A
+// set pixel's ID inside its frame is tile * 4096 + its rank among the tile's set pixels: ids grow in raster order, need no per-frame
+// prefix (no scan in front of this stage), and index a sparse array of NODES {parent, accumulator} that rest at zero between batches -
+// no pass initialises them, and only pixels with neighbours ever have theirs written.  Three passes; a work ITEM is 64 consecutive tiles
+// of one frame and belongs to a one-wave workgroup (few fat waves instead of a quarter of a million one-tile waves: next to the following
+// batch's reduce kernel a CU has room for a handful of small waves, and a pass of one-tile waves cost ~190 us however little they did):
+//   k_l2_link    the item's NON-EMPTY words are listed first (ballot + rank: half the words at 1 %, one in sixteen at 0.1 %), then a
+//                lane per listed word: which of its pixels have a set neighbour among W, NW, N, NE comes from WORD arithmetic on the
+//                word, its left neighbour and the words one row up (funnel-shifted: the row length need not be a multiple of 64) - at
+//                1 % Bernoulli 96 % of the set pixels have none and are done.  The others are listed in LDS and then taken a LANE
+//                PER PIXEL: union with N, or with W / NW and NE (the rest of the four hang on those through their
+//                own links); neighbour id = directory entry + a popcount; union-find with the smaller id as root (compare-and-swap links, path halving)
+//   k_l2_stats   a lane per set pixel of the item (pixels numbered through, tile by binary search): a pixel that is not its own
+//                root finds it and adds its raw value (atomicMax / atomicAdd on the root's accumulator)
+//   k_l2_emit    the same walk: roots - in id order, i.e. in scipy's label order - leave their statistic (own value joined with what
+//                the others added) in an ordered LDS list; then every tile's share of the list is bit-packed into the tile-local d-bit
+//                stream exactly as the reduce kernel leaves level-1 residuals and written back to the tile's slot with the tile's
+//                new count.  From there on the batch IS a level-1 batch: scans, record layout, k_gather and every codec run unchanged.
+// Rounds 2-4 compacted every set pixel into batch-global arrays (position, value, parent, accumulator: 14 bytes each), looked every
+// pixel's four neighbours up in the map one by one, and emitted per frame with ONE workgroup: 870 us per 64 frames of 4096^2 at 1 %
+// (profiles/r05_exp4_level2_traces_dense_sweep.log), 1.5 ms on clustered events.
 #include "rc_launch.h"
-#include "rc_pack.h"
 
 namespace rc {
 
-__device__ __forceinline__ uint32_t uf_find(uint32_t *__restrict__ parent, uint32_t x)
+__device__ __forceinline__ uint32_t *node_parent(u32x2 *node, uint32_t id) { return reinterpret_cast<uint32_t *>(node + id); }
+__device__ __forceinline__ uint32_t *node_stat(u32x2 *node, uint32_t id) { return reinterpret_cast<uint32_t *>(node + id) + 1; }
+
+// Nodes rest at {0, 0} between batches (zeroed once at allocation; k_l2_emit puts back what a batch changed): parent = 0 says "a root",
+// anything else is the parent's id + 1.  No pass initialises them - and the nine set pixels in ten that have no neighbour never have
+// theirs written at all.
+__device__ __forceinline__ uint32_t uf_find(u32x2 *__restrict__ node, uint32_t x)
 {
-    uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (p != x) {
-        const uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
-        x = p;
+    uint32_t p = __hip_atomic_load(node_parent(node, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != 0) {
+        const uint32_t gp = __hip_atomic_load(node_parent(node, p - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != 0) __hip_atomic_store(node_parent(node, x), gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+        x = p - 1;
         p = gp;
     }
     return x;
 }
-__device__ __forceinline__ void uf_union(uint32_t *__restrict__ parent, uint32_t a, uint32_t b)
+__device__ __attribute__((noinline)) void uf_union(u32x2 *__restrict__ node, uint32_t a, uint32_t b)
 {
     for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+        a = uf_find(node, a);
+        b = uf_find(node, b);
         if (a == b) return;
-        if (a > b) { const uint32_t t = a; a = b; b = t; }   // a < b: hang b's root under a
-        const uint32_t old = atomicMin(&parent[b], a);
-        if (old == b) return;                                // b was still a root: linked
-        b = old;                                             // somebody re-parented b meanwhile: retry from there
+        if (a > b) { const uint32_t t = a; a = b; b = t; }   // a < b: hang b's root under a (the smaller id - the earlier pixel - stays root)
+        const uint32_t old = atomicCAS(node_parent(node, b), 0u, a + 1u);
+        if (old == 0) return;                                // b was still a root: linked
+        b = old - 1;                                         // somebody hung b elsewhere meanwhile: go on from there
     }
 }
 
-// 64 map bits from bit position q of the frame's map on (q may be negative: the bits in front of the map are 0; the map's rows are padded
-// to whole tiles with zeros and `nwords` words long)
-__device__ __forceinline__ uint64_t map_bits(const uint64_t *__restrict__ bm, uint32_t nwords, int64_t q)
-{
-    if (q <= -64) return 0;
-    if (q < 0) return bm[0] << (uint32_t)(-q);
-    const uint32_t idx = (uint32_t)(q >> 6), sh = (uint32_t)(q & 63);
-    if (idx >= nwords) return 0;
-    const uint64_t lo = bm[idx];
-    if (!sh) return lo;
-    const uint64_t hi = idx + 1 < nwords ? bm[idx + 1] : 0ull;
-    return (lo >> sh) | (hi << (64u - sh));
-}
+__device__ __forceinline__ uint32_t l2_lane_get(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src_lane), (int)v); }
 
-// grid (ceil(ntiles / WAVES), B), a wavefront per tile
-__global__ __launch_bounds__(WG) void k_l2_prep(Scratch sc, L2Work w)
-{
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
-    if (t >= sc.ntiles) return;
-    const uint64_t *bm = reinterpret_cast<const uint64_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride);
-    const uint64_t bits = bm[(uint64_t)t * 64 + lane];
-    const uint32_t cnt = (uint32_t)__builtin_popcountll(bits);
-    const uint32_t inc = wave_incl_scan(cnt);
-    w.word_base[((uint64_t)f * sc.ntiles + t) * 64 + lane] = (uint16_t)(inc - cnt);   // (< 4096: the last word's base is at most 4032)
-    const uint32_t total = wave_last(inc);
-    const uint64_t fbase = (uint64_t)f * w.ids_per_frame;
-    const uint32_t id0 = t * (uint32_t)TILE_PX;
-    for (uint32_t r = lane; r < total; r += 64) {
-        w.parent[fbase + id0 + r] = id0 + r;
-        w.stat[fbase + id0 + r] = 0;
-    }
-}
-
+// The item's view of the frame: the tiles [tlo, tlo + ntv) whose words' rank bases (set pixels of the tile in front of each 64-pixel word)
+// k_l2_link has put into LDS - the item's own 64 tiles and as many tiles in front of them as a row is long, i.e. every tile a W, NW, N or
+// NE neighbour of one of its pixels can lie in
+struct L2View { const uint64_t *bm; const uint16_t *base; uint32_t tlo; };
 // id of the set pixel at linear position p of the frame (the caller has seen its bit)
-__device__ __forceinline__ uint32_t l2_id(const uint64_t *__restrict__ bm, const uint16_t *__restrict__ wbase, uint32_t p)
+__device__ __forceinline__ uint32_t l2_id(const L2View &v, uint32_t p)
 {
     const uint32_t wi = p >> 6;
-    return (p >> 12) * (uint32_t)TILE_PX + wbase[wi] + (uint32_t)__builtin_popcountll(bm[wi] & ((1ull << (p & 63u)) - 1ull));
+    return (p >> 12) * (uint32_t)TILE_PX + v.base[wi - v.tlo * 64u] + (uint32_t)__builtin_popcountll(v.bm[wi] & ((1ull << (p & 63u)) - 1ull));
+}
+// pixel p (id self) joins the earlier ones among its neighbours: N, or W / NW and NE - the rest of the four hang on those through their own links
+__device__ __forceinline__ void l2_link_pixel(u32x2 *node, const L2View &v, uint32_t nx, uint32_t p, uint32_t self, bool n, bool w, bool nw, bool ne)
+{
+    if (n) uf_union(node, self, l2_id(v, p - nx));
+    else {
+        if (w) uf_union(node, self, l2_id(v, p - 1));                  // (NW is W's northern neighbour)
+        else if (nw) uf_union(node, self, l2_id(v, p - nx - 1));
+        if (ne) uf_union(node, self, l2_id(v, p - nx + 1));
+    }
 }
 
-// grid (ceil(ntiles / WAVES), B), a wavefront per tile, a lane per word
-__global__ __launch_bounds__(WG) void k_l2_link(Scratch sc, L2Work w, uint32_t nx)
+constexpr uint32_t L2_WORDS = 1024;  // the words of a chunk of 16 tiles: its non-empty ones are listed in LDS (uint16 each)
+constexpr uint32_t L2_DESC = 1024;   // linked pixels listed per round (LDS, one dword each)
+constexpr uint32_t L2_VIEW = 64 + 18;  // tiles whose word bases the item keeps: its own and ceil((nx + 1) / 4096) + 1 <= 18 in front (nx < 65536: launch_l2)
+
+// grid: one-wave workgroups over the items (64 tiles of one frame each)
+__global__ __launch_bounds__(64) void k_l2_link(Scratch sc, uint32_t nx, uint32_t gpf, uint32_t nitems)
 {
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
-    if (t >= sc.ntiles) return;
+    __shared__ uint16_t s_words[L2_WORDS];
+    __shared__ uint32_t s_desc[L2_DESC];
+    __shared__ uint16_t s_base[L2_VIEW * 64];
+    const uint32_t lane = (uint32_t)lane_id();
     const uint32_t nwords = sc.ntiles * 64u;
-    const uint64_t *bm = reinterpret_cast<const uint64_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride);
-    const uint16_t *wbase = w.word_base + (uint64_t)f * nwords;
-    const uint32_t wi = t * 64u + (uint32_t)lane;
-    const uint64_t W = bm[wi];
-    if (!W) return;                       // (nothing below crosses lanes)
-    const uint32_t p0 = wi * 64u;         // first pixel of the word (N < 2^32)
-    // pixels of this word in the first / last column of their row
-    uint64_t col0 = 0, colL = 0;
-    for (uint64_t r = (((uint64_t)p0 + nx - 1) / nx) * nx; r < (uint64_t)p0 + 64; r += nx) col0 |= 1ull << (r - p0);        // row starts inside the word
-    for (uint64_t r = (((uint64_t)p0 + nx) / nx) * nx; r < (uint64_t)p0 + 65; r += nx) colL |= 1ull << (r - 1 - p0);        // pixel r - 1 ends a row
-    // neighbour maps, bit i = "pixel p0 + i has that neighbour set"
-    const uint64_t west = map_bits(bm, nwords, (int64_t)p0 - 1) & ~col0;
-    const uint64_t A = map_bits(bm, nwords, (int64_t)p0 - nx - 1), Bn = map_bits(bm, nwords, (int64_t)p0 - nx + 63);
-    const uint64_t nw = A & ~col0, north = (A >> 1) | (Bn << 63), ne = ((A >> 2) | (Bn << 62)) & ~colL;
-    uint32_t *parent = w.parent + (uint64_t)f * w.ids_per_frame;
-    const uint32_t id0 = t * (uint32_t)TILE_PX + wbase[wi];
-    for (uint64_t todo = W & (west | nw | north | ne); todo; todo &= todo - 1) {
-        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
-        const uint64_t bit = 1ull << i;
-        const uint32_t p = p0 + i, self = id0 + (uint32_t)__builtin_popcountll(W & (bit - 1ull));
-        if (north & bit) uf_union(parent, self, l2_id(bm, wbase, p - nx));            // (W, NW, NE hang on N through their own links)
-        else {
-            if (west & bit) uf_union(parent, self, l2_id(bm, wbase, p - 1));          // (NW is W's northern neighbour)
-            else if (nw & bit) uf_union(parent, self, l2_id(bm, wbase, p - nx - 1));
-            if (ne & bit) uf_union(parent, self, l2_id(bm, wbase, p - nx + 1));
+    const uint32_t back = (nx + 1u + (uint32_t)TILE_PX - 1u) / (uint32_t)TILE_PX + 1u;   // tiles in front of the item a neighbour can lie in
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const uint32_t f = item / gpf, t0 = 64u * (item - f * gpf);
+        const uint64_t *bm = reinterpret_cast<const uint64_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride);
+        u32x2 *node = sc.l2_node + (uint64_t)f * sc.l2_ids_per_frame;
+        const uint32_t ntl = min(64u, sc.ntiles - t0);
+        const uint32_t tlo = t0 > back ? t0 - back : 0u, ntv = t0 + ntl - tlo;      // the item's view: tiles [tlo, t0 + ntl)
+        const L2View view{bm, s_base, tlo};
+        // ---- A: every word of the view once: its rank base inside its tile (a wave scan per tile) into LDS - the directory neighbours are
+        //      looked up in; the item's own non-empty words (half of them at 1 % of the pixels set, one in sixteen at 0.1 %) listed by
+        //      ballot + rank.  (Rounds of this stage that took the bases from a directory the reduce kernel wrote cost THAT kernel 8 %.)
+        uint32_t listed = 0;
+        auto drain = [&]() {   // desc = word index inside the item (12 bits) << 10 | bit (6) << 4 | N W NW NE
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < listed; j += 64) {
+                const uint32_t d = s_desc[j];
+                const uint32_t p = ((t0 * 64u + (d >> 10)) << 6) + ((d >> 4) & 63u);
+                l2_link_pixel(node, view, nx, p, l2_id(view, p), (d & 8u) != 0, (d & 4u) != 0, (d & 2u) != 0, (d & 1u) != 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            listed = 0;
+        };
+        for (uint32_t c0 = 0; c0 < ntv; c0 += 16) {
+            uint32_t nw = 0;
+            uint64_t W[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) W[k] = c0 + k < ntv ? bm[(tlo + c0 + k) * 64u + lane] : 0ull;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (c0 + k >= ntv) break;                       // (uniform)
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(W[k]);
+                s_base[(c0 + k) * 64u + lane] = (uint16_t)(wave_incl_scan(cnt) - cnt);
+                if (tlo + c0 + k < t0) continue;                // (uniform) a tile in front of the item: bases only
+                const uint64_t m = __builtin_amdgcn_ballot_w64(W[k] != 0);
+                if (W[k]) s_words[nw + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)((tlo + c0 + k - t0) * 64u + lane);
+                nw += (uint32_t)__builtin_popcountll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- B: a lane per non-empty word of the chunk - which of its pixels have a set neighbour among W, NW, N, NE; C: those pixels, a lane each
+            for (uint32_t j0 = 0; j0 < nw; j0 += 64) {
+                const bool have = j0 + lane < nw;
+                const uint32_t wrel = have ? s_words[j0 + lane] : 0u;
+                const uint32_t wi = t0 * 64u + wrel;
+                const uint64_t p0 = (uint64_t)wi * 64;
+                const int64_t q = (int64_t)p0 - (int64_t)nx - 1;          // the map bit of pixel 0's NW neighbour
+                const int64_t idx = q >> 6;                                // (floor: q may be negative)
+                const uint32_t sh = (uint32_t)(q & 63);
+                uint64_t Wd = 0, Wl = 0, n0 = 0, n1 = 0, n2 = 0;
+                if (have) {
+                    Wd = bm[wi];
+                    Wl = wi > 0 ? bm[wi - 1] : 0ull;
+                    n0 = idx >= 0 && idx < (int64_t)nwords ? bm[idx] : 0ull;
+                    n1 = idx + 1 >= 0 && idx + 1 < (int64_t)nwords ? bm[idx + 1] : 0ull;
+                    n2 = sh >= 62 && idx + 2 >= 0 && idx + 2 < (int64_t)nwords ? bm[idx + 2] : 0ull;   // (only bits 0 and 1 of the continuation are used)
+                }
+                // A: bit i = pixel p0 + i - nx - 1 (NW); Bn: its continuation, for N and NE
+                const uint64_t A = sh ? (n0 >> sh) | (n1 << (64u - sh)) : n0;
+                const uint64_t Bn = sh ? (n1 >> sh) | (n2 << (64u - sh)) : n1;
+                uint64_t col0 = 0, colL = 0;   // pixels of this word in the first / last column of their row
+                if (have) {
+                    for (uint64_t r = ((p0 + nx - 1) / nx) * nx; r < p0 + 64; r += nx) col0 |= 1ull << (r - p0);
+                    for (uint64_t r = ((p0 + nx) / nx) * nx; r < p0 + 65; r += nx) colL |= 1ull << (r - 1 - p0);
+                }
+                const uint64_t fW = ((Wd << 1) | (Wl >> 63)) & ~col0, fNW = A & ~col0, fN = (A >> 1) | (Bn << 63), fNE = ((A >> 2) | (Bn << 62)) & ~colL;
+                uint64_t todo = Wd & (fW | fNW | fN | fNE);
+                const uint32_t n = (uint32_t)__builtin_popcountll(todo);
+                const uint32_t inc = wave_incl_scan(n), total = wave_last(inc);
+                if (total == 0) continue;
+                const bool fits = total <= L2_DESC;            // (dense maps: 64 words can hold more linked pixels than the list - then every lane links its own)
+                if (fits && listed + total > L2_DESC) drain();
+                uint32_t o = listed + inc - n;
+                const uint32_t id0 = (wi >> 6) * (uint32_t)TILE_PX + ((fits || !todo) ? 0u : (uint32_t)s_base[wi - tlo * 64u]);
+                for (; todo; todo &= todo - 1) {
+                    const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+                    const uint64_t bit = 1ull << i;
+                    if (fits) s_desc[o++] = (wrel << 10) | (i << 4) | ((fN & bit) ? 8u : 0u) | ((fW & bit) ? 4u : 0u) | ((fNW & bit) ? 2u : 0u) | ((fNE & bit) ? 1u : 0u);
+                    else l2_link_pixel(node, view, nx, wi * 64u + i, id0 + (uint32_t)__builtin_popcountll(Wd & (bit - 1ull)), (fN & bit) != 0, (fW & bit) != 0, (fNW & bit) != 0, (fNE & bit) != 0);
+                }
+                if (fits) listed += total;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        drain();
+        __builtin_amdgcn_wave_barrier();
     }
+}
+
+// The item's set pixels numbered through: cum = exclusive wave scan of the tiles' counts (a lane per tile); pixel P belongs to the last tile
+// whose first pixel is <= P.
+__device__ __forceinline__ uint32_t l2_tile_of(uint32_t cum, uint32_t P)
+{
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t step = 32; step; step >>= 1) {
+        const uint32_t c = l2_lane_get(cum, k + step);
+        if (c <= P) k += step;
+    }
+    return k;
 }
 
 // use_sum: 0 = maximum, 1 = sum.  The sum wraps the way the reference's arithmetic would: its statistic is cast to the source dtype
 // (recode_writer.py:446 hands `self._src_dtype` to get_summary_stats_nb) and stored in src_bit_depth bits (_bit_pack drops the bits above,
 // recode_writer.py:637-652) - i.e. the sum modulo 2^d.  The accumulator is 32 bits wide (2^d divides 2^32: wrapping it changes nothing),
 // k_l2_emit keeps its low 16 bits, the d-bit pack the low d.
-__global__ __launch_bounds__(WG) void k_l2_stats(Scratch sc, L2Work w, uint32_t use_sum)
+__global__ __launch_bounds__(64) void k_l2_stats(Scratch sc, uint32_t use_sum, uint32_t gpf, uint32_t nitems)
 {
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
-    if (t >= sc.ntiles) return;
-    const uint64_t frow = (uint64_t)f * sc.ntiles;
-    const uint32_t total = sc.tile_cnt[frow + t];
-    uint32_t *parent = w.parent + (uint64_t)f * w.ids_per_frame, *stat = w.stat + (uint64_t)f * w.ids_per_frame;
-    const uint16_t *vals = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(sc.pix_slots) + (frow + t) * sc.pix_slot_bytes);
-    const uint32_t id0 = t * (uint32_t)TILE_PX;
-    for (uint32_t r = lane; r < total; r += 64) {
-        const uint32_t id = id0 + r;
-        if (parent[id] == id) continue;                      // a root (every pixel without neighbours): its own value joins at the emit
-        const uint32_t root = uf_find(parent, id);
-        parent[id] = root;
-        if (use_sum) atomicAdd(&stat[root], (uint32_t)vals[r]);
-        else atomicMax(&stat[root], (uint32_t)vals[r]);
-    }
-}
-
-// The tile's roots -> its new value list (see the head of the file).  The workgroup's LDS holds a tile's worst case per wavefront.
-__global__ __launch_bounds__(WG) void k_l2_emit(Scratch sc, L2Work w, uint32_t use_sum, uint32_t depth)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t s_list[WAVES][TILE_PX];
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    const uint32_t t = blockIdx.x * WAVES + wv, f = blockIdx.y;
-    if (t >= sc.ntiles) return;
-    const uint64_t frow = (uint64_t)f * sc.ntiles;
-    const uint32_t total = sc.tile_cnt[frow + t];
-    if (total == 0) return;               // (the tile stays empty)
-    const uint32_t *parent = w.parent + (uint64_t)f * w.ids_per_frame, *stat = w.stat + (uint64_t)f * w.ids_per_frame;
-    uint16_t *slot = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(sc.pix_slots) + (frow + t) * sc.pix_slot_bytes);
-    uint16_t *list = s_list[wv];
-    const uint32_t id0 = t * (uint32_t)TILE_PX;
-    uint32_t nroot = 0;
-    for (uint32_t r0 = 0; r0 < total; r0 += 64) {
-        const uint32_t r = r0 + lane;
-        uint32_t isroot = 0, v = 0;
-        if (r < total) {
-            const uint32_t id = id0 + r;
-            isroot = parent[id] == id ? 1u : 0u;
-            if (isroot) {
-                const uint32_t own = slot[r], acc = stat[id];
-                v = use_sum ? acc + own : max(acc, own);
+    const uint32_t lane = (uint32_t)lane_id();
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const uint32_t f = item / gpf, t0 = 64u * (item - f * gpf), t = t0 + lane;
+        const uint64_t frow = (uint64_t)f * sc.ntiles;
+        const uint32_t cnt = t < sc.ntiles ? sc.tile_cnt[frow + t] : 0u;
+        const uint32_t inc = wave_incl_scan(cnt), cum = inc - cnt, T = wave_last(inc);
+        u32x2 *node = sc.l2_node + (uint64_t)f * sc.l2_ids_per_frame;
+        const uint8_t *slots = reinterpret_cast<const uint8_t *>(sc.pix_slots) + (frow + t0) * sc.pix_slot_bytes;
+        constexpr int U = 4;
+        for (uint32_t i0 = 0; 64u * i0 < T; i0 += U) {
+            uint32_t id[U], par[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t P = 64u * (i0 + u) + lane;
+                const uint32_t k = l2_tile_of(cum, P), r = P - l2_lane_get(cum, k);
+                id[u] = P < T ? (t0 + k) * (uint32_t)TILE_PX + r : 0xFFFFFFFFu;
+                par[u] = P < T ? node[id[u]][0] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (par[u] == 0) continue;                       // a root (every pixel without neighbours): its own value joins at the emit
+                const uint32_t root = uf_find(node, id[u]);
+                const uint32_t v = reinterpret_cast<const uint16_t *>(slots + (uint64_t)((id[u] >> 12) - t0) * sc.pix_slot_bytes)[id[u] & (TILE_PX - 1)];
+                if (use_sum) atomicAdd(node_stat(node, root), v);
+                else atomicMax(node_stat(node, root), v);
             }
         }
-        const uint32_t inc = wave_incl_scan(isroot);
-        if (isroot) list[nroot + inc - 1] = (uint16_t)v;
-        nroot += wave_last(inc);
     }
-    __builtin_amdgcn_wave_barrier();
-    if (depth < 16 && nroot) pack_stage(list, nroot, depth);
-    __builtin_amdgcn_wave_barrier();
-    // whole lines, like the reduce kernel's residual lines (k_gather reads whole 16-byte pieces of the stream)
-    const uint32_t ndw = (((nroot * (depth < 16 ? depth : 16u) + 31) >> 5) + 31u) & ~31u;
-    for (uint32_t i = lane; i < ndw; i += 64) reinterpret_cast<uint32_t *>(slot)[i] = reinterpret_cast<const uint32_t *>(list)[i];
-    if (lane == 0) sc.tile_cnt[frow + t] = nroot;
 }
 
-void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, uint32_t depth, hipStream_t s)
+constexpr uint32_t L2_LIST = 6144;   // roots' statistics listed per round (LDS, uint16 each); a tile has at most TILE_PX
+
+// the tile-local stream of the d-bit fields of list[0 .. n) -> out (whole 128-byte lines, zero behind the stream); d = 16: the values
+__device__ __forceinline__ void l2_write_stream(const uint16_t *list, uint32_t n, uint32_t d, uint32_t *__restrict__ out)
 {
-    const dim3 grid((sc.ntiles + WAVES - 1) / WAVES, B);
-    hipLaunchKernelGGL(k_l2_prep, grid, dim3(WG), 0, s, sc, w);
-    hipLaunchKernelGGL(k_l2_link, grid, dim3(WG), 0, s, sc, w, nx);
-    hipLaunchKernelGGL(k_l2_stats, grid, dim3(WG), 0, s, sc, w, use_sum);
-    hipLaunchKernelGGL(k_l2_emit, grid, dim3(WG), 0, s, sc, w, use_sum, depth);
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t nbits = n * d, ndw = (((nbits + 31) >> 5) + 31u) & ~31u;
+    const uint32_t dmask = d >= 16 ? 0xFFFFu : (1u << d) - 1u;
+    for (uint32_t w = lane; w < ndw; w += 64) {
+        uint32_t v = (32u * w) / d;
+        const uint32_t o = 32u * w - v * d;
+        uint64_t acc = 0;
+        uint32_t filled = 0;
+        if (v < n) { acc = (list[v] & dmask) >> o; filled = d - o; ++v; }
+        while (filled < 32 && v < n) {
+            acc |= (uint64_t)(list[v] & dmask) << filled;
+            filled += d;
+            ++v;
+        }
+        out[w] = (uint32_t)acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_l2_emit(Scratch sc, uint32_t use_sum, uint32_t depth, uint32_t gpf, uint32_t nitems)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[L2_LIST];
+    __shared__ uint32_t s_first[64], s_n[64];     // per tile of the round: where its roots start in the list, how many
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t d = depth < 16 ? depth : 16u;
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const uint32_t f = item / gpf, t0 = 64u * (item - f * gpf), t = t0 + lane;
+        const uint64_t frow = (uint64_t)f * sc.ntiles;
+        const uint32_t cnt = t < sc.ntiles ? sc.tile_cnt[frow + t] : 0u;
+        const uint32_t inc = wave_incl_scan(cnt), cum = inc - cnt, T = wave_last(inc);
+        if (T == 0) continue;
+        u32x2 *node = sc.l2_node + (uint64_t)f * sc.l2_ids_per_frame;
+        uint8_t *slots = reinterpret_cast<uint8_t *>(sc.pix_slots) + (frow + t0) * sc.pix_slot_bytes;
+        // rounds of whole tiles whose pixels fit the list (all 64 in one round up to 2.3 % of the pixels set)
+        for (uint32_t ka = 0; ka < 64;) {
+            // kb: one behind the round's last tile = the first tile whose end lies more than L2_LIST pixels behind tile ka's start
+            const uint32_t start = l2_lane_get(cum, ka);
+            const uint64_t over = __builtin_amdgcn_ballot_w64(lane >= ka && inc - start > L2_LIST);
+            uint32_t kb = over ? (uint32_t)__builtin_ctzll(over) : 64u;
+            if (kb == ka) kb = ka + 1;      // (cannot happen: a tile holds at most TILE_PX <= L2_LIST pixels; kept as a guard against a stall)
+            const uint32_t end = kb < 64 ? l2_lane_get(cum, kb) : T;
+            s_n[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t nlist = 0;
+            constexpr int U = 4;
+            for (uint32_t P0 = start; P0 < end; P0 += 64u * U) {
+                uint32_t k[U], r[U];
+                u32x2 nd[U];
+                uint32_t own[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t P = P0 + 64u * u + lane;
+                    k[u] = l2_tile_of(cum, P);
+                    r[u] = P - l2_lane_get(cum, k[u]);
+                    nd[u] = u32x2{1u, 0u};
+                    own[u] = 0;
+                    if (P < end) {
+                        nd[u] = node[(t0 + k[u]) * (uint32_t)TILE_PX + r[u]];
+                        own[u] = reinterpret_cast<const uint16_t *>(slots + (uint64_t)k[u] * sc.pix_slot_bytes)[r[u]];
+                        if (nd[u][0] | nd[u][1]) node[(t0 + k[u]) * (uint32_t)TILE_PX + r[u]] = u32x2{0u, 0u};   // back to rest for the next batch
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t P = P0 + 64u * u + lane;
+                    const bool isroot = P < end && nd[u][0] == 0;
+                    const uint32_t ri = wave_incl_scan(isroot ? 1u : 0u);
+                    const uint32_t at = nlist + ri - 1;          // (roots only)
+                    if (isroot) {
+                        s_list[at] = (uint16_t)(use_sum ? nd[u][1] + own[u] : max(nd[u][1], own[u]));
+                        atomicAdd(&s_n[k[u]], 1u);
+                    }
+                    if (P < end && r[u] == 0) s_first[k[u]] = at + (isroot ? 0u : 1u);   // the tile's first pixel: its roots start here (the next root's place)
+                    nlist += wave_last(ri);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // every tile of the round: its share of the list -> its slot, as the tile-local packed stream; its new count.  A tile with at
+            // most eight roots whose fields fit 16 bytes (every tile at 0.1 % of the pixels set) is finished by ITS OWN lane with one 16-byte
+            // store - all such tiles in one instruction; the others one after the other by the whole wave
+            const bool mine = lane >= ka && lane < kb && cnt != 0;
+            const uint32_t my_n = mine ? s_n[lane] : 0u, my_first = mine ? s_first[lane] : 0u;
+            const bool small = mine && my_n <= 8u && my_n * d <= 128u;
+            if (small) {
+                const uint32_t dmask = d >= 16 ? 0xFFFFu : (1u << d) - 1u;
+                uint64_t lo = 0, hi = 0;
+                for (uint32_t j = 0; j < my_n; ++j) {
+                    const uint64_t v = s_list[my_first + j] & dmask;
+                    const uint32_t b = j * d;
+                    if (b < 64) { lo |= v << b; if (b + d > 64) hi |= v >> (64 - b); }
+                    else hi |= v << (b - 64);
+                }
+                *reinterpret_cast<u32x4 *>(slots + (uint64_t)lane * sc.pix_slot_bytes) = u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+                sc.tile_cnt[frow + t] = my_n;
+            }
+            for (uint64_t rest = __builtin_amdgcn_ballot_w64(mine && !small); rest; rest &= rest - 1) {
+                const uint32_t kk = (uint32_t)__builtin_ctzll(rest);
+                const uint32_t n = s_n[kk], first = s_first[kk];
+                l2_write_stream(s_list + first, n, d, reinterpret_cast<uint32_t *>(slots + (uint64_t)kk * sc.pix_slot_bytes));
+                if (lane == 0) sc.tile_cnt[frow + t0 + kk] = n;
+            }
+            __builtin_amdgcn_wave_barrier();
+            ka = kb;
+        }
+    }
+}
+
+void launch_l2(const Scratch &sc, uint32_t B, uint32_t nx, uint32_t use_sum, uint32_t depth, hipStream_t s)
+{
+    const uint32_t gpf = (sc.ntiles + 63) / 64, nitems = gpf * B;
+    hipLaunchKernelGGL(k_l2_link, dim3(nitems), dim3(64), 0, s, sc, nx, gpf, nitems);
+    hipLaunchKernelGGL(k_l2_stats, dim3(nitems), dim3(64), 0, s, sc, use_sum, gpf, nitems);
+    hipLaunchKernelGGL(k_l2_emit, dim3(nitems), dim3(64), 0, s, sc, use_sum, depth, gpf, nitems);
 }
 
 // ---- validation frames (reference recode_writer.py:402-415): the dose-rate count on the streaming path ---------------------

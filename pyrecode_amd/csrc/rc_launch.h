@@ -28,7 +28,7 @@ struct Scratch {
     // slot - 1: at the next 16-byte boundary behind the block image (LZ4 / blosc: the image is final when the reduce kernel writes it),
     // 2: at offset BLK_SLOT (zstd: the FSE pass and the frame's definitions still grow the block) - whenever block + residual lines fit
     // blk_stride; a tile too dense for that keeps its residuals in pix_slots as before.  One run of lines per tile and frame instead of
-    // two runs 8 KiB apart: fewer lines written by the reduce kernel and read by k_assemble (each run wastes half a line on average).
+    // two runs 8 KiB apart: fewer lines written by the reduce kernel and read by k_gather (each run wastes half a line on average).
     uint32_t comb = 0;
     uint32_t *blk_size = nullptr;      // [B][ntiles]               bytes used in each slot
     uint32_t *blk_off = nullptr;       // [B][ntiles]               exclusive prefix of blk_size inside the frame
@@ -50,15 +50,9 @@ struct Scratch {
     const void *zm_model = nullptr;    // ZstdModel
     const void *zm_lit_code = nullptr; // &model->lit_code
     uint32_t zm_valid = 0, zm_budget = 0, zm_seq_bits = 12;
-};
-
-// workspace of reduction level 2 (connected-component statistics, rc_l2.hip): a set pixel's id inside its frame is tile * TILE_PX + its rank
-// among the tile's set pixels; parent / stat are indexed by frame * ids_per_frame + id (sparse: only set pixels' entries are touched)
-struct L2Work {
-    uint32_t *parent = nullptr;      // [B][ids_per_frame] union-find parent (smaller id wins)
-    uint32_t *stat = nullptr;        // [B][ids_per_frame] per-root accumulator of the OTHER pixels' raw values
-    uint16_t *word_base = nullptr;   // [B][ntiles * 64]   set pixels of the tile in front of each 64-pixel word
-    uint64_t ids_per_frame = 0;      // ntiles * TILE_PX
+    // level 2 (rc_l2.hip)
+    u32x2 *l2_node = nullptr;          // [B][ntiles * TILE_PX] {parent id, accumulator} per set pixel, id = tile * TILE_PX + rank in the tile
+    uint64_t l2_ids_per_frame = 0;
 };
 
 struct RecordParams {
@@ -68,7 +62,7 @@ struct RecordParams {
     uint32_t packed_slots; // 1: pix_slots hold tile-local packed streams (level 1); 0: uint16 values (level 2 statistics)
     uint32_t first_frame_id;
     uint64_t frame_bytes;  // raw frame size = N * 2 (record upper bound, recode_writer.py:565-566)
-    uint32_t pix_mode = 0; // k_assemble / k_layout: 0 = the residual stream goes into the record as it is (stored chunks);
+    uint32_t pix_mode = 0; // k_gather / k_layout: 0 = the residual stream goes into the record as it is (stored chunks);
                            // 1 = ONLY the residual stream, flat, into Scratch::pixraw (input of the Huffman stage);
                            // 2 = everything but the residual stream, whose encoded size is Scratch::frame_pbytes
 };
@@ -87,7 +81,7 @@ void launch_threshold32(const uint32_t *dark, int64_t eps, uint64_t N, uint32_t 
 void launch_reduce32(const Scratch &sc, const uint32_t *frames, const uint32_t *thr32, uint32_t B, uint32_t level, uint32_t depth, hipStream_t s,
                      uint32_t codec = 0, bool keep_bitmap = true);   // codec 2 / 4: the LZ4 block encoder (runs / events) fused
 // rc_l2.hip
-void launch_l2(const Scratch &sc, const L2Work &w, uint32_t B, uint32_t nx, uint32_t use_sum, uint32_t depth, hipStream_t s);
+void launch_l2(const Scratch &sc, uint32_t B, uint32_t nx, uint32_t use_sum, uint32_t depth, hipStream_t s);
 void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blocks, hipStream_t s);
 void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64_t out_cap, uint64_t *rec_off,
                    uint32_t *md, hipStream_t s);

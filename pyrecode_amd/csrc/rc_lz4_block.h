@@ -407,7 +407,9 @@ __device__ __forceinline__ uint32_t lz4_encode_block(uint64_t own, uint32_t n, L
             }
         }
     }
-    LZ4_PH(3);   // (measured and dropped in round 4: a sequence's bytes put together in a register and written with byte-aligned ds_write_b32 /
+    LZ4_PH(3);   // (measured and dropped in round 5: literal runs of more than four bytes copied by the whole wave, a byte per lane - nothing on the
+                 //  sparse headline, 4.6 % SLOWER on the detector-like stack whose blocks hold many such runs: profiles/r05_exp9_level2_resting_nodes_ab.log;
+                 //  in round 4: a sequence's bytes put together in a register and written with byte-aligned ds_write_b32 /
                  //  b16 - the compiler emits them, LDS runs in unaligned access mode - instead of one byte-write each: 1-2 % SLOWER everywhere)
     return total;
 }

@@ -7,7 +7,7 @@ namespace rc {
 
 // A5 inside the tile: the cnt compacted values (uint16, in the wave's LDS stage) become the tile-local LSB-first stream of
 // their low d bits, IN PLACE: output dword w needs values >= 32w/d >= 2w, which lie at or behind byte 4w, and all lanes
-// of a step read before any of them writes.  The rest of the last 128-byte line is zeroed (k_assemble ORs across tiles).
+// of a step read before any of them writes.  The rest of the last 128-byte line is zeroed (k_gather reads whole 16-byte pieces).
 __device__ __forceinline__ void pack_stage(uint16_t *pix, uint32_t cnt, uint32_t d)
 {
     const int lane = lane_id();

@@ -3,7 +3,7 @@
 // Replaces the second `compress()` of the reference's per-frame step, the one on the packed pixel intensities
 // (pyrecode/recode_writer.py:507-511 -> recode_compressors.py:88, ZstdCompressor.compress).  The packed stream has no
 // repeats to speak of (stock libzstd finds none either: its 0.80 on the bench data is all Huffman), so the encoder is the
-// literal half of a zstd block only: the frame's stream, laid out flat by k_assemble (pix_mode 1), is cut into chunks of
+// literal half of a zstd block only: the frame's stream, laid out flat by k_gather (pix_mode 1), is cut into chunks of
 // PIX_CHUNK bytes; every chunk becomes one block of Huffman-coded literals without sequences (single stream, treeless: the
 // tree of the ctx's model travels in the frame's first such block, k_pix_scan puts it there), or a Raw block when that would
 // not be smaller.  Serial specification of a chunk: zm_encode_pix_chunk (rc_zstd_block.h), judged by stock libzstd in

@@ -1,4 +1,4 @@
-// rc_record.h - the byte layout of a record's two streams (shared by the layout kernel, k_assemble and k_gather): stream framing of the device
+// rc_record.h - the byte layout of a record's two streams (shared by the layout kernel and k_gather): stream framing of the device
 // codecs, stored-chunk positions, the fixed fields of a record.  Reference: pyrecode/recode_writer.py:485-494,518-525,546-550 (record),
 // lz4_Frame_format.md / RFC 8878 / the blosc1 chunk header for the containers.
 #pragma once

@@ -357,13 +357,21 @@ __device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const u32x
     const uint32_t rounds = (total + STAGE_CAP - 1) / STAGE_CAP;
     for (uint32_t c = 0; c < rounds; ++c) {
         const uint32_t lim = (c + 1) * STAGE_CAP;
-        while (e < lim && (q0 | q1)) {
-            uint32_t i;
-            if (q0) { i = (uint32_t)__builtin_ctz(q0); q0 &= q0 - 1; }
-            else { i = 32u + (uint32_t)__builtin_ctz(q1); q1 &= q1 - 1; }
-            st->out[e - c * STAGE_CAP] = mine[i];
-            ++e;
+        // (two values per trip, both reads in flight: the trip count - the densest lane's values in the window - times an LDS round trip
+        // is what this path costs: 57 % of a wave's time at 10 % of the pixels set, profiles/r05_exp7_phase_shares_batch_gaps.log)
+        uint64_t q = (uint64_t)q0 | ((uint64_t)q1 << 32);
+        while (e < lim && q) {
+            const uint32_t i0 = (uint32_t)__builtin_ctzll(q);
+            q &= q - 1;
+            const bool two = q != 0 && e + 1 < lim;
+            const uint32_t i1 = two ? (uint32_t)__builtin_ctzll(q) : i0;
+            if (two) q &= q - 1;
+            const uint16_t v0 = mine[i0], v1 = mine[i1];
+            st->out[e - c * STAGE_CAP] = v0;
+            if (two) st->out[e + 1 - c * STAGE_CAP] = v1;
+            e += two ? 2u : 1u;
         }
+        q0 = (uint32_t)q; q1 = (uint32_t)(q >> 32);
         __builtin_amdgcn_wave_barrier();
         const uint32_t n_c = min((uint32_t)STAGE_CAP, total - c * STAGE_CAP);
         for (uint32_t j = lane; j < n_c; j += 64) st->val[c * STAGE_CAP + j] = st->out[j];
@@ -1135,10 +1143,7 @@ void launch_scans(const Scratch &sc, uint32_t B, bool with_counts, bool with_blo
 }
 
 // ---- record layout: sizes, offsets, metadata, status (stream framing: rc_record.h) ----------------------------------------
-#ifndef RC_SMALL_WG
-#define RC_SMALL_WG 0
-#endif
-constexpr int LWG = RC_SMALL_WG ? 64 : WG, AWAVES = RC_SMALL_WG ? 1 : WAVES, AWG = 64 * AWAVES;
+constexpr int LWG = WG;
 __global__ __launch_bounds__(LWG) void k_layout(const uint32_t *__restrict__ frame_nnz,
                                                  const uint32_t *__restrict__ frame_cbytes, const uint32_t *__restrict__ frame_pbytes,
                                                  RecordParams rp, uint64_t nb,
@@ -1201,319 +1206,7 @@ void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64
                        rec_off, md, sc.status);
 }
 
-// ---- record assembly ------------------------------------------------------------------------------------------
-// ---- wave-cooperative copy of small segments with any destination alignment -----------------------------------------
-// A segment is n bytes at a 4-byte aligned source going to an arbitrarily aligned destination.  The body is written as
-// aligned dwords: destination dword j = source bytes [head + 4j, head + 4j + 4) = byte funnel shift (v_alignbyte_b32) of
-// the source dwords j and j+1, which each lane fetches with ONE 8-byte load; head / tail bytes are stored singly.
-// The load and the store are separate calls so that a caller can keep several segments in flight.
-// Reads at most 8 bytes past src + n (every slot / row / buffer is padded accordingly).
-struct SegLoad { u32x2 v; };
-
-__device__ __forceinline__ SegLoad seg_load(const uint8_t *__restrict__ src, uint32_t n, uint32_t chunk)
-{
-    SegLoad r;
-    const uint32_t j = chunk * 64 + lane_id();
-    r.v = u32x2{0u, 0u};
-    if (4 * j < n + 4) r.v = *reinterpret_cast<const u32x2 *>(src + 4 * j);  // dwords j and j+1 (j == nd holds the tail)
-    return r;
-}
-__device__ __forceinline__ void seg_store(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n, uint32_t chunk,
-                                          const SegLoad &ld)
-{
-    (void)src;
-    const uint32_t lane = lane_id();
-    const uint32_t head = min(n, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
-    const uint32_t n2 = n - head, nd = n2 >> 2, tail = n2 & 3u;
-    const uint32_t j = chunk * 64 + lane;
-    const uint32_t val = __builtin_amdgcn_alignbyte(ld.v[1], ld.v[0], head);  // source bytes [head + 4j, head + 4j + 4)
-    if (j < nd) reinterpret_cast<uint32_t *>(dst + head)[j] = val;
-    if (j == nd && tail) {  // the lane just behind the body holds the tail bytes in `val`
-        uint8_t *t = dst + head + 4 * nd;
-        t[0] = (uint8_t)val;
-        if (tail > 1) t[1] = (uint8_t)(val >> 8);
-        if (tail > 2) t[2] = (uint8_t)(val >> 16);
-    }
-    if (j == 0 && head) {   // lane 0 holds source dword 0 = the head bytes
-        dst[0] = (uint8_t)ld.v[0];
-        if (head > 1) dst[1] = (uint8_t)(ld.v[0] >> 8);
-        if (head > 2) dst[2] = (uint8_t)(ld.v[0] >> 16);
-    }
-}
-// whole segment, one call (used for the rare segments longer than one 256-byte chunk and by simple callers)
-__device__ __forceinline__ void wave_copy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n)
-{
-    for (uint32_t c = 0; c * 256 < n + 4; ++c) {
-        const SegLoad ld = seg_load(src, n, c);
-        seg_store(dst, src, n, c, ld);
-    }
-}
-
-struct PixSrc {
-    const uint16_t *slots;       // frame base: [ntiles][TILE_PX]
-    const uint32_t *cnt, *next;  // frame rows
-    uint32_t ntiles, t, P, c, nnz;
-};
-// value with frame-level index v >= P (this tile's first value), 0 beyond the frame's last value
-__device__ __forceinline__ uint32_t pix_fetch(const PixSrc &s, uint32_t v)
-{
-    if (v >= s.nnz) return 0;
-    uint32_t idx = v - s.P;
-    if (idx < s.c) return s.slots[(uint64_t)s.t * TILE_PX + idx];
-    idx -= s.c;
-    uint32_t tt = s.next[s.t];
-    while (tt < s.ntiles) {
-        const uint32_t cc = s.cnt[tt];
-        if (idx < cc) return s.slots[(uint64_t)tt * TILE_PX + idx];
-        idx -= cc;
-        tt = s.next[tt];
-    }
-    return 0;
-}
-
-// a quarter-wave handles one tile per pass; 2 passes (8 tiles per wavefront) keep the kernel at ~80 VGPRs: measured 44 us
-// against 58 us with 4 passes / 142 VGPRs (latency-bound: resident waves are what counts), 1 pass is no better
-constexpr int ASM_PASSES = 2;
-constexpr uint32_t ASM_TPW = 4 * ASM_PASSES;  // tiles per wavefront
-
-// One wavefront per ASM_TPW consecutive tiles of a frame, a quarter-wave (16 lanes) per tile and pass: each quarter copies
-// its tile's encoded bitmap block (or raw bitmap bytes) and its residuals to their places in the record.  Residual slots
-// hold tile-local packed streams of d-bit fields (rc_reduce's pack_stage; plain uint16 = the d = 16 case), so the copy is a
-// bit-granular funnel shift; the byte a tile shares with its successor is completed from the successor's first bits.
-// Value lists that are still uint16 and need packing (level-2 statistics with d < 16) take the byte-granular path at the end.
-__global__ __launch_bounds__(AWG) void k_assemble(Scratch sc, RecordParams rp, uint32_t B, uint8_t *__restrict__ out,
-                                                   const uint64_t *__restrict__ rec_off, uint32_t lz4f_hdr_bitmap,
-                                                   uint32_t lz4f_hdr_pix, uint32_t batch_seq)
-{
-    if (sc.status->code != 0) {
-        // last kernel of the batch: remember the first failure across asynchronously enqueued batches (one writer per
-        // batch, batches are ordered on their stream)
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && sc.first_err && sc.first_err->code == 0) {
-            sc.first_err->frame = sc.status->frame;
-            sc.first_err->total = batch_seq;
-            sc.first_err->code = sc.status->code;
-        }
-        return;
-    }
-    const uint32_t f = blockIdx.y;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t t0 = (blockIdx.x * AWAVES + w) * ASM_TPW;
-    const int lane = lane_id();
-    if (t0 >= sc.ntiles) return;
-    // pix_mode 1: ONLY the packed residual stream, flat (no container), into the frame's row of sc.pixraw - record offsets do
-    // not exist yet; pix_mode 2: everything but the residual stream (k_pix_gather places its encoded chunks)
-    const bool flat = rp.pix_mode == 1, skip_pix = rp.pix_mode == 2;
-    uint8_t *rec = flat ? sc.pixraw + (uint64_t)f * sc.pixraw_stride : out + rec_off[f];
-    const uint64_t frow = (uint64_t)f * sc.ntiles;
-    const uint32_t nnz = rp.level == 1 ? sc.frame_nnz[f] : 0;
-    const uint32_t npk = rp.level == 1 ? packed_bytes(nnz, rp.depth) : 0;
-
-    uint64_t bitmap_pos, pix_pos;  // record offsets of the bitmap stream and of packed-pixel byte 0's container
-    uint32_t cb = 0;
-    const FrameFmt ff = frame_fmt(rp.emit);
-    const uint32_t bhdr = bitmap_hdr(ff, rp.emit, sc.ntiles);
-    if (flat) {
-        bitmap_pos = 0;
-        pix_pos = 0;
-    } else if (rp.emit == 0) {
-        bitmap_pos = rp.level == 1 ? 8 : 4;
-        pix_pos = bitmap_pos + sc.nb;
-    } else {
-        cb = bhdr + sc.frame_cbytes[f] + ff.end;
-        bitmap_pos = rp.level == 1 ? 16 : 8;
-        pix_pos = bitmap_pos + cb;
-    }
-
-    // fixed fields
-    if (t0 == 0 && lane == 0 && !flat) record_fixed_fields(sc, rp, f, rec, bitmap_pos, pix_pos, cb, npk, ff, skip_pix, lz4f_hdr_bitmap, lz4f_hdr_pix);
-
-    // ---- copies: 16 lanes per segment, 4 segments per wave-instruction, no scalar address arithmetic --------------------
-    // Quarter q of the wavefront (lanes 16q..16q+15) handles tile t0 + 4*pass + q in pass 0..ASM_PASSES-1.  A segment is n bytes from
-    // a 4-byte aligned source to an arbitrarily aligned destination: destination dword j = source bytes [head+4j, head+4j+4)
-    // = byte funnel shift (v_alignbyte_b32) of source dwords j, j+1 (one 8-byte load per lane); head / tail bytes are
-    // stored singly by the lanes that already hold them.  All loads of the wavefront's tiles are issued before the
-    // first store (loads and stores share one in-order counter).
-    const uint32_t ntl = min(ASM_TPW, sc.ntiles - t0);
-    const uint32_t sub = (uint32_t)lane >> 4, sl = (uint32_t)lane & 15u;
-    const uint32_t d = rp.depth;
-    // residual slots holding a tile-local packed stream of d-bit fields (level 1; uint16 values are the d = 16 case)
-    const bool pixp = rp.level == 1 && rp.packed_slots && !skip_pix;   // (level-2 statistics: one contiguous list, packed at the end of this kernel)
-    const bool plain_pos = rp.emit == 0 || flat;   // residual byte b sits at offset b (no stored-chunk headers in between)
-    uint8_t *pdst = rec + pix_pos;
-#ifndef RC_ASM_BIT
-#define RC_ASM_BIT 4
-#endif
-#ifndef RC_ASM_PIT
-#define RC_ASM_PIT 2
-#endif
-    constexpr int BIT = RC_ASM_BIT, PIT = RC_ASM_PIT;  // unrolled 16-dword steps per segment: 256 B of block, 128 B of residuals; longer: loop
-    uint8_t *bdst[ASM_PASSES], *pdstp[ASM_PASSES];
-    const uint8_t *bsrc[ASM_PASSES], *psrc[ASM_PASSES];
-    uint32_t bn[ASM_PASSES], pn[ASM_PASSES], ps0[ASM_PASSES];
-    // a tile owns the stream bytes whose FIRST bit is one of its bits; when its last owned byte is only partly its own
-    // (fin_avail bits), the rest comes from the next non-empty tile(s): that byte is written separately
-    uint32_t fin_avail[ASM_PASSES], fin_q[ASM_PASSES], fin_next[ASM_PASSES], fin_ncnt[ASM_PASSES], fin_nfirst[ASM_PASSES];
-    uint64_t fin_b[ASM_PASSES];
-    u32x2 bv[ASM_PASSES][BIT], pv[ASM_PASSES][PIT];
-#pragma unroll
-    for (int ps = 0; ps < ASM_PASSES; ++ps) {
-        const uint32_t k = 4u * ps + sub;
-        const uint32_t tl = t0 + k;
-        const bool have = k < ntl;
-        bn[ps] = 0; pn[ps] = 0; ps0[ps] = 0; fin_avail[ps] = 0; fin_q[ps] = 0; fin_next[ps] = sc.ntiles; fin_b[ps] = 0;
-        bdst[ps] = rec; pdstp[ps] = rec; bsrc[ps] = sc.blk_slots; psrc[ps] = sc.blk_slots;
-        if (have && !flat) {
-            if (rp.emit == 0) {
-                const uint64_t b0 = (uint64_t)tl * TILE_BM;
-                bn[ps] = (uint32_t)min((uint64_t)TILE_BM, sc.nb - b0);
-                bdst[ps] = rec + bitmap_pos + b0;
-                bsrc[ps] = sc.bitmap + (uint64_t)f * sc.nb_stride + b0;
-            } else {
-                bn[ps] = sc.blk_size[frow + tl];
-                const uint32_t boff = bhdr + sc.blk_off[frow + tl];
-                bdst[ps] = rec + bitmap_pos + boff;
-                bsrc[ps] = sc.blk_slots + (frow + tl) * sc.blk_stride;
-                if (rp.emit == 8 && sl == 0) store_u32_le(rec + bitmap_pos + 16 + 4 * (uint64_t)tl, boff);  // blosc bstarts[tl]
-            }
-        }
-        if (have) {
-            if (pixp) {
-                const uint32_t c = sc.tile_cnt[frow + tl];
-                if (c) {
-                    const uint64_t dbit = (uint64_t)sc.tile_off[frow + tl] * d;  // stream position of the tile's first bit
-                    const uint32_t nbits = c * d;
-                    const uint64_t b_lo = (dbit + 7) >> 3, b_hi = (dbit + nbits + 7) >> 3;
-                    const uint32_t avail = (uint32_t)((dbit + nbits) & 7u);
-                    uint32_t n = (uint32_t)(b_hi - b_lo);
-                    ps0[ps] = (uint32_t)(8 * b_lo - dbit);
-                    psrc[ps] = residual_src(sc, frow + tl, sc.comb == 1 ? sc.blk_size[frow + tl] : 0u, c, d);
-                    if (avail && n) {  // (n == 0: the tile's few bits all live in a byte that an earlier tile owns)
-                        --n;
-                        fin_avail[ps] = avail;
-                        fin_q[ps] = 8 * n + ps0[ps];
-                        fin_b[ps] = b_hi - 1;
-                        fin_next[ps] = sc.tile_next[frow + tl];
-                    }
-                    pn[ps] = n;
-                    if (n && !plain_pos && (b_lo >> ff.chunk_shift) != ((b_lo + n - 1) >> ff.chunk_shift)) {
-                        // straddles a stored-chunk header of the pixel frame (once per 4 MiB): byte by byte
-                        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(psrc[ps]);
-                        for (uint32_t i = sl; i < n; i += 16) {
-                            const uint32_t q = 8 * i + ps0[ps];
-                            pdst[stored_pos(ff, b_lo + i)] = (uint8_t)__builtin_amdgcn_alignbit(s32[(q >> 5) + 1], s32[q >> 5], q & 31u);
-                        }
-                        pn[ps] = 0;
-                    }
-                    pdstp[ps] = pdst + (plain_pos ? b_lo : stored_pos(ff, b_lo));
-                }
-            }
-        }
-    }
-    // loads
-#pragma unroll
-    for (int ps = 0; ps < ASM_PASSES; ++ps) {
-#pragma unroll
-        for (int it = 0; it < BIT; ++it) {
-            const uint32_t j = sl + 16u * it;
-            bv[ps][it] = u32x2{0u, 0u};
-            if (4 * j < bn[ps] + 4 && bn[ps]) bv[ps][it] = *reinterpret_cast<const u32x2 *>(bsrc[ps] + 4 * j);
-        }
-        if (pixp) {
-#pragma unroll
-            for (int it = 0; it < PIT; ++it) {
-                const uint32_t j = sl + 16u * it;
-                pv[ps][it] = u32x2{0u, 0u};
-                if (4 * j < pn[ps] + 4 && pn[ps]) pv[ps][it] = *reinterpret_cast<const u32x2 *>(psrc[ps] + 4 * j);
-            }
-            fin_ncnt[ps] = 0; fin_nfirst[ps] = 0;
-            if (fin_avail[ps] && fin_next[ps] < sc.ntiles) {
-                fin_ncnt[ps] = sc.tile_cnt[frow + fin_next[ps]];
-                fin_nfirst[ps] = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + fin_next[ps], sc.comb == 1 ? sc.blk_size[frow + fin_next[ps]] : 0u,
-                                                                                 fin_ncnt[ps], d));
-            }
-        }
-    }
-    // stores.  Destination dword j (behind `head` bytes that align it) = source bits [8*head + s0 + 32j, +32) = dwords j, j+1
-    // funnel-shifted (v_alignbit_b32); s0 = 0 for byte-aligned sources (encoded blocks, d = 16)
-    auto put = [&](uint8_t *dst, uint32_t n, uint32_t j, const u32x2 &v, uint32_t s0) {
-        const uint32_t head = min(n, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
-        const uint32_t n2 = n - head, nd = n2 >> 2, tail = n2 & 3u;
-        const uint32_t val = __builtin_amdgcn_alignbit(v[1], v[0], 8 * head + s0);
-        if (j < nd) reinterpret_cast<uint32_t *>(dst + head)[j] = val;
-        if (j == nd && tail) {
-            uint8_t *t = dst + head + 4 * nd;
-            t[0] = (uint8_t)val;
-            if (tail > 1) t[1] = (uint8_t)(val >> 8);
-            if (tail > 2) t[2] = (uint8_t)(val >> 16);
-        }
-        if (j == 0 && head) {
-            const uint32_t h0 = __builtin_amdgcn_alignbit(v[1], v[0], s0);
-            dst[0] = (uint8_t)h0;
-            if (head > 1) dst[1] = (uint8_t)(h0 >> 8);
-            if (head > 2) dst[2] = (uint8_t)(h0 >> 16);
-        }
-    };
-#pragma unroll
-    for (int ps = 0; ps < ASM_PASSES; ++ps) {
-        if (bn[ps]) {
-#pragma unroll
-            for (int it = 0; it < BIT; ++it) put(bdst[ps], bn[ps], sl + 16u * it, bv[ps][it], 0);
-            for (uint32_t j = sl + 16u * BIT; 4 * j < bn[ps] + 4; j += 16)  // rare: longer than the unrolled part
-                put(bdst[ps], bn[ps], j, *reinterpret_cast<const u32x2 *>(bsrc[ps] + 4 * j), 0);
-        }
-        if (pixp && pn[ps]) {
-#pragma unroll
-            for (int it = 0; it < PIT; ++it) put(pdstp[ps], pn[ps], sl + 16u * it, pv[ps][it], ps0[ps]);
-            for (uint32_t j = sl + 16u * PIT; 4 * j < pn[ps] + 4; j += 16)
-                put(pdstp[ps], pn[ps], j, *reinterpret_cast<const u32x2 *>(psrc[ps] + 4 * j), ps0[ps]);
-        }
-        if (pixp && fin_avail[ps] && sl == 0) {
-            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(psrc[ps]);
-            const uint32_t q = fin_q[ps], avail = fin_avail[ps];
-            uint32_t byte = __builtin_amdgcn_alignbit(s32[(q >> 5) + 1], s32[q >> 5], q & 31u) & ((1u << avail) - 1u);
-            uint32_t got = avail, tt = fin_next[ps], cc = fin_ncnt[ps], first = fin_nfirst[ps];
-            while (tt < sc.ntiles) {  // one round unless the next tile holds fewer than 8 - avail bits (d < 8 only)
-                const uint32_t take = min(8u - got, cc * d);
-                byte |= (first & ((1u << take) - 1u)) << got;
-                got += take;
-                if (got >= 8) break;
-                tt = sc.tile_next[frow + tt];
-                if (tt < sc.ntiles) {
-                    cc = sc.tile_cnt[frow + tt];
-                    first = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + tt, sc.comb == 1 ? sc.blk_size[frow + tt] : 0u, cc, d));
-                }
-            }
-            pdst[plain_pos ? fin_b[ps] : stored_pos(ff, fin_b[ps])] = (uint8_t)byte;
-        }
-    }
-    if (rp.level != 1 || pixp || skip_pix) return;
-
-    // ---- uint16 value lists that still need packing (level 2 statistics with d < 16): bit-packed on the way, byte-wise -------
-    // The list is ONE contiguous run of nnz values from the start of the frame's slots (k_l2_emit writes it that way and describes it
-    // as full pseudo-tiles), so every wavefront of the frame's launch row packs its own share of the output bytes.  (Tile by tile, as
-    // the description reads, all the work fell to the frame's first wavefront: 161 us for 24 KB per frame at 4096 x 4096, 0.1 %.)
-    const uint16_t *vals = sc.pix_slots + frow * TILE_PX;
-    const uint32_t wave_id = blockIdx.x * AWAVES + (uint32_t)w;
-    const uint32_t nwaves = (sc.ntiles + ASM_TPW - 1) / ASM_TPW;
-    const uint64_t per = (((uint64_t)npk + nwaves - 1) / nwaves + 63) & ~63ull;
-    const uint64_t b_end = min((uint64_t)npk, (uint64_t)(wave_id + 1) * per);
-    const uint32_t dmask = (1u << d) - 1;
-    for (uint64_t b = (uint64_t)wave_id * per + lane; b < b_end; b += 64) {
-        const uint64_t bit0 = b * 8;
-        uint32_t v = (uint32_t)(bit0 / d);
-        const uint32_t o = (uint32_t)(bit0 - (uint64_t)v * d);
-        uint32_t acc = ((v < nnz ? (uint32_t)vals[v] : 0u) & dmask) >> o;
-        uint32_t filled = d - o;
-        while (filled < 8) {
-            ++v;
-            acc |= ((v < nnz ? (uint32_t)vals[v] : 0u) & dmask) << filled;
-            filled += d;
-        }
-        pdst[plain_pos ? b : stored_pos(ff, b)] = (uint8_t)acc;
-    }
-}
-
-
+// ---- record assembly: k_gather (rc_gather.hip); here the LZ4 frame descriptors and its launcher ----------------------------------
 // xxHash32 of the two descriptor bytes -> LZ4 frame header checksum byte (lz4_Frame_format.md, "HC")
 static uint32_t xxh32_small(const uint8_t *p, size_t n)
 {
@@ -1539,16 +1232,7 @@ void launch_assemble(const Scratch &sc, const RecordParams &rp, uint32_t B, uint
 {
     static const uint32_t hdr_bitmap = lz4f_descriptor(0x40);  // 64 KiB max block (blocks are <= 2 KiB)
     static const uint32_t hdr_pix = lz4f_descriptor(0x70);     // 4 MiB max block (stored chunks)
-    // Everything but level-2 value lists (uint16 values that k_assemble packs on the way) goes through k_gather (rc_gather.hip)
-    static const char *old_env = RC_KNOB("RC_OLD_ASSEMBLE");
-    const bool lists = rp.level == 1 && !rp.packed_slots && rp.pix_mode != 2;
-    if (!lists && !old_env) {
-        launch_gather(sc, rp, B, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, s);
-        return;
-    }
-    const uint32_t per_wg = AWAVES * ASM_TPW;
-    const dim3 grid((sc.ntiles + per_wg - 1) / per_wg, B), block(AWG);
-    hipLaunchKernelGGL(k_assemble, grid, block, 0, s, sc, rp, B, out, rec_off, hdr_bitmap, hdr_pix, batch_seq);
+    launch_gather(sc, rp, B, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, s);
 }
 
 }  // namespace rc

@@ -13,7 +13,7 @@
 // run inside the kernel on the tile's map in LDS, as in the uint16 kernel; reduce-only records take the raw binary map.  Either
 // way it leaves what rc_reduce.hip's kernel leaves - per tile the encoded block (or the map), the packed residual stream in its slot (whole
 // 128-byte lines, zero behind the last field) and the count - so scans, record layout and assembly are the uint16 path's, unchanged
-// (k_assemble concatenates bit streams of any field width up to 32).  Algorithmic bytes: 4 N per frame in; blocks and residual lines out.
+// (k_gather concatenates bit streams of any field width up to 32).  Algorithmic bytes: 4 N per frame in; blocks and residual lines out.
 #include <type_traits>
 
 #include "rc_launch.h"

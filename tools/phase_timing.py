@@ -23,7 +23,7 @@ else:
 ctx = hip.ReduceContext(nx, ny, d, level, 1, scheme, clevel, 0, max_batch=B)
 ctx.set_threshold(dark.data_ptr())
 ctx.keep_binary_maps(False)
-cap = B * (N // 2 + 4096)
+cap = int(L.rc_out_capacity(ctx.handle, B))
 out = torch.empty(cap, dtype=torch.uint8, device="cuda")
 recn = np.zeros(B + 1, np.uint64); mdn = np.zeros((B, 3), np.uint32)
 ph = (C.c_ulonglong * 16)()

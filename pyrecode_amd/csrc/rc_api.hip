@@ -528,16 +528,9 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     c->sc = c->sets[k];
     const rc::Scratch &sc = c->sets[k];
     hipStream_t ps = c->pstream;
-    if (c->post_pending[k]) {   // the batch two calls ago must have left this set
-        // ... which it usually has long ago: then nothing is put on the stream (every packet between two reduce kernels - a wait, an
-        // event record - is a few microseconds during which the chip drains: 18.6 us between consecutive reduce kernels with three of
-        // them, profiles/r05_exp7_phase_shares_batch_gaps.log)
-        if (hipEventQuery(c->ev_post[k]) == hipSuccess) c->post_pending[k] = false;
-        else {
-            (void)hipGetLastError();
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
-        }
-    }
+    // the batch two calls ago must have left this set.  (Round 5 tried to skip the wait when hipEventQuery says the event has completed -
+    // it always has, in steady state: no gain in the step, 9 us more host time per call.)
+    if (c->post_pending[k]) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     // every device codec's block encoder runs inside the reduce kernel (LZ4; blosc = bit-shuffle + LZ4; zstd: the
     // byte-parallel half - literals, sequence tokens - with the serial FSE half lane-per-block behind it)

@@ -95,7 +95,7 @@ __device__ __forceinline__ ResidGeom resid_geom(uint32_t coff, uint32_t cnt, uin
 #endif
 template <bool BITS, int U>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WPE))) void k_gather(GatherArgs sc, RecordParams rp, uint8_t *__restrict__ out, const uint64_t *__restrict__ rec_off,
-                                               uint32_t lz4f_hdr_bitmap, uint32_t lz4f_hdr_pix, uint32_t batch_seq, uint32_t gpf, uint32_t nitems)
+                                               uint32_t lz4f_hdr_bitmap, uint32_t lz4f_hdr_pix, uint32_t batch_seq, uint32_t gpf, uint32_t nitems, uint32_t tpi)
 {
     if (sc.status->code != 0) {   // (the batch's last kernel remembers the first failure across asynchronously enqueued batches)
         if (blockIdx.x == 0 && threadIdx.x == 0 && sc.first_err && sc.first_err->code == 0) {
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
     const uint32_t bhdr = bitmap_hdr(ff, rp.emit, sc.ntiles);
     const uint8_t *pix_base = reinterpret_cast<const uint8_t *>(sc.pix_slots);
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const uint32_t f = item / gpf, g = item - f * gpf, t0 = 64u * g, t = t0 + lane;
-        const bool have = t < sc.ntiles;
+        const uint32_t f = item / gpf, g = item - f * gpf, t0 = tpi * g, t = t0 + lane;   // tpi tiles per item: 64, fewer for small batches
+        const bool have = lane < tpi && t < sc.ntiles;
         const uint64_t frow = (uint64_t)f * sc.ntiles;
         uint8_t *rec = flat ? sc.pixraw + (uint64_t)f * sc.pixraw_stride : out + rec_off[f];
         const uint32_t nnz = rp.level == 1 ? sc.frame_nnz[f] : 0;
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
         }
         // the first tile behind the item, for the last tile's shared byte (BITS)
         uint32_t ext_cnt = 0, ext_first = 0;
-        if (BITS && pixp && t0 + 64 < sc.ntiles) {
-            ext_cnt = sc.tile_cnt[frow + t0 + 64];
+        if (BITS && pixp && t0 + tpi < sc.ntiles) {
+            ext_cnt = sc.tile_cnt[frow + t0 + tpi];
             if (ext_cnt)
-                ext_first = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + t0 + 64, sc.comb == 1 ? sc.blk_size[frow + t0 + 64] : 0u, ext_cnt, d));
+                ext_first = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + t0 + tpi, sc.comb == 1 ? sc.blk_size[frow + t0 + tpi] : 0u, ext_cnt, d));
         }
         const uint8_t *slot = rp.emit == 0 ? sc.bitmap + (uint64_t)f * sc.nb_stride + (uint64_t)t0 * TILE_BM : sc.blk_slots + (frow + t0) * sc.blk_stride;
         const uint32_t slot_stride = rp.emit == 0 ? (uint32_t)TILE_BM : sc.blk_stride;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
             }
         }
         if (got < 8) {   // rare: the chain leaves the item's neighbourhood
-            uint32_t tt = cur == 65 ? (t0 + 63 < sc.ntiles ? sc.tile_next[frow + t0 + 63] : sc.ntiles) : (t0 + 64 < sc.ntiles ? sc.tile_next[frow + t0 + 64] : sc.ntiles);
+            uint32_t tt = cur == 65 ? (t0 + tpi - 1 < sc.ntiles ? sc.tile_next[frow + t0 + tpi - 1] : sc.ntiles) : (t0 + tpi < sc.ntiles ? sc.tile_next[frow + t0 + tpi] : sc.ntiles);
             while (tt < sc.ntiles) {
                 const uint32_t cc = sc.tile_cnt[frow + tt];
                 const uint32_t fd = *reinterpret_cast<const uint32_t *>(residual_src(sc, frow + tt, sc.comb == 1 ? sc.blk_size[frow + tt] : 0u, cc, d));
@@ -278,15 +278,19 @@ void launch_gather(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_
 {
     // a one-wave workgroup per item of 64 tiles (RC_GATHER_WGS, development builds: fewer workgroups, each walking several items)
     static const char *wgs_env = RC_KNOB("RC_GATHER_WGS");
-    const uint32_t gpf = (sc.ntiles + 63) / 64, nitems = gpf * B;
+    // 64 tiles per item; fewer where that leaves the chip without work (configs[0]: nine 512 x 512 frames are nine items of 64 tiles -
+    // nine wavefronts walking 64 tiles each took twice k_assemble's time; with eight tiles per item they are 72)
+    uint32_t tpi = 64;
+    while (tpi > 8 && (uint64_t)B * ((sc.ntiles + tpi - 1) / tpi) < 1024) tpi >>= 1;
+    const uint32_t gpf = (sc.ntiles + tpi - 1) / tpi, nitems = gpf * B;
     uint32_t wgs = wgs_env ? (uint32_t)atoi(wgs_env) : 0u;
     if (wgs == 0 || wgs > nitems) wgs = nitems;
     const GatherArgs ga{sc.blk_slots, sc.bitmap, sc.pix_slots, sc.blk_size, sc.blk_off, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.frame_nnz, sc.frame_cbytes,
                         sc.frame_pbytes, sc.pixraw, sc.status, sc.first_err, sc.nb, sc.nb_stride, sc.pixraw_stride, sc.ntiles, sc.blk_stride, sc.pix_slot_bytes, sc.comb};
     if (rp.level == 1 && rp.depth % 8 != 0)
-        hipLaunchKernelGGL((k_gather<true, RC_GATHER_UB>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems);
+        hipLaunchKernelGGL((k_gather<true, RC_GATHER_UB>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
     else
-        hipLaunchKernelGGL((k_gather<false, RC_GATHER_U>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems);
+        hipLaunchKernelGGL((k_gather<false, RC_GATHER_U>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
 }
 
 }  // namespace rc

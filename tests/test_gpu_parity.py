@@ -1069,8 +1069,13 @@ def _l2_expected(frame, thr, stat, d=16):
 
 @pytest.mark.parametrize("ny,nx,s,d,stat,scheme,mode", [
     (64, 64, 0.05, 16, 1, 0, 0), (129, 127, 0.10, 12, 0, 0, 0), (37, 53, 0.20, 12, 2, 0, 0), (200, 300, 0.30, 16, 2, 2, 1),
-    (256, 1024, 0.02, 12, 1, 2, 1), (100, 300, 0.45, 16, 0, 1, 1), (128, 128, 0.62, 14, 2, 8, 1), (96, 160, 0.0, 12, 1, 2, 1)])
+    (256, 1024, 0.02, 12, 1, 2, 1), (100, 300, 0.45, 16, 0, 1, 1), (128, 128, 0.62, 14, 2, 8, 1), (96, 160, 0.0, 12, 1, 2, 1),
+    # round 5 (the stage works on 64-pixel words and items of 64 tiles): one-pixel-wide and one-pixel-high frames, rows longer than a
+    # tile, frames of more than one item (neighbours in the previous item's tiles), sparse and dense
+    (1, 300, 0.40, 12, 2, 0, 0), (300, 1, 0.40, 16, 0, 0, 0), (20, 9000, 0.10, 16, 2, 0, 0), (700, 650, 0.20, 12, 1, 2, 1), (520, 1030, 0.004, 16, 0, 8, 1)])
 def test_l2_summary_statistics(hip, orc, ny, nx, s, d, stat, scheme, mode):
+    """Level-2 records against scipy.ndimage.label + numpy - twice over the same ctx with different frames: the labelling stage's nodes
+    rest at zero between batches and the second batch finds out whether the first one put them back."""
     dark, frames = synth_frames(77 + ny + stat, 3, ny, nx, s, d)
     if s > 0.4:  # blobs: make components large and snaky so that unions have real work
         rng = np.random.default_rng(5)
@@ -1080,20 +1085,21 @@ def test_l2_summary_statistics(hip, orc, ny, nx, s, d, stat, scheme, mode):
     ctx = hip.ReduceContext(nx, ny, d, 2, mode, scheme, 1, 0, max_batch=3)
     ctx.set_dark(dark, 1)
     ctx.set_l2_statistics(stat)
-    out, rec, md = ctx.reduce_compress_batch(frames, first_frame_id=0)
-    for z in range(frames.shape[0]):
-        r = out[int(rec[z]):int(rec[z + 1])].tobytes()
-        binary, vals = _l2_expected(frames[z], thr, stat, d)
-        bitmap = orc.pack_binary_frame(binary).tobytes()
-        packed = orc.bit_pack(vals, d).tobytes()
-        if mode == 0:
-            assert r == struct.pack("<II", z, len(packed)) + bitmap + packed, "frame %d" % z
-        else:
-            fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
-            assert fid == z and npk == len(packed) and len(r) == 16 + cb + cp
-            dec = {2: lambda b, n: orc.lz4f_decode(b, n + 8), 1: lambda b, n: _zstd_system_decode(b), 8: lambda b, n: orc.blosc1_decode(b)}[scheme]
-            assert dec(r[16:16 + cb], len(bitmap)) == bitmap
-            assert dec(r[16 + cb:], len(packed)) == packed
+    for batch in (frames, np.ascontiguousarray(np.roll(frames[::-1], 3, axis=2))):
+        out, rec, md = ctx.reduce_compress_batch(batch, first_frame_id=0)
+        for z in range(batch.shape[0]):
+            r = out[int(rec[z]):int(rec[z + 1])].tobytes()
+            binary, vals = _l2_expected(batch[z], thr, stat, d)
+            bitmap = orc.pack_binary_frame(binary).tobytes()
+            packed = orc.bit_pack(vals, d).tobytes()
+            if mode == 0:
+                assert r == struct.pack("<II", z, len(packed)) + bitmap + packed, "frame %d" % z
+            else:
+                fid, cb, cp, npk = struct.unpack_from("<IIII", r, 0)
+                assert fid == z and npk == len(packed) and len(r) == 16 + cb + cp
+                dec = {2: lambda b, n: orc.lz4f_decode(b, n + 8), 1: lambda b, n: _zstd_system_decode(b), 8: lambda b, n: orc.blosc1_decode(b)}[scheme]
+                assert dec(r[16:16 + cb], len(bitmap)) == bitmap
+                assert dec(r[16 + cb:], len(packed)) == packed
     ctx.close()
 
 

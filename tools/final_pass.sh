@@ -31,6 +31,11 @@ line k2_3838x3710_zstd_d12 --ny 3710 --nx 3838 --batch 64 --stack 128 --scheme 1
 line odd_1023x1023_lz4 --ny 1023 --nx 1023 --batch 1024 --stack 2048 $Q
 line lz4_2pct_d12 --sparsity-ppm 20000 --depth 12 $Q
 line zstd_2pct_d12 --sparsity-ppm 20000 --depth 12 --scheme 1 $Q
+line l2_1pct --level 2 --sparsity-ppm 10000 $Q
+line l2_clustered --level 2 --clustered --sparsity-ppm 2000 --depth 12 $Q
+line dense_10pct --sparsity-ppm 100000 --stack 64 --batch 32 $Q
+line dense_30pct --sparsity-ppm 300000 --stack 64 --batch 32 $Q
+line headline_events_every_launch --kernel-events-every 1 $Q
 line read_zstd --read --scheme 1 --steps 30 --warmup 5 --min-seconds 1
 line read_lz4 --read --scheme 2 --steps 30 --warmup 5 --min-seconds 1
 line read_zstd_fast --read --scheme 1 --clevel 0 --steps 30 --warmup 5 --min-seconds 1

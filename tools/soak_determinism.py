@@ -13,7 +13,8 @@ CFGS = [  # ny, nx, B, ppm, depth, scheme, level, clevel
     (4096, 4096, 64, 10000, 16, 2, 1, 1), (4096, 4096, 64, 10000, 16, 1, 1, 1), (4096, 4096, 64, 10000, 12, 2, 1, 0),
     (4096, 4096, 32, 100000, 12, 2, 1, 1), (4096, 4096, 32, 1000, 16, 8, 2, 1), (8184, 11520, 8, 50000, 12, 1, 1, 1),
     (4096, 4096, 64, 10000, 16, 2, 3, 1), (1000, 1003, 16, 30000, 10, 1, 1, 1),
-    (3710, 3838, 32, 10000, 12, 2, 1, 1), (1023, 1023, 128, 20000, 12, 2, 1, 1), (4096, 4096, 32, 20000, 12, 2, 1, 1)]   # N % 8 = 4, odd N, the two-events-per-lane parser
+    (3710, 3838, 32, 10000, 12, 2, 1, 1), (1023, 1023, 128, 20000, 12, 2, 1, 1), (4096, 4096, 32, 20000, 12, 2, 1, 1),   # N % 8 = 4, odd N, the two-events-per-lane parser
+    (4096, 4096, 32, 10000, 12, 2, 2, 1), (2000, 3000, 16, 60000, 16, 1, 2, 1), (512, 512, 9, 145000, 12, 0, 1, 1)]        # round 5: level 2 at 1 % / dense (unions race for roots; results must not), small items
 for ny, nx, B, ppm, d, scheme, level, clevel in CFGS:
     N = ny * nx
     dark = torch.empty(N, dtype=torch.int16, device="cuda")

@@ -589,13 +589,15 @@ def run_rank(a):
     ctx.set_dark(dark.data_ptr(), 0)  # eps = 0 -> thr = dark
     ctx.keep_binary_maps(False)       # no validation frames in this workload: records only (recode_writer.py:402-415)
     out_cap = int(L.rc_out_capacity(ctx.handle, B))   # the worst case the library itself states: B raw frames (a record may not exceed its frame, recode_writer.py:565-566)
-    out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
-    rec = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    # two sets of output buffers, alternating: a pipelined ctx may run step i + 1's second stage while step i's is still writing its records
+    # (include/recode_hip.h: "the caller must not reuse a batch's output buffers before" it has ordered itself behind the batch)
+    outs = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+    recs = [torch.empty(B + 1, dtype=torch.int64, device=dev) for _ in range(2)]
     nb = S // B
     # rank r's frames of step i carry the ids of its contiguous block of the job's frames (recode_writer.py:320-322,385)
     batch_ptr = [stack[j * B].data_ptr() for j in range(nb)]      # (no tensor indexing in the step loop: N loops share the host's cores)
     collective = use_dist and not a.no_collective
-    loop = ShardedStepLoop(ctx, B, lambda i: (batch_ptr[i % nb], rank * S + (i % nb) * B), out, rec, dev, collective=collective,
+    loop = ShardedStepLoop(ctx, B, lambda i: (batch_ptr[i % nb], rank * S + (i % nb) * B), outs, recs, dev, collective=collective,
                            gather_every=a.gather_every, region_steps=max(a.steps, a.warmup, 1), fence_barrier=use_dist)
     stream = loop.stream
     if not os.environ.get("RC_BENCH_OWN_STREAM"):     # (experiments with a CU-masked stream of the library's own: RC_RSTREAM_EXCL)
@@ -654,7 +656,7 @@ def run_rank(a):
     last_step = it - 1
     frames_total = world * B * a.steps
     fps = frames_total / dt_max
-    rec_h = rec.cpu().numpy()
+    rec_h = loop.rec.cpu().numpy()
     assert rec_h[0] == 0 and rec_h[-1] > 0
     gather_verified = loop.verify_gather()   # collective: every rank's block of the gathered table, on every rank
     gathers_in_region = loop.gathers_issued
@@ -664,6 +666,7 @@ def run_rank(a):
 
     def verify_batch(j, z):
         """Outside the timing: record z of the records `out` holds now - batch j of the stack - against the oracle."""
+        out, rec = loop.out, loop.rec         # (the buffers the most recent step wrote)
         rec_now = rec.cpu().numpy()
         if corrupt:
             mid_byte = (int(rec_now[z]) + int(rec_now[z + 1])) // 2

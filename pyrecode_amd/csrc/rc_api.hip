@@ -21,6 +21,9 @@ struct rc_ctx {
     int last = 0;                         // set of the most recent batch
     hipStream_t pstream = nullptr;        // carries everything behind the reduce kernel: one of the two below
     hipStream_t pstream_all = nullptr, pstream_masked = nullptr;
+    hipStream_t pstream_b = nullptr;      // two chains (pipelined, level 2): the second stage of the batches on scratch set 1
+    hipStream_t last_ps = nullptr;        // the stream the most recent batch's second stage went to
+    bool two_chains = false;
     hipEvent_t ev_red[2] = {}, ev_post[2] = {}, ev_in[2] = {};
     bool post_pending[2] = {false, false};
     bool pipelined = false;
@@ -41,7 +44,8 @@ struct rc_ctx {
     rc::ZstdModel *d_model = nullptr, *h_model = nullptr;
     rc::ZstdSample *d_sample = nullptr, *h_sample = nullptr;
     uint32_t l2_sum = 0;                  // L2_statistics: 0/1 max, 2 sum
-    rc::u32x2 *d_l2_node = nullptr;       // level 2: the labelling stage's nodes (rc_l2.hip), shared by both scratch sets
+    rc::u32x2 *d_l2_node[2] = {};         // level 2: the labelling stage's nodes (rc_l2.hip) - one workspace per chain of second stages
+    uint16_t *d_l2_base[2] = {};          // ... and its directory of rank bases
     rc::BatchStatus *h_status = nullptr;  // pinned: [0] most recent batch, [1] first failed batch since the last sync
     rc::BatchStatus *d_first_err = nullptr;
     uint32_t batch_seq = 0;               // batches enqueued since the last rc_ctx_sync
@@ -194,7 +198,15 @@ static int ctx_alloc(rc_ctx *c)
             }
         }
     }
+    {
+        // (the second chain's stream: created at another priority so that it gets a hardware queue of its own - a plain third stream shared
+        // the reduce stream's queue on the default four and cost every configuration 10 %, profiles/r05_exp23_two_chains_shared_queue.log)
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->pstream_b, hipStreamNonBlocking, hi));
+    }
     c->pstream = c->pstream_all;
+    c->last_ps = c->pstream;
     c->stream = c->own_stream;
     HIP_TRY(hipMalloc((void **)&c->sc.thr, c->sc.N * 2));
     HIP_TRY(hipMalloc((void **)&c->d_first_err, sizeof(BatchStatus)));
@@ -205,15 +217,27 @@ static int ctx_alloc(rc_ctx *c)
         int r = alloc_set(c, set);
         if (r != RC_OK) return r;
     }
+    // Two chains (level 2): the second stage of a level-2 batch - directory, links, statistics, emit, then the level-1 stages - is a chain of
+    // latency-bound kernels about as long as the reduce kernel itself; on ONE stream it paces the batches (step 0.70 ms against a reduce kernel
+    // of 0.58).  The batches on scratch set 1 take a second stream and a second workspace (nodes + directory), so two consecutive
+    // batches' chains overlap each other as well as the reduce kernels: +4 % at 1 % of the pixels set, +9 % on clustered events, nothing for
+    // level 1 whose chain is a quarter of its reduce kernel (profiles/r05_exp24_two_chains.log).  Batches still COMPLETE in order.
+    c->two_chains = c->level == 2 && !RC_KNOB("RC_ONE_CHAIN");
     if (c->level == 2) {
         // level 2 (rc_l2.hip): a node {parent, accumulator} for every pixel of a batch (8 bytes each: 8.6 GB for 64 frames of 4096^2, of
-        // which only the entries of set pixels with neighbours are ever touched), at rest - zero - between batches.  One workspace for
-        // both scratch sets (the labelling stages of two batches never overlap: they share the second-stage stream); sized by the
-        // geometry, so no batch can exceed it.
+        // which only the entries of set pixels with neighbours are ever touched), at rest - zero - between batches, and the directory of
+        // rank bases (2 bytes per 64 pixels).  One workspace per chain (above): two in all, 17 GB at that size - sized by the geometry, so
+        // no batch can exceed it.
         const uint64_t ids = (uint64_t)c->sc.ntiles * rc::TILE_PX;
-        HIP_TRY(hipMalloc((void **)&c->d_l2_node, B * ids * 8));
-        HIP_TRY(hipMemset(c->d_l2_node, 0, B * ids * 8));
-        for (Scratch &set : c->sets) { set.l2_node = c->d_l2_node; set.l2_ids_per_frame = ids; }
+        for (int i = 0; i < (c->two_chains ? 2 : 1); ++i) {
+            HIP_TRY(hipMalloc((void **)&c->d_l2_node[i], B * ids * 8));
+            HIP_TRY(hipMemset(c->d_l2_node[i], 0, B * ids * 8));
+            HIP_TRY(hipMalloc((void **)&c->d_l2_base[i], B * (uint64_t)c->sc.ntiles * 64 * 2));   // (written by k_l2_dir before anything reads it)
+        }
+        for (int i = 0; i < 2; ++i) {
+            Scratch &set = c->sets[i];
+            set.l2_node = c->d_l2_node[c->two_chains ? i : 0]; set.l2_ids_per_frame = ids; set.l2_base = c->d_l2_base[c->two_chains ? i : 0];
+        }
     }
     c->sc = c->sets[0];
     if (c->emit == RC_SCHEME_ZSTD) {
@@ -308,6 +332,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->pstream_all) (void)hipStreamSynchronize(c->pstream_all);
     if (c->pstream_masked) (void)hipStreamSynchronize(c->pstream_masked);
+    if (c->pstream_b) (void)hipStreamSynchronize(c->pstream_b);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (rc::Scratch &sc : c->sets) {
         void *per_set[] = {sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
@@ -329,7 +354,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_sample) (void)hipHostFree(c->h_sample);
     void *bufs[] = {c->sc.thr, c->thr32, c->d_first_err, c->d_frames, c->d_out, c->d_dark, c->d_rec_off,
-                    c->d_md, c->d_ztab, c->d_model, c->d_sample, c->d_l2_node};
+                    c->d_md, c->d_ztab, c->d_model, c->d_sample, c->d_l2_node[0], c->d_l2_node[1], c->d_l2_base[0], c->d_l2_base[1]};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     hipEvent_t sync_ev[] = {c->ev_red[0], c->ev_red[1], c->ev_post[0], c->ev_post[1], c->ev_in[0], c->ev_in[1]};
@@ -337,6 +362,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
         if (e) (void)hipEventDestroy(e);
     if (c->pstream_all) (void)hipStreamDestroy(c->pstream_all);
     if (c->pstream_masked) (void)hipStreamDestroy(c->pstream_masked);
+    if (c->pstream_b) (void)hipStreamDestroy(c->pstream_b);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -527,7 +553,10 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     c->last = k;
     c->sc = c->sets[k];
     const rc::Scratch &sc = c->sets[k];
-    hipStream_t ps = c->pstream;
+    // (two chains: consecutive batches' second stages on two streams - they overlap each other as well as the reduce kernels)
+    const bool two = c->pipelined && c->two_chains && c->pstream == c->pstream_all;
+    hipStream_t ps = two && k == 1 ? c->pstream_b : c->pstream;
+    c->last_ps = ps;
     // the batch two calls ago must have left this set.  (Round 5 tried to skip the wait when hipEventQuery says the event has completed -
     // it always has, in steady state: no gain in the step, 9 us more host time per call.)
     if (c->post_pending[k]) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
@@ -585,6 +614,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     ++c->batch_seq;
     if (pix_huff && !(skip & 32)) launch_pix_gather(sc, n, c->depth, 16, out_dev, rec_off_dev, ps);
     if (ev) HIP_TRY(hipEventRecord(ev[4], ps));
+    if (two && c->post_pending[k ^ 1]) HIP_TRY(hipStreamWaitEvent(ps, c->ev_post[k ^ 1], 0));   // batches still COMPLETE in order
     HIP_TRY(hipEventRecord(c->ev_post[k], ps));
     c->post_pending[k] = true;
     if (!c->pipelined) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[k], 0));
@@ -615,6 +645,7 @@ RC_EXPORT int rc_ctx_set_pipelined(rc_ctx *c, int on)
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
     RC_ON_DEVICE(c->device);
     HIP_TRY(hipStreamSynchronize(c->pstream));  // the second stage changes streams: drain the old one first
+    HIP_TRY(hipStreamSynchronize(c->pstream_b));
     c->pipelined = on != 0;
     c->pstream = (c->pipelined && c->pstream_masked) ? c->pstream_masked : c->pstream_all;
     return RC_OK;
@@ -632,6 +663,7 @@ RC_EXPORT int rc_ctx_sync(rc_ctx *c)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
     RC_ON_DEVICE(c->device);
+    HIP_TRY(hipStreamSynchronize(c->pstream_b));
     HIP_TRY(hipMemcpyAsync(&c->h_status[0], c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->pstream));
     HIP_TRY(hipMemcpyAsync(&c->h_status[1], c->d_first_err, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, c->pstream));
     HIP_TRY(hipMemsetAsync(c->d_first_err, 0, sizeof(rc::BatchStatus), c->pstream));
@@ -650,6 +682,7 @@ RC_EXPORT int rc_ctx_sync(rc_ctx *c)
         ++c->prof_batches;
     }
     c->prof_used = 0;
+    if (c->h_status[1].total != 0) c->h_status[1] = rc::first_err_decode(c->h_status[1].total);   // (k_gather leaves a key: rc_device.h)
     if (c->h_status[1].code != 0) {  // the first batch that failed since the last sync (not only the most recent one)
         char msg[160];
         if (n_batches > 1)
@@ -814,7 +847,7 @@ RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const void *frames_host, 
         HIP_TRY(hipEventRecord(p.ev_val, c->stream));
     }
     if (p.zero_copy) HIP_TRY(hipEventRecord(p.ev_h2d, c->stream));   // "input consumed" = the reduce kernel (and the count) have run
-    hipStream_t ps = c->pstream;   // carries the batch's assembly: the metadata follows it
+    hipStream_t ps = c->last_ps;   // carries the batch's assembly: the metadata follows it
     HIP_TRY(hipMemcpyAsync(p.h_rec, p.d_rec, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, ps));
     HIP_TRY(hipMemcpyAsync(p.h_md, p.d_md, (uint64_t)n * 12, hipMemcpyDeviceToHost, ps));
     HIP_TRY(hipMemcpyAsync(p.h_stat, c->sc.status, sizeof(rc::BatchStatus), hipMemcpyDeviceToHost, ps));

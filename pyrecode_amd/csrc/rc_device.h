@@ -102,5 +102,16 @@ struct BatchStatus {
     uint32_t frame;     // first offending frame
     uint64_t total;     // total record bytes of the batch
 };
+// "the first batch that failed since the last sync" (Scratch::first_err->total; 0 = none): ~(batch << 40 | -code << 32 | frame) - the earliest
+// batch has the LARGEST key, so concurrent second stages settle it with one atomicMax
+__host__ __device__ inline unsigned long long first_err_key(uint32_t batch_seq, int32_t code, uint32_t frame)
+{
+    return ~(((unsigned long long)(batch_seq & 0xFFFFFFu) << 40) | ((unsigned long long)((uint32_t)(-code) & 0xFFu) << 32) | frame);
+}
+inline BatchStatus first_err_decode(unsigned long long key)
+{
+    const unsigned long long k = ~key;
+    return BatchStatus{-(int32_t)((k >> 32) & 0xFFu), (uint32_t)k, k >> 40};
+}
 
 }  // namespace rc

@@ -98,11 +98,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
                                                uint32_t lz4f_hdr_bitmap, uint32_t lz4f_hdr_pix, uint32_t batch_seq, uint32_t gpf, uint32_t nitems, uint32_t tpi)
 {
     if (sc.status->code != 0) {   // (the batch's last kernel remembers the first failure across asynchronously enqueued batches)
-        if (blockIdx.x == 0 && threadIdx.x == 0 && sc.first_err && sc.first_err->code == 0) {
-            sc.first_err->frame = sc.status->frame;
-            sc.first_err->total = batch_seq;
-            sc.first_err->code = sc.status->code;
-        }
+        // ONE 64-bit key per failure, the earliest batch's the largest (rc_api.hip::rc_ctx_sync decodes it): two batches' second stages may
+        // run at the same time (two chains), and a systematic failure - an output buffer too small - fails them all
+        if (blockIdx.x == 0 && threadIdx.x == 0 && sc.first_err)
+            atomicMax(reinterpret_cast<unsigned long long *>(&sc.first_err->total), first_err_key(batch_seq, sc.status->code, sc.status->frame));
         return;
     }
     const uint32_t lane = (uint32_t)lane_id();

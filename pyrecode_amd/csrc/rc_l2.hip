@@ -10,9 +10,11 @@
 // values of its set pixels in raster order (the tile's value slot) - exactly what it left in rounds 2-4.  A
 // set pixel's ID inside its frame is tile * 4096 + its rank among the tile's set pixels: ids grow in raster order, need no per-frame
 // prefix (no scan in front of this stage), and index a sparse array of NODES {parent, accumulator} that rest at zero between batches -
-// no pass initialises them, and only pixels with neighbours ever have theirs written.  Three passes; a work ITEM is 64 consecutive tiles
+// no pass initialises them, and only pixels with neighbours ever have theirs written.  Four passes; a work ITEM is 64 consecutive tiles
 // of one frame and belongs to a one-wave workgroup (few fat waves instead of a quarter of a million one-tile waves: next to the following
 // batch's reduce kernel a CU has room for a handful of small waves, and a pass of one-tile waves cost ~190 us however little they did):
+//   k_l2_dir     the directory: for every 64-pixel word the set pixels of its tile in front of it (a lane per word, a wave scan per tile) -
+//                what turns a neighbour's position into its id
 //   k_l2_link    the item's NON-EMPTY words are listed first (ballot + rank: half the words at 1 %, one in sixteen at 0.1 %), then a
 //                lane per listed word: which of its pixels have a set neighbour among W, NW, N, NE comes from WORD arithmetic on the
 //                word, its left neighbour and the words one row up (funnel-shifted: the row length need not be a multiple of 64) - at
@@ -64,15 +66,19 @@ __device__ __attribute__((noinline)) void uf_union(u32x2 *__restrict__ node, uin
 
 __device__ __forceinline__ uint32_t l2_lane_get(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src_lane), (int)v); }
 
-// The item's view of the frame: the tiles [tlo, tlo + ntv) whose words' rank bases (set pixels of the tile in front of each 64-pixel word)
-// k_l2_link has put into LDS - the item's own 64 tiles and as many tiles in front of them as a row is long, i.e. every tile a W, NW, N or
-// NE neighbour of one of its pixels can lie in
-struct L2View { const uint64_t *bm; const uint16_t *base; uint32_t tlo; };
+// Rank bases: base[w] = set pixels of word w's tile in front of the word (w: word index inside the frame) - the directory a neighbour's id is
+// looked up in.  k_l2_dir writes it for the whole batch before k_l2_link runs.  (Round 5 kept the bases of an item's 64 + 18 tiles in the
+// item's LDS - 10.5 KB; with the word and pixel lists a k_l2_link workgroup held 16.6 KB and k_l2_emit 12.8 KB.  The reduce kernel of the next
+// batch fills the CUs' LDS up to 32 KB and their registers up to 104 per SIMD: a second-stage workgroup that needs more of either than is
+// free waits for a reduce workgroup to retire and then runs IN ITS PLACE.  Padding these workgroups with another 16 KB cost the step
+// 19 %, profiles/r05_exp20_level2_lds_room.log.  And the compiler raises a kernel's register claim to 129 when its LDS alone limits it to
+// three waves per SIMD.  Hence: every kernel of this file within 2.6 KB of LDS and 64 registers.)
+struct L2View { const uint64_t *bm; const uint16_t *base; };
 // id of the set pixel at linear position p of the frame (the caller has seen its bit)
 __device__ __forceinline__ uint32_t l2_id(const L2View &v, uint32_t p)
 {
     const uint32_t wi = p >> 6;
-    return (p >> 12) * (uint32_t)TILE_PX + v.base[wi - v.tlo * 64u] + (uint32_t)__builtin_popcountll(v.bm[wi] & ((1ull << (p & 63u)) - 1ull));
+    return (p >> 12) * (uint32_t)TILE_PX + v.base[wi] + (uint32_t)__builtin_popcountll(v.bm[wi] & ((1ull << (p & 63u)) - 1ull));
 }
 // pixel p (id self) joins the earlier ones among its neighbours: N, or W / NW and NE - the rest of the four hang on those through their own links
 __device__ __forceinline__ void l2_link_pixel(u32x2 *node, const L2View &v, uint32_t nx, uint32_t p, uint32_t self, bool n, bool w, bool nw, bool ne)
@@ -85,29 +91,45 @@ __device__ __forceinline__ void l2_link_pixel(u32x2 *node, const L2View &v, uint
     }
 }
 
-constexpr uint32_t L2_WORDS = 1024;  // the words of a chunk of 16 tiles: its non-empty ones are listed in LDS (uint16 each)
-constexpr uint32_t L2_DESC = 1024;   // linked pixels listed per round (LDS, one dword each)
-constexpr uint32_t L2_VIEW = 64 + 18;  // tiles whose word bases the item keeps: its own and ceil((nx + 1) / 4096) + 1 <= 18 in front (nx < 65536: launch_l2)
+// grid: one-wave workgroups over items of 64 tiles of one frame; a lane per 64-pixel word, one wave scan per tile, eight tiles in flight
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_l2_dir(Scratch sc, uint32_t gpf, uint32_t nitems)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const uint32_t f = item / gpf, t0 = 64u * (item - f * gpf);
+        const uint64_t *bm = reinterpret_cast<const uint64_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride);
+        uint16_t *base = sc.l2_base + (uint64_t)f * sc.ntiles * 64u;
+        const uint32_t ntl = min(64u, sc.ntiles - t0);
+        for (uint32_t c0 = 0; c0 < ntl; c0 += 8) {
+            uint64_t W[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) W[k] = c0 + k < ntl ? bm[(t0 + c0 + k) * 64u + lane] : 0ull;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (c0 + k >= ntl) break;                       // (uniform)
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(W[k]);
+                base[(t0 + c0 + k) * 64u + lane] = (uint16_t)(wave_incl_scan(cnt) - cnt);
+            }
+        }
+    }
+}
+
+constexpr uint32_t L2_WORDS = 512;   // the words of a chunk of 8 tiles: its non-empty ones are listed in LDS (uint16 each)
+constexpr uint32_t L2_DESC = 256;    // linked pixels listed per round (LDS, one dword each)
 
 // grid: one-wave workgroups over the items (64 tiles of one frame each)
-__global__ __launch_bounds__(64) void k_l2_link(Scratch sc, uint32_t nx, uint32_t gpf, uint32_t nitems)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_l2_link(Scratch sc, uint32_t nx, uint32_t gpf, uint32_t nitems)
 {
     __shared__ uint16_t s_words[L2_WORDS];
     __shared__ uint32_t s_desc[L2_DESC];
-    __shared__ uint16_t s_base[L2_VIEW * 64];
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t nwords = sc.ntiles * 64u;
-    const uint32_t back = (nx + 1u + (uint32_t)TILE_PX - 1u) / (uint32_t)TILE_PX + 1u;   // tiles in front of the item a neighbour can lie in
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         const uint32_t f = item / gpf, t0 = 64u * (item - f * gpf);
         const uint64_t *bm = reinterpret_cast<const uint64_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride);
         u32x2 *node = sc.l2_node + (uint64_t)f * sc.l2_ids_per_frame;
         const uint32_t ntl = min(64u, sc.ntiles - t0);
-        const uint32_t tlo = t0 > back ? t0 - back : 0u, ntv = t0 + ntl - tlo;      // the item's view: tiles [tlo, t0 + ntl)
-        const L2View view{bm, s_base, tlo};
-        // ---- A: every word of the view once: its rank base inside its tile (a wave scan per tile) into LDS - the directory neighbours are
-        //      looked up in; the item's own non-empty words (half of them at 1 % of the pixels set, one in sixteen at 0.1 %) listed by
-        //      ballot + rank.  (Rounds of this stage that took the bases from a directory the reduce kernel wrote cost THAT kernel 8 %.)
+        const L2View view{bm, sc.l2_base + (uint64_t)f * sc.ntiles * 64u};
         uint32_t listed = 0;
         auto drain = [&]() {   // desc = word index inside the item (12 bits) << 10 | bit (6) << 4 | N W NW NE
             __builtin_amdgcn_wave_barrier();
@@ -119,19 +141,16 @@ __global__ __launch_bounds__(64) void k_l2_link(Scratch sc, uint32_t nx, uint32_
             __builtin_amdgcn_wave_barrier();
             listed = 0;
         };
-        for (uint32_t c0 = 0; c0 < ntv; c0 += 16) {
+        for (uint32_t c0 = 0; c0 < ntl; c0 += 8) {
+            // ---- A: the chunk's NON-EMPTY words (half of them at 1 % of the pixels set, one in sixteen at 0.1 %) listed by ballot + rank
             uint32_t nw = 0;
-            uint64_t W[16];
+            uint64_t W[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) W[k] = c0 + k < ntv ? bm[(tlo + c0 + k) * 64u + lane] : 0ull;
+            for (int k = 0; k < 8; ++k) W[k] = c0 + k < ntl ? bm[(t0 + c0 + k) * 64u + lane] : 0ull;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (c0 + k >= ntv) break;                       // (uniform)
-                const uint32_t cnt = (uint32_t)__builtin_popcountll(W[k]);
-                s_base[(c0 + k) * 64u + lane] = (uint16_t)(wave_incl_scan(cnt) - cnt);
-                if (tlo + c0 + k < t0) continue;                // (uniform) a tile in front of the item: bases only
+            for (int k = 0; k < 8; ++k) {
                 const uint64_t m = __builtin_amdgcn_ballot_w64(W[k] != 0);
-                if (W[k]) s_words[nw + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)((tlo + c0 + k - t0) * 64u + lane);
+                if (W[k]) s_words[nw + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)((c0 + k) * 64u + lane);
                 nw += (uint32_t)__builtin_popcountll(m);
             }
             __builtin_amdgcn_wave_barrier();
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(64) void k_l2_link(Scratch sc, uint32_t nx, uint32_
                 const bool fits = total <= L2_DESC;            // (dense maps: 64 words can hold more linked pixels than the list - then every lane links its own)
                 if (fits && listed + total > L2_DESC) drain();
                 uint32_t o = listed + inc - n;
-                const uint32_t id0 = (wi >> 6) * (uint32_t)TILE_PX + ((fits || !todo) ? 0u : (uint32_t)s_base[wi - tlo * 64u]);
+                const uint32_t id0 = (wi >> 6) * (uint32_t)TILE_PX + ((fits || !todo) ? 0u : (uint32_t)view.base[wi]);
                 for (; todo; todo &= todo - 1) {
                     const uint32_t i = (uint32_t)__builtin_ctzll(todo);
                     const uint64_t bit = 1ull << i;
@@ -201,7 +220,7 @@ __device__ __forceinline__ uint32_t l2_tile_of(uint32_t cum, uint32_t P)
 // (recode_writer.py:446 hands `self._src_dtype` to get_summary_stats_nb) and stored in src_bit_depth bits (_bit_pack drops the bits above,
 // recode_writer.py:637-652) - i.e. the sum modulo 2^d.  The accumulator is 32 bits wide (2^d divides 2^32: wrapping it changes nothing),
 // k_l2_emit keeps its low 16 bits, the d-bit pack the low d.
-__global__ __launch_bounds__(64) void k_l2_stats(Scratch sc, uint32_t use_sum, uint32_t gpf, uint32_t nitems)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_l2_stats(Scratch sc, uint32_t use_sum, uint32_t gpf, uint32_t nitems)
 {
     const uint32_t lane = (uint32_t)lane_id();
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -233,13 +252,15 @@ __global__ __launch_bounds__(64) void k_l2_stats(Scratch sc, uint32_t use_sum, u
     }
 }
 
-constexpr uint32_t L2_LIST = 6144;   // roots' statistics listed per round (LDS, uint16 each); a tile has at most TILE_PX
+constexpr uint32_t L2_ROUND = 1024;            // pixels walked per round: whole tiles while they fit, a big tile's pixels 1024 at a time
+constexpr uint32_t L2_LIST = L2_ROUND + 32;    // roots' statistics listed per round (LDS, uint16 each) + what a big tile's round left over
 
-// the tile-local stream of the d-bit fields of list[0 .. n) -> out (whole 128-byte lines, zero behind the stream); d = 16: the values
-__device__ __forceinline__ void l2_write_stream(const uint16_t *list, uint32_t n, uint32_t d, uint32_t *__restrict__ out)
+// the tile-local stream of the d-bit fields of list[0 .. n) -> out; d = 16: the values.  pad: whole 128-byte lines, zero behind the stream
+// (the end of a tile's stream); otherwise exactly the n * d / 32 dwords (n a multiple of 32: the stream goes on at a dword boundary)
+__device__ __forceinline__ void l2_write_stream(const uint16_t *list, uint32_t n, uint32_t d, uint32_t *__restrict__ out, bool pad)
 {
     const uint32_t lane = (uint32_t)lane_id();
-    const uint32_t nbits = n * d, ndw = (((nbits + 31) >> 5) + 31u) & ~31u;
+    const uint32_t nbits = n * d, ndw = pad ? (((nbits + 31) >> 5) + 31u) & ~31u : nbits >> 5;
     const uint32_t dmask = d >= 16 ? 0xFFFFu : (1u << d) - 1u;
     for (uint32_t w = lane; w < ndw; w += 64) {
         uint32_t v = (32u * w) / d;
@@ -256,12 +277,22 @@ __device__ __forceinline__ void l2_write_stream(const uint16_t *list, uint32_t n
     }
 }
 
-__global__ __launch_bounds__(64) void k_l2_emit(Scratch sc, uint32_t use_sum, uint32_t depth, uint32_t gpf, uint32_t nitems)
+// one pixel of the emit walk: its node (put back to rest if the batch touched it) and its raw value
+__device__ __forceinline__ void l2_take(u32x2 *node, uint32_t id, const uint16_t *vals, uint32_t r, u32x2 &nd, uint32_t &own)
+{
+    nd = node[id];
+    own = vals[r];
+    if (nd[0] | nd[1]) node[id] = u32x2{0u, 0u};
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_l2_emit(Scratch sc, uint32_t use_sum, uint32_t depth, uint32_t gpf, uint32_t nitems)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_list[L2_LIST];
-    __shared__ uint32_t s_first[64], s_n[64];     // per tile of the round: where its roots start in the list, how many
+    __shared__ uint32_t s_n[64];                  // per tile of the round: how many roots,
+    __shared__ uint16_t s_first[64];              // where they start in the list
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t d = depth < 16 ? depth : 16u;
+    constexpr int U = 4;
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         const uint32_t f = item / gpf, t0 = 64u * (item - f * gpf), t = t0 + lane;
         const uint64_t frow = (uint64_t)f * sc.ntiles;
@@ -270,18 +301,61 @@ __global__ __launch_bounds__(64) void k_l2_emit(Scratch sc, uint32_t use_sum, ui
         if (T == 0) continue;
         u32x2 *node = sc.l2_node + (uint64_t)f * sc.l2_ids_per_frame;
         uint8_t *slots = reinterpret_cast<uint8_t *>(sc.pix_slots) + (frow + t0) * sc.pix_slot_bytes;
-        // rounds of whole tiles whose pixels fit the list (all 64 in one round up to 2.3 % of the pixels set)
+        // rounds of whole tiles whose pixels fit the list (25 tiles a round at 1 % of the pixels set, all 64 up to 0.4 %)
         for (uint32_t ka = 0; ka < 64;) {
-            // kb: one behind the round's last tile = the first tile whose end lies more than L2_LIST pixels behind tile ka's start
+            // kb: one behind the round's last tile = the first tile whose end lies more than L2_ROUND pixels behind tile ka's start
             const uint32_t start = l2_lane_get(cum, ka);
-            const uint64_t over = __builtin_amdgcn_ballot_w64(lane >= ka && inc - start > L2_LIST);
-            uint32_t kb = over ? (uint32_t)__builtin_ctzll(over) : 64u;
-            if (kb == ka) kb = ka + 1;      // (cannot happen: a tile holds at most TILE_PX <= L2_LIST pixels; kept as a guard against a stall)
+            const uint64_t over = __builtin_amdgcn_ballot_w64(lane >= ka && inc - start > L2_ROUND);
+            const uint32_t kb = over ? (uint32_t)__builtin_ctzll(over) : 64u;
+            if (kb == ka) {
+                // ---- a tile with more pixels than a round walks: alone, L2_ROUND pixels at a time.  A round lists its roots behind the (< 32) the
+                // round before left over and writes the largest multiple of 32 of them - whole dwords whatever d is, so the stream goes on at a dword
+                // boundary; the last round writes the rest and the zeros up to the line's end.  In place: the stream never reaches the values
+                // still to be read (no more roots than pixels, no more than 16 bits each).
+                const uint32_t n_px = l2_lane_get(cnt, ka), id0 = (t0 + ka) * (uint32_t)TILE_PX;
+                uint8_t *slot = slots + (uint64_t)ka * sc.pix_slot_bytes;
+                const uint16_t *vals = reinterpret_cast<const uint16_t *>(slot);
+                uint32_t rem = 0, written = 0;
+                for (uint32_t r0 = 0; r0 < n_px; r0 += L2_ROUND) {
+                    const uint32_t r1 = min(n_px, r0 + L2_ROUND);
+                    uint32_t nlist = rem;
+                    for (uint32_t q0 = r0; q0 < r1; q0 += 64u * U) {
+                        u32x2 nd[U];
+                        uint32_t own[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t r = q0 + 64u * u + lane;
+                            nd[u] = u32x2{1u, 0u};
+                            own[u] = 0;
+                            if (r < r1) l2_take(node, id0 + r, vals, r, nd[u], own[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const bool isroot = nd[u][0] == 0;          // (lanes behind r1 carry parent 1)
+                            const uint32_t ri = wave_incl_scan(isroot ? 1u : 0u);
+                            if (isroot) s_list[nlist + ri - 1] = (uint16_t)(use_sum ? nd[u][1] + own[u] : max(nd[u][1], own[u]));
+                            nlist += wave_last(ri);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const bool last = r1 == n_px;
+                    const uint32_t n_out = last ? nlist : nlist & ~31u;
+                    l2_write_stream(s_list, n_out, d, reinterpret_cast<uint32_t *>(slot) + ((written * d) >> 5), last);
+                    rem = nlist - n_out;
+                    const uint16_t keep = lane < rem ? s_list[n_out + lane] : (uint16_t)0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rem) s_list[lane] = keep;
+                    __builtin_amdgcn_wave_barrier();
+                    written += n_out;
+                }
+                if (lane == 0) sc.tile_cnt[frow + t0 + ka] = written;
+                ka += 1;
+                continue;
+            }
             const uint32_t end = kb < 64 ? l2_lane_get(cum, kb) : T;
             s_n[lane] = 0;
             __builtin_amdgcn_wave_barrier();
             uint32_t nlist = 0;
-            constexpr int U = 4;
             for (uint32_t P0 = start; P0 < end; P0 += 64u * U) {
                 uint32_t k[U], r[U];
                 u32x2 nd[U];
@@ -293,11 +367,7 @@ __global__ __launch_bounds__(64) void k_l2_emit(Scratch sc, uint32_t use_sum, ui
                     r[u] = P - l2_lane_get(cum, k[u]);
                     nd[u] = u32x2{1u, 0u};
                     own[u] = 0;
-                    if (P < end) {
-                        nd[u] = node[(t0 + k[u]) * (uint32_t)TILE_PX + r[u]];
-                        own[u] = reinterpret_cast<const uint16_t *>(slots + (uint64_t)k[u] * sc.pix_slot_bytes)[r[u]];
-                        if (nd[u][0] | nd[u][1]) node[(t0 + k[u]) * (uint32_t)TILE_PX + r[u]] = u32x2{0u, 0u};   // back to rest for the next batch
-                    }
+                    if (P < end) l2_take(node, (t0 + k[u]) * (uint32_t)TILE_PX + r[u], reinterpret_cast<const uint16_t *>(slots + (uint64_t)k[u] * sc.pix_slot_bytes), r[u], nd[u], own[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -309,14 +379,14 @@ __global__ __launch_bounds__(64) void k_l2_emit(Scratch sc, uint32_t use_sum, ui
                         s_list[at] = (uint16_t)(use_sum ? nd[u][1] + own[u] : max(nd[u][1], own[u]));
                         atomicAdd(&s_n[k[u]], 1u);
                     }
-                    if (P < end && r[u] == 0) s_first[k[u]] = at + (isroot ? 0u : 1u);   // the tile's first pixel: its roots start here (the next root's place)
+                    if (P < end && r[u] == 0) s_first[k[u]] = (uint16_t)(at + (isroot ? 0u : 1u));   // the tile's first pixel: its roots start here (the next root's place)
                     nlist += wave_last(ri);
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            // every tile of the round: its share of the list -> its slot, as the tile-local packed stream; its new count.  A tile with at
-            // most eight roots whose fields fit 16 bytes (every tile at 0.1 % of the pixels set) is finished by ITS OWN lane with one 16-byte
-            // store - all such tiles in one instruction; the others one after the other by the whole wave
+            // every tile of the round: its share of the list -> its slot, as the tile-local packed stream; its new count.  A tile with at most eight roots whose fields fit 16 bytes (every tile at 0.1 % of the pixels
+            // set) is finished by ITS OWN lane with one 16-byte store - all such tiles in one instruction; the others one after the other by
+            // the whole wave
             const bool mine = lane >= ka && lane < kb && cnt != 0;
             const uint32_t my_n = mine ? s_n[lane] : 0u, my_first = mine ? s_first[lane] : 0u;
             const bool small = mine && my_n <= 8u && my_n * d <= 128u;
@@ -332,10 +402,11 @@ __global__ __launch_bounds__(64) void k_l2_emit(Scratch sc, uint32_t use_sum, ui
                 *reinterpret_cast<u32x4 *>(slots + (uint64_t)lane * sc.pix_slot_bytes) = u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
                 sc.tile_cnt[frow + t] = my_n;
             }
+            __builtin_amdgcn_wave_barrier();
             for (uint64_t rest = __builtin_amdgcn_ballot_w64(mine && !small); rest; rest &= rest - 1) {
                 const uint32_t kk = (uint32_t)__builtin_ctzll(rest);
                 const uint32_t n = s_n[kk], first = s_first[kk];
-                l2_write_stream(s_list + first, n, d, reinterpret_cast<uint32_t *>(slots + (uint64_t)kk * sc.pix_slot_bytes));
+                l2_write_stream(s_list + first, n, d, reinterpret_cast<uint32_t *>(slots + (uint64_t)kk * sc.pix_slot_bytes), true);
                 if (lane == 0) sc.tile_cnt[frow + t0 + kk] = n;
             }
             __builtin_amdgcn_wave_barrier();
@@ -347,9 +418,12 @@ __global__ __launch_bounds__(64) void k_l2_emit(Scratch sc, uint32_t use_sum, ui
 void launch_l2(const Scratch &sc, uint32_t B, uint32_t nx, uint32_t use_sum, uint32_t depth, hipStream_t s)
 {
     const uint32_t gpf = (sc.ntiles + 63) / 64, nitems = gpf * B;
-    hipLaunchKernelGGL(k_l2_link, dim3(nitems), dim3(64), 0, s, sc, nx, gpf, nitems);
-    hipLaunchKernelGGL(k_l2_stats, dim3(nitems), dim3(64), 0, s, sc, use_sum, gpf, nitems);
-    hipLaunchKernelGGL(k_l2_emit, dim3(nitems), dim3(64), 0, s, sc, use_sum, depth, gpf, nitems);
+    static const char *wgs_env = RC_KNOB("RC_L2_WGS"), *lds_env = RC_KNOB("RC_L2_DYNLDS");   // (experiments: persistent grids, extra LDS per workgroup)
+    const uint32_t grid = wgs_env ? min(nitems, (uint32_t)atoi(wgs_env)) : nitems, dyn = lds_env ? (uint32_t)atoi(lds_env) : 0u;
+    hipLaunchKernelGGL(k_l2_dir, dim3(grid), dim3(64), 0, s, sc, gpf, nitems);
+    hipLaunchKernelGGL(k_l2_link, dim3(grid), dim3(64), dyn, s, sc, nx, gpf, nitems);
+    hipLaunchKernelGGL(k_l2_stats, dim3(grid), dim3(64), 0, s, sc, use_sum, gpf, nitems);
+    hipLaunchKernelGGL(k_l2_emit, dim3(grid), dim3(64), dyn, s, sc, use_sum, depth, gpf, nitems);
 }
 
 // ---- validation frames (reference recode_writer.py:402-415): the dose-rate count on the streaming path ---------------------

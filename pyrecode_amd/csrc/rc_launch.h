@@ -53,6 +53,7 @@ struct Scratch {
     // level 2 (rc_l2.hip)
     u32x2 *l2_node = nullptr;          // [B][ntiles * TILE_PX] {parent id, accumulator} per set pixel, id = tile * TILE_PX + rank in the tile
     uint64_t l2_ids_per_frame = 0;
+    uint16_t *l2_base = nullptr;       // [B][ntiles * 64] set pixels of a word's tile in front of the word (k_l2_dir)
 };
 
 struct RecordParams {

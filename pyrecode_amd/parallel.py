@@ -274,7 +274,16 @@ class ShardedStepLoop:
     def __init__(self, ctx, batch, frames_of, out, rec, device, collective=True, gather_every=1, region_steps=1, fence_barrier=False):
         import torch
         self._torch = torch
-        self.ctx, self.B, self.frames_of, self.out, self.rec, self.device = ctx, int(batch), frames_of, out, rec, device
+        self.ctx, self.B, self.frames_of, self.device = ctx, int(batch), frames_of, device
+        # out / rec: one buffer, or a list of two that consecutive steps alternate between (a pipelined ctx may still be writing step i's
+        # records when step i + 1's second stage starts: include/recode_hip.h, rc_ctx_set_pipelined)
+        self.outs = list(out) if isinstance(out, (list, tuple)) else [out]
+        self.recs = list(rec) if isinstance(rec, (list, tuple)) else [rec]
+        if len(self.outs) != len(self.recs):
+            raise ValueError('as many rec_offsets buffers as output buffers')
+        self._out_ptr = [(o.data_ptr(), o.numel()) for o in self.outs]
+        self._rec_ptr = [r.data_ptr() for r in self.recs]
+        self._enq = 0                     # steps enqueued so far: step n writes buffer n % len(outs)
         self.dist = _dist() if collective else None
         # collective=False, fence_barrier=True: no exchange step, but the ranks still meet at the fences (a rehearsal of N host-side
         # step loops whose timed regions must start and end together)
@@ -330,11 +339,22 @@ class ShardedStepLoop:
         if self._pos == 0 and self.dist and self.gathered[k] is not None:
             self.stream.wait_event(self.gathered[k])   # md2[k] is rewritten from here on: its previous gather (two groups back) must have read it
         frames_ptr, first_id = self.frames_of(i)
-        self.ctx.enqueue(frames_ptr, self.B, first_id, self.out.data_ptr(), self.out.numel(), self.rec.data_ptr(), self._md_ptr[k][self._pos])
+        b = self._enq % len(self._out_ptr)
+        self._enq += 1
+        self.ctx.enqueue(frames_ptr, self.B, first_id, self._out_ptr[b][0], self._out_ptr[b][1], self._rec_ptr[b], self._md_ptr[k][self._pos])
         self._pos += 1
         if self._pos == self.G:       # (gather_every = 0: only when a region outgrows region_steps - the buffer is full)
             self._gather_group()
         self.steps_done = i + 1
+
+    @property
+    def out(self):
+        """the output buffer the most recent step's records went to"""
+        return self.outs[(self._enq - 1) % len(self.outs)]
+
+    @property
+    def rec(self):
+        return self.recs[(self._enq - 1) % len(self.recs)]
 
     def flush(self):
         """gather a group the steps so far have left incomplete (gather_every = 0: the region's ONE gather)"""

@@ -91,15 +91,23 @@ __device__ __forceinline__ void l2_link_pixel(u32x2 *node, const L2View &v, uint
     }
 }
 
-// grid: one-wave workgroups over items of 64 tiles of one frame; a lane per 64-pixel word, one wave scan per tile, eight tiles in flight
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_l2_dir(Scratch sc, uint32_t gpf, uint32_t nitems)
+// grid: one-wave workgroups over items of 64 tiles of one frame; a lane per 64-pixel word, one wave scan per tile, eight tiles in flight.
+// The same pass hangs every pixel that has a W neighbour on the first pixel of its horizontal RUN (a plain store: no other kernel runs yet,
+// nothing races) - or, where the run comes in from the word in front, on that word's last pixel, which hangs on ITS run's first.  What is
+// left for k_l2_link are the links between rows: of a run's first pixel, and of a later pixel only where it has a NE neighbour and no N (its
+// W neighbour has every other upper neighbour of its own among its neighbours).  A 4 x 4 blob: 3 unions instead of 15.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_l2_dir(Scratch sc, uint32_t nx, uint32_t gpf, uint32_t nitems)
 {
     const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t step = (uint32_t)TILE_PX % nx;     // a tile further on is this much further along its row (mod nx)
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         const uint32_t f = item / gpf, t0 = 64u * (item - f * gpf);
+        const uint64_t frow = (uint64_t)f * sc.ntiles;
         const uint64_t *bm = reinterpret_cast<const uint64_t *>(sc.bitmap + (uint64_t)f * sc.nb_stride);
-        uint16_t *base = sc.l2_base + (uint64_t)f * sc.ntiles * 64u;
+        uint16_t *base = sc.l2_base + frow * 64u;
+        u32x2 *node = sc.l2_node + (uint64_t)f * sc.l2_ids_per_frame;
         const uint32_t ntl = min(64u, sc.ntiles - t0);
+        uint32_t x0 = (uint32_t)(((uint64_t)t0 * TILE_PX + 64u * lane) % nx);   // column of the word's first pixel
         for (uint32_t c0 = 0; c0 < ntl; c0 += 8) {
             uint64_t W[8];
 #pragma unroll
@@ -107,8 +115,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (c0 + k >= ntl) break;                       // (uniform)
-                const uint32_t cnt = (uint32_t)__builtin_popcountll(W[k]);
-                base[(t0 + c0 + k) * 64u + lane] = (uint16_t)(wave_incl_scan(cnt) - cnt);
+                const uint32_t tile = t0 + c0 + k;
+                const uint64_t Wd = W[k];
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(Wd);
+                const uint32_t b = wave_incl_scan(cnt) - cnt;
+                base[tile * 64u + lane] = (uint16_t)b;
+                uint32_t pm = wave_prev((uint32_t)(Wd >> 63));  // the last pixel of the word in front
+                if (lane == 0) pm = tile > 0 ? (uint32_t)(bm[tile * 64u - 1u] >> 63) : 0u;
+                uint64_t col0 = 0;                               // pixels of this word in the first column of their row: no W neighbour
+                for (uint32_t i = x0 ? nx - x0 : 0u; i < 64; i += nx) col0 |= 1ull << i;
+                const uint64_t Lk = ((Wd << 1) | pm) & ~col0;    // bit i: pixel i - 1 is set and in the same row
+                uint64_t nh = Wd & Lk;
+                if (nh) {
+                    const uint64_t H = Wd & ~Lk;                 // the runs' first pixels
+                    const uint32_t id0 = tile * (uint32_t)TILE_PX + b;
+                    // the set pixel in front of this word's first: one id down, or the previous tile's last
+                    const uint32_t prev_id = (nh & 1ull) && b == 0 ? (tile - 1u) * (uint32_t)TILE_PX + sc.tile_cnt[frow + tile - 1u] - 1u : id0 - 1u;
+                    for (; nh; nh &= nh - 1) {
+                        const uint32_t i = (uint32_t)__builtin_ctzll(nh);
+                        const uint64_t below = (1ull << i) - 1ull, hb = H & below;
+                        const uint32_t par = hb ? id0 + (uint32_t)__builtin_popcountll(Wd & ((1ull << (63 - __builtin_clzll(hb))) - 1ull)) : prev_id;
+                        *node_parent(node, id0 + (uint32_t)__builtin_popcountll(Wd & below)) = par + 1u;
+                    }
+                }
+                x0 += step;
+                if (x0 >= nx) x0 -= nx;
             }
         }
     }
@@ -180,7 +211,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
                     for (uint64_t r = ((p0 + nx) / nx) * nx; r < p0 + 65; r += nx) colL |= 1ull << (r - 1 - p0);
                 }
                 const uint64_t fW = ((Wd << 1) | (Wl >> 63)) & ~col0, fNW = A & ~col0, fN = (A >> 1) | (Bn << 63), fNE = ((A >> 2) | (Bn << 62)) & ~colL;
-                uint64_t todo = Wd & (fW | fNW | fN | fNE);
+                // a pixel with a W neighbour hangs on its run already (k_l2_dir) and needs a link of its own only to a NE neighbour its W neighbour
+                // cannot see (no N between them)
+                uint64_t todo = Wd & ((~fW & (fNW | fN | fNE)) | (fW & fNE & ~fN));
                 const uint32_t n = (uint32_t)__builtin_popcountll(todo);
                 const uint32_t inc = wave_incl_scan(n), total = wave_last(inc);
                 if (total == 0) continue;
@@ -191,8 +224,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
                 for (; todo; todo &= todo - 1) {
                     const uint32_t i = (uint32_t)__builtin_ctzll(todo);
                     const uint64_t bit = 1ull << i;
-                    if (fits) s_desc[o++] = (wrel << 10) | (i << 4) | ((fN & bit) ? 8u : 0u) | ((fW & bit) ? 4u : 0u) | ((fNW & bit) ? 2u : 0u) | ((fNE & bit) ? 1u : 0u);
-                    else l2_link_pixel(node, view, nx, wi * 64u + i, id0 + (uint32_t)__builtin_popcountll(Wd & (bit - 1ull)), (fN & bit) != 0, (fW & bit) != 0, (fNW & bit) != 0, (fNE & bit) != 0);
+                    const bool nwl = (fNW & ~fW & bit) != 0;
+                    if (fits) s_desc[o++] = (wrel << 10) | (i << 4) | ((fN & bit) ? 8u : 0u) | (nwl ? 2u : 0u) | ((fNE & bit) ? 1u : 0u);
+                    else l2_link_pixel(node, view, nx, wi * 64u + i, id0 + (uint32_t)__builtin_popcountll(Wd & (bit - 1ull)), (fN & bit) != 0, false, nwl, (fNE & bit) != 0);
                 }
                 if (fits) listed += total;
             }
@@ -420,7 +454,7 @@ void launch_l2(const Scratch &sc, uint32_t B, uint32_t nx, uint32_t use_sum, uin
     const uint32_t gpf = (sc.ntiles + 63) / 64, nitems = gpf * B;
     static const char *wgs_env = RC_KNOB("RC_L2_WGS"), *lds_env = RC_KNOB("RC_L2_DYNLDS");   // (experiments: persistent grids, extra LDS per workgroup)
     const uint32_t grid = wgs_env ? min(nitems, (uint32_t)atoi(wgs_env)) : nitems, dyn = lds_env ? (uint32_t)atoi(lds_env) : 0u;
-    hipLaunchKernelGGL(k_l2_dir, dim3(grid), dim3(64), 0, s, sc, gpf, nitems);
+    hipLaunchKernelGGL(k_l2_dir, dim3(grid), dim3(64), 0, s, sc, nx, gpf, nitems);
     hipLaunchKernelGGL(k_l2_link, dim3(grid), dim3(64), dyn, s, sc, nx, gpf, nitems);
     hipLaunchKernelGGL(k_l2_stats, dim3(grid), dim3(64), 0, s, sc, use_sum, gpf, nitems);
     hipLaunchKernelGGL(k_l2_emit, dim3(grid), dim3(64), dyn, s, sc, use_sum, depth, gpf, nitems);

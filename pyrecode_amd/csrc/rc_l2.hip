@@ -40,17 +40,27 @@ __device__ __forceinline__ uint32_t *node_stat(u32x2 *node, uint32_t id) { retur
 // Nodes rest at {0, 0} between batches (zeroed once at allocation; k_l2_emit puts back what a batch changed): parent = 0 says "a root",
 // anything else is the parent's id + 1.  No pass initialises them - and the nine set pixels in ten that have no neighbour never have
 // theirs written at all.
-__device__ __forceinline__ uint32_t uf_find(u32x2 *__restrict__ node, uint32_t x)
+#ifndef RC_L2_PLAIN_LINK_FIND
+#define RC_L2_PLAIN_LINK_FIND 0
+#endif
+// PLAIN: ordinary loads and stores (served by the XCD's own caches) instead of device-scope ones.  Right wherever no link is made meanwhile
+// (k_l2_stats: the forest is final, every pointer a find can see - however stale - is an ancestor, and ancestors are forever).
+template <bool PLAIN>
+__device__ __forceinline__ uint32_t uf_find_t(u32x2 *__restrict__ node, uint32_t x)
 {
-    uint32_t p = __hip_atomic_load(node_parent(node, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t p = PLAIN ? *node_parent(node, x) : __hip_atomic_load(node_parent(node, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != 0) {
-        const uint32_t gp = __hip_atomic_load(node_parent(node, p - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gp != 0) __hip_atomic_store(node_parent(node, x), gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+        const uint32_t gp = PLAIN ? *node_parent(node, p - 1) : __hip_atomic_load(node_parent(node, p - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != 0) {  // path halving
+            if (PLAIN) *node_parent(node, x) = gp;
+            else __hip_atomic_store(node_parent(node, x), gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         x = p - 1;
         p = gp;
     }
     return x;
 }
+__device__ __forceinline__ uint32_t uf_find(u32x2 *__restrict__ node, uint32_t x) { return uf_find_t<RC_L2_PLAIN_LINK_FIND != 0>(node, x); }
 __device__ __attribute__((noinline)) void uf_union(u32x2 *__restrict__ node, uint32_t a, uint32_t b)
 {
     for (;;) {
@@ -274,13 +284,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
                 id[u] = P < T ? (t0 + k) * (uint32_t)TILE_PX + r : 0xFFFFFFFFu;
                 par[u] = P < T ? node[id[u]][0] : 0u;
             }
+            // A pixel that is not its own root finds it (plain loads: the forest is final) - and consecutive lanes that found the SAME root (the
+            // pixels of a horizontal run are consecutive ids) join their values first: one atomic per streak instead of one per pixel (the
+            // accumulators are device-scope atomics, ~19 G/s for the whole device; a blob of 16 pixels sent 15 of them to one address)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (par[u] == 0) continue;                       // a root (every pixel without neighbours): its own value joins at the emit
-                const uint32_t root = uf_find(node, id[u]);
-                const uint32_t v = reinterpret_cast<const uint16_t *>(slots + (uint64_t)((id[u] >> 12) - t0) * sc.pix_slot_bytes)[id[u] & (TILE_PX - 1)];
-                if (use_sum) atomicAdd(node_stat(node, root), v);
-                else atomicMax(node_stat(node, root), v);
+                const bool hung = par[u] != 0;
+                const uint64_t hb = __builtin_amdgcn_ballot_w64(hung);
+                if (hb == 0) continue;                                         // (uniform)
+                uint32_t root = 0xFFFFFFFFu, v = 0;
+                if (hung) {
+                    root = uf_find_t<true>(node, id[u]);
+                    v = reinterpret_cast<const uint16_t *>(slots + (uint64_t)((id[u] >> 12) - t0) * sc.pix_slot_bytes)[id[u] & (TILE_PX - 1)];
+                }
+                if (__builtin_popcountll(hb) <= 8) {                           // (uniform) a few scattered ones - 1 % Bernoulli: nothing to join
+                    if (hung) {
+                        if (use_sum) atomicAdd(node_stat(node, root), v);
+                        else atomicMax(node_stat(node, root), v);
+                    }
+                    continue;
+                }
+                // segmented inclusive scan over the lanes, a segment = a streak of equal roots
+                const uint32_t before = l2_lane_get(root, lane ? lane - 1u : 0u);
+                uint32_t head = (lane == 0 || before != root) ? 1u : 0u;
+#pragma unroll
+                for (uint32_t st = 1; st < 64; st <<= 1) {
+                    const uint32_t ov = l2_lane_get(v, lane >= st ? lane - st : lane), oh = l2_lane_get(head, lane >= st ? lane - st : lane);
+                    if (lane >= st && !head) { v = use_sum ? v + ov : max(v, ov); head = oh; }
+                }
+                const uint32_t after = l2_lane_get(root, lane < 63 ? lane + 1u : lane);
+                if (hung && (lane == 63 || after != root)) {              // the streak's last lane has its total
+                    if (use_sum) atomicAdd(node_stat(node, root), v);
+                    else atomicMax(node_stat(node, root), v);
+                }
             }
         }
     }

@@ -143,7 +143,9 @@ int rc_ctx_sync(rc_ctx *ctx);
  * records before anything enqueued later - plain stream order.  On: it does not, so the next batch's reduce kernel
  * overlaps this batch's second stage (small latency-bound kernels that leave most of the GPU idle); a consumer of out /
  * rec_offsets / md orders itself behind the most recent batch with rc_ctx_wait_results(ctx, its_stream) (NULL = the ctx's
- * stream), or calls rc_ctx_sync.  The caller must not reuse a batch's output buffers before that.
+ * stream), or calls rc_ctx_sync.  The caller must not reuse a batch's output buffers before that: consecutive batches need their own
+ * out / rec_offsets / md (two sets, alternating, are enough - batch i + 2 is ordered behind batch i; at reduction level 2 the second
+ * stages of batches i and i + 1 really do run at the same time).  Batches complete in the order they were enqueued.
  * No counterpart in the reference (one frame at a time on one core, recode_writer.py:383-399). */
 int rc_ctx_set_pipelined(rc_ctx *ctx, int on);
 int rc_ctx_wait_results(rc_ctx *ctx, void *hip_stream);

@@ -173,10 +173,10 @@ static int ctx_alloc(rc_ctx *c)
     }
     if (!c->own_stream) HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     // (a high-priority second-stage stream was measured: no gain with LZ4 or zstd, 2 % slower at 11520x8184 - tools/ab_bench.sh)
-    if (RC_KNOB("RC_PSTREAM_PRIO")) {   // experiment knob: the second stage on a high-priority stream
+    if (const char *pe = RC_KNOB("RC_PSTREAM_PRIO")) {   // experiment knob: the second stage on a high-priority stream (2: a low-priority one)
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&c->pstream_all, hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->pstream_all, hipStreamNonBlocking, atoi(pe) == 2 ? lo : hi));
     } else
         HIP_TRY(hipStreamCreateWithFlags(&c->pstream_all, hipStreamNonBlocking));
     {

@@ -1198,6 +1198,45 @@ def test_async_error_is_not_lost_behind_later_batches(hip, orc):
     ctx.close()
 
 
+def test_async_first_failure_wins_when_every_batch_fails_level2_two_chains(hip, orc):
+    """Reduction level 2 in pipelined mode runs consecutive batches' second stages on two streams at once: when EVERY batch fails (an
+    output capacity far too small) rc_ctx_sync still names the FIRST one, and the batches behind a failure that fit are intact and
+    complete in order (each batch has its own output buffers, as recode_hip.h asks of a pipelined caller)."""
+    import torch
+    ny, nx, B, nbatch = 96, 256, 2, 4
+    dark, frames = synth_frames(11, nbatch * B, ny, nx, 0.05, 16)
+    ctx = hip.ReduceContext(nx, ny, 16, 2, 1, 2, 1, 0, max_batch=B)
+    ctx.set_threshold(orc.threshold(dark, 0))
+    dev = torch.device("cuda", 0)
+    fr_d = torch.from_numpy(frames.view(np.int16)).to(dev)
+    cap = B * ny * nx * 2
+    outs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(nbatch)]
+    recs = [torch.zeros(B + 1, dtype=torch.int64, device=dev) for _ in range(nbatch)]
+    mds = [torch.zeros((B, 3), dtype=torch.int32, device=dev) for _ in range(nbatch)]
+    torch.cuda.synchronize()
+    ctx.set_pipelined(True)
+    for rounds in range(3):
+        for b in range(nbatch):
+            ctx.enqueue(fr_d[b * B].data_ptr(), B, b * B, outs[b].data_ptr(), 64, recs[b].data_ptr(), mds[b].data_ptr())
+        with pytest.raises(ValueError, match="batch 0 of the %d" % nbatch):
+            ctx.sync()
+    for b in range(nbatch):   # a failure in the middle: batch 2 of the 4
+        ctx.enqueue(fr_d[b * B].data_ptr(), B, b * B, outs[b].data_ptr(), 64 if b >= 2 else cap, recs[b].data_ptr(), mds[b].data_ptr())
+    with pytest.raises(ValueError, match="batch 2 of the %d" % nbatch):
+        ctx.sync()
+    for b in range(nbatch):
+        ctx.enqueue(fr_d[b * B].data_ptr(), B, b * B, outs[b].data_ptr(), cap, recs[b].data_ptr(), mds[b].data_ptr())
+    ctx.sync()
+    ctx.set_pipelined(False)
+    thr = orc.threshold(dark, 0)
+    for b in range(nbatch):
+        e_out, e_rec, _ = ctx.reduce_compress_batch(frames[b * B:(b + 1) * B], b * B)
+        n = int(e_rec[-1])
+        assert np.array_equal(recs[b].cpu().numpy().astype(np.uint64), e_rec.astype(np.uint64)), b
+        assert np.array_equal(outs[b][:n].cpu().numpy(), e_out[:n]), b
+    ctx.close()
+
+
 def test_random_shapes_depths_schemes_fuzz(hip, orc):
     """Seeded fuzz over tiny and odd geometries (1x1 upwards, pixel counts around multiples of 8 / 512 / 4096), every
     packing depth 9..16, reduce-only and the three device codecs, levels 1 and 3, random densities including 0 and

@@ -245,7 +245,7 @@ __device__ __forceinline__ void vm_wait_loads(uint32_t later, X (&x)[R])
 
 // Wave-private LDS stage of the residual path.  `val` receives the tile's 4096 values in pixel order (8 x ds_write_b128 per
 // lane); sparse tiles are compacted from there into `out`, tiles with more than STAGE_CAP set pixels are compacted inside `val`,
-// STAGE_CAP values at a time through `out` (compact_dense_in_place).  STAGE_CAP = 256 (6.25 % of a tile) is what lets FIVE workgroups of
+// group by group (compact_dense_in_place).  STAGE_CAP = 256 (6.25 % of a tile) is what lets FIVE workgroups of
 // three waves share a CU's 160 KB: 3 x (this + Lz4Lds) = 31.9 KB.
 #ifndef RC_STAGE_CAP
 #define RC_STAGE_CAP 256
@@ -342,40 +342,40 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)nst);
 }
 
-// A tile with more set pixels than `out` holds: `val` has the tile's values in pixel order, a lane owns the mask of 64 consecutive
-// pixels (own), inc / cnt are the inclusive scan and the counts of the lanes' set pixels, total their sum.  The values are compacted
-// INSIDE `val`, STAGE_CAP of them per round: every lane moves those of its values whose compact index falls into the round's window
-// into `out`, then the window goes to its final place val[round * STAGE_CAP ...).  A value's pixel index is never below its compact
-// index, so what a round overwrites has been read in this round or an earlier one.  ceil(total / STAGE_CAP) rounds; needs no register
-// of the frame (the frame registers already carry the next frame's loads).
-__device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const u32x2 &own, uint32_t inc, uint32_t cnt, uint32_t total)
+// A tile with more set pixels than `out` holds (STAGE_CAP: 6 % of the tile): compacted INSIDE `val`, group by group.  `val` has the tile's
+// values in pixel order and `bm` its mask bytes as the subtract phase left them: byte r * 64 + lane = the 8 pixels r * 512 + 8 * lane + (0..7),
+// whose values are ONE 16-byte LDS read for the lane.  For r = 0 .. 7 in turn: every lane reads its 8 values of group r, then writes the
+// set ones to val[base_r + (set pixels of the group in the lanes in front) ...), lowest pixel first.  In place: a value's compact index is
+// never above its pixel index, so group r's writes end below 512 (r + 1), where the unread groups begin, and a wave's LDS operations execute
+// in the order they were issued - the group's reads are in registers before its writes land.  Three wave scans give all eight groups'
+// prefixes (counts packed 10 bits apiece: a group's total is at most 512); no loop whose trip count depends on the data.
+// (Until late in round 5 a lane moved the set pixels of ITS 64 consecutive pixels two per trip through a window of STAGE_CAP values, window
+// after window: 57 % of a wave's time at 10 % of the pixels set, 88 % at 30 % - profiles/r05_exp7_phase_shares_batch_gaps.log.)
+__device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const uint8_t *bm)
 {
     const int lane = lane_id();
-    const uint16_t *mine = st->val + 64 * lane;
-    uint32_t q0 = own[0], q1 = own[1];   // this lane's set pixels still to move (low half first)
-    uint32_t e = inc - cnt;              // compact index of the next one
-    const uint32_t rounds = (total + STAGE_CAP - 1) / STAGE_CAP;
-    for (uint32_t c = 0; c < rounds; ++c) {
-        const uint32_t lim = (c + 1) * STAGE_CAP;
-        // (two values per trip, both reads in flight: the trip count - the densest lane's values in the window - times an LDS round trip
-        // is what this path costs: 57 % of a wave's time at 10 % of the pixels set, profiles/r05_exp7_phase_shares_batch_gaps.log)
-        uint64_t q = (uint64_t)q0 | ((uint64_t)q1 << 32);
-        while (e < lim && q) {
-            const uint32_t i0 = (uint32_t)__builtin_ctzll(q);
-            q &= q - 1;
-            const bool two = q != 0 && e + 1 < lim;
-            const uint32_t i1 = two ? (uint32_t)__builtin_ctzll(q) : i0;
-            if (two) q &= q - 1;
-            const uint16_t v0 = mine[i0], v1 = mine[i1];
-            st->out[e - c * STAGE_CAP] = v0;
-            if (two) st->out[e + 1 - c * STAGE_CAP] = v1;
-            e += two ? 2u : 1u;
-        }
-        q0 = (uint32_t)q; q1 = (uint32_t)(q >> 32);
+    uint32_t inc[3], tot[3];     // (the mask bytes are read again group by group: eight more registers would not fit this kernel's 128)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (3 * g + k < R) pk |= (uint32_t)__builtin_popcount((uint32_t)bm[(3 * g + k) * 64 + lane]) << (10 * k);
+        inc[g] = wave_incl_scan(pk);
+        tot[g] = wave_last(inc[g]);
+    }
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t m = bm[r * 64 + lane];
+        uint32_t dst = base + ((inc[r / 3] >> (10 * (r % 3))) & 0x3FFu) - (uint32_t)__builtin_popcount(m);
+        const u32x4 v = (reinterpret_cast<const u32x4 *>(st->val) + lane)[r * 64];
         __builtin_amdgcn_wave_barrier();
-        const uint32_t n_c = min((uint32_t)STAGE_CAP, total - c * STAGE_CAP);
-        for (uint32_t j = lane; j < n_c; j += 64) st->val[c * STAGE_CAP + j] = st->out[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if ((m >> j) & 1u) st->val[dst++] = (uint16_t)(v[j >> 1] >> (16 * (j & 1)));
         __builtin_amdgcn_wave_barrier();
+        base += (tot[r / 3] >> (10 * (r % 3))) & 0x3FFu;
     }
 }
 
@@ -528,7 +528,7 @@ __device__ __forceinline__ void reduce_one_frame(typename Src<SB>::X (&x)[R], co
         } else {
             pend.buf = st->val;
             __builtin_amdgcn_wave_barrier();
-            compact_dense_in_place(st, pend.own, inc, cnt, wave_total);
+            compact_dense_in_place(st, CODEC ? s_lz->raw : s_bm);
         }
         __builtin_amdgcn_wave_barrier();
         pend.cnt = wave_total;

@@ -7,6 +7,7 @@
 //   A4 LSB-first bitmap                         pyrecode/recode_writer.py:622-634
 //   A5 LSB-first d-bit pack                     pyrecode/recode_writer.py:637-652
 //   A7 record assembly                          pyrecode/recode_writer.py:485-494,518-525,546-550,559-574
+#include <cstddef>
 #include <cstdlib>
 #include <type_traits>
 
@@ -255,6 +256,7 @@ struct __attribute__((aligned(16))) WaveStage {
     uint16_t val[TILE_PX];
     uint16_t out[STAGE_CAP];
 };
+static_assert(offsetof(WaveStage, out) == sizeof(uint16_t) * TILE_PX && STAGE_CAP >= 64, "compact_dense_in_place: `out` lies right behind `val`, an entry per lane");
 
 // All line-sized results of one (tile, frame) - the residual stream's lines and the encoded block's lines, both complete images
 // in the wave's LDS - leave through ONE kind of store: every lane moves 16 bytes (ds_read_b128 + global_store_dwordx4), the
@@ -348,7 +350,7 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
 // set ones to val[base_r + (set pixels of the group in the lanes in front) ...), lowest pixel first.  In place: a value's compact index is
 // never above its pixel index, so group r's writes end below 512 (r + 1), where the unread groups begin, and a wave's LDS operations execute
 // in the order they were issued - the group's reads are in registers before its writes land.  Three wave scans give all eight groups'
-// prefixes (counts packed 10 bits apiece: a group's total is at most 512); no loop whose trip count depends on the data.
+// prefixes (counts packed 10 bits apiece: a group's total is at most 512); no loop whose trip count depends on the data, no branch.
 // (Until late in round 5 a lane moved the set pixels of ITS 64 consecutive pixels two per trip through a window of STAGE_CAP values, window
 // after window: 57 % of a wave's time at 10 % of the pixels set, 88 % at 30 % - profiles/r05_exp7_phase_shares_batch_gaps.log.)
 __device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const uint8_t *bm)
@@ -368,12 +370,17 @@ __device__ __forceinline__ void compact_dense_in_place(WaveStage *st, const uint
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t m = bm[r * 64 + lane];
-        uint32_t dst = base + ((inc[r / 3] >> (10 * (r % 3))) & 0x3FFu) - (uint32_t)__builtin_popcount(m);
+        const uint32_t dst = base + ((inc[r / 3] >> (10 * (r % 3))) & 0x3FFu) - (uint32_t)__builtin_popcount(m);
         const u32x4 v = (reinterpret_cast<const u32x4 *>(st->val) + lane)[r * 64];
         __builtin_amdgcn_wave_barrier();
+        // eight unconditional writes: a pixel that is not set sends its value to this lane's entry of `out` (right behind `val`; a dense tile
+        // does not use it) - no branch, no exec-mask round trip per pixel
+        uint16_t *const vo = st->val;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if ((m >> j) & 1u) st->val[dst++] = (uint16_t)(v[j >> 1] >> (16 * (j & 1)));
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t a = (m >> j) & 1u ? dst + (uint32_t)__builtin_popcount(m & ((1u << j) - 1u)) : (uint32_t)TILE_PX + (uint32_t)lane;
+            vo[a] = (uint16_t)(v[j >> 1] >> (16 * (j & 1)));
+        }
         __builtin_amdgcn_wave_barrier();
         base += (tot[r / 3] >> (10 * (r % 3))) & 0x3FFu;
     }

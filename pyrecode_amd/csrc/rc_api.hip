@@ -284,7 +284,7 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
         *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 4 (centroiding) is not implemented on device");
         return nullptr;
     }
-    if (reduction_level == 2 && nx > 65535u) {   // (the labelling stage keeps the word bases of a row's worth of tiles in LDS; the reference's C type holds nx in 16 bits, pyrecode.cpp:21-22)
+    if (reduction_level == 2 && nx > 65535u) {   // (the reference's C type holds nx in 16 bits, pyrecode.cpp:21-22; the labelling stage is tested up to there)
         *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 2 needs nx <= 65535");
         return nullptr;
     }

@@ -90,13 +90,13 @@ __device__ __forceinline__ uint32_t l2_id(const L2View &v, uint32_t p)
     const uint32_t wi = p >> 6;
     return (p >> 12) * (uint32_t)TILE_PX + v.base[wi] + (uint32_t)__builtin_popcountll(v.bm[wi] & ((1ull << (p & 63u)) - 1ull));
 }
-// pixel p (id self) joins the earlier ones among its neighbours: N, or W / NW and NE - the rest of the four hang on those through their own links
-__device__ __forceinline__ void l2_link_pixel(u32x2 *node, const L2View &v, uint32_t nx, uint32_t p, uint32_t self, bool n, bool w, bool nw, bool ne)
+// pixel p (id self) joins the earlier ones among its upper neighbours: N, or NW and NE (its W neighbour, if it has one, is its run's business:
+// k_l2_dir; the rest hang on these through their own links)
+__device__ __forceinline__ void l2_link_pixel(u32x2 *node, const L2View &v, uint32_t nx, uint32_t p, uint32_t self, bool n, bool nw, bool ne)
 {
     if (n) uf_union(node, self, l2_id(v, p - nx));
     else {
-        if (w) uf_union(node, self, l2_id(v, p - 1));                  // (NW is W's northern neighbour)
-        else if (nw) uf_union(node, self, l2_id(v, p - nx - 1));
+        if (nw) uf_union(node, self, l2_id(v, p - nx - 1));
         if (ne) uf_union(node, self, l2_id(v, p - nx + 1));
     }
 }
@@ -172,12 +172,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
         const uint32_t ntl = min(64u, sc.ntiles - t0);
         const L2View view{bm, sc.l2_base + (uint64_t)f * sc.ntiles * 64u};
         uint32_t listed = 0;
-        auto drain = [&]() {   // desc = word index inside the item (12 bits) << 10 | bit (6) << 4 | N W NW NE
+        auto drain = [&]() {   // desc = word index inside the item (12 bits) << 10 | bit (6) << 4 | N (8) NW (2) NE (1)
             __builtin_amdgcn_wave_barrier();
             for (uint32_t j = lane; j < listed; j += 64) {
                 const uint32_t d = s_desc[j];
                 const uint32_t p = ((t0 * 64u + (d >> 10)) << 6) + ((d >> 4) & 63u);
-                l2_link_pixel(node, view, nx, p, l2_id(view, p), (d & 8u) != 0, (d & 4u) != 0, (d & 2u) != 0, (d & 1u) != 0);
+                l2_link_pixel(node, view, nx, p, l2_id(view, p), (d & 8u) != 0, (d & 2u) != 0, (d & 1u) != 0);
             }
             __builtin_amdgcn_wave_barrier();
             listed = 0;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
                     const uint64_t bit = 1ull << i;
                     const bool nwl = (fNW & ~fW & bit) != 0;
                     if (fits) s_desc[o++] = (wrel << 10) | (i << 4) | ((fN & bit) ? 8u : 0u) | (nwl ? 2u : 0u) | ((fNE & bit) ? 1u : 0u);
-                    else l2_link_pixel(node, view, nx, wi * 64u + i, id0 + (uint32_t)__builtin_popcountll(Wd & (bit - 1ull)), (fN & bit) != 0, false, nwl, (fNE & bit) != 0);
+                    else l2_link_pixel(node, view, nx, wi * 64u + i, id0 + (uint32_t)__builtin_popcountll(Wd & (bit - 1ull)), (fN & bit) != 0, nwl, (fNE & bit) != 0);
                 }
                 if (fits) listed += total;
             }

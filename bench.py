@@ -720,7 +720,8 @@ def run_rank(a):
         achieved = B * frame_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_note = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        key = "%dx%d_b%d_ppm%d_d%d_s%d%s%s" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme, "_clustered" if a.clustered else "", {1: "_u8", 2: "", 4: "_u32"}[a.source_bytes])
+        key = "%dx%d_b%d_ppm%d_d%d_s%d%s%s%s" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme, "_clustered" if a.clustered else "", {1: "_u8", 2: "", 4: "_u32"}[a.source_bytes],
+                                              "" if a.level == 1 else "_l%d" % a.level)   # (the reduce kernel of levels 2 / 3 writes other things)
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(key, {}).get("reduce_kernel_hbm_bytes_per_launch")
         if traffic is None:

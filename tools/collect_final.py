@@ -9,7 +9,8 @@ ARGS = {"lz4": "", "zstd": "--scheme 1", "zstd_fast": "--scheme 1 --clevel 0", "
         "cfg5_b16": "--ny 8184 --nx 11520 --batch 16 --stack 32 --sparsity-ppm 50000 --scheme 1 --depth 12",
         "cfg4": "--scheme 8 --level 2 --sparsity-ppm 1000", "d12": "--depth 12",
         "det_lz4": "--clustered --sparsity-ppm 11000 --depth 12", "det_zstd": "--clustered --sparsity-ppm 11000 --depth 12 --scheme 1",
-        "u32": "--source-bytes 4", "u8": "--source-bytes 1", "k2": "--ny 3710 --nx 3838 --batch 64 --stack 128"}
+        "u32": "--source-bytes 4", "u8": "--source-bytes 1", "k2": "--ny 3710 --nx 3838 --batch 64 --stack 128",
+        "l2_1pct": "--level 2 --sparsity-ppm 10000", "l2_clustered": "--level 2 --clustered --sparsity-ppm 2000 --depth 12"}
 os.makedirs("profiles/%s_final_lines" % rnd, exist_ok=True)
 for f in glob.glob("gpurun_out/final_%s/*.json" % tag):
     shutil.copy(f, "profiles/%s_final_lines/%s" % (rnd, os.path.basename(f)))
@@ -34,9 +35,10 @@ open("profiles/%s_bench_profiles.md" % rnd, "w").write("".join(out))
 # profiles/traffic.json: PMC-derived HBM bytes per launch of the dominant kernel, per configuration key (bench.py reads it)
 import re
 KEYS = {"lz4": "4096x4096_b64_ppm10000_d16_s2", "zstd": "4096x4096_b64_ppm10000_d16_s1", "cfg5": "8184x11520_b32_ppm50000_d12_s1",
-        "cfg5_b16": "8184x11520_b16_ppm50000_d12_s1", "cfg4": "4096x4096_b64_ppm1000_d16_s8", "d12": "4096x4096_b64_ppm10000_d12_s2",
+        "cfg5_b16": "8184x11520_b16_ppm50000_d12_s1", "cfg4": "4096x4096_b64_ppm1000_d16_s8_l2", "d12": "4096x4096_b64_ppm10000_d12_s2",
         "zstd_fast": None, "det_lz4": "4096x4096_b64_ppm11000_d12_s2_clustered", "det_zstd": "4096x4096_b64_ppm11000_d12_s1_clustered",
-        "u32": "4096x4096_b64_ppm10000_d20_s2_u32", "u8": "4096x4096_b64_ppm10000_d8_s2_u8", "k2": "3710x3838_b64_ppm10000_d16_s2"}
+        "u32": "4096x4096_b64_ppm10000_d20_s2_u32", "u8": "4096x4096_b64_ppm10000_d8_s2_u8", "k2": "3710x3838_b64_ppm10000_d16_s2",
+        "l2_1pct": "4096x4096_b64_ppm10000_d16_s2_l2", "l2_clustered": "4096x4096_b64_ppm2000_d12_s2_clustered_l2"}
 tj = json.load(open("profiles/traffic.json"))
 for cfg, key in KEYS.items():
     d = "gpurun_out/prof_%s_%s" % (tag, cfg)

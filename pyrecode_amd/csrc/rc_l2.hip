@@ -40,11 +40,10 @@ __device__ __forceinline__ uint32_t *node_stat(u32x2 *node, uint32_t id) { retur
 // Nodes rest at {0, 0} between batches (zeroed once at allocation; k_l2_emit puts back what a batch changed): parent = 0 says "a root",
 // anything else is the parent's id + 1.  No pass initialises them - and the nine set pixels in ten that have no neighbour never have
 // theirs written at all.
-#ifndef RC_L2_PLAIN_LINK_FIND
-#define RC_L2_PLAIN_LINK_FIND 0
-#endif
 // PLAIN: ordinary loads and stores (served by the XCD's own caches) instead of device-scope ones.  Right wherever no link is made meanwhile
-// (k_l2_stats: the forest is final, every pointer a find can see - however stale - is an ancestor, and ancestors are forever).
+// (k_l2_stats: the forest is final, every pointer a find can see - however stale - is an ancestor, and ancestors are forever).  While links
+// ARE made (k_l2_link) the device-scope form stays: plain finds would be right there too - the compare-and-swap at the root validates
+// them - but gained nothing (profiles/r05_exp28_level2_stats_streaks_plain_finds.log).
 template <bool PLAIN>
 __device__ __forceinline__ uint32_t uf_find_t(u32x2 *__restrict__ node, uint32_t x)
 {
@@ -60,7 +59,7 @@ __device__ __forceinline__ uint32_t uf_find_t(u32x2 *__restrict__ node, uint32_t
     }
     return x;
 }
-__device__ __forceinline__ uint32_t uf_find(u32x2 *__restrict__ node, uint32_t x) { return uf_find_t<RC_L2_PLAIN_LINK_FIND != 0>(node, x); }
+__device__ __forceinline__ uint32_t uf_find(u32x2 *__restrict__ node, uint32_t x) { return uf_find_t<false>(node, x); }
 __device__ __attribute__((noinline)) void uf_union(u32x2 *__restrict__ node, uint32_t a, uint32_t b)
 {
     for (;;) {

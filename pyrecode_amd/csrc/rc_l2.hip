@@ -117,6 +117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
         u32x2 *node = sc.l2_node + (uint64_t)f * sc.l2_ids_per_frame;
         const uint32_t ntl = min(64u, sc.ntiles - t0);
         uint32_t x0 = (uint32_t)(((uint64_t)t0 * TILE_PX + 64u * lane) % nx);   // column of the word's first pixel
+        uint32_t last_hi = t0 > 0 ? (uint32_t)(bm[t0 * 64u - 1u] >> 63) : 0u;  // (uniform) the last pixel of the tile in front: one load per item
         for (uint32_t c0 = 0; c0 < ntl; c0 += 8) {
             uint64_t W[8];
 #pragma unroll
@@ -129,8 +130,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
                 const uint32_t cnt = (uint32_t)__builtin_popcountll(Wd);
                 const uint32_t b = wave_incl_scan(cnt) - cnt;
                 base[tile * 64u + lane] = (uint16_t)b;
-                uint32_t pm = wave_prev((uint32_t)(Wd >> 63));  // the last pixel of the word in front
-                if (lane == 0) pm = tile > 0 ? (uint32_t)(bm[tile * 64u - 1u] >> 63) : 0u;
+                const uint32_t hi = (uint32_t)(Wd >> 63);
+                uint32_t pm = wave_prev(hi);                     // the last pixel of the word in front
+                if (lane == 0) pm = last_hi;
+                last_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
                 uint64_t col0 = 0;                               // pixels of this word in the first column of their row: no W neighbour
                 for (uint32_t i = x0 ? nx - x0 : 0u; i < 64; i += nx) col0 |= 1ull << i;
                 const uint64_t Lk = ((Wd << 1) | pm) & ~col0;    // bit i: pixel i - 1 is set and in the same row

@@ -35,6 +35,7 @@ line l2_1pct --level 2 --sparsity-ppm 10000 $Q
 line l2_clustered --level 2 --clustered --sparsity-ppm 2000 --depth 12 $Q
 line dense_10pct --sparsity-ppm 100000 --stack 64 --batch 32 $Q
 line dense_30pct --sparsity-ppm 300000 --stack 64 --batch 32 $Q
+line dense_60pct --sparsity-ppm 600000 --stack 32 --batch 16 $Q
 line headline_events_every_launch --kernel-events-every 1 $Q
 line read_zstd --read --scheme 1 --steps 30 --warmup 5 --min-seconds 1
 line read_lz4 --read --scheme 2 --steps 30 --warmup 5 --min-seconds 1

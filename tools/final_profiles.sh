@@ -11,6 +11,8 @@ tools/prof_round.sh ${T}_cfg5 --config 5 > $OUT/prof_cfg5.log 2>&1
 tools/prof_round.sh ${T}_cfg4 --config 4 > $OUT/prof_cfg4.log 2>&1
 tools/prof_round.sh ${T}_d12 --depth 12 > $OUT/prof_d12.log 2>&1
 tools/prof_round.sh ${T}_det_lz4 --clustered --sparsity-ppm 11000 --depth 12 > $OUT/prof_det_lz4.log 2>&1
+tools/prof_round.sh ${T}_l2_1pct --level 2 --sparsity-ppm 10000 > $OUT/prof_l2_1pct.log 2>&1
+tools/prof_round.sh ${T}_l2_clustered --level 2 --clustered --sparsity-ppm 2000 --depth 12 > $OUT/prof_l2_clustered.log 2>&1
 else
 tools/prof_round.sh ${T}_det_zstd --clustered --sparsity-ppm 11000 --depth 12 --scheme 1 > $OUT/prof_det_zstd.log 2>&1
 tools/prof_round.sh ${T}_cfg5_b16 --config 5 --batch 16 --stack 32 > $OUT/prof_cfg5_b16.log 2>&1

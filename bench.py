@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--depth", type=int, default=16)
     ap.add_argument("--clustered", action="store_true", help="detector-like events: clusters of 1..6 pixels; --sparsity-ppm then counts SEEDS per million pixels (11000 = ~4.3 %% set pixels, the real acquisition the reference's notebook records)")
     ap.add_argument("--scheme", type=int, default=2, help="2 = LZ4 (headline), 1 = zstd, 8 = blosc-lz4, 0 = reduce-only pieces")
+    ap.add_argument("--device-zlib", action="store_true", help="--scheme 0: both streams of a record made by the device's DEFLATE encoder (RC_SCHEME_ZLIB_DEVICE: zlib streams that "
+                    "stdlib zlib expands to the oracle's bytes) instead of the reduce-only pieces for the host's zlib.compress")
     ap.add_argument("--level", type=int, default=1, help="reduction level: 1 (headline), 2 = summary statistics, 3 = bitmap only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--source-bytes", type=int, default=2, choices=[1, 2, 4], help="bytes per source pixel: 2 = uint16 frames (every BASELINE configuration), 1 = uint8 frames (source_bit_depth <= 8: the reference's map_dtype, misc.py:41-49; implies --depth 8 unless given lower), 4 = uint32 frames (> 16 bits; implies --depth 20 unless given above 16); both without the CPU baseline / ingest legs")
@@ -97,11 +99,14 @@ def parse(argv=None):
     return a
 
 
-def cpu_baseline(frames_h, thr_h, depth, scheme):
-    """Oracle (CPU restatement, oracle/recode_oracle.c) + stock liblz4 on the host cores; bounded to ~15 core-seconds."""
+def cpu_baseline(frames_h, thr_h, depth, scheme, zlib_level=None):
+    """Oracle (CPU restatement, oracle/recode_oracle.c) + stock liblz4 on the host cores; bounded to ~15 core-seconds.
+    zlib_level (scheme 0 with the device encoder): the reference's own compress stage - zlib.compress(data, level) on both streams
+    (recode_compressors.py:84-85; the call releases the GIL)."""
     import ctypes as C
     import ctypes.util
     import threading
+    import zlib
     from oracle import oracle as orc
     orc.lib()
     lz4 = None
@@ -122,6 +127,9 @@ def cpu_baseline(frames_h, thr_h, depth, scheme):
             for src in (bitmap, packed):
                 n = lz4.LZ4F_compressFrame(scratch.ctypes.data, scratch.size, src.ctypes.data, src.size, None)
                 assert n > 0
+        if zlib_level is not None:
+            for src in (bitmap, packed):
+                zlib.compress(src, zlib_level)
         return nnz
 
     bound = int(lz4.LZ4F_compressFrameBound(n_pix // 8 + 64, None)) + n_pix * 2 if lz4 is not None else 16
@@ -172,11 +180,12 @@ def cpu_baseline(frames_h, thr_h, depth, scheme):
         "single_core_value": round(single, 2),
         "sample": "%d frame passes over %d distinct synthetic frames of the GPU stack (%.1f s wall), oracle C reduce+pack%s" % (
             total, nfr, dt, " + liblz4 LZ4F_compressFrame on bitmap and pixvals" if lz4 is not None else
-            (" (no compress stage: liblz4 not found)" if scheme == 2 else " (reduce-only)")),
+            (" + zlib.compress(level %d) on bitmap and pixvals (stdlib zlib: the reference's own call)" % zlib_level if zlib_level is not None else
+             (" (no compress stage: liblz4 not found)" if scheme == 2 else " (reduce-only)"))),
     }
 
 
-def ingest_inclusive(stack, dark, a, nframes=512, validation_frame_gap=-1, passes=3, data=None):
+def ingest_inclusive(stack, dark, a, nframes=512, validation_frame_gap=-1, passes=3, data=None, device_zlib=None):
     """Extra, NOT `value`: ReCoDeWriter.run on frames that start in host memory, records appended to a part file on tmpfs
     (the reference's whole writer loop, recode_writer.py:292-428): staging copy + link + kernels + records back + file append.
     >= 512 frames per pass where they fit 16 GiB of host memory (0.4 s at 4096^2: long enough to tell a stall from noise), one warm-up
@@ -205,7 +214,8 @@ def ingest_inclusive(stack, dark, a, nframes=512, validation_frame_gap=-1, passe
         times = []
         for k in range(passes + 1):   # first pass warms the staging buffers and the model
             w = ReCoDeWriter("bench_stack.bin", dark_data=dark_h, output_directory=out_dir, input_params=ip, mode="batch", node_id=0,
-                             batch_size=min(32, a.batch), validation_frame_gap=validation_frame_gap)
+                             batch_size=min(32, a.batch), validation_frame_gap=validation_frame_gap,
+                             device_zlib=(a.device_zlib if device_zlib is None else device_zlib))
             w.start()
             t0 = time.perf_counter()
             w.run(data)
@@ -446,6 +456,9 @@ def verify_record(a, r, frame, thr_h, frame_id):
         dec = lambda b, n: _zstd_host_decompress(b)
     elif a.scheme == 8:
         dec = lambda b, n: orc.blosc1_decode(b)
+    elif a.scheme == 0 and a.device_zlib:
+        import zlib
+        dec = lambda b, n: zlib.decompress(b)      # stdlib zlib: the reference reader's own call (recode_compressors.py:43)
     else:
         dec = None
     if a.level in (1, 2):
@@ -585,7 +598,7 @@ def run_rank(a):
         torch.cuda.empty_cache()
         stack, dark = stack32, dark32
     op_mode = 1
-    ctx = hip.ReduceContext(a.nx, a.ny, a.depth, a.level, op_mode, a.scheme, a.clevel, local, max_batch=B, src_dtype=src_dtype)
+    ctx = hip.ReduceContext(a.nx, a.ny, a.depth, a.level, op_mode, a.scheme, a.clevel, local, max_batch=B, src_dtype=src_dtype, device_zlib=a.device_zlib)
     ctx.set_dark(dark.data_ptr(), 0)  # eps = 0 -> thr = dark
     ctx.keep_binary_maps(False)       # no validation frames in this workload: records only (recode_writer.py:402-415)
     out_cap = int(L.rc_out_capacity(ctx.handle, B))   # the worst case the library itself states: B raw frames (a record may not exceed its frame, recode_writer.py:565-566)
@@ -720,8 +733,8 @@ def run_rank(a):
         achieved = B * frame_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_note = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        key = "%dx%d_b%d_ppm%d_d%d_s%d%s%s%s" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme, "_clustered" if a.clustered else "", {1: "_u8", 2: "", 4: "_u32"}[a.source_bytes],
-                                              "" if a.level == 1 else "_l%d" % a.level)   # (the reduce kernel of levels 2 / 3 writes other things)
+        key = "%dx%d_b%d_ppm%d_d%d_s%d%s%s%s%s" % (a.ny, a.nx, B, a.sparsity_ppm, a.depth, a.scheme, "_clustered" if a.clustered else "", {1: "_u8", 2: "", 4: "_u32"}[a.source_bytes],
+                                              "" if a.level == 1 else "_l%d" % a.level, "_devzlib" if a.device_zlib and a.scheme == 0 else "")   # (the reduce kernel of levels 2 / 3 writes other things)
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(key, {}).get("reduce_kernel_hbm_bytes_per_launch")
         if traffic is None:
@@ -747,7 +760,8 @@ def run_rank(a):
                     ("BASELINE configs[%d]: " % (a.config - 1)) if a.config else "", a.ny, a.nx, {1: "uint8", 2: "uint16", 4: "uint32"}[a.source_bytes],
                     ("detector-like clusters of 1..6 pixels, %d seeds per million pixels" % a.sparsity_ppm) if a.clustered else "%.2f%% sparsity" % (a.sparsity_ppm / 1e4), a.level,
                     {2: "LZ4 frame", 1: "zstd frame (%s encoder)" % ("modelled" if a.clevel else "fast"), 8: "blosc-lz4 chunk",
-                     0: "reduce-only pieces (the host library compresses them, as the reference does)"}.get(a.scheme, str(a.scheme)),
+                     0: ("zlib streams from the device DEFLATE encoder (compression_scheme 0)" if a.device_zlib else
+                         "reduce-only pieces (the host library compresses them, as the reference does)")}.get(a.scheme, str(a.scheme)),
                     a.depth, B, S),
                 "parallelism": "dp%d (contiguous frame blocks per rank; %s)" % (world, (
                     "no collective: the ranks meet only at the fences (host-side rehearsal)" if use_dist and not collective else
@@ -780,7 +794,7 @@ def run_rank(a):
             ns = min(32, S)
             frames_h = stack[:ns].cpu().numpy().view(np.uint16)
             thr_h = dark.cpu().numpy().view(np.uint16)
-            result["cpu_baseline"] = cpu_baseline(frames_h, thr_h, a.depth, a.scheme)
+            result["cpu_baseline"] = cpu_baseline(frames_h, thr_h, a.depth, a.scheme, zlib_level=(a.clevel if a.scheme == 0 and a.device_zlib else None))
         else:
             result["cpu_baseline"] = None
         if world == 1 and not a.no_ingest and a.level in (1, 3):

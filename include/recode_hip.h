@@ -44,8 +44,13 @@ typedef enum rc_status {
 
 /* compression_scheme codes of the reference (recode_compressors.py:3-4, config/README.md). Device codecs:
  * 2 (LZ4 frame), 1 (zstd frame), 8 (blosc1 chunk: bit-shuffle + LZ4, typesize 8).  Every other code: the ctx emits the
- * reduce-only pieces and the host layer runs the reference's own library call (zlib, bz2, lzma, ...). */
-enum { RC_SCHEME_ZLIB = 0, RC_SCHEME_ZSTD = 1, RC_SCHEME_LZ4 = 2, RC_SCHEME_BLOSC_LZ4 = 8 };
+ * reduce-only pieces and the host layer runs the reference's own library call (zlib, bz2, lzma, ...).
+ * RC_SCHEME_ZLIB_DEVICE is not a code of the reference: a ctx created with it writes compression_scheme 0 records (file header
+ * field 0, recode_compressors.py:42-43,84-85) whose two streams are zlib streams (RFC 1950) made by the device's own DEFLATE
+ * encoder - a byte-aligned fixed-Huffman block per 512-byte tile of the binary map, stored blocks for the packed values, Adler-32
+ * trailers - which `zlib.decompress` (the reference's reader, recode_compressors.py:43) expands to the exact bytes; like every other
+ * device codec it promises a VALID stream, not stock zlib's bytes (RC_SCHEME_ZLIB through the host layer keeps those). */
+enum { RC_SCHEME_ZLIB = 0, RC_SCHEME_ZSTD = 1, RC_SCHEME_LZ4 = 2, RC_SCHEME_BLOSC_LZ4 = 8, RC_SCHEME_ZLIB_DEVICE = 0x100 };
 
 typedef struct rc_ctx rc_ctx;
 

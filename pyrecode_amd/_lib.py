@@ -20,6 +20,7 @@ RC_ERR_UNSUPPORTED = -4
 RC_ERR_RECORD_TOO_LARGE = -5
 RC_ERR_CORRUPT = -6
 RC_ERR_WORKSPACE = -7
+RC_SCHEME_ZLIB_DEVICE = 0x100   # compression_scheme 0 records from the device's own DEFLATE encoder (include/recode_hip.h)
 
 # every symbol include/recode_hip.h declares: (restype, argtypes)
 _u8p, _u16p, _u32p, _u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses: host or device
@@ -171,8 +172,12 @@ class ReduceContext:
     """One writer's device state: rc_ctx_create .. rc_ctx_destroy.  Mirrors what ReCoDeWriter.start() sets up
     (reference recode_writer.py:212-230) plus the threshold frame of __init__ (:126-137)."""
 
-    def __init__(self, nx, ny, src_bit_depth, reduction_level=1, op_mode=1, scheme=2, clevel=1, device_id=0, max_batch=16, src_dtype=np.uint16):
-        """src_dtype: numpy dtype of the frames and the dark frame - uint16, or uint8 (source_bit_depth <= 8: rc_ctx_set_source_bytes)"""
+    def __init__(self, nx, ny, src_bit_depth, reduction_level=1, op_mode=1, scheme=2, clevel=1, device_id=0, max_batch=16, src_dtype=np.uint16,
+                 device_zlib=False):
+        """src_dtype: numpy dtype of the frames and the dark frame - uint16, or uint8 (source_bit_depth <= 8: rc_ctx_set_source_bytes)
+        device_zlib: compression_scheme 0 encoded by the device's DEFLATE encoder (valid zlib streams, not stock zlib's bytes)"""
+        if device_zlib and scheme == 0 and op_mode == 1:
+            scheme = RC_SCHEME_ZLIB_DEVICE
         st = C.c_int(0)
         self.src_dtype = np.dtype(src_dtype)
         if self.src_dtype not in (np.dtype(np.uint16), np.dtype(np.uint8), np.dtype(np.uint32)):

@@ -109,7 +109,7 @@ RC_EXPORT int rc_device_count(int *count)
 }
 RC_EXPORT int rc_scheme_on_device(uint32_t scheme)
 {
-    return (scheme == RC_SCHEME_LZ4 || scheme == RC_SCHEME_ZSTD || scheme == RC_SCHEME_BLOSC_LZ4) ? 1 : 0;
+    return (scheme == RC_SCHEME_LZ4 || scheme == RC_SCHEME_ZSTD || scheme == RC_SCHEME_BLOSC_LZ4 || scheme == RC_SCHEME_ZLIB_DEVICE) ? 1 : 0;
 }
 
 // ---- seam 1 --------------------------------------------------------------------------------------------------
@@ -138,6 +138,11 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
         HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * (uint64_t)sc.blk_stride + 256));
         HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
         HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
+        if (c->emit == rc::EMIT_DEFLATE) {   // the zlib streams' Adler-32: per-tile partials of the map, per-frame sums (rc_deflate.hip)
+            HIP_TRY(hipMalloc((void **)&sc.blk_aux, B * T * 4));
+            HIP_TRY(hipMalloc((void **)&sc.zl_acc, B * 32));
+            HIP_TRY(hipMemset(sc.zl_acc, 0, B * 32));
+        }
     }
     if (c->emit == RC_SCHEME_ZSTD && c->clevel != 0 && c->level == 1) {   // modelled zstd: Huffman stage of the residual stream
         sc.pixraw_stride = ((sc.N * 2 + 15) & ~15ull) + 32;
@@ -335,7 +340,7 @@ RC_EXPORT int rc_ctx_destroy(rc_ctx *c)
     if (c->pstream_b) (void)hipStreamSynchronize(c->pstream_b);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (rc::Scratch &sc : c->sets) {
-        void *per_set[] = {sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size,
+        void *per_set[] = {sc.bitmap, sc.pix_slots, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.blk_slots, sc.blk_size, sc.blk_aux, sc.zl_acc,
                            sc.blk_off, sc.frame_nnz, sc.frame_cbytes, sc.scan_part, sc.status, sc.pixraw, sc.pix_chunks, sc.chunk_size, 
                            sc.chunk_off, sc.frame_pbytes};
         for (void *b : per_set)
@@ -429,6 +434,7 @@ RC_EXPORT int rc_ctx_set_source_bytes(rc_ctx *c, uint32_t bytes_per_pixel)
         // alike); zstd takes the fast encoder (the modelled one is fitted inside the uint16 kernel).
         if (c->depth <= 16) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: uint32 sources are what source_bit_depth > 16 means (misc.py:41-49)");
         if (c->level == 2) return fail(RC_ERR_UNSUPPORTED, "rc_ctx_set_source_bytes: reduction level 2 is not implemented for uint32 sources");
+        if (c->emit == rc::EMIT_DEFLATE) return fail(RC_ERR_UNSUPPORTED, "rc_ctx_set_source_bytes: the device DEFLATE encoder is not implemented for uint32 sources (use RC_SCHEME_ZLIB: the host's zlib)");
         RC_ON_DEVICE(c->device);
         // Everything that can fail happens first, into temporaries; the ctx changes only once all of it has succeeded (a failed
         // allocation leaves the uint16 ctx as it was).
@@ -571,7 +577,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
         tail = ps;
     }
     // codec of the fused block encoder: 1 zstd fast, 3 zstd modelled, 2 LZ4 runs (compression_level 0), 4 LZ4 events (>= 1), 8 blosc
-    const uint32_t codec = c->modelled ? 3u : (c->emit == RC_SCHEME_LZ4 && c->clevel != 0 ? 4u : c->emit);
+    const uint32_t codec = c->modelled ? 3u : (c->emit == RC_SCHEME_LZ4 && c->clevel != 0 ? 4u : (c->emit == EMIT_DEFLATE ? 5u : c->emit));
     if (c->src_bytes == 4) {
         // uint32 sources (rc_reduce32.hip): reduce + pack with the codec's block encoder inside the kernel, as in the uint16 path (zstd in its
         // fast form)
@@ -611,6 +617,7 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
     }
     if (!(skip & 8)) launch_layout(sc, rp, n, out_cap, rec_off_dev, md_dev, ps);
     if (!(skip & 16)) launch_assemble(sc, rp, n, out_dev, rec_off_dev, c->batch_seq, ps);
+    if (c->emit == EMIT_DEFLATE) launch_zlib_trailers(sc, rp, n, out_dev, rec_off_dev, ps);   // the zlib streams' Adler-32 (rc_deflate.hip)
     ++c->batch_seq;
     if (pix_huff && !(skip & 32)) launch_pix_gather(sc, n, c->depth, 16, out_dev, rec_off_dev, ps);
     if (ev) HIP_TRY(hipEventRecord(ev[4], ps));

@@ -31,6 +31,9 @@ struct Scratch {
     // two runs 8 KiB apart: fewer lines written by the reduce kernel and read by k_gather (each run wastes half a line on average).
     uint32_t comb = 0;
     uint32_t *blk_size = nullptr;      // [B][ntiles]               bytes used in each slot
+    uint32_t *blk_aux = nullptr;       // [B][ntiles]               deflate: the tiles' Adler-32 partials (rc_deflate_block.h::deflate_adler_word)
+    uint32_t *zl_acc = nullptr;        // [B][8]                    deflate: per frame {A, W of the map, A, W of the residual stream, arrivals}
+                                       //                           (zeroed by k_layout, summed and turned into the two trailers by k_zlib_trailers)
     uint32_t *blk_off = nullptr;       // [B][ntiles]               exclusive prefix of blk_size inside the frame
     uint32_t *frame_nnz = nullptr;     // [B]
     uint32_t *frame_cbytes = nullptr;  // [B]                       sum of blk_size
@@ -56,9 +59,12 @@ struct Scratch {
     uint16_t *l2_base = nullptr;       // [B][ntiles * 64] set pixels of a word's tile in front of the word (k_l2_dir)
 };
 
+// RecordParams::emit / rc_ctx::emit of the device DEFLATE encoder (include/recode_hip.h: RC_SCHEME_ZLIB_DEVICE); the others are the
+// reference's compression_scheme codes
+constexpr uint32_t EMIT_DEFLATE = 0x100u;
 struct RecordParams {
     uint32_t level;        // 1 or 3
-    uint32_t emit;         // 0 = raw pieces (mode-0 record), 2 = LZ4 frames, 1 = zstd frames, 8 = blosc-lz4
+    uint32_t emit;         // 0 = raw pieces (mode-0 record), 2 = LZ4 frames, 1 = zstd frames, 8 = blosc-lz4, EMIT_DEFLATE = zlib streams
     uint32_t depth;        // source_bit_depth
     uint32_t packed_slots; // 1: pix_slots hold tile-local packed streams (level 1); 0: uint16 values (level 2 statistics)
     uint32_t first_frame_id;
@@ -70,7 +76,7 @@ struct RecordParams {
 
 // rc_reduce.hip
 void launch_threshold(const void *dark, int64_t eps, uint64_t N, uint16_t *thr, hipStream_t s, uint32_t src_bytes = 2);   // dark: uint16, or uint8 for src_bytes 1
-// codec: 0 none, 2 LZ4, 1 zstd (plain), 3 zstd (modelled), 8 blosc-lz4.
+// codec: 0 none, 2 LZ4, 1 zstd (plain), 3 zstd (modelled), 8 blosc-lz4, 5 deflate (fixed-Huffman block per tile).
 // level: 1 residuals, 2 raw values of the set pixels (input of launch_l2), 3 bitmap only.  depth < 16 (level 1 only):
 // every tile's residuals are left in its slot already bit-packed (tile-local LSB-first stream of depth-bit fields)
 // src_bytes: bytes per source pixel - 2 (uint16 frames) or 1 (uint8 frames, source_bit_depth <= 8)
@@ -97,6 +103,8 @@ void launch_pix_huff(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t 
 void launch_pix_scan(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t s);   // (rc_reduce.hip)
 void launch_pix_gather(const Scratch &sc, uint32_t B, uint32_t depth, uint32_t level1_hdr, uint8_t *out, const uint64_t *rec_off,
                        hipStream_t s);
+// rc_deflate.hip: the Adler-32 trailers of a batch's zlib streams (behind launch_assemble)
+void launch_zlib_trailers(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off, hipStream_t s);
 // rc_lz4.hip
 struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
 void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s, bool events = false);  // sc.bitmap = the buffer, sc.nb = its length

@@ -13,10 +13,13 @@ namespace rc {
 //                                     final block instead of an end mark, 128 KiB chunks (Block_Maximum_Size), >= 1 block
 //   blosc1 chunk (scheme 8):          bitmap: 16-byte header + int32 bstarts[ntiles] + blocks; pixels: 16-byte header with the
 //                                     "memcpyed" flag + the bytes (what c-blosc itself emits for incompressible input)
+//   zlib stream (RFC 1950 / 1951):    2-byte header, deflate blocks (the map: a byte-aligned block pair per tile, rc_deflate_block.h; the
+//                                     residuals: stored blocks of 32 KiB with 5-byte headers, BFINAL on the last, >= 1 block), Adler-32
+//                                     of the uncompressed bytes, big-endian (written behind the gather by k_zlib_trailers)
 struct FrameFmt { uint32_t hdr, end, chunk_shift, chunk_hdr, min_chunks; };
 __host__ __device__ inline FrameFmt frame_fmt(uint32_t emit)
 {
-    return emit == 1 ? FrameFmt{6, 0, 17, 3, 1} : emit == 8 ? FrameFmt{16, 0, 31, 0, 0} : FrameFmt{7, 4, 22, 4, 0};
+    return emit == 1 ? FrameFmt{6, 0, 17, 3, 1} : emit == 8 ? FrameFmt{16, 0, 31, 0, 0} : emit == EMIT_DEFLATE ? FrameFmt{2, 4, 15, 5, 1} : FrameFmt{7, 4, 22, 4, 0};
 }
 // bytes in front of the encoded bitmap blocks
 __host__ __device__ inline uint32_t bitmap_hdr(const FrameFmt &ff, uint32_t emit, uint32_t ntiles)
@@ -70,6 +73,8 @@ __device__ __forceinline__ void record_fixed_fields(const S &sc, const RecordPar
             store_u32_le(bf + 4, (uint32_t)sc.nb);
             store_u32_le(bf + 8, (uint32_t)min((uint64_t)TILE_BM, sc.nb));
             store_u32_le(bf + 12, cb);
+        } else if (rp.emit == EMIT_DEFLATE) {  // zlib: CMF = deflate with a 32 KiB window, FLG = fastest level + check bits
+            bf[0] = 0x78; bf[1] = 0x01;
         } else {
             store_u32_le(bf, 0x184D2204u);
             bf[4] = (uint8_t)(lz4f_hdr_bitmap & 0xFF); bf[5] = (uint8_t)((lz4f_hdr_bitmap >> 8) & 0xFF);
@@ -90,6 +95,14 @@ __device__ __forceinline__ void record_fixed_fields(const S &sc, const RecordPar
                 store_u32_le(pf + 4, npk);
                 store_u32_le(pf + 8, npk);
                 store_u32_le(pf + 12, 16 + npk);
+            } else if (rp.emit == EMIT_DEFLATE) {  // stored blocks: [BFINAL][LEN][NLEN]
+                pf[0] = 0x78; pf[1] = 0x01;
+                for (uint32_t k = 0; k < nch; ++k) {
+                    const uint32_t o = k * chunk, len = npk > o ? min(chunk, npk - o) : 0u;
+                    uint8_t *q = pf + ff.hdr + (uint64_t)k * (chunk + 5);
+                    q[0] = k + 1 == nch ? 1 : 0;
+                    q[1] = (uint8_t)len; q[2] = (uint8_t)(len >> 8); q[3] = (uint8_t)~len; q[4] = (uint8_t)(~len >> 8);
+                }
             } else if (rp.emit == 1) {  // 128 KiB window so that 128 KiB raw blocks are legal
                 store_u32_le(pf, 0xFD2FB528u);
                 pf[4] = 0; pf[5] = 7u << 3;

@@ -20,6 +20,7 @@ __device__ unsigned long long g_phase[16];
 #endif
 #include "rc_lz4_block.h"
 #include "rc_zstd_wave.h"
+#include "rc_deflate_block.h"
 
 namespace rc {
 
@@ -165,6 +166,7 @@ struct Pending {
     uint32_t staged;    // zstd: bytes staged in LDS for the slot
     u32x2 own;          // this lane's 8 bitmap bytes (raw-block fallback / raw bitmap store)
     uint64_t cown;      // blosc: this lane's 8 bytes of the bit-shuffled block (stored-block fallback)
+    uint32_t aux;       // deflate: the tile's Adler-32 partials (rc_deflate_block.h::deflate_adler_word)
     bool last;          // zstd: the tile is the frame's last block
     uint32_t depth;     // bits per staged value (16 = plain uint16)
     uint16_t *buf;      // where the compacted (and packed) values sit in the wave's LDS stage
@@ -285,7 +287,7 @@ template <bool LEVEL1, int CODEC, bool KEEP_BITMAP>
 __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t tile, uint32_t n_blk, uint8_t *__restrict__ bitmap,
                                                   uint64_t nb_stride, uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
                                                   uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, Lz4Lds *lz,
-                                                  const WaveStage *st, uint32_t blk_stride, uint32_t comb)
+                                                  const WaveStage *st, uint32_t blk_stride, uint32_t comb, uint32_t *__restrict__ blk_aux)
 {
     if (!p.valid) return 0;
     const int lane = lane_id();
@@ -307,6 +309,7 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
         (void)zstd_stage_slot(n_blk, p.last, p.staged, *lz);
         bsz = p.staged ? p.staged : 4u;
     }
+    if (CODEC == 5) bsz = p.csize;   // deflate: the tile's share of the stream stands complete in the stage (rc_deflate_block.h)
     if (CODEC) {
         s1 = lz->out;
         d1 = blk_slots + p.ft * blk_stride;
@@ -332,10 +335,15 @@ __device__ __forceinline__ uint32_t flush_pending(const Pending &p, uint32_t til
     // the 4-byte results: lane 0 the count, lane 1 the block's size word, one instruction
     if ((LEVEL1 || CODEC) && !(RC_ABLATE & 4)) {
         const uint32_t word = CODEC == 1 || CODEC == 3 ? p.csize : bsz;   // zstd: the tokenizer's word (k_zstd_fse finishes the block)
-        if (LEVEL1 && CODEC) {
+        // (deflate: one lane more, the tile's Adler-32 partials)
+        if (LEVEL1 && CODEC == 5) {
+            if (lane < 3) *(lane == 0 ? &tile_cnt[p.ft] : (lane == 1 ? &blk_size[p.ft] : &blk_aux[p.ft])) = lane == 0 ? p.cnt : (lane == 1 ? word : p.aux);
+        } else if (LEVEL1 && CODEC) {
             if (lane < 2) *(lane == 0 ? &tile_cnt[p.ft] : &blk_size[p.ft]) = lane == 0 ? p.cnt : word;
         } else if (LEVEL1) {
             if (lane == 0) tile_cnt[p.ft] = p.cnt;
+        } else if (CODEC == 5) {
+            if (lane < 2) *(lane == 0 ? &blk_size[p.ft] : &blk_aux[p.ft]) = lane == 0 ? word : p.aux;
         } else {
             if (lane == 0) blk_size[p.ft] = word;
         }
@@ -439,7 +447,8 @@ __device__ __forceinline__ void reduce_one_frame(typename Src<SB>::X (&x)[R], co
                                                  uint64_t nb_stride, uint16_t *__restrict__ pix_slots,
                                                  uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ blk_slots,
                                                  uint32_t *__restrict__ blk_size, Lz4Lds *s_lz, uint8_t *s_bm, WaveStage *st,
-                                                 Pending &pend, uint32_t &stores_behind, const ZmParams &zp, uint32_t blk_stride, uint32_t comb)
+                                                 Pending &pend, uint32_t &stores_behind, const ZmParams &zp, uint32_t blk_stride, uint32_t comb,
+                                                 uint32_t *__restrict__ blk_aux)
 {
     const int lane = lane_id();
     RC_PHASE_BEGIN
@@ -558,13 +567,18 @@ __device__ __forceinline__ void reduce_one_frame(typename Src<SB>::X (&x)[R], co
         const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
         pend.csize = zstd_tokenize_block_m(bytes, n_blk, pend.last, *s_lz, pend.staged, zp);
     }
+    if (CODEC == 5) {  // deflate (compression_scheme 0 on the device): a fixed-Huffman block per tile + its Adler-32 partials (rc_deflate_block.h)
+        const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
+        pend.aux = deflate_adler_word(bytes, tile);
+        pend.csize = deflate_encode_block<true>(bytes, n_blk, pend.last, *s_lz);
+    }
     if (CODEC == 8) {  // blosc1 block: bit-shuffle (typesize 8), then the LZ4 block encoder
         const uint64_t bytes = (uint64_t)pend.own[0] | ((uint64_t)pend.own[1] << 32);
         pend.cown = bitshuffle_block(bytes, n_blk, *s_lz);
         pend.csize = lz4_encode_block(pend.cown, n_blk, *s_lz);
     }
     RC_PHASE(5);
-    stores_behind = flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st, blk_stride, comb);
+    stores_behind = flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, s_lz, st, blk_stride, comb, blk_aux);
     pend.valid = false;
     RC_PHASE(6);
 }
@@ -602,7 +616,8 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
                                                        uint8_t *__restrict__ bitmap, uint64_t nb_stride,
                                                        uint16_t *__restrict__ pix_slots, uint32_t *__restrict__ tile_cnt,
                                                        uint8_t *__restrict__ blk_slots, uint32_t *__restrict__ blk_size, uint32_t depth,
-                                                       BatchStatus *__restrict__ status, ZmParams zm, uint32_t blk_stride, uint32_t comb)
+                                                       BatchStatus *__restrict__ status, ZmParams zm, uint32_t blk_stride, uint32_t comb,
+                                                       uint32_t *__restrict__ blk_aux)
 {
 #ifdef RC_REDUCE_PRIO
     __builtin_amdgcn_s_setprio(RC_REDUCE_PRIO);   // (experiment: the reduce kernel's waves in front of the second stage's at the issue arbiter)
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
     Pending pend;
     pend.valid = false;
     pend.ft = 0; pend.f = 0; pend.cnt = 0; pend.csize = 0; pend.own = u32x2{0u, 0u};
-    pend.staged = 0; pend.last = tile + 1 == ntiles; pend.cown = 0;
+    pend.staged = 0; pend.last = tile + 1 == ntiles; pend.cown = 0; pend.aux = 0;
     pend.depth = (LEVEL1 && !RAWVAL) ? depth : 16u;
     pend.buf = nullptr;
 
@@ -659,10 +674,10 @@ __global__ __launch_bounds__(64 * RWAVES) __attribute__((amdgpu_waves_per_eu((AL
         reduce_one_frame<ALIGNED, ASMLOAD, LEVEL1, CODEC, KEEP_BITMAP, RAWVAL, SB>(xa, frames + (uint64_t)f * N, frames + (uint64_t)(f + 1) * N, nxt, t,
                                                                              lane_px0, N, full, f, tile, (uint64_t)f * ntiles + tile, n_blk,
                                                                              bitmap, nb_stride, pix_slots, tile_cnt, blk_slots,
-                                                                             blk_size, lz, bm, st, pend, stores_behind, zm, blk_stride, comb);
+                                                                             blk_size, lz, bm, st, pend, stores_behind, zm, blk_stride, comb, blk_aux);
         if (!nxt) break;
     }
-    flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st, blk_stride, comb);
+    flush_pending<LEVEL1, CODEC, KEEP_BITMAP>(pend, tile, n_blk, bitmap, nb_stride, pix_slots, tile_cnt, blk_slots, blk_size, lz, st, blk_stride, comb, blk_aux);
 }
 
 #ifndef RC_RW_ALT
@@ -692,25 +707,25 @@ static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames
     static const char *rw_env = RC_KNOB("RC_REDUCE_WG_WAVES");   // (experiments: 3 or 4)
     // (modelled zstd whose blocks carry literals only - dense maps, rc_zstd_model.h - has no FSE pass behind the reduce kernel: its
     // second stage is as short as LZ4's, and three-wave workgroups gain 0.5-3 % there as well)
-    const bool three = rw_env ? atoi(rw_env) == 3 : (L1 && !RAW && (CODEC == 2 || CODEC == 4 || sc.ntiles > 8192 || (CODEC == 3 && (sc.zm_valid & ZM_LITS_ONLY))));
+    const bool three = rw_env ? atoi(rw_env) == 3 : (L1 && !RAW && (CODEC == 2 || CODEC == 4 || CODEC == 5 || sc.ntiles > 8192 || (CODEC == 3 && (sc.zm_valid & ZM_LITS_ONLY))));
     auto go = [&](auto rw) {
         constexpr int RW = decltype(rw)::value;
         auto grid_for = [&](uint32_t nt) { return (((nt + RW - 1) / RW + 7) / 8) * 8 * ngroups; };
         if (nfull)
             hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, AL, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(nfull)), dim3(64 * RW), 0, s, frames, sc.thr, sc.N,
                                sc.ntiles, 0u, nfull, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt, sc.blk_slots,
-                               sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
+                               sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb, sc.blk_aux);
         if (nfull < sc.ntiles) {   // (on s_tail: a few workgroups that need not hold up the stream the big launch runs on)
             // the partial last tile: guarded single loads when the frame does not end on a bitmap byte (N % 8 != 0: its last group of
             // eight pixels reaches past the frame), the plain vector-load instantiation otherwise
             if (AL && sc.N % 8 != 0)
                 hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, false, false, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
                                    sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
-                                   sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
+                                   sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb, sc.blk_aux);
             else
                 hipLaunchKernelGGL((k_reduce_tiles<RW, BZ, AL, false, L1, CODEC, KEEP, RAW, SB>), dim3(grid_for(sc.ntiles - nfull)), dim3(64 * RW), 0, nfull ? s_tail : s, frames,
                                    sc.thr, sc.N, sc.ntiles, nfull, sc.ntiles, B, ngroups, sc.nb, sc.bitmap, sc.nb_stride, sc.pix_slots, sc.tile_cnt,
-                                   sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb);
+                                   sc.blk_slots, sc.blk_size, depth, sc.status, zm, sc.blk_stride, comb, sc.blk_aux);
         }
     };
     if constexpr (SB == 2) {
@@ -733,6 +748,7 @@ static void launch_reduce_c(const Scratch &sc, const typename Src<SB>::T *frames
     else if (codec == 1) RC_CODEC(1);
     else if (codec == 3) RC_CODEC(3);
     else if (codec == 8) RC_CODEC(8);
+    else if (codec == 5) RC_CODEC(5);
     else launch_reduce_t<BZ, AL, L1, 0, true, RAW, SB>(sc, frames, B, depth, s, s_tail);
 #undef RC_CODEC
 }
@@ -1155,7 +1171,7 @@ __global__ __launch_bounds__(LWG) void k_layout(const uint32_t *__restrict__ fra
                                                  const uint32_t *__restrict__ frame_cbytes, const uint32_t *__restrict__ frame_pbytes,
                                                  RecordParams rp, uint64_t nb,
                                                  uint32_t ntiles, uint32_t B, uint64_t out_cap, uint64_t *__restrict__ rec_off,
-                                                 uint32_t *__restrict__ md, BatchStatus *__restrict__ st)
+                                                 uint32_t *__restrict__ md, BatchStatus *__restrict__ st, u32x4 *__restrict__ zl_acc)
 {
     __shared__ uint64_t s_part[LWG];
     __shared__ uint32_t s_bad;
@@ -1182,6 +1198,7 @@ __global__ __launch_bounds__(LWG) void k_layout(const uint32_t *__restrict__ fra
             } else { sz = 8 + (uint64_t)cb; m0 = cb; }
         }
         md[3 * f] = m0; md[3 * f + 1] = m1; md[3 * f + 2] = m2;
+        if (zl_acc) { zl_acc[2 * f] = u32x4{0u, 0u, 0u, 0u}; zl_acc[2 * f + 1] = u32x4{0u, 0u, 0u, 0u}; }   // deflate: the frame's Adler-32 sums
         if (sz > rp.frame_bytes) atomicMin(&s_bad, f);
         rec_off[f + 1] = sz;  // sizes first; turned into offsets below
         sum += sz;
@@ -1210,7 +1227,7 @@ void launch_layout(const Scratch &sc, const RecordParams &rp, uint32_t B, uint64
                    uint32_t *md, hipStream_t s)
 {
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(LWG), 0, s, sc.frame_nnz, sc.frame_cbytes, sc.frame_pbytes, rp, sc.nb, sc.ntiles, B, out_cap,
-                       rec_off, md, sc.status);
+                       rec_off, md, sc.status, reinterpret_cast<u32x4 *>(sc.zl_acc));
 }
 
 // ---- record assembly: k_gather (rc_gather.hip); here the LZ4 frame descriptors and its launcher ----------------------------------

@@ -47,10 +47,14 @@ class ReCoDeWriter:
     def __init__(self, image_filename, dark_data=None, dark_filename='', output_directory='', input_params=None,
                  params_filename='', mode='batch', validation_frame_gap=-1, log_filename='recode.log', run_name='run',
                  verbosity=0, use_c=False, max_count=-1, chunk_time_in_sec=0, node_id=0, buffer_size_in_frames=10.0,
-                 device_id=None, batch_size=None):
-        """Arguments as in the reference (recode_writer.py:29-66).  Two additions, both optional:
+                 device_id=None, batch_size=None, device_zlib=None):
+        """Arguments as in the reference (recode_writer.py:29-66).  Three additions, all optional:
         device_id   HIP device ordinal (default: LOCAL_RANK, else node_id modulo the visible GPUs)
         batch_size  frames handed to the GPU per call (default: sized to ~1 GiB of input, at most 64)
+        device_zlib compression_scheme 0 only: True = both streams of a record are made by the device's DEFLATE encoder (valid zlib
+                    streams that the reference's reader - zlib.decompress, recode_compressors.py:43 - expands to the same bytes; the file
+                    header still says scheme 0), False = the reference's own `zlib.compress` call on the host (byte-identical files, two
+                    orders of magnitude slower).  Default: the environment's RC_DEVICE_ZLIB (1 / 0), else False.
         use_c is accepted for compatibility; the native path is always the HIP library."""
         self._init_params = InitParams(mode, output_directory, image_filename=image_filename,
                                        calibration_filename=dark_filename, params_filename=params_filename,
@@ -111,6 +115,10 @@ class ReCoDeWriter:
         self._node_id = node_id
         self._device_id = device_id
         self._batch_size = batch_size
+        if device_zlib is None:
+            device_zlib = os.environ.get('RC_DEVICE_ZLIB', '0') not in ('', '0')
+        self._device_zlib = bool(device_zlib) and ip.compression_scheme == 0 and ip.rc_operation_mode == 1 \
+            and np.dtype(ip.source_numpy_dtype) != np.dtype(np.uint32)   # (uint32 sources: the host call, include/recode_hip.h)
         self._buffer_size_in_frames = buffer_size_in_frames
         self._structures = ReCoDeStructures(self._header)
         self._intermediate_file_name = self._intermediate_file = None
@@ -170,7 +178,7 @@ class ReCoDeWriter:
             self._batch_size = int(max(1, min(64, (1 << 30) // self._frame_sz)))
         self._ctx = _lib.ReduceContext(nx, ny, ip.source_bit_depth, ip.reduction_level, ip.rc_operation_mode,
                                        ip.compression_scheme, ip.compression_level, self._pick_device(), self._batch_size,
-                                       src_dtype=self._src_dtype)
+                                       src_dtype=self._src_dtype, device_zlib=self._device_zlib)
         self._ctx.set_dark(np.ascontiguousarray(self._calibration_frame), ip.calibration_threshold_epsilon)
         if ip.reduction_level == 2:
             self._ctx.set_l2_statistics(ip.L2_statistics)  # 0/1 max, 2 sum (reference :358-365)

@@ -66,6 +66,9 @@ def _stock_lz4f_decompress(data, cap):
 
 
 def _decode(orc, scheme, stream, cap):
+    if scheme == "zd":      # compression_scheme 0 from the device's DEFLATE encoder: stdlib zlib, the reference reader's own call
+        import zlib
+        return zlib.decompress(stream)
     if scheme == 2:
         got = orc.lz4f_decode(stream, cap)
         assert _stock_lz4f_decompress(stream, cap) == got      # both judges, and they agree
@@ -74,20 +77,20 @@ def _decode(orc, scheme, stream, cap):
     return _zstd_host_decompress(stream)
 
 
-@pytest.mark.parametrize("depth,ppm,scheme", [(16, 10000, 2), (12, 10000, 2), (16, 1000, 2), (16, 10000, 1), (12, 1000, 1)])
+@pytest.mark.parametrize("depth,ppm,scheme", [(16, 10000, 2), (12, 10000, 2), (16, 1000, 2), (16, 10000, 1), (12, 1000, 1), (16, 10000, "zd"), (12, 10000, "zd")])
 def test_4096_device_codec_records_full_oracle_compare(env, depth, ppm, scheme):
     """configs[1] / configs[2] (and d = 12 / 0.1 % variants): 4096x4096 uint16, L1 + LZ4 or zstd, device-resident in and out."""
     _full_oracle_compare(env, 4096, 4096, 6, depth, ppm, scheme)
 
 
-@pytest.mark.parametrize("depth,ppm,scheme", [(12, 10000, 2), (14, 20000, 1)])
+@pytest.mark.parametrize("depth,ppm,scheme", [(12, 10000, 2), (14, 20000, 1), (12, 10000, "zd")])
 def test_3838x3710_frames_full_oracle_compare(env, depth, ppm, scheme):
     """A common detector format whose frames do not end on a bitmap byte (N % 8 = 4; every other frame of a stack starts 8 bytes off a
     16-byte boundary): the tiles inside the frame take the vector-load kernel, the partial last tile the guarded loads."""
     _full_oracle_compare(env, 3710, 3838, 5, depth, ppm, scheme)
 
 
-@pytest.mark.parametrize("depth,ppm,scheme", [(16, 100000, 2), (12, 300000, 2), (16, 300000, 1), (12, 600000, 2), (16, 600000, 1)])
+@pytest.mark.parametrize("depth,ppm,scheme", [(16, 100000, 2), (12, 300000, 2), (16, 300000, 1), (12, 600000, 2), (16, 600000, 1), (12, 100000, "zd"), (16, 300000, "zd")])
 def test_4096_dense_frames_full_oracle_compare(env, depth, ppm, scheme):
     """Beyond the sparse regime (10 %, 30 %, 60 % of the pixels set): tiles past the staged compaction's capacity in every frame, blocks
     stored raw, residual slots instead of combined slots, records of 4 - 22 MB - still the reference's bytes (recode_writer.py:437-440,
@@ -135,7 +138,7 @@ def _full_oracle_compare(env, ny, nx, B, depth, ppm, scheme):
     torch, hip, synth, orc = env
     N = ny * nx
     dark_d, frames_d = _device_stack(torch, hip, 7, B, N, ppm)
-    ctx = hip.ReduceContext(nx, ny, depth, 1, 1, scheme, 1, 0, max_batch=B)
+    ctx = hip.ReduceContext(nx, ny, depth, 1, 1, 0 if scheme == "zd" else scheme, 1, 0, max_batch=B, device_zlib=scheme == "zd")
     ctx.set_dark(dark_d.data_ptr(), 0)
     cap = int(hip.lib().rc_out_capacity(ctx.handle, B))   # B raw frames: what a batch of legal records cannot exceed
     out = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -411,3 +414,61 @@ def test_frames_with_more_than_4096_tiles_take_the_segmented_scans(env, scheme, 
             assert _decode(orc, scheme, r[16:16 + cb], bitmap.size + 8) == bitmap.tobytes(), "frame %d" % z
             assert _decode(orc, scheme, r[16 + cb:], packed.size + 8) == packed.tobytes(), "frame %d" % z
     ctx.close()
+
+
+def test_direct_electron_size_device_zlib_write_read(env, tmp_path):
+    """configs[4]'s shape with compression_scheme 0 from the device's DEFLATE encoder (ReCoDeWriter(device_zlib=True)): every stream of the
+    part files inflates under stdlib zlib to the oracle's bytes, and the reference-shaped reader (zlib.decompress per stream,
+    recode_compressors.py:43) gives back where(frame > thr, frame - thr, 0) - frame at a time and batched."""
+    import zlib
+    torch, hip, synth, orc = env
+    from pyrecode_amd.params import InputParams
+    from pyrecode_amd.recode_writer import ReCoDeWriter
+    from pyrecode_amd.recode_reader import ReCoDeReader, merge_parts
+    from pyrecode_amd import parallel
+    ny, nx, depth, nz = 8184, 11520, 12, 3
+    N = ny * nx
+    dark_d, frames_d = _device_stack(torch, hip, 17, nz, N, 50000)
+    dark = dark_d.cpu().numpy().view(np.uint16).reshape(ny, nx)
+    frames = frames_d.cpu().numpy().view(np.uint16).reshape(nz, ny, nx)
+    del frames_d
+    cfg = dict(l4_centroiding=0, source_file_type=0, num_frames=nz, source_header_length=0, calibration_frame_offset=0,
+               compression_scheme=0, calibration_file_type=0, compression_level=1, l2_statistics=0,
+               calibration_threshold_epsilon=0, frame_offset=0, num_threads=2, rc_operation_mode=1, num_calibration_frames=1,
+               reduction_level=1, keep_calibration_data=1, source_bit_depth=depth, target_bit_depth=depth, keep_part_files=1,
+               num_rows=ny, num_cols=nx, source_data_type=0, target_data_type=0)
+    pf = tmp_path / "p.txt"
+    pf.write_text("".join("%s = %d\n" % kv for kv in cfg.items()))
+    for node in range(2):
+        ip = InputParams()
+        ip.load(str(pf))
+        w = ReCoDeWriter("dz", dark_data=dark, output_directory=str(tmp_path), input_params=ip, node_id=node, batch_size=2, device_zlib=True)
+        w.start()
+        assert w._ctx.on_device_codec and not w._host_compress
+        w.run(frames)
+        w.close()
+    thr = dark.ravel()
+    seen = 0
+    for node in range(2):
+        hdr, recs = parallel.read_part_records(str(tmp_path / ("dz.rc1_part%03d" % node)))
+        assert hdr.as_dict()["compression_scheme"] == 0
+        for fid, md, data in recs:
+            cb, cp, npk = (int(v) for v in md[:3])
+            bitmap, packed, nnz = orc.reduce_frame_l1(frames[fid].ravel(), thr, depth)
+            assert zlib.decompress(bytes(data[:cb])) == bitmap.tobytes() and zlib.decompress(bytes(data[cb:cb + cp])) == packed.tobytes() and npk == packed.size
+            seen += 1
+    assert seen == nz
+    merge_parts(str(tmp_path), "dz.rc1", 2)
+    rd = ReCoDeReader(str(tmp_path / "dz.rc1"))
+    rd.open(print_header=False)
+    for z in (1, 0, 2):
+        got = np.asarray(rd.get_frame(z)[z]["data"].todense())
+        assert np.array_equal(got, np.where(frames[z] > dark, frames[z] - dark, 0).astype(np.uint16))
+    prefix, trip = rd.get_frames_triplets(0, nz)
+    for z in range(nz):
+        t = trip[int(prefix[z]):int(prefix[z + 1])]
+        want = np.where(frames[z] > dark, frames[z] - dark, 0).astype(np.uint16)
+        rows, cols = np.nonzero(want)
+        assert np.array_equal(t[:, 0], rows.astype(np.uint64)) and np.array_equal(t[:, 1], cols.astype(np.uint64))
+        assert np.array_equal(t[:, 2], want[rows, cols].astype(np.uint64))
+    rd.close()

@@ -37,9 +37,12 @@ typedef enum rc_status {
     RC_ERR_RECORD_TOO_LARGE = -5, /* a record exceeds the raw frame size; python: ValueError('Buffer size smaller
                                      than compressed data size') (recode_writer.py:565-566) */
     RC_ERR_CORRUPT = -6,          /* malformed compressed stream / bitmap-vs-pixvals mismatch on the read side */
-    RC_ERR_WORKSPACE = -7         /* reserved (rounds 2-4: reduction level 2 with more foreground pixels than a compacted workspace
-                                     held; since round 5 the level-2 workspace has an entry per pixel and no batch can exceed
-                                     it); never returned */
+    RC_ERR_WORKSPACE = -7         /* the device memory a ctx or a call needs could not be allocated (hipErrorOutOfMemory; rc_last_error
+                                     names the allocation): python MemoryError.  A ctx's scratch is sized by its geometry and max_batch
+                                     alone - per frame of the batch and scratch set (two sets): 2 * nx * ny bytes of residual slots +
+                                     ceil(nx * ny / 4096) * 1.5 KiB of block slots (reduction level 2 adds 8 bytes per pixel and frame
+                                     for the labelling nodes, a second copy of them once the ctx is pipelined) - so a ctx that was
+                                     created never runs out of memory in a batch */
 } rc_status;
 
 /* compression_scheme codes of the reference (recode_compressors.py:3-4, config/README.md). Device codecs:

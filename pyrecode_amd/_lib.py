@@ -123,8 +123,10 @@ def check(status, what=""):
     msg = "%s%s: %s" % (what + ": " if what else "", lib().rc_strerror(status).decode(), last_error())
     if status == RC_ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
-    if status in (RC_ERR_BAD_ARG, RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL, RC_ERR_CORRUPT, RC_ERR_WORKSPACE):
+    if status in (RC_ERR_BAD_ARG, RC_ERR_RECORD_TOO_LARGE, RC_ERR_OUT_TOO_SMALL, RC_ERR_CORRUPT):
         raise ValueError(msg)
+    if status == RC_ERR_WORKSPACE:
+        raise MemoryError(msg)
     raise RecodeHipError(msg)
 
 

@@ -49,6 +49,10 @@ struct rc_ctx {
     rc::BatchStatus *h_status = nullptr;  // pinned: [0] most recent batch, [1] first failed batch since the last sync
     rc::BatchStatus *d_first_err = nullptr;
     uint32_t batch_seq = 0;               // batches enqueued since the last rc_ctx_sync
+    // the previous batch's output buffers (two chains: a caller that hands consecutive batches the SAME buffers is serialised, see enqueue_batch)
+    const uint8_t *prev_out = nullptr, *prev_rec = nullptr, *prev_md = nullptr;
+    uint64_t prev_out_cap = 0;
+    uint32_t prev_n = 0;
     hipEvent_t ev[5] = {};
     float stage_ms[5] = {};
     // optional per-enqueue stage events for the asynchronous path (rc_ctx_set_profiling)
@@ -90,7 +94,7 @@ RC_EXPORT const char *rc_strerror(int status)
     case RC_ERR_UNSUPPORTED: return "not implemented on device";
     case RC_ERR_RECORD_TOO_LARGE: return "Buffer size smaller than compressed data size";
     case RC_ERR_CORRUPT: return "corrupt input stream";
-    case RC_ERR_WORKSPACE: return "level-2 workspace exceeded (too many foreground pixels in the batch)";
+    case RC_ERR_WORKSPACE: return "out of device memory for the ctx's workspace";
     default: return "unknown status";
     }
 }
@@ -138,7 +142,7 @@ static int alloc_set(rc_ctx *c, rc::Scratch &sc)
         HIP_TRY(hipMalloc((void **)&sc.blk_slots, B * T * (uint64_t)sc.blk_stride + 256));
         HIP_TRY(hipMalloc((void **)&sc.blk_size, B * T * 4));
         HIP_TRY(hipMalloc((void **)&sc.blk_off, B * T * 4));
-        if (c->emit == rc::EMIT_DEFLATE) {   // the zlib streams' Adler-32: per-tile partials of the map, per-frame sums (rc_deflate.hip)
+        if (c->emit == rc::EMIT_DEFLATE) {   // the zlib streams' Adler-32: per-tile partials of the map, per-frame sums (rc_deflate_block.h, k_gather)
             HIP_TRY(hipMalloc((void **)&sc.blk_aux, B * T * 4));
             HIP_TRY(hipMalloc((void **)&sc.zl_acc, B * 32));
             HIP_TRY(hipMemset(sc.zl_acc, 0, B * 32));
@@ -227,21 +231,19 @@ static int ctx_alloc(rc_ctx *c)
     // of 0.58).  The batches on scratch set 1 take a second stream and a second workspace (nodes + directory), so two consecutive
     // batches' chains overlap each other as well as the reduce kernels: +4 % at 1 % of the pixels set, +9 % on clustered events, nothing for
     // level 1 whose chain is a quarter of its reduce kernel (profiles/r05_exp24_two_chains.log).  Batches still COMPLETE in order.
-    c->two_chains = c->level == 2 && !RC_KNOB("RC_ONE_CHAIN");
+    c->two_chains = false;   // (the second chain's workspace comes with the first rc_ctx_set_pipelined(ctx, 1): l2_second_chain)
     if (c->level == 2) {
         // level 2 (rc_l2.hip): a node {parent, accumulator} for every pixel of a batch (8 bytes each: 8.6 GB for 64 frames of 4096^2, of
         // which only the entries of set pixels with neighbours are ever touched), at rest - zero - between batches, and the directory of
-        // rank bases (2 bytes per 64 pixels).  One workspace per chain (above): two in all, 17 GB at that size - sized by the geometry, so
-        // no batch can exceed it.
+        // rank bases (2 bytes per 64 pixels) - sized by the geometry, so no batch can exceed it.  One workspace per chain: a ctx that is
+        // never pipelined has one chain and one workspace.
         const uint64_t ids = (uint64_t)c->sc.ntiles * rc::TILE_PX;
-        for (int i = 0; i < (c->two_chains ? 2 : 1); ++i) {
-            HIP_TRY(hipMalloc((void **)&c->d_l2_node[i], B * ids * 8));
-            HIP_TRY(hipMemset(c->d_l2_node[i], 0, B * ids * 8));
-            HIP_TRY(hipMalloc((void **)&c->d_l2_base[i], B * (uint64_t)c->sc.ntiles * 64 * 2));   // (written by k_l2_dir before anything reads it)
-        }
+        HIP_TRY(hipMalloc((void **)&c->d_l2_node[0], B * ids * 8));
+        HIP_TRY(hipMemset(c->d_l2_node[0], 0, B * ids * 8));
+        HIP_TRY(hipMalloc((void **)&c->d_l2_base[0], B * (uint64_t)c->sc.ntiles * 64 * 2));   // (written by k_l2_dir before anything reads it)
         for (int i = 0; i < 2; ++i) {
             Scratch &set = c->sets[i];
-            set.l2_node = c->d_l2_node[c->two_chains ? i : 0]; set.l2_ids_per_frame = ids; set.l2_base = c->d_l2_base[c->two_chains ? i : 0];
+            set.l2_node = c->d_l2_node[0]; set.l2_ids_per_frame = ids; set.l2_base = c->d_l2_base[0];
         }
     }
     c->sc = c->sets[0];
@@ -285,6 +287,14 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
         *status = fail(RC_ERR_BAD_ARG, "nx*ny must be < 2^32");
         return nullptr;
     }
+    // A record may be as large as its raw frame (recode_writer.py:565-566), the format keeps every size of a record in a u32 metadata field
+    // (structures.py:18-46) and k_gather places bytes at u32 offsets inside a record: a raw frame of 4 GiB or more cannot be represented
+    // (uint16 sources: nx * ny < 2^31, e.g. 46 340^2; the reference's own C type holds nx, ny in 16 bits each, pyrecode.cpp:21-22, which
+    // would allow 65 535^2).  rc_ctx_set_source_bytes checks again for the pixel size it is given.
+    if ((uint64_t)nx * ny * 2 >= (1ull << 32)) {
+        *status = fail(RC_ERR_UNSUPPORTED, "a raw frame of 4 GiB or more (nx*ny*bytes_per_pixel >= 2^32) does not fit the format's u32 size fields");
+        return nullptr;
+    }
     if (reduction_level < 1 || reduction_level > 3) {
         *status = fail(RC_ERR_UNSUPPORTED, "reduction_level 4 (centroiding) is not implemented on device");
         return nullptr;
@@ -318,6 +328,7 @@ RC_EXPORT rc_ctx *rc_ctx_create(uint32_t nx, uint32_t ny, uint32_t src_bit_depth
     sc.nb = (sc.N + 7) / 8;
     sc.nb_stride = (uint64_t)sc.ntiles * rc::TILE_BM;
     sc.max_batch = max_batch;
+    sc.guarded_loads = getenv("RC_REDUCE_GUARDED_LOADS") != nullptr;   // (tests; read once per ctx)
     int rcode = ctx_alloc(c);
     if (rcode != RC_OK) {
         *status = rcode;
@@ -428,6 +439,8 @@ RC_EXPORT int rc_ctx_set_source_bytes(rc_ctx *c, uint32_t bytes_per_pixel)
     if (bytes_per_pixel == 1 && c->depth > 8) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: uint8 sources need src_bit_depth <= 8");
     if (bytes_per_pixel == 2 && c->depth > 16) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: uint16 sources need src_bit_depth <= 16");
     if (c->batch_seq || c->thr_set) return fail(RC_ERR_BAD_ARG, "rc_ctx_set_source_bytes: call before rc_set_dark / rc_set_threshold and the first batch");
+    if (c->sc.N * bytes_per_pixel >= (1ull << 32))
+        return fail(RC_ERR_UNSUPPORTED, "rc_ctx_set_source_bytes: a raw frame of 4 GiB or more (nx*ny*bytes_per_pixel >= 2^32) does not fit the format's u32 size fields");
     if (bytes_per_pixel == 4) {
         // uint32 sources (source_bit_depth > 16, misc.py:41-49): rc_reduce32.hip.  Levels 1 and 3; the residual fields are depth bits wide, or
         // the values' four raw bytes when the depth is a multiple of 8 (`.tobytes()` of a uint32 array, recode_writer.py:463-464: 32 and 24
@@ -615,9 +628,20 @@ static int enqueue_batch(rc_ctx *c, const void *frames_dev, uint32_t n, uint32_t
         launch_pix_scan(sc, n, c->depth, ps);
         rp.pix_mode = 2;
     }
+    if (two && c->post_pending[k ^ 1]) {
+        // Two chains run the second stages of batches i and i + 1 at the same time, which is why include/recode_hip.h asks a pipelined caller for
+        // two sets of output buffers.  A caller that hands this batch a buffer the previous batch is still writing (rounds 1-4 tolerated that: one
+        // second-stage stream serialised them) gets that order back instead of torn records: this batch's layout waits for the other chain.
+        auto overlap = [](const uint8_t *a, uint64_t an, const uint8_t *b, uint64_t bn) { return a && b && a < b + bn && b < a + an; };
+        const uint8_t *rec8 = reinterpret_cast<const uint8_t *>(rec_off_dev), *md8 = reinterpret_cast<const uint8_t *>(md_dev);
+        if (overlap(out_dev, out_cap, c->prev_out, c->prev_out_cap) || overlap(rec8, (uint64_t)(n + 1) * 8, c->prev_rec, (uint64_t)(c->prev_n + 1) * 8) ||
+            overlap(md8, (uint64_t)n * 12, c->prev_md, (uint64_t)c->prev_n * 12))
+            HIP_TRY(hipStreamWaitEvent(ps, c->ev_post[k ^ 1], 0));
+    }
+    c->prev_out = out_dev; c->prev_out_cap = out_cap; c->prev_n = n;
+    c->prev_rec = reinterpret_cast<const uint8_t *>(rec_off_dev); c->prev_md = reinterpret_cast<const uint8_t *>(md_dev);
     if (!(skip & 8)) launch_layout(sc, rp, n, out_cap, rec_off_dev, md_dev, ps);
     if (!(skip & 16)) launch_assemble(sc, rp, n, out_dev, rec_off_dev, c->batch_seq, ps);
-    if (c->emit == EMIT_DEFLATE) launch_zlib_trailers(sc, rp, n, out_dev, rec_off_dev, ps);   // the zlib streams' Adler-32 (rc_deflate.hip)
     ++c->batch_seq;
     if (pix_huff && !(skip & 32)) launch_pix_gather(sc, n, c->depth, 16, out_dev, rec_off_dev, ps);
     if (ev) HIP_TRY(hipEventRecord(ev[4], ps));
@@ -647,12 +671,36 @@ RC_EXPORT int rc_reduce_compress_batch_async(rc_ctx *c, const void *frames_dev, 
     return enqueue_batch(c, frames_dev, n, first_frame_id, out_dev, out_cap, rec_offsets_dev, md_dev, false);
 }
 
+// Level 2, first rc_ctx_set_pipelined(ctx, 1): the second chain's workspace (another 8 bytes per pixel and frame of the batch).  A GPU that
+// cannot hold it keeps ONE chain - a few per cent slower (rc_api.hip, "two chains"), not an error.  The streams are drained when this runs.
+static void l2_second_chain(rc_ctx *c)
+{
+    if (c->level != 2 || c->two_chains || RC_KNOB("RC_ONE_CHAIN")) return;
+    const uint64_t B = c->max_batch, ids = (uint64_t)c->sc.ntiles * rc::TILE_PX;
+    if (!c->d_l2_node[1]) {
+        bool ok = hipMalloc((void **)&c->d_l2_node[1], B * ids * 8) == hipSuccess && hipMemset(c->d_l2_node[1], 0, B * ids * 8) == hipSuccess &&
+                  hipMalloc((void **)&c->d_l2_base[1], B * (uint64_t)c->sc.ntiles * 64 * 2) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (c->d_l2_node[1]) (void)hipFree(c->d_l2_node[1]);
+            if (c->d_l2_base[1]) (void)hipFree(c->d_l2_base[1]);
+            c->d_l2_node[1] = nullptr; c->d_l2_base[1] = nullptr;
+            return;
+        }
+    }
+    c->sets[1].l2_node = c->d_l2_node[1];
+    c->sets[1].l2_base = c->d_l2_base[1];
+    if (c->last == 1) c->sc = c->sets[1];
+    c->two_chains = true;
+}
+
 RC_EXPORT int rc_ctx_set_pipelined(rc_ctx *c, int on)
 {
     if (!c) return fail(RC_ERR_BAD_ARG, "ctx is NULL");
     RC_ON_DEVICE(c->device);
     HIP_TRY(hipStreamSynchronize(c->pstream));  // the second stage changes streams: drain the old one first
     HIP_TRY(hipStreamSynchronize(c->pstream_b));
+    if (on) l2_second_chain(c);
     c->pipelined = on != 0;
     c->pstream = (c->pipelined && c->pstream_masked) ? c->pstream_masked : c->pstream_all;
     return RC_OK;
@@ -823,6 +871,8 @@ RC_EXPORT int rc_pipe_submit(rc_ctx *c, uint32_t slot, const void *frames_host, 
     }
     if (!c->pipelined) {   // the streaming form always lets consecutive batches overlap
         HIP_TRY(hipStreamSynchronize(c->pstream));
+        HIP_TRY(hipStreamSynchronize(c->pstream_b));
+        l2_second_chain(c);
         c->pipelined = true;
         c->pstream = c->pstream_masked ? c->pstream_masked : c->pstream_all;
     }

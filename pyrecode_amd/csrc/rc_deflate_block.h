@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t deflate_count_hi(const uint8_t *raw, uint32_
 // Adler-32 of the frame's map from per-tile partials (RFC 1950): with A = sum of the bytes and W = sum of i * b_i over the stream
 // positions i,  s1 = 1 + A,  s2 = n + n A - W  (mod 65521).  A tile leaves  (A_t mod p) | ((512 t A_t + W_t) mod p) << 16  where
 // W_t weighs its bytes by their position inside the tile: the frame's sums are then plain sums of the tiles' halves
-// (rc_deflate.hip::k_zlib_trailers).  Wave-collective; `own` = the lane's 8 bytes (bytes behind the map's end are zero).
+// (k_gather adds them up, rc_gather.hip).  Wave-collective; `own` = the lane's 8 bytes (bytes behind the map's end are zero).
 __device__ __forceinline__ uint32_t deflate_adler_word(uint64_t own, uint32_t tile)
 {
     const uint32_t lo = (uint32_t)own, hi = (uint32_t)(own >> 32), lane = (uint32_t)lane_id();
@@ -119,14 +119,56 @@ __device__ __forceinline__ uint32_t deflate_adler_word(uint64_t own, uint32_t ti
     return Am | (Wm << 16);
 }
 
+// the trailer of a zlib stream of n bytes whose byte sum is A and position-weighted byte sum W (any representatives mod 65521); it is
+// stored big-endian (RFC 1950)
+__device__ __forceinline__ uint32_t adler_from_sums(uint64_t n, uint32_t A, uint32_t W)
+{
+    const uint64_t a = A % ADLER_P, w = W % ADLER_P, nm = n % ADLER_P;
+    const uint32_t s1 = (uint32_t)((1 + a) % ADLER_P);
+    const uint32_t s2 = (uint32_t)((nm * (1 + a) + ADLER_P - w) % ADLER_P);
+    return (s2 << 16) | s1;
+}
+__device__ __forceinline__ void store_u32_be(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v;
+}
+
+// OR v (a bit string of up to 64 bits, zero above its end) into the zeroed image at bit `pos`: three dwords, unconditionally (an OR of
+// zero changes nothing, and three LDS instructions are cheaper than the exec-mask branches that would skip them; pos + 96 must lie
+// inside the image's allocation).  Neighbouring lanes share dwords: LDS atomics.
+__device__ __forceinline__ void or_bits64(uint32_t *out32, uint32_t pos, uint32_t lo, uint32_t hi)
+{
+    const uint32_t w = pos >> 5, sh = pos & 31u;
+    const uint64_t a = (uint64_t)lo << sh, b = (uint64_t)hi << sh;
+    __hip_atomic_fetch_or(&out32[w], (uint32_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_or(&out32[w + 1], (uint32_t)(a >> 32) | (uint32_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_or(&out32[w + 2], (uint32_t)(b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void or_bits32(uint32_t *out32, uint32_t pos, uint32_t v)
+{
+    const uint32_t w = pos >> 5, sh = pos & 31u;
+    const uint64_t a = (uint64_t)v << sh;
+    __hip_atomic_fetch_or(&out32[w], (uint32_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_or(&out32[w + 1], (uint32_t)(a >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 // Wave-collective.  Precondition: L.raw holds the block in position order (written by this wavefront) and `own` is this lane's
 // 8 bytes raw[8*lane .. 8*lane+8), little-endian.  n: valid bytes (1..512); last: the frame's last tile (BFINAL).
 // Leaves the complete image of the tile's share of the deflate stream in L.out[0 .. size) and returns size (<= n + 5, wave-uniform).
+//
+// A sequence is [literals][match]; in a sparse map almost every one is at most two literals and one match of at most 258 bytes: the lane
+// builds those as two 32-bit strings while it sizes them - LIT (the block header on sequence 0, up to two literals: <= 21 bits) and
+// M1 (<= 25 bits) -, the wave scan of the sizes places them, three LDS ORs write them.  What does not fit - the second half of a match
+// of more than 258 bytes (M2), literal runs of three and more (a loop over the run through a BitSink) - goes beside them, in branches the
+// wave only enters when one of its lanes needs them.  Rounds of 64 sequences are sized and written one after the other (nothing is kept
+// across rounds); a tile that turns out not to shrink is rewritten as a stored block.
 template <bool EVENTS = true>
 __device__ __forceinline__ uint32_t deflate_encode_block(uint64_t own, uint32_t n, bool last, Lz4Lds &L)
 {
+    static_assert(sizeof(L.out) >= TILE_BM + 5 + 16 && sizeof(L.out) % 16 == 0, "the image: a stored block, and three dwords behind the last code");
     const int lane = lane_id();
     uint32_t *const out32 = reinterpret_cast<uint32_t *>(L.out);
+    LZ4_PH_BEGIN
     // ---- phase 1: the parse (rc_lz4_block.h) ---------------------------------------------------------------------------------
     uint32_t nm = 0xFFFFFFFFu;
     bool off1 = true, store = false;
@@ -137,99 +179,99 @@ __device__ __forceinline__ uint32_t deflate_encode_block(uint64_t own, uint32_t 
         store = nev > (uint32_t)LZ4_NZ_STORE;        // hopeless (see LZ4_NZ_STORE): stored without a parse
     }
     if (!store && nm == 0xFFFFFFFFu) nm = lz4_parse_runs(own, n, L);
+    LZ4_PH(0);
+    // the image: zeroed, then ORed together (the parsers' event list in L.out is dead by now)
+    if (lane < (int)(sizeof(L.out) / 16)) reinterpret_cast<u32x4 *>(L.out)[lane] = u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- phase 2: one sequence per lane - sizes in bits ---------------------------------------------------------------------------
-    uint32_t carry = 3;                                    // the block header
-    uint32_t seq_o[2], seq_fs[2], seq_ll[2], seq_ml[2], seq_off[2];   // at most 2 rounds of 64 sequences
+    // ---- phase 2: one sequence per lane, sized and written round by round ---------------------------------------------------------
+    uint32_t carry = 0;
     const uint32_t nrounds = store ? 0u : (nm + 64) / 64;
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        seq_ll[rd] = 0xFFFFFFFFu;  // "no sequence"
-        if ((uint32_t)rd < nrounds) {
-            const uint32_t k = rd * 64 + lane;
-            uint32_t bits = 0;
-            if (k <= nm) {
-                const uint32_t fs = L.fl[k], msk = L.ms[k], fnext = L.fl[k + 1];
-                const uint32_t off = EVENTS && !off1 ? (uint32_t)L.off[k] : 1u;
-                const uint32_t q = k < nm ? msk : n;
-                const uint32_t ll = q - fs, ml = k < nm ? fnext - q : 0u;
-                bits = 8u * ll + deflate_count_hi(L.raw, fs, ll);
-                if (ml) {
-                    uint32_t len;
-                    const uint32_t p1 = deflate_first_part(ml);
-                    (void)deflate_match(p1, off, len);
-                    bits += len;
-                    if (p1 != ml) { (void)deflate_match(ml - p1, off, len); bits += len; }
-                }
-                seq_fs[rd] = fs; seq_ll[rd] = ll; seq_ml[rd] = ml; seq_off[rd] = off;
+    const uint32_t *raw32 = reinterpret_cast<const uint32_t *>(L.raw);
+    const uint32_t hdr = (last ? 1u : 0u) | 2u;      // BFINAL, BTYPE 01
+#pragma unroll 1
+    for (uint32_t rd = 0; rd < nrounds; ++rd) {
+        const uint32_t k = rd * 64 + lane;
+        const bool act = k <= nm;
+        const uint32_t fs = L.fl[k], msk = L.ms[k], fnext = L.fl[k + 1];       // (entries behind the tables' ends: never used)
+        const uint32_t off = EVENTS && !off1 ? (uint32_t)L.off[k] : 1u;
+        const uint32_t q = k < nm ? msk : n;
+        const uint32_t ll = act ? q - fs : 0u, ml = (act && k < nm) ? fnext - q : 0u;
+        const bool longlit = ll > 2u;
+        const uint64_t anylong = __builtin_amdgcn_ballot_w64(longlit);
+        uint32_t lit = 0, nl = 0, pre = 0;        // LIT and its bits; bits in front of it (a long literal run and its header)
+        if (k == 0 && !longlit) { lit = hdr; nl = 3; }
+        if (ll && !longlit) {
+            const uint32_t a = fs >> 2;
+            const uint32_t v = __builtin_amdgcn_alignbyte(raw32[a + 1], raw32[a], fs & 3u);
+            uint32_t len;
+            lit |= deflate_lit(v & 0xFFu, len) << nl;
+            nl += len;
+            if (ll == 2u) {
+                lit |= deflate_lit((v >> 8) & 0xFFu, len) << nl;
+                nl += len;
             }
-            const uint32_t sinc = wave_incl_scan(bits);
-            seq_o[rd] = carry + sinc - bits;
-            carry += wave_last(sinc);
         }
+        if (anylong) {
+            if (longlit) pre = (k == 0 ? 3u : 0u) + 8u * ll + deflate_count_hi(L.raw, fs, ll);
+        }
+        const uint32_t p1 = deflate_first_part(ml);
+        uint32_t m1 = 0, n1 = 0, m2 = 0, n2 = 0;
+        if (ml) m1 = deflate_match(p1, off, n1);
+        const uint64_t anysplit = __builtin_amdgcn_ballot_w64(ml > 258u);
+        if (anysplit) {
+            if (ml > 258u) m2 = deflate_match(ml - p1, off, n2);
+        }
+        const uint32_t bits = pre + nl + n1 + n2;
+        LZ4_PH(1);
+        const uint32_t sinc = wave_incl_scan(bits);
+        const uint32_t o = carry + sinc - bits;
+        carry += wave_last(sinc);
+        if (anylong) {
+            if (longlit) {
+                BitSink s = sink_at(out32, o);
+                if (k == 0) sink_put(s, hdr, 3);
+                for (uint32_t i = 0; i < ll; i += 4) {
+                    const uint32_t a = (fs + i) >> 2;
+                    const uint32_t v = __builtin_amdgcn_alignbyte(raw32[a + 1], raw32[a], (fs + i) & 3u);
+                    const uint32_t rem = ll - i;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        if (j < rem) {
+                            uint32_t len;
+                            const uint32_t code = deflate_lit((v >> (8 * j)) & 0xFFu, len);
+                            sink_put(s, code, len);
+                        }
+                    }
+                }
+                sink_flush(s);
+            }
+        }
+        // LIT and M1 as one string of <= 46 bits (a lane without a sequence: zero bits at the round's end - an OR of nothing)
+        const uint64_t u = (uint64_t)lit | ((uint64_t)m1 << nl);
+        or_bits64(out32, o + pre, (uint32_t)u, (uint32_t)(u >> 32));
+        if (anysplit) or_bits32(out32, o + pre + nl + n1, m2);
+        LZ4_PH(2);
     }
     const uint32_t T = carry + 7u;                         // ... and the end-of-block code (seven zero bits)
     uint32_t size = last ? (T + 7u) >> 3 : ((T + 3u + 7u) >> 3) + 4u;
-    if (store || size >= n + 5u) { store = true; size = n + 5u; }
-
-    // ---- the image: zeroed, then ORed together ---------------------------------------------------------------------------------------
-    if (lane < (int)(sizeof(L.out) / 16)) reinterpret_cast<u32x4 *>(L.out)[lane] = u32x4{0u, 0u, 0u, 0u};
-    __builtin_amdgcn_wave_barrier();
-    if (store) {
+    if (store || size >= n + 5u) {
         // stored block: [BFINAL, BTYPE 00, padding][LEN][NLEN][the bytes]
-        if (lane == 0) {
-            BitSink s = sink_at(out32, 0);
-            sink_put(s, last ? 1u : 0u, 8);
-            sink_put(s, n | ((~n & 0xFFFFu) << 16), 32);
-            sink_flush(s);
+        if (!store) {   // (a parse that did not pay: the image is cleared again)
+            __builtin_amdgcn_wave_barrier();
+            if (lane < (int)(sizeof(L.out) / 16)) reinterpret_cast<u32x4 *>(L.out)[lane] = u32x4{0u, 0u, 0u, 0u};
+            __builtin_amdgcn_wave_barrier();
         }
-        if ((uint32_t)(8 * lane) < n) {
-            BitSink s = sink_at(out32, 8u * (5u + 8u * (uint32_t)lane));
-            sink_put(s, (uint32_t)own, 32);
-            sink_put(s, (uint32_t)(own >> 32), 32);
-            sink_flush(s);
-        }
+        size = n + 5u;
+        if (lane == 0) or_bits64(out32, 0, (last ? 1u : 0u) | (n << 8) | ((~n & 0xFFu) << 24), (~n >> 8) & 0xFFu);
+        if ((uint32_t)(8 * lane) < n) or_bits64(out32, 8u * (5u + 8u * (uint32_t)lane), (uint32_t)own, (uint32_t)(own >> 32));
         __builtin_amdgcn_wave_barrier();
         return size;
     }
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        if ((uint32_t)rd < nrounds && seq_ll[rd] != 0xFFFFFFFFu) {
-            const uint32_t ll = seq_ll[rd], fs = seq_fs[rd], ml = seq_ml[rd], off = seq_off[rd];
-            const bool first = rd == 0 && lane == 0;
-            BitSink s = sink_at(out32, first ? 0u : seq_o[rd]);
-            if (first) sink_put(s, (last ? 1u : 0u) | 2u, 3);     // BFINAL, BTYPE 01
-            const uint32_t *raw32 = reinterpret_cast<const uint32_t *>(L.raw);
-            for (uint32_t i = 0; i < ll; i += 4) {
-                const uint32_t a = (fs + i) >> 2;
-                const uint32_t v = __builtin_amdgcn_alignbyte(raw32[a + 1], raw32[a], (fs + i) & 3u);
-                const uint32_t rem = ll - i;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    if (j < rem) {
-                        uint32_t len;
-                        const uint32_t code = deflate_lit((v >> (8 * j)) & 0xFFu, len);
-                        sink_put(s, code, len);
-                    }
-                }
-            }
-            if (ml) {
-                uint32_t len;
-                const uint32_t p1 = deflate_first_part(ml);
-                uint32_t code = deflate_match(p1, off, len);
-                sink_put(s, code, len);
-                if (p1 != ml) { code = deflate_match(ml - p1, off, len); sink_put(s, code, len); }
-            }
-            sink_flush(s);
-        }
-    }
     // the empty stored block behind the end-of-block code: only its NLEN has set bits
-    if (!last && lane == 63) {
-        BitSink s = sink_at(out32, 8u * (size - 2u));
-        sink_put(s, 0xFFFFu, 16);
-        sink_flush(s);
-    }
+    if (!last && lane == 63) or_bits32(out32, 8u * (size - 2u), 0xFFFFu);
     __builtin_amdgcn_wave_barrier();
+    LZ4_PH(3);
     return size;
 }
 

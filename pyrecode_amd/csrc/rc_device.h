@@ -5,7 +5,7 @@
 
 // Experiment knobs read from the environment exist only in development builds (-DRC_DEV_KNOBS: tools/build_def.sh); in the product every
 // RC_KNOB(...) is a null pointer at compile time.  (Switches that tests use and that cannot produce a wrong record - RC_REDUCE_GUARDED_LOADS,
-// RC_L2_SMALL_WORKSPACE, RC_ZSTD_LITS_ALWAYS / RC_ZSTD_SEQ_ALWAYS - and plain tuning / measurement settings - RC_DEVICE, RC_DECODE_THREADS,
+// RC_ZSTD_LITS_ALWAYS / RC_ZSTD_SEQ_ALWAYS - and plain tuning / measurement settings - RC_DEVICE, RC_DECODE_THREADS,
 // RC_READ_THREADS, RC_PROFILE_ALL_STAGES, RC_READ_TIMING, RC_READ_SERIAL - stay ordinary getenv calls.)
 #ifdef RC_DEV_KNOBS
 #include <cstdlib>

@@ -4,6 +4,7 @@
 
 #include "rc_launch.h"
 #include "rc_record.h"
+#include "rc_deflate_block.h"
 
 namespace rc {
 
@@ -32,6 +33,8 @@ struct GatherArgs {
     const uint8_t *blk_slots, *bitmap;
     const uint16_t *pix_slots;
     const uint32_t *blk_size, *blk_off, *tile_cnt, *tile_off, *tile_next, *frame_nnz, *frame_cbytes, *frame_pbytes;
+    const uint32_t *blk_aux;   // deflate: the tiles' Adler-32 partials of the map
+    uint32_t *zl_acc;          // deflate: per frame {A, W of the map, A, W of the residual stream, items arrived}
     uint8_t *pixraw;
     BatchStatus *status, *first_err;
     uint64_t nb, nb_stride, pixraw_stride;
@@ -50,19 +53,46 @@ __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t src_lane)   //
 
 // one piece: y = the 160-bit string (x, e) >> sh, its first `valid` (1..16) bytes to p
 template <bool BITS>
-__device__ __forceinline__ void put_piece(uint8_t *p, const u32x4 &x, uint32_t e, uint32_t sh, uint32_t valid)
+__device__ __forceinline__ u32x4 shift_piece(const u32x4 &x, uint32_t e, uint32_t sh)
 {
     u32x4 y = x;
     if (BITS) {
         y[0] = __builtin_amdgcn_alignbit(x[1], x[0], sh); y[1] = __builtin_amdgcn_alignbit(x[2], x[1], sh);
         y[2] = __builtin_amdgcn_alignbit(x[3], x[2], sh); y[3] = __builtin_amdgcn_alignbit(e, x[3], sh);
     }
+    return y;
+}
+__device__ __forceinline__ void put_piece(uint8_t *p, const u32x4 &y, uint32_t valid)
+{
     if (valid >= 16) { *reinterpret_cast<u32x4_u *>(p) = y; return; }
     uint32_t a0 = y[0], a1 = y[1];
     if (valid & 8u) { *reinterpret_cast<u32x2_u *>(p) = u32x2{a0, a1}; p += 8; a0 = y[2]; a1 = y[3]; }
     if (valid & 4u) { *reinterpret_cast<u32_u *>(p) = a0; p += 4; a0 = a1; }
     if (valid & 2u) { *reinterpret_cast<u16_u *>(p) = (uint16_t)a0; p += 2; a0 >>= 16; }
     if (valid & 1u) *p = (uint8_t)a0;
+}
+
+// deflate (ADLER): the residual stream's Adler-32 is summed up from the bytes as they pass through the registers on their way into the record
+// (rc_deflate_block.h: A = sum of the bytes, W = sum of position * byte, both mod 65521; 32-bit arithmetic: a piece of <= 16 bytes at
+// stream byte sp adds (sp mod p) * a + q, a <= 4080 its byte sum, q its bytes weighted by their place in the piece)
+struct AdlerAcc { uint32_t A, W; };
+__device__ __forceinline__ void adler_piece(AdlerAcc &acc, const u32x4 &y, uint32_t valid, uint32_t sp)
+{
+    uint32_t a = 0, q = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t nb = valid > 4u * k ? min(valid - 4u * k, 4u) : 0u;
+        const uint32_t v = y[k] & (nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u));
+        a = __builtin_amdgcn_sad_u8(v, 0u, a);
+        q = __builtin_amdgcn_udot4(v, 0x03020100u + 0x04040404u * (uint32_t)k, q, false);
+    }
+    acc.A += a;                                      // (a lane's pieces of one item: far below 2^32)
+    acc.W = (acc.W + (sp % ADLER_P) * a + q) % ADLER_P;
+}
+__device__ __forceinline__ void adler_byte(AdlerAcc &acc, uint32_t byte, uint32_t sp)
+{
+    acc.A += byte;
+    acc.W = (acc.W + (sp % ADLER_P) * byte) % ADLER_P;
 }
 
 // Where a tile's packed residuals lie in the frame's stream: coff = set pixels in front of the tile, cnt = its own, d bits each.
@@ -93,8 +123,8 @@ __device__ __forceinline__ ResidGeom resid_geom(uint32_t coff, uint32_t cnt, uin
 #ifndef RC_GATHER_WPE
 #define RC_GATHER_WPE 8   // waves per SIMD the register allocation aims at (8: at most 64 VGPRs)
 #endif
-template <bool BITS, int U>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WPE))) void k_gather(GatherArgs sc, RecordParams rp, uint8_t *__restrict__ out, const uint64_t *__restrict__ rec_off,
+template <bool BITS, int U, bool ADLER>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ADLER ? RC_GATHER_WPE / 2 : RC_GATHER_WPE))) void k_gather(GatherArgs sc, RecordParams rp, uint8_t *__restrict__ out, const uint64_t *__restrict__ rec_off,
                                                uint32_t lz4f_hdr_bitmap, uint32_t lz4f_hdr_pix, uint32_t batch_seq, uint32_t gpf, uint32_t nitems, uint32_t tpi)
 {
     if (sc.status->code != 0) {   // (the batch's last kernel remembers the first failure across asynchronously enqueued batches)
@@ -134,7 +164,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
         // (rs = ~0: the tile's residual slot)
         // (what the copy loop does not need - the shared byte's geometry, a slow tile's length - is not kept across it but derived again
         // behind it from cnt and a second read of tile_off: registers; `packed` carries two flags for it)
-        uint32_t word = 0, bsz = 0, bdst = 0, cnt = 0, rn = 0, rdst = 0, rs = 0xFFFFFFFFu, ps0 = 0, flags = 0;
+        uint32_t word = 0, bsz = 0, bdst = 0, cnt = 0, rn = 0, rdst = 0, rs = 0xFFFFFFFFu, ps0 = 0, flags = 0, blo = 0;
+        AdlerAcc ad{0u, 0u};
         if (have && rp.emit != 0 && (!flat || (sc.comb == 1 && pixp))) word = sc.blk_size[frow + t];
         if (have && !flat) {
             if (rp.emit == 0) {
@@ -153,6 +184,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
             if (cnt) {
                 const ResidGeom q = resid_geom(sc.tile_off[frow + t], cnt, d);
                 ps0 = q.ps0;
+                if (ADLER) blo = q.b_lo;
                 if (sc.comb) {   // (rc_launch.h::residual_src)
                     const uint32_t ro16 = sc.comb == 2 ? (uint32_t)BLK_SLOT / 16 : (word + 15) >> 4, r16 = (cnt * d + 127) >> 7;
                     if (16 * (ro16 + r16) <= sc.blk_stride) rs = 16 * ro16;
@@ -181,6 +213,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
         for (uint32_t i0 = 0; 64u * i0 < T; i0 += U) {
             u32x4 x[U];
             uint32_t e[U], dsto[U], meta[U];   // meta: valid bytes | shift << 8
+            uint32_t spos[ADLER ? U : 1];      // deflate: the piece's first byte in the residual stream (~0: a piece of a block)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t P = 64u * (i0 + u) + lane;
@@ -191,6 +224,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
                     if (c <= P) k += step;
                 }
                 const uint32_t ck = lane_get(cum, k), pk = lane_get(packed, k), bd = lane_get(bdst, k), rd = lane_get(rdst, k), rsk = lane_get(rs, k);
+                const uint32_t blk = ADLER ? lane_get(blo, k) : 0u;
                 const uint32_t bsz_k = pk & 1023u, ps0_k = (pk >> 10) & 7u, rn_k = (pk >> 13) & 0x7FFFu;
                 const uint32_t idx = P - ck, nbk = (bsz_k + 15) >> 4;
                 const bool isb = idx < nbk;
@@ -201,6 +235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
                                          : (rsk == 0xFFFFFFFFu ? rslot + (uint64_t)k * sc.pix_slot_bytes : slot + (uint64_t)k * slot_stride + rsk) + 16u * j;
                 dsto[u] = (isb ? bd : rd) + 16u * j;
                 meta[u] = act ? (min(left, 16u) | ((isb ? 0u : ps0_k) << 8)) : 0u;
+                if (ADLER) spos[u] = isb ? 0xFFFFFFFFu : blk + 16u * j;
                 x[u] = u32x4{0u, 0u, 0u, 0u};
                 e[u] = 0;
                 if (act) {
@@ -210,10 +245,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (meta[u] & 0xFFu) put_piece<BITS>(rec + dsto[u], x[u], e[u], meta[u] >> 8, meta[u] & 0xFFu);
+                if (meta[u] & 0xFFu) {
+                    const u32x4 y = shift_piece<BITS>(x[u], e[u], meta[u] >> 8);
+                    put_piece(rec + dsto[u], y, meta[u] & 0xFFu);
+                    if (ADLER && spos[u] != 0xFFFFFFFFu) adler_piece(ad, y, meta[u] & 0xFFu, spos[u]);
+                }
         }
-        if (!pixp) continue;
-
+        if (pixp) {
         // the residual geometry again (see the bookkeeping)
         ResidGeom q{0u, 0u, 0u, 0u};
         if (cnt) q = resid_geom(sc.tile_off[frow + t], cnt, d);
@@ -224,10 +262,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(rsk == 0xFFFFFFFFu ? rslot + (uint64_t)k * sc.pix_slot_bytes : slot + (uint64_t)k * slot_stride + rsk);
             for (uint32_t i = lane; i < n; i += 64) {
                 const uint32_t qb = 8 * i + p0;
-                pdst[stored_pos(ff, (uint64_t)b0 + i)] = (uint8_t)__builtin_amdgcn_alignbit(s32[(qb >> 5) + 1], s32[qb >> 5], qb & 31u);
+                const uint32_t v = __builtin_amdgcn_alignbit(s32[(qb >> 5) + 1], s32[qb >> 5], qb & 31u) & 0xFFu;
+                pdst[stored_pos(ff, (uint64_t)b0 + i)] = (uint8_t)v;
+                if (ADLER) adler_byte(ad, v, b0 + i);
             }
         }
-        if (!BITS) continue;
+        if (BITS) {
 
         // ---- the stream byte a tile shares with its successor(s) --------------------------------------------------------------------------
         const uint32_t fin_avail = q.avail, fin_q = 8 * q.n + q.ps0, fin_b = q.b_lo + q.n;
@@ -267,7 +307,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WP
                 tt = sc.tile_next[frow + tt];
             }
         }
-        if (fin_avail) pdst[plain_pos ? (uint64_t)fin_b : stored_pos(ff, fin_b)] = (uint8_t)byte;
+        if (fin_avail) {
+            pdst[plain_pos ? (uint64_t)fin_b : stored_pos(ff, fin_b)] = (uint8_t)byte;
+            if (ADLER) adler_byte(ad, byte & 0xFFu, fin_b);
+        }
+        }   // BITS
+        }   // pixp
+        if (ADLER && !flat) {
+            // the item's sums -> the frame's accumulators (zeroed by k_layout); k_zlib_finish, behind this kernel, turns them into the trailers.
+            // Relaxed device-scope adds and NO fence: a "last item writes the trailers" form needs a release fence per item, and on this chip
+            // a device-scope release writes the XCD's whole L2 back - 4096 of them per batch took 230 us and stretched the reduce kernel
+            // running next to them from 0.53 to 0.72 ms (profiles/r06_exp1_trailers.md).
+            const uint32_t aux = have ? sc.blk_aux[frow + t] : 0u;
+            const uint32_t tA0 = wave_last(wave_incl_scan(aux & 0xFFFFu)), tW0 = wave_last(wave_incl_scan(aux >> 16));
+            const uint32_t tA1 = wave_last(wave_incl_scan(ad.A % ADLER_P)), tW1 = wave_last(wave_incl_scan(ad.W));
+            if (lane == 0) {
+                uint32_t *acc = sc.zl_acc + 8 * (uint64_t)f;
+                if (tA0 | tW0) {
+                    __hip_atomic_fetch_add(&acc[0], tA0 % ADLER_P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&acc[1], tW0 % ADLER_P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tA1 | tW1) {
+                    __hip_atomic_fetch_add(&acc[2], tA1 % ADLER_P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&acc[3], tW1 % ADLER_P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+// deflate: the frames' Adler-32 sums -> the two trailers of each record (a thread per frame; the kernel boundary orders it behind k_gather's adds)
+__global__ __launch_bounds__(64) void k_zlib_finish(GatherArgs sc, RecordParams rp, uint8_t *__restrict__ out, const uint64_t *__restrict__ rec_off, uint32_t B)
+{
+    const uint32_t f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= B || sc.status->code != 0) return;
+    const FrameFmt ff = frame_fmt(rp.emit);
+    const uint32_t *acc = sc.zl_acc + 8 * (uint64_t)f;
+    uint8_t *rec = out + rec_off[f];
+    const uint32_t cb = bitmap_hdr(ff, rp.emit, sc.ntiles) + sc.frame_cbytes[f] + ff.end, bitmap_pos = rp.level == 1 ? 16u : 8u;
+    store_u32_be(rec + bitmap_pos + cb - 4, adler_from_sums(sc.nb, acc[0], acc[1]));
+    if (rp.level == 1 && rp.pix_mode != 2) {
+        const uint32_t npk = packed_bytes(sc.frame_nnz[f], rp.depth);
+        store_u32_be(rec + bitmap_pos + cb + stored_size(ff, npk) - 4, adler_from_sums(npk, acc[2], acc[3]));
     }
 }
 
@@ -285,11 +366,16 @@ void launch_gather(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_
     uint32_t wgs = wgs_env ? (uint32_t)atoi(wgs_env) : 0u;
     if (wgs == 0 || wgs > nitems) wgs = nitems;
     const GatherArgs ga{sc.blk_slots, sc.bitmap, sc.pix_slots, sc.blk_size, sc.blk_off, sc.tile_cnt, sc.tile_off, sc.tile_next, sc.frame_nnz, sc.frame_cbytes,
-                        sc.frame_pbytes, sc.pixraw, sc.status, sc.first_err, sc.nb, sc.nb_stride, sc.pixraw_stride, sc.ntiles, sc.blk_stride, sc.pix_slot_bytes, sc.comb};
-    if (rp.level == 1 && rp.depth % 8 != 0)
-        hipLaunchKernelGGL((k_gather<true, RC_GATHER_UB>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
+                        sc.frame_pbytes, sc.blk_aux, sc.zl_acc, sc.pixraw, sc.status, sc.first_err, sc.nb, sc.nb_stride, sc.pixraw_stride, sc.ntiles, sc.blk_stride, sc.pix_slot_bytes, sc.comb};
+    const bool bits = rp.level == 1 && rp.depth % 8 != 0;
+    if (rp.emit == EMIT_DEFLATE) {   // (the zlib streams' Adler-32 is summed up on the way: the ADLER instantiations)
+        if (bits) hipLaunchKernelGGL((k_gather<true, RC_GATHER_UB, true>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
+        else hipLaunchKernelGGL((k_gather<false, RC_GATHER_U, true>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
+        if (rp.pix_mode != 1) hipLaunchKernelGGL(k_zlib_finish, dim3((B + 63) / 64), dim3(64), 0, s, ga, rp, out, rec_off, B);
+    } else if (bits)
+        hipLaunchKernelGGL((k_gather<true, RC_GATHER_UB, false>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
     else
-        hipLaunchKernelGGL((k_gather<false, RC_GATHER_U>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
+        hipLaunchKernelGGL((k_gather<false, RC_GATHER_U, false>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
 }
 
 }  // namespace rc

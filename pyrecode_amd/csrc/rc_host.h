@@ -39,6 +39,10 @@ int fail(int code, const char *what)
 int hip_fail(hipError_t e, const char *where)
 {
     g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+    if (e == hipErrorOutOfMemory) {   // the workspace does not fit this GPU's free memory: a status of its own, and no sticky HIP error left behind
+        (void)hipGetLastError();
+        return RC_ERR_WORKSPACE;
+    }
     return RC_ERR_DEVICE;
 }
 #define HIP_TRY(expr)                                         \

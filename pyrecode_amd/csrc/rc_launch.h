@@ -14,6 +14,8 @@ struct Scratch {
     uint64_t nb = 0;           // ceil(N / 8) bitmap bytes per frame
     uint64_t nb_stride = 0;    // ntiles * TILE_BM (bitmap rows padded to whole tiles)
     uint32_t max_batch = 0;
+    bool guarded_loads = false;        // every tile through the guarded single-load instantiation of the reduce kernel (tests: RC_REDUCE_GUARDED_LOADS=1
+                                       // in the environment when the ctx is created; the product reads the switch nowhere else)
     uint16_t *thr = nullptr;           // [N]
     uint8_t *bitmap = nullptr;         // [B][nb_stride]            packed binary maps
     uint16_t *pix_slots = nullptr;     // [B][ntiles][TILE_PX]      per-tile residuals, row-major inside the tile
@@ -32,8 +34,8 @@ struct Scratch {
     uint32_t comb = 0;
     uint32_t *blk_size = nullptr;      // [B][ntiles]               bytes used in each slot
     uint32_t *blk_aux = nullptr;       // [B][ntiles]               deflate: the tiles' Adler-32 partials (rc_deflate_block.h::deflate_adler_word)
-    uint32_t *zl_acc = nullptr;        // [B][8]                    deflate: per frame {A, W of the map, A, W of the residual stream, arrivals}
-                                       //                           (zeroed by k_layout, summed and turned into the two trailers by k_zlib_trailers)
+    uint32_t *zl_acc = nullptr;        // [B][8]                    deflate: per frame {A, W of the map, A, W of the residual stream}
+                                       //                           (zeroed by k_layout, summed up by k_gather, turned into the two trailers by k_zlib_finish)
     uint32_t *blk_off = nullptr;       // [B][ntiles]               exclusive prefix of blk_size inside the frame
     uint32_t *frame_nnz = nullptr;     // [B]
     uint32_t *frame_cbytes = nullptr;  // [B]                       sum of blk_size
@@ -66,7 +68,8 @@ struct RecordParams {
     uint32_t level;        // 1 or 3
     uint32_t emit;         // 0 = raw pieces (mode-0 record), 2 = LZ4 frames, 1 = zstd frames, 8 = blosc-lz4, EMIT_DEFLATE = zlib streams
     uint32_t depth;        // source_bit_depth
-    uint32_t packed_slots; // 1: pix_slots hold tile-local packed streams (level 1); 0: uint16 values (level 2 statistics)
+    uint32_t packed_slots; // 1: the tiles' slots hold tile-local packed streams - level-1 residuals and, since round 5, level-2 statistics (k_l2_emit);
+                           // 0: no value stream is gathered (no caller passes it any more)
     uint32_t first_frame_id;
     uint64_t frame_bytes;  // raw frame size = N * 2 (record upper bound, recode_writer.py:565-566)
     uint32_t pix_mode = 0; // k_gather / k_layout: 0 = the residual stream goes into the record as it is (stored chunks);
@@ -103,8 +106,6 @@ void launch_pix_huff(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t 
 void launch_pix_scan(const Scratch &sc, uint32_t B, uint32_t depth, hipStream_t s);   // (rc_reduce.hip)
 void launch_pix_gather(const Scratch &sc, uint32_t B, uint32_t depth, uint32_t level1_hdr, uint8_t *out, const uint64_t *rec_off,
                        hipStream_t s);
-// rc_deflate.hip: the Adler-32 trailers of a batch's zlib streams (behind launch_assemble)
-void launch_zlib_trailers(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_t *out, const uint64_t *rec_off, hipStream_t s);
 // rc_lz4.hip
 struct Lz4Block { uint64_t src_off; uint32_t size; uint32_t raw; };
 void launch_lz4_encode_buffer(const Scratch &sc, hipStream_t s, bool events = false);  // sc.bitmap = the buffer, sc.nb = its length

@@ -15,7 +15,7 @@ namespace rc {
 //                                     "memcpyed" flag + the bytes (what c-blosc itself emits for incompressible input)
 //   zlib stream (RFC 1950 / 1951):    2-byte header, deflate blocks (the map: a byte-aligned block pair per tile, rc_deflate_block.h; the
 //                                     residuals: stored blocks of 32 KiB with 5-byte headers, BFINAL on the last, >= 1 block), Adler-32
-//                                     of the uncompressed bytes, big-endian (written behind the gather by k_zlib_trailers)
+//                                     of the uncompressed bytes, big-endian (summed up inside k_gather, written by k_zlib_finish behind it)
 struct FrameFmt { uint32_t hdr, end, chunk_shift, chunk_hdr, min_chunks; };
 __host__ __device__ inline FrameFmt frame_fmt(uint32_t emit)
 {

@@ -707,7 +707,7 @@ static void launch_reduce_t(const Scratch &sc, const typename Src<SB>::T *frames
     static const char *rw_env = RC_KNOB("RC_REDUCE_WG_WAVES");   // (experiments: 3 or 4)
     // (modelled zstd whose blocks carry literals only - dense maps, rc_zstd_model.h - has no FSE pass behind the reduce kernel: its
     // second stage is as short as LZ4's, and three-wave workgroups gain 0.5-3 % there as well)
-    const bool three = rw_env ? atoi(rw_env) == 3 : (L1 && !RAW && (CODEC == 2 || CODEC == 4 || CODEC == 5 || sc.ntiles > 8192 || (CODEC == 3 && (sc.zm_valid & ZM_LITS_ONLY))));
+    const bool three = rw_env ? atoi(rw_env) == 3 : (L1 && !RAW && CODEC != 5 && (CODEC == 2 || CODEC == 4 || sc.ntiles > 8192 || (CODEC == 3 && (sc.zm_valid & ZM_LITS_ONLY))));
     auto go = [&](auto rw) {
         constexpr int RW = decltype(rw)::value;
         auto grid_for = [&](uint32_t nt) { return (((nt + RW - 1) / RW + 7) / 8) * 8 * ngroups; };
@@ -743,6 +743,9 @@ static void launch_reduce_c(const Scratch &sc, const typename Src<SB>::T *frames
         if (keep) launch_reduce_t<BZ, AL, L1, C, true, RAW, SB>(sc, frames, B, depth, s, s_tail);                \
         else if (!RAW && C != 0) launch_reduce_t<BZ, AL, L1, C, false, false, SB>(sc, frames, B, depth, s, s_tail); \
     } while (0)
+#ifdef RC_DEV_ONLY_CODEC   // (development: one codec's instantiations only - a translation unit that compiles in a quarter of the time, for reading its ISA)
+    if (codec == RC_DEV_ONLY_CODEC) RC_CODEC(RC_DEV_ONLY_CODEC);
+#else
     if (codec == 2) RC_CODEC(2);
     else if (codec == 4) RC_CODEC(4);
     else if (codec == 1) RC_CODEC(1);
@@ -750,6 +753,7 @@ static void launch_reduce_c(const Scratch &sc, const typename Src<SB>::T *frames
     else if (codec == 8) RC_CODEC(8);
     else if (codec == 5) RC_CODEC(5);
     else launch_reduce_t<BZ, AL, L1, 0, true, RAW, SB>(sc, frames, B, depth, s, s_tail);
+#endif
 #undef RC_CODEC
 }
 template <int BZ, bool AL, int SB>
@@ -781,8 +785,8 @@ void launch_reduce(const Scratch &sc, const void *frames, uint32_t B, uint32_t l
     // alignment: amdhsa runs gfx9+ in unaligned access mode (the compiler emits global_load_dwordx4 for an align-1 16-byte load
     // itself), so a frame may start on any pixel.  Until late in round 4 the rule here was N % 8 == 0 and a 16-byte aligned base, and
     // 3838 x 3710 frames - a common detector format, N % 8 = 4 - took the guarded single loads throughout, at a sixth of the rate.
-    // (RC_REDUCE_GUARDED_LOADS=1: the guarded instantiation for every tile - tests keep it alive.)
-    const bool aligned = getenv("RC_REDUCE_GUARDED_LOADS") == nullptr;   // (read per launch: a test switches it inside one process)
+    // (Scratch::guarded_loads - RC_REDUCE_GUARDED_LOADS=1 when the ctx was created: the guarded instantiation for every tile - tests keep it alive.)
+    const bool aligned = !sc.guarded_loads;
     if (src_bytes == 1) {   // uint8 frames (source_bit_depth <= 8)
         const uint8_t *f8 = static_cast<const uint8_t *>(frames);
         if (aligned) launch_reduce_a<RC_BZ, true, 1>(sc, f8, B, level, codec, keep_bitmap, depth, s, s_tail);

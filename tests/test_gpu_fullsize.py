@@ -224,7 +224,8 @@ def test_4096_host_buffer_path_and_pcie_inclusive_rate(env, capsys):
     ctx.close()
 
 
-def test_4096_l2_blosc_config4(env):
+@pytest.mark.parametrize("depth", [16, 12])   # 16: BASELINE's "uint16" and bench.py --config 4; 12: the packed form
+def test_4096_l2_blosc_config4(env, depth):
     """configs[3]: 4096x4096 uint16, 0.1 % sparsity, L2 (component maxima) + blosc-lz4.  No oracle exists in the reference for
     L2: the checker is the stated intent, scipy.ndimage.label (8-connectivity) + per-label maximum of the raw frame."""
     import scipy.ndimage as nd
@@ -232,7 +233,7 @@ def test_4096_l2_blosc_config4(env):
     ny = nx = 4096
     N, B = ny * nx, 3
     dark_d, frames_d = _device_stack(torch, hip, 21, B, N, 1000)
-    ctx = hip.ReduceContext(nx, ny, 12, 2, 1, 8, 1, 0, max_batch=B)
+    ctx = hip.ReduceContext(nx, ny, depth, 2, 1, 8, 1, 0, max_batch=B)
     ctx.set_dark(dark_d.data_ptr(), 0)
     ctx.set_l2_statistics(1)
     cap = B * (N // 4)
@@ -252,8 +253,8 @@ def test_4096_l2_blosc_config4(env):
         labels, n = nd.label(binary, structure=np.ones((3, 3), int))
         vals = np.asarray(nd.maximum(frames[z].astype(np.int64), labels, np.arange(1, n + 1)), np.int64).astype(np.uint16)
         assert orc.blosc1_decode(r[16:16 + cb]) == orc.pack_binary_frame(binary).tobytes()
-        assert npk == (n * 12 + 7) // 8
-        assert orc.blosc1_decode(r[16 + cb:]) == orc.bit_pack(vals, 12).tobytes()
+        assert npk == (n * depth + 7) // 8
+        assert orc.blosc1_decode(r[16 + cb:]) == orc.bit_pack(vals, depth).tobytes()
     ctx.close()
 
 

@@ -391,3 +391,34 @@ def test_batched_access_on_an_empty_part_file(tmp_path):
     with pytest.raises(ValueError):
         rd.get_frames_triplets(0, 1)
     rd.close()
+
+
+def test_frames_of_4_gib_and_more_are_refused_before_any_gpu_work():
+    """A record may be as large as its raw frame and every size in a record is a u32 (structures.py:18-46): nx * ny * bytes_per_pixel >= 2^32 cannot
+    be represented.  rc_ctx_create says so (RC_ERR_UNSUPPORTED -> NotImplementedError) instead of wrapping - argument checks come before the
+    device is looked for, so this runs without a GPU."""
+    import ctypes as C
+    from pyrecode_amd import _lib
+    L = _lib.lib()
+    st = C.c_int(0)
+    for nx, ny in ((50000, 50000), (65535, 32769), (46341, 46341)):          # uint16: 2 * nx * ny >= 2^32
+        assert not L.rc_ctx_create(nx, ny, 16, 1, 1, 2, 1, 0, 4, C.byref(st))
+        assert st.value == _lib.RC_ERR_UNSUPPORTED, (nx, ny, st.value)
+        assert b"4 GiB" in L.rc_last_error()
+    with pytest.raises(NotImplementedError):
+        _lib.ReduceContext(50000, 50000, 16, 1, 1, 2, 1, 0, max_batch=1)
+    assert not L.rc_ctx_create(70000, 70000, 16, 1, 1, 2, 1, 0, 4, C.byref(st)) and st.value == _lib.RC_ERR_BAD_ARG   # nx * ny itself >= 2^32
+    assert not L.rc_ctx_create(46340, 46340, 16, 1, 1, 2, 1, 0, 4, C.byref(st)) and st.value == _lib.RC_ERR_DEVICE    # representable: only the GPU is missing here
+
+
+def test_out_of_memory_has_a_status_and_an_exception_of_its_own():
+    from pyrecode_amd import _lib
+    assert _lib.lib().rc_strerror(_lib.RC_ERR_WORKSPACE) == b"out of device memory for the ctx's workspace"
+    import pyrecode_amd._lib as m
+    orig = m.last_error
+    m.last_error = lambda: "hipMalloc"
+    try:
+        with pytest.raises(MemoryError):
+            _lib.check(_lib.RC_ERR_WORKSPACE, "rc_ctx_create")
+    finally:
+        m.last_error = orig

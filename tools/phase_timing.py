@@ -39,6 +39,9 @@ print("shape %dx%d B=%d ppm=%d d=%d scheme=%d level=%d clevel=%d; reduce %.3f ms
 for n_, x in zip(names, v):
     print("  %-28s %6.1f %%   %7.0f memtime ticks per tile-frame" % (n_, 100 * x / v.sum(), x / ntf))
 sub = np.array(list(ph)[8:12], np.float64)
-if sub.sum():
+if sub.sum() and scheme == 256:
+    for n_, x in zip(["deflate: parse (rc_lz4_block.h's parsers)", "deflate: clear the image, build the units", "deflate: scan + LDS ORs", "deflate: tail (sync marker / stored)"], sub):
+        print("    %-50s %7.0f ticks per tile-frame" % (n_, x / ntf))
+elif sub.sum():
     for n_, x in zip(["LZ4: event parse (list, one / two events per lane)", "LZ4: run parse (blocks the event parser left)", "LZ4: sequence sizes + scan", "LZ4: emit (tokens, literals, offsets)"], sub):
         print("    %-50s %7.0f ticks per tile-frame" % (n_, x / ntf))

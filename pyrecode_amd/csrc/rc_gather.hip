@@ -124,7 +124,7 @@ __device__ __forceinline__ ResidGeom resid_geom(uint32_t coff, uint32_t cnt, uin
 #define RC_GATHER_WPE 8   // waves per SIMD the register allocation aims at (8: at most 64 VGPRs)
 #endif
 template <bool BITS, int U, bool ADLER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ADLER ? RC_GATHER_WPE / 2 : RC_GATHER_WPE))) void k_gather(GatherArgs sc, RecordParams rp, uint8_t *__restrict__ out, const uint64_t *__restrict__ rec_off,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GATHER_WPE))) void k_gather(GatherArgs sc, RecordParams rp, uint8_t *__restrict__ out, const uint64_t *__restrict__ rec_off,
                                                uint32_t lz4f_hdr_bitmap, uint32_t lz4f_hdr_pix, uint32_t batch_seq, uint32_t gpf, uint32_t nitems, uint32_t tpi)
 {
     if (sc.status->code != 0) {   // (the batch's last kernel remembers the first failure across asynchronously enqueued batches)
@@ -369,7 +369,7 @@ void launch_gather(const Scratch &sc, const RecordParams &rp, uint32_t B, uint8_
                         sc.frame_pbytes, sc.blk_aux, sc.zl_acc, sc.pixraw, sc.status, sc.first_err, sc.nb, sc.nb_stride, sc.pixraw_stride, sc.ntiles, sc.blk_stride, sc.pix_slot_bytes, sc.comb};
     const bool bits = rp.level == 1 && rp.depth % 8 != 0;
     if (rp.emit == EMIT_DEFLATE) {   // (the zlib streams' Adler-32 is summed up on the way: the ADLER instantiations)
-        if (bits) hipLaunchKernelGGL((k_gather<true, RC_GATHER_UB, true>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
+        if (bits) hipLaunchKernelGGL((k_gather<true, RC_GATHER_UB - 1, true>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
         else hipLaunchKernelGGL((k_gather<false, RC_GATHER_U, true>), dim3(wgs), dim3(64), 0, s, ga, rp, out, rec_off, hdr_bitmap, hdr_pix, batch_seq, gpf, nitems, tpi);
         if (rp.pix_mode != 1) hipLaunchKernelGGL(k_zlib_finish, dim3((B + 63) / 64), dim3(64), 0, s, ga, rp, out, rec_off, B);
     } else if (bits)
